@@ -1,0 +1,385 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING THE REAL REFERENCE.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box).
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+Fixtures are data only (inputs, parameters, expected outputs/gradients); no reference source
+is copied.  Versions of torch / transformers used are recorded in every file.
+
+Version-skew shim: the reference is written for transformers 4.55
+where ``WhisperEncoderLayer.forward`` returns a tuple; the installed 5.x returns a bare tensor, so
+``hidden_states = layer_outputs[0]`` (reference encoder.py:223) would silently index the batch.
+We wrap the HF layer forward to return ``(hidden_states,)`` again.
+
+Import-time placeholders: ``src/data/local_datasets.py`` imports lhotse / torchaudio / omegaconf
+... at module scope; those packages are absent here.  We register empty placeholder modules so
+the module body executes; the only function we then call (``_create_stno_masks``) is pure numpy
+and touches none of them.
+"""
+import os
+import sys
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+REF = "/root/reference/src"
+sys.path.insert(0, REF)
+sys.path.insert(1, os.path.dirname(REF))   # utils/general.py does `from src.utils...`
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import numpy as np
+import torch
+import transformers
+import transformers.models.whisper.modeling_whisper as mw
+
+_orig_layer_fwd = mw.WhisperEncoderLayer.forward
+
+
+def _tuple_fwd(self, hidden_states, attention_mask=None, layer_head_mask=None, output_attentions=False, **kw):
+    return (_orig_layer_fwd(self, hidden_states, attention_mask, **kw),)
+
+
+mw.WhisperEncoderLayer.forward = _tuple_fwd
+
+from models.dicow.modeling_dicow import DiCoWForConditionalGeneration  # noqa: E402
+from models.dicow.config import DiCoWConfig  # noqa: E402
+from models.dicow.FDDT import FDDT  # noqa: E402
+from models.dicow.layers import SpeakerCommunicationBlock  # noqa: E402
+
+VERS = {"torch": torch.__version__, "transformers": transformers.__version__, "numpy": np.__version__}
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = v
+    out["_versions"] = np.array(repr(VERS))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}  {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+# ----------------------------------------------------------------------------- F1: STNO builder
+def f1_stno():
+    import importlib.abc
+    import importlib.machinery
+
+    absent = ("lhotse", "torchaudio", "omegaconf", "wandb", "hydra", "peft", "meeteval", "jiwer")
+
+    class _Any(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return type(k, (), {})
+
+    class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, name, path=None, target=None):
+            if name.split(".")[0] in absent:
+                return importlib.machinery.ModuleSpec(name, self, is_package=True)
+            return None
+
+        def create_module(self, spec):
+            return _Any(spec.name)
+
+        def exec_module(self, module):
+            pass
+
+    sys.meta_path.append(_Finder())
+    try:
+        from data.local_datasets import TS_ASR_DatasetSuperclass
+        fn = TS_ASR_DatasetSuperclass._create_stno_masks
+    except Exception as ex:  # pragma: no cover
+        raise SystemExit(f"cannot import reference STNO builder: {ex!r}")
+    rng = np.random.default_rng(1)
+    arrs = {}
+    case = 0
+    for S in (1, 2, 3, 4):
+        for s_index in list(range(S)) + [-1]:
+            T = 150
+            a = rng.random((S, T)).astype(np.float32)
+            a[rng.random((S, T)) < 0.3] = 0.0          # exact silences
+            a[rng.random((S, T)) < 0.3] = 1.0          # exact activity
+            if s_index == -1:                          # unknown speaker: caller appends a zero row
+                a = np.pad(a, ((0, 1), (0, 0)))
+            arrs[f"in_{case}"] = a
+            arrs[f"idx_{case}"] = np.array(s_index)
+            arrs[f"out_{case}"] = fn(a.copy(), s_index)
+            case += 1
+    arrs["n_cases"] = np.array(case)
+    save("f1_stno", **arrs)
+
+
+# ----------------------------------------------------------------------------- F2: log-mel
+def synth_wave(seed, seconds):
+    rng = np.random.default_rng(seed)
+    n = int(seconds * 16000)
+    t = np.arange(n) / 16000.0
+    w = 0.3 * np.sin(2 * np.pi * (220.0 + 40 * seed) * t) + 0.1 * np.sin(2 * np.pi * 3100.0 * t) * (t > 0.5)
+    w = w + 0.05 * rng.standard_normal(n)
+    return np.round(w * 8192).astype(np.int16)         # stored as int16, used as int16/32768
+
+
+def f2_logmel():
+    from transformers import WhisperFeatureExtractor
+    arrs = {}
+    for i, (mels, secs) in enumerate([(80, 3.3), (128, 7.1)]):
+        fe = WhisperFeatureExtractor(feature_size=mels)
+        w16 = synth_wave(i, secs)
+        wave = w16.astype(np.float32) / 32768.0
+        out = fe(wave, return_tensors="np", sampling_rate=16000, return_attention_mask=True, truncation=False,
+                 padding="longest", pad_to_multiple_of=fe.n_samples)
+        arrs[f"wave_{i}"] = w16
+        arrs[f"mels_{i}"] = np.array(mels)
+        arrs[f"feat_{i}"] = out["input_features"][0].astype(np.float32)
+        arrs[f"attn_sum_{i}"] = np.array(int(out["attention_mask"][0].sum()))
+    arrs["n_cases"] = np.array(2)
+    save("f2_logmel", **arrs)
+
+
+# ----------------------------------------------------------------------------- helpers
+def randomize_(module, seed):
+    """Overwrite every parameter with seeded values so all of them matter."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if n.endswith("layer_norm.weight") or n.endswith("_layer_norm.weight"):
+                p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+            elif "fddt" in n and n.endswith(".weight") and p.dim() == 1:
+                base = 0.5 if ("initial_fddt" in n and ("silence" in n or "non_target" in n)) else 1.0
+                p.copy_(base + 0.1 * torch.randn(p.shape, generator=g))
+            elif "fddt" in n and n.endswith(".weight") and p.dim() == 2:
+                p.copy_(torch.eye(p.shape[0]) + 0.3 * p.shape[0] ** -0.5 * torch.randn(p.shape, generator=g))
+            elif n.endswith("gate"):
+                p.copy_(0.3 + 0.5 * torch.randn(p.shape, generator=g))
+            elif "embed_positions" in n and "encoder" in n:
+                pass                                    # keep sinusoids
+            elif p.dim() >= 2:
+                fan_in = p[0].numel()
+                p.copy_(fan_in ** -0.5 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+
+
+def soft_stno(B, T, seed, hard_frac=0.3):
+    g = torch.Generator().manual_seed(seed)
+    s = torch.softmax(2.0 * torch.randn(B, 4, T, generator=g), dim=1)
+    hard = torch.nn.functional.one_hot(torch.randint(0, 4, (B, T), generator=g), 4).permute(0, 2, 1).float()
+    pick = (torch.rand(B, 1, T, generator=g) < hard_frac).float()
+    s = pick * hard + (1 - pick) * s
+    s[:, :, -T // 10:] = 0.0                            # padding frames = silence 1 (collators.py:157-161)
+    s[:, 0, -T // 10:] = 1.0
+    return s
+
+
+# ----------------------------------------------------------------------------- F3: FDDT module
+def f3_fddt():
+    D, B, T = 128, 2, 100
+    arrs = {}
+    variants = {
+        "diag": dict(is_diagonal=True),
+        "full": dict(is_diagonal=False),
+        "bias": dict(is_diagonal=True, bias_only=True),
+        "diag_no_sil_ovl": dict(is_diagonal=True, use_silence=False, use_overlap=False),
+        "full_no_tgt": dict(is_diagonal=False, use_target=False),
+    }
+    for vi, (vn, kw) in enumerate(variants.items()):
+        torch.manual_seed(10 + vi)
+        m = FDDT(D, non_target_rate=0.5, fddt_init="suppressive", **kw)
+        randomize_(m, 20 + vi)
+        if kw.get("bias_only"):
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.copy_(0.1 * torch.randn(p.shape))
+        g = torch.Generator().manual_seed(30 + vi)
+        h = torch.randn(B, T, D, generator=g, requires_grad=True)
+        st = soft_stno(B, T, 40 + vi)
+        go = torch.randn(B, T, D, generator=g)
+        out = m(h.clone() if kw.get("bias_only") else h, st)      # bias_only mutates its input in place
+        out.backward(go)
+        arrs[f"{vn}.h"], arrs[f"{vn}.stno"], arrs[f"{vn}.gout"] = h, st, go
+        arrs[f"{vn}.out"], arrs[f"{vn}.gh"] = out, h.grad
+        for n, p in m.named_parameters():
+            arrs[f"{vn}.p.{n}"] = p
+            arrs[f"{vn}.g.{n}"] = p.grad
+    save("f3_fddt", **arrs)
+
+
+# ----------------------------------------------------------------------------- configs
+def small_cfg(**over):
+    kw = dict(vocab_size=512, num_mel_bins=80, d_model=128, encoder_layers=2, encoder_attention_heads=2,
+              decoder_layers=2, decoder_attention_heads=2, encoder_ffn_dim=256, decoder_ffn_dim=256,
+              max_source_positions=100, max_target_positions=32, pad_token_id=500, bos_token_id=500,
+              eos_token_id=500, decoder_start_token_id=501, use_fddt=True, fddt_is_diagonal=True,
+              use_pre_pos_fddt=True, fddt_init="suppressive", non_target_fddt_value=0.5)
+    kw.update(over)
+    return DiCoWConfig(**kw)
+
+
+CFG_KEYS = ["vocab_size", "num_mel_bins", "d_model", "encoder_layers", "encoder_attention_heads", "decoder_layers",
+            "decoder_attention_heads", "encoder_ffn_dim", "decoder_ffn_dim", "max_source_positions",
+            "max_target_positions", "pad_token_id", "decoder_start_token_id", "use_fddt", "fddt_is_diagonal",
+            "fddt_bias_only", "fddt_use_silence", "fddt_use_target", "fddt_use_overlap", "fddt_use_non_target",
+            "apply_fddt_to_n_layers", "use_pre_pos_fddt", "use_enrollments", "scb_layers", "ctc_weight"]
+
+
+def cfg_dict(cfg):
+    return {k: getattr(cfg, k) for k in CFG_KEYS}
+
+
+class StubTokenizer:
+    """Only what SoftLabelCreator needs (modeling_dicow.py:37): a vocab with <|t.tt|> tokens."""
+
+    def __init__(self, vocab_size, ts_start, n_ts):
+        self.vocab = {f"tok{i}": i for i in range(vocab_size)}
+        for j in range(n_ts):
+            del self.vocab[f"tok{ts_start + j}"]
+            self.vocab[f"<|{0.02 * j:.2f}|>"] = ts_start + j
+        self.prefix_tokens = [501]
+
+    def get_vocab(self):
+        return self.vocab
+
+
+def make_inputs(cfg, B, L, seed, ts_range=None):
+    g = torch.Generator().manual_seed(seed)
+    Tm = 2 * cfg.max_source_positions
+    x = torch.randn(B, cfg.num_mel_bins, Tm, generator=g).clamp(-1.5, 1.5)
+    st = soft_stno(B, cfg.max_source_positions, seed + 1)
+    lab = torch.randint(0, 400, (B, L), generator=g)
+    if ts_range is not None:
+        lab[:, 0] = ts_range[0] + 3
+        lab[:, L // 2] = ts_range[0] + 17
+        lab[0, 3] = ts_range[0] + ts_range[1] - 1
+    upp = lab.clone()
+    chg = torch.rand(B, L, generator=g) < 0.3
+    upp[chg] = (lab[chg] + 7) % 400
+    if ts_range is not None:
+        upp[:, 0], upp[:, L // 2], upp[0, 3] = lab[:, 0], lab[:, L // 2], lab[0, 3]
+    lab[1, L - 3:] = -100                              # padding
+    upp[1, L - 3:] = -100
+    return x, st, lab, upp
+
+
+def run_model(model, batch, autocast=False):
+    model.zero_grad(set_to_none=True)
+    if autocast:
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            out = model(**batch)
+    else:
+        out = model(**batch)
+    return out
+
+
+# ----------------------------------------------------------------------------- F7: end-to-end small DiCoW
+def f7_e2e():
+    cfg = small_cfg()
+    torch.manual_seed(0)
+    model = DiCoWForConditionalGeneration(cfg).eval()
+    randomize_(model, 7)
+    x, st, lab, upp = make_inputs(cfg, B=2, L=12, seed=70, ts_range=(400, 100))
+    batch = dict(input_features=x, stno_mask=st, labels=lab, upp_labels=upp)
+    arrs = {"cfg": np.array(repr(cfg_dict(cfg))), "x": x, "stno": st, "labels": lab, "upp_labels": upp}
+    for n, p in model.state_dict().items():
+        arrs["p." + n] = p
+    # hard-label fallback loss (no tokenizer)
+    out = run_model(model, batch)
+    out.loss.backward()
+    arrs["hard.loss"], arrs["logits"], arrs["enc"] = out.loss, out.logits, out.encoder_last_hidden_state
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            arrs["hard.g." + n] = p.grad
+    # soft-label loss (stub tokenizer: timestamps at ids 400..499)
+    model.set_tokenizer(StubTokenizer(cfg.vocab_size, 400, 100))
+    out = run_model(model, batch)
+    out.loss.backward()
+    arrs["soft.loss"] = out.loss
+    for n in ["model.encoder.fddts.0.target_linear.weight", "model.encoder.fddts.0.target_linear.bias",
+              "model.encoder.initial_fddt.silence_linear.weight", "model.encoder.layers.0.fc1.weight",
+              "model.encoder.conv1.weight", "model.decoder.layers.1.encoder_attn.q_proj.weight",
+              "model.decoder.embed_tokens.weight"]:
+        arrs["soft.g." + n] = dict(model.named_parameters())[n].grad
+    arrs["ts_start"], arrs["ts_n"] = np.array(400), np.array(100)
+    # bf16 autocast deviation (F9)
+    model.soft_label_creator = None
+    out_bf = run_model(model, batch, autocast=True)
+    arrs["bf16.loss"], arrs["bf16.logits"] = out_bf.loss.float(), out_bf.logits.float()
+    save("f7_e2e_small", **arrs)
+
+
+# ----------------------------------------------------------------------------- F8: end-to-end small SE-DiCoW
+def f8_se():
+    cfg = small_cfg(use_enrollments=True, scb_layers=1, encoder_layers=2)
+    torch.manual_seed(1)
+    model = DiCoWForConditionalGeneration(cfg).eval()
+    randomize_(model, 8)
+    x, st, lab, upp = make_inputs(cfg, B=2, L=10, seed=80)
+    xe, ste, _, _ = make_inputs(cfg, B=2, L=10, seed=81)
+    enr = {"input_features": xe, "stno_mask": ste, "attention_mask": torch.ones(2, 2 * cfg.max_source_positions)}
+    batch = dict(input_features=x, stno_mask=st, labels=lab, upp_labels=upp, enrollments=enr)
+    out = run_model(model, batch)
+    out.loss.backward()
+    arrs = {"cfg": np.array(repr(cfg_dict(cfg))), "x": x, "stno": st, "labels": lab, "upp_labels": upp,
+            "enr.x": xe, "enr.stno": ste, "loss": out.loss, "logits": out.logits,
+            "enc": out.encoder_last_hidden_state}
+    for n, p in model.state_dict().items():
+        arrs["p." + n] = p
+    for n, p in model.named_parameters():
+        if p.grad is not None and ("ca_enrolls" in n or "fddt" in n or n.endswith("conv1.weight")
+                                   or "layers.0.self_attn.q_proj" in n):
+            arrs["g." + n] = p.grad
+    save("f8_e2e_se", **arrs)
+
+
+# ----------------------------------------------------------------------------- F5: full-length (T=1500) encoder
+def f5_encoder_fulllen():
+    cfg = small_cfg(max_source_positions=1500, encoder_layers=1, decoder_layers=1, vocab_size=64,
+                    pad_token_id=60, bos_token_id=60, eos_token_id=60, decoder_start_token_id=61)
+    torch.manual_seed(2)
+    model = DiCoWForConditionalGeneration(cfg).eval()
+    randomize_(model, 5)
+    with torch.no_grad():      # Whisper's sinusoidal table (HF modeling_whisper.sinusoids); not stored in the fixture
+        model.model.encoder.embed_positions.weight.copy_(mw.sinusoids(1500, cfg.d_model))
+    g = torch.Generator().manual_seed(50)
+    x = torch.randn(1, 80, 3000, generator=g).clamp(-1.5, 1.5).half().float()    # stored as fp16
+    st = soft_stno(1, 1500, 51).half().float()
+    enc = model.model.encoder(x, stno_mask=st).last_hidden_state
+    arrs = {"cfg": np.array(repr(cfg_dict(cfg))), "x": x.half(), "stno": st.half(),
+            "enc_head": enc[:, :48], "enc_tail": enc[:, -48:], "enc_mean": enc.mean(dim=-1)}
+    for n, p in model.state_dict().items():
+        if n.startswith("model.encoder.") and "embed_positions" not in n:
+            arrs["p." + n] = p
+    save("f5_encoder_T1500", **arrs)
+
+
+# ----------------------------------------------------------------------------- F6: SCB block alone
+def f6_scb():
+    cfg = small_cfg(use_enrollments=True, scb_layers=1)
+    torch.manual_seed(3)
+    blk = SpeakerCommunicationBlock(cfg)
+    randomize_(blk, 6)
+    g = torch.Generator().manual_seed(60)
+    x = torch.randn(4, 100, 128, generator=g, requires_grad=True)
+    go = torch.randn(4, 100, 128, generator=g)
+    out = blk(x)
+    out.backward(go)
+    arrs = {"x": x, "gout": go, "out": out, "gx": x.grad}
+    for n, p in blk.named_parameters():
+        arrs["p." + n], arrs["g." + n] = p.detach().clone(), p.grad.clone()
+    # gate = 0 must be an exact identity on the mixture rows
+    with torch.no_grad():
+        blk.cae.cross_gate.gate.zero_()
+    arrs["out_gate0"] = blk(x.detach())
+    save("f6_scb", **arrs)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8"]
+    fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
+           "f8": f8_se}
+    for w in which:
+        fns[w]()
