@@ -1,0 +1,183 @@
+/*
+ * libdicow_hip.so -- C ABI of the MI355X-native (gfx950 / CDNA4) DiCoW / SE-DiCoW training-step hot path.
+ *
+ * The reference (BUTSpeechFIT/TS-ASR-Whisper) has NO native/FFI layer: its seam is the Python module surface
+ * (SURVEY.md section 8b).  This header is therefore build-defined; every entry point cites the reference
+ * arithmetic (file:line under /root/reference, or HF: = transformers' modeling_whisper.py that the reference
+ * subclasses) that it replaces.  The Python host side (the .py files under ts-asr-whisper_amd/) binds these with ctypes and
+ * keeps the reference's module names, constructor/forward signatures and state-dict keys.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller (PyTorch's caching
+ *     allocator in practice).  The library never allocates, frees or retains device memory.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it; entry points are re-entrant and
+ *     may be called from any host thread (autograd runs backward on its own thread).
+ *   - return 0 on success, negative DICOW_ERR_* otherwise; dicow_last_error() gives a thread-local message.
+ *   - bf16 tensors are passed as void* (raw 16-bit storage), row-major, rows 16-byte aligned.
+ *   - "rows" = B*T flattened (batch-major); the fp32 residual stream is [rows, D].
+ *   - STNO masks are fp32 [B,4,T] with channel order 0=silence 1=target 2=non-target 3=overlap
+ *     (src/data/local_datasets.py:184-194); `stno_bstride` is the element stride between batch rows so that
+ *     interleaved SE-DiCoW batches (encoder.py:152-154, 210-213) need no copy.
+ */
+#ifndef DICOW_HIP_H
+#define DICOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DICOW_OK 0
+#define DICOW_ERR_INVALID (-1)  /* bad argument / unsupported shape */
+#define DICOW_ERR_LAUNCH (-2)   /* HIP launch failure */
+
+#define DICOW_ABI_VERSION 1
+
+int dicow_abi_version(void);
+const char* dicow_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------ casts
+ * AMP weight preparation (configs/base.yaml:49 `bf16: true`): fp32 master -> bf16 compute copies.      */
+int dicow_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* [R,C] fp32 -> bf16 [R,C] (dst, may be NULL) and bf16 [C,R] (dst_t, may be NULL): the transposed copy is the
+ * dgrad operand of every Linear. */
+int dicow_cast_transpose_f32_to_bf16(const float* src, void* dst, void* dst_t, int R, int C, void* stream);
+/* Conv1d weight [O,C,3] fp32 -> bf16 [O,Kpad], k = tap*C + c (tap-major), zero padded to Kpad >= 3C:
+ * the GEMM view of conv1/conv2 (encoder.py:167-168). */
+int dicow_conv_weight_pack(const float* w, void* dst, int O, int C, int Kpad, void* stream);
+/* inverse mapping for the weight gradient: [O,Kpad] fp32 (tap-major) accumulated into [O,C,3] fp32 */
+int dicow_conv_weight_unpack_grad(const float* g_packed, float* g_w, int O, int C, int Kpad, void* stream);
+/* input_features [B,M,Tin] fp32 -> time-major bf16 [B, Tin+2, M], rows 0 and Tin+1 zero (conv padding=1). */
+int dicow_mel_to_timemajor(const float* mel, void* dst, int B, int M, int Tin, void* stream);
+/* column sums of a bf16 [rows, N] matrix accumulated (+=) into fp32 out[N] (bias gradients). */
+int dicow_colsum_bf16(const void* x, int64_t ld, float* out, int rows, int N, void* stream);
+/* out[t,:] += sum_b g[b,t,:]   (gradient of encoder.embed_positions, encoder.py:177-179) */
+int dicow_sum_over_batch(const float* g, float* out, int B, int64_t TD, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ FDDT + LayerNorm
+ * Fused row kernel.  Replaces FDDT.forward (src/models/dicow/FDDT.py:41-63) with CustomDiagonalLinear
+ * (layers.py:73-77), the optional position-embedding add (encoder.py:177-179) and the LayerNorm that follows
+ * in WhisperEncoderLayer (HF:modeling_whisper.py:392,402).
+ *   mode 0: no FDDT (plain LayerNorm / copy)
+ *   mode 1: diagonal FDDT  h' = ((wS*h+bS)*mS + (wT*h+bT)*mT) + (wN*h+bN)*mN + (wO*h+bO)*mO   -- evaluated in
+ *           exactly this order with separate fp32 mul/add (no FMA contraction) => bit-exact vs the fp32 reference;
+ *           a NULL w[c] means the class is disabled (identity branch, FDDT.py:55-62)
+ *   mode 2: bias-only FDDT h' = h + mS*bS + mT*bT + mN*bN + mO*bO (FDDT.py:43-51), NULL b[c] = disabled
+ * Class order in w[]/b[] is S,T,N,O (the stno channel order).                                             */
+typedef struct {
+    const void* h_in;        /* [rows,D] fp32, or bf16 when in_bf16 != 0 */
+    int in_bf16;
+    int mode;
+    const float* stno;       /* [B,4,T] fp32 (mode != 0) */
+    int64_t stno_bstride;    /* elements between consecutive batch entries (4*T when dense) */
+    const float* w[4];
+    const float* b[4];
+    const float* pos;        /* [T,D] fp32 added after the FDDT, or NULL */
+    float* h_out;            /* [rows,D] fp32 post-FDDT(+pos) residual stream, or NULL */
+    const float* ln_w;       /* LayerNorm affine; NULL => no LayerNorm (h_out only) */
+    const float* ln_b;
+    void* y_bf16;            /* [rows,D] bf16 LayerNorm output, or NULL */
+    float* y_f32;            /* [rows,D] fp32 LayerNorm output, or NULL */
+    float* mean;             /* [rows] saved statistics (may be NULL) */
+    float* rstd;
+    int rows, T, D;
+    float eps;
+} dicow_fddt_ln_fwd_args;
+int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream);
+
+/* Backward of the same fused row op (+ residual-gradient add):
+ *   g   = g_res + LayerNormBackward(d_y; x, mean, rstd, ln_w)          (x = FDDT(h_in)+pos, recomputed)
+ *   g0  = FDDTBackward(g)  (diag: g * sum_c m_c w_c ; bias-only / mode 0: g)
+ * and the column reductions  dln_w += sum_r d_y*xhat, dln_b += sum_r d_y,
+ *   dw[c] += sum_r m_c*h_in*g, db[c] += sum_r m_c*g, colsum_out += sum_r g0  (bias grad of the producing Linear).
+ * All parameter-gradient outputs are fp32 and ACCUMULATED with atomics (NULL = not needed).             */
+typedef struct {
+    const void* h_in; int in_bf16; int mode;
+    const float* stno; int64_t stno_bstride;
+    const float* w[4]; const float* b[4];
+    const float* pos;
+    const float* ln_w;       /* NULL => no LayerNorm in this op (g = g_res) */
+    const float* mean; const float* rstd;
+    const void* d_y;         /* [rows,D] bf16 grad wrt LayerNorm output (or fp32 when dy_f32 != 0) */
+    int dy_f32;
+    const float* g_res;      /* [rows,D] fp32 residual-path gradient, or NULL */
+    float* g_out;            /* [rows,D] fp32 g0, or NULL */
+    void* g_out_bf16;        /* [rows,D] bf16 copy of g0 (dgrad/wgrad GEMM operand), or NULL */
+    float* dln_w; float* dln_b;
+    float* dw[4]; float* db[4];
+    float* colsum_out;
+    float* dpos_rows;        /* unused, reserved */
+    int rows, T, D;
+} dicow_fddt_ln_bwd_args;
+int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream);
+
+/* Full (D x D) FDDT combine: y4 = h @ [W_S;W_T;W_N;W_O]^T (bf16 [rows,4D], from dicow_gemm_nt with bias) ->
+ * h' = sum_c m_c * y4[:, cD:(c+1)D]; disabled classes pass y4 block = h via use_mask.  (FDDT.py:13-16, 53-62) */
+int dicow_fddt_full_combine_fwd(const void* y4, const void* h_in, int in_bf16, const float* stno, int64_t stno_bstride,
+                                int use_mask, float* h_out, int rows, int T, int D, void* stream);
+/* backward: d_y4[:, cD:(c+1)D] = m_c * g (bf16), dh_direct = g * sum_{c disabled} m_c (fp32) */
+int dicow_fddt_full_combine_bwd(const float* g, const float* stno, int64_t stno_bstride, int use_mask,
+                                void* d_y4, float* dh_direct, int rows, int T, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ GEMM (MFMA bf16)
+ * C[M,N] = epilogue( A[M,K] . B[N,K]^T ): every Linear / conv-as-GEMM forward and dgrad on the path
+ * (HF:modeling_whisper.py:279-282,309,332-333,354,403-405; encoder.py:167-168; modeling_dicow.py:302).
+ * fp32 accumulation on v_mfma_f32_32x32x16_bf16, 128x128x64 LDS tiles.
+ * Requirements: K % 64 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, N % 4 == 0; M, N tails handled.          */
+#define DICOW_EPI_BIAS      1    /* + bias[n] */
+#define DICOW_EPI_GELU      2    /* exact-erf GELU; pre-activation stored to aux (bf16) when aux != NULL */
+#define DICOW_EPI_RESIDUAL  4    /* + residual[m,n] (fp32, ld = ldr) */
+#define DICOW_EPI_OUT_F32   8    /* C is fp32 (else bf16) */
+#define DICOW_EPI_SCALE_N  16    /* columns n < scale_ncols multiplied by scale AFTER bias (q * head_dim^-0.5) */
+#define DICOW_EPI_GELU_BWD 32    /* C = acc * gelu'(aux[m,n])  (aux = saved pre-activation, bf16) */
+#define DICOW_EPI_ACCUM    64    /* C += result (fp32 C only) */
+typedef struct {
+    const void* A; const void* B; void* C;
+    const float* bias; const float* residual; void* aux;
+    int M, N, K;
+    int64_t lda, ldb, ldc, ldr, ldaux;
+    int batch; int64_t strideA, strideB, strideC;   /* grid.z batches (conv stem: per-utterance strided views) */
+    int flags; float scale; int scale_ncols;
+} dicow_gemm_args;
+int dicow_gemm_nt(const dicow_gemm_args* a, void* stream);
+
+/* C[N1,N2] (+)= sum_m A[m,N1] * B[m,N2]  (fp32 C): every weight gradient dW = dY^T X.  Split over m
+ * across grid.z with fp32 atomics.  Requirements: N1 % 8 == 0, N2 % 8 == 0, lda/ldb % 8 == 0.          */
+typedef struct {
+    const void* A; const void* B; float* C;
+    int Mk, N1, N2;
+    int64_t lda, ldb, ldc;
+    int batch; int64_t strideA, strideB;            /* extra contraction batches (conv views) */
+    int accumulate;                                 /* 0: C must be pre-zeroed by the caller as well (atomics) */
+} dicow_gemm_tn_args;
+int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ attention
+ * Flash-style softmax(Q K^T) V with head_dim 64, scaling 1.0 (q is pre-scaled by the projection epilogue,
+ * HF:modeling_whisper.py:309,337-351).  Dense (encoder 1500x1500, SE enrollment cross-attention
+ * layers.py:152-157), causal (decoder self-attention) and rectangular (decoder cross-attention) shapes.
+ * q/k/v/o are bf16 with explicit strides (elements): element (b, t, h, d) at  base + b*bs + t*rs + h*64 + d. */
+typedef struct {
+    const void* q; const void* k; const void* v; void* o;
+    float* lse;                                     /* [B,H,Lq] natural-log-sum-exp, saved for backward */
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
+    int B, H, Lq, Lk; int causal;
+} dicow_attn_fwd_args;
+int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream);
+
+typedef struct {
+    const void* q; const void* k; const void* v; const void* o; const void* d_o;
+    const float* lse; float* delta;                 /* delta [B,H,Lq] workspace = rowsum(dO*O) */
+    void* dq; void* dk; void* dv;                   /* bf16, same addressing as q/k/v */
+    int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs;
+    int64_t dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
+    int B, H, Lq, Lk; int causal;
+    float dq_scale;                                 /* head_dim^-0.5 folded into dq (gradient of the pre-scale) */
+} dicow_attn_bwd_args;
+int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DICOW_HIP_H */

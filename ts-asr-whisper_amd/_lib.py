@@ -1,0 +1,123 @@
+"""ctypes binding of libdicow_hip.so (include/dicow_hip.h).  Plain pointers and sizes only."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdicow_hip.so")
+_lib = None
+
+c_vp, c_i, c_i64, c_f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class FddtLnFwdArgs(C.Structure):
+    _fields_ = [("h_in", c_vp), ("in_bf16", c_i), ("mode", c_i), ("stno", c_vp), ("stno_bstride", c_i64),
+                ("w", c_vp * 4), ("b", c_vp * 4), ("pos", c_vp), ("h_out", c_vp), ("ln_w", c_vp), ("ln_b", c_vp),
+                ("y_bf16", c_vp), ("y_f32", c_vp), ("mean", c_vp), ("rstd", c_vp),
+                ("rows", c_i), ("T", c_i), ("D", c_i), ("eps", c_f)]
+
+
+class FddtLnBwdArgs(C.Structure):
+    _fields_ = [("h_in", c_vp), ("in_bf16", c_i), ("mode", c_i), ("stno", c_vp), ("stno_bstride", c_i64),
+                ("w", c_vp * 4), ("b", c_vp * 4), ("pos", c_vp), ("ln_w", c_vp), ("mean", c_vp), ("rstd", c_vp),
+                ("d_y", c_vp), ("dy_f32", c_i), ("g_res", c_vp), ("g_out", c_vp), ("g_out_bf16", c_vp),
+                ("dln_w", c_vp), ("dln_b", c_vp), ("dw", c_vp * 4), ("db", c_vp * 4), ("colsum_out", c_vp),
+                ("dpos_rows", c_vp), ("rows", c_i), ("T", c_i), ("D", c_i)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("bias", c_vp), ("residual", c_vp), ("aux", c_vp),
+                ("M", c_i), ("N", c_i), ("K", c_i),
+                ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("ldr", c_i64), ("ldaux", c_i64),
+                ("batch", c_i), ("strideA", c_i64), ("strideB", c_i64), ("strideC", c_i64),
+                ("flags", c_i), ("scale", c_f), ("scale_ncols", c_i)]
+
+
+class GemmTnArgs(C.Structure):
+    _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("Mk", c_i), ("N1", c_i), ("N2", c_i),
+                ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64),
+                ("batch", c_i), ("strideA", c_i64), ("strideB", c_i64), ("accumulate", c_i)]
+
+
+class AttnFwdArgs(C.Structure):
+    _fields_ = [("q", c_vp), ("k", c_vp), ("v", c_vp), ("o", c_vp), ("lse", c_vp),
+                ("q_bs", c_i64), ("q_rs", c_i64), ("k_bs", c_i64), ("k_rs", c_i64),
+                ("v_bs", c_i64), ("v_rs", c_i64), ("o_bs", c_i64), ("o_rs", c_i64),
+                ("B", c_i), ("H", c_i), ("Lq", c_i), ("Lk", c_i), ("causal", c_i)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("q", c_vp), ("k", c_vp), ("v", c_vp), ("o", c_vp), ("d_o", c_vp), ("lse", c_vp), ("delta", c_vp),
+                ("dq", c_vp), ("dk", c_vp), ("dv", c_vp),
+                ("q_bs", c_i64), ("q_rs", c_i64), ("k_bs", c_i64), ("k_rs", c_i64), ("v_bs", c_i64), ("v_rs", c_i64),
+                ("o_bs", c_i64), ("o_rs", c_i64), ("do_bs", c_i64), ("do_rs", c_i64),
+                ("dq_bs", c_i64), ("dq_rs", c_i64), ("dk_bs", c_i64), ("dk_rs", c_i64), ("dv_bs", c_i64), ("dv_rs", c_i64),
+                ("B", c_i), ("H", c_i), ("Lq", c_i), ("Lk", c_i), ("causal", c_i), ("dq_scale", c_f)]
+
+
+EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_SCALE_N, EPI_GELU_BWD, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
+
+# name -> argtypes ; every function returns int
+_SIGS = {
+    "dicow_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
+    "dicow_cast_transpose_f32_to_bf16": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
+    "dicow_conv_weight_pack": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "dicow_conv_weight_unpack_grad": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "dicow_mel_to_timemajor": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "dicow_colsum_bf16": [c_vp, c_i64, c_vp, c_i, c_i, c_vp],
+    "dicow_sum_over_batch": [c_vp, c_vp, c_i, c_i64, c_vp],
+    "dicow_fddt_ln_fwd": [C.POINTER(FddtLnFwdArgs), c_vp],
+    "dicow_fddt_ln_bwd": [C.POINTER(FddtLnBwdArgs), c_vp],
+    "dicow_fddt_full_combine_fwd": [c_vp, c_vp, c_i, c_vp, c_i64, c_i, c_vp, c_i, c_i, c_i, c_vp],
+    "dicow_fddt_full_combine_bwd": [c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "dicow_gemm_nt": [C.POINTER(GemmArgs), c_vp],
+    "dicow_gemm_tn": [C.POINTER(GemmTnArgs), c_vp],
+    "dicow_attn_fwd": [C.POINTER(AttnFwdArgs), c_vp],
+}
+
+
+class DicowError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load the HIP library; fail loudly (no fallback) if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DicowError(f"{LIB_PATH} is missing: build it with ts-asr-whisper_amd/csrc/build.sh "
+                             "(or __graft_entry__.build()); there is no CPU fallback")
+        l = C.CDLL(LIB_PATH)
+        l.dicow_abi_version.restype = c_i
+        l.dicow_last_error.restype = C.c_char_p
+        for name, at in _SIGS.items():
+            fn = getattr(l, name)
+            fn.argtypes = at
+            fn.restype = c_i
+        _lib = l
+    return _lib
+
+
+def declared_symbols():
+    return ["dicow_abi_version", "dicow_last_error"] + list(_SIGS)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DicowError(f"{what} failed ({rc}): {lib().dicow_last_error().decode()}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args), name)
+
+
+def call_struct(name, st):
+    check(getattr(lib(), name)(C.byref(st), stream()), name)

@@ -1,0 +1,244 @@
+// Flash-style attention for head_dim 64 on gfx950: forward and backward, dense / causal / rectangular.
+//
+// Replaces the SDPA / flash-attn call the reference reaches through HF WhisperAttention
+// (HF:modeling_whisper.py:337-351; encoder self-attention encoder.py:216-221, SE-DiCoW enrollment cross-attention
+// layers.py:152-157, decoder self/cross attention HF:469-494).  q arrives pre-scaled (HF:309), scaling = 1.
+//
+// Forward structure (one workgroup = 4 waves = 128 query rows of one (batch, head); wave = 32 query rows):
+//   S^T[key][q] = K . Q^T      "swapped" MFMA (a = K rows from LDS, b = Q rows held in registers) so that a lane
+//                              owns ONE query column: row max / sum / rescale are lane-local (+1 half-wave exchange)
+//   P^T -> bf16 in registers   the accumulator layout of S^T *is* a valid B-operand layout for the next MFMA as
+//                              long as the A operand uses the same k-slot permutation
+//                              key(x, half, e) = 16x + 8(e>>2) + 4 half + (e&3)   -- no cross-lane traffic at all
+//   O^T[d][q] += V^T . P^T     A operand = V^T fragments fetched with ds_read_b64_tr_b16 (transposing LDS read)
+//                              from the row-major [key][d] V tile
+// K/V tiles (64 keys) stream through a 2-stage LDS ring filled by global_load_lds DMA (16 B/lane), swizzled on
+// the source address (K: ds_read_b128 conflict-free; V: tr-read conflict-free).
+#include "common.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)lds_dst, 16, 0, 0);
+}
+
+#define HD 64
+#define KV_TILE 64
+#define TILE_BYTES (KV_TILE * HD * 2)        // 8 KiB
+#define LOG2E 1.4426950408889634f
+#define LN2 0.6931471805599453f
+
+// K-style image ([rows][64] bf16, 128-B rows): chunk c of row r at c ^ ((r>>1)&7)   (ds_read_b128 fragments)
+__device__ __forceinline__ int kswz(int row, int c) { return row * 128 + ((c ^ ((row >> 1) & 7)) << 4); }
+// V-style image: chunk c of row r at c ^ (((r>>1)&1)<<2)                              (ds_read_b64_tr_b16 fragments)
+__device__ __forceinline__ int vswz(int row, int c) { return row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4); }
+
+// one wave-instruction moves 8 rows x 128 B; a 64-row tile needs 8 of them -> 2 per wave
+template <bool VSTYLE>
+__device__ __forceinline__ void stage_tile64(const unsigned short* __restrict__ base, int64_t rs, int row0, int nrows,
+                                             char* lds, int wave, int lane) {
+    const int rr = lane >> 3, p = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + rr;
+        const int c = VSTYLE ? (p ^ (((row >> 1) & 1) << 2)) : (p ^ ((row >> 1) & 7));
+        int g = row0 + row; g = g < nrows ? g : nrows - 1;
+        glds16(base + (int64_t)g * rs + c * 8, lds + (wave * 2 + i) * 1024);
+    }
+}
+
+// 8 transposing reads (one 32-key block x 64 d) + wait, as ONE asm statement (see gemm.hip for the rationale).
+// a0/a1 = lane base addresses for d-block 0/1; OFF selects the 32-key block inside the tile.
+template <int OFF>
+__device__ __forceinline__ void tr_read_block(bf16x8_t (&f)[2][2], unsigned a0, unsigned a1) {
+    bf16x4_t r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %2, %9 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %5, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %6, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %7, %9 offset:%13\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(a0), "v"(a1), "i"(OFF), "i"(OFF + 1024), "i"(OFF + 2048), "i"(OFF + 3072)
+        : "memory");
+    // f[x][dblk]
+    f[0][0] = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[0][1] = __builtin_shufflevector(r2, r3, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[1][0] = __builtin_shufflevector(r4, r5, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[1][1] = __builtin_shufflevector(r6, r7, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+// lane base address (bytes, LDS) of the transposing read for d-block `dblk` of a V-style tile at `s`
+__device__ __forceinline__ unsigned tr_base(const char* s, int lane, int dblk) {
+    const int G = lane >> 4, u = lane & 15, hh = G >> 1;
+    const int row = 4 * hh + (u >> 2);
+    const int c = (dblk * 4 + 2 * (G & 1) + ((u & 3) >> 1)) ^ (((u >> 3) & 1) << 2);
+    return (unsigned)(uintptr_t)(s + row * 128 + (c << 4) + ((u & 1) << 3));
+}
+
+__device__ __forceinline__ bf16x8_t pack8(const f32x16_t& s, int r0) {
+    bf16x8_t o;
+    unsigned* ou = reinterpret_cast<unsigned*>(&o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ou[e] = pack_bf16x2(s[r0 + 2 * e], s[r0 + 2 * e + 1]);
+    return o;
+}
+
+__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_args a) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];      // K0 V0 K1 V1
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128;
+    const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
+    const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
+    const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
+
+    // Q fragments (b-operand): column q = lane&31, k-slots d = 16kk + 8hh + e
+    int qrow = q0 + wave * 32 + (lane & 31);
+    const int qrow_c = qrow < a.Lq ? qrow : a.Lq - 1;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        qf[kk] = *reinterpret_cast<const bf16x8_t*>(Q + (int64_t)qrow_c * a.q_rs + kk * 16 + hh * 8);
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int kv_end = a.Lk;
+    if (a.causal) { const int lim = q0 + 128 < a.Lk ? q0 + 128 : a.Lk; kv_end = lim; }   // keys <= last q row of the block
+    const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
+
+    stage_tile64<false>(K, a.k_rs, 0, a.Lk, smem, wave, lane);
+    stage_tile64<true>(V, a.v_rs, 0, a.Lk, smem + TILE_BYTES, wave, lane);
+    for (int t = 0; t < nt; ++t) {
+        char* sK = smem + (t & 1) * 2 * TILE_BYTES;
+        char* sV = sK + TILE_BYTES;
+        if (t + 1 < nt) {
+            char* nK = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+            stage_tile64<false>(K, a.k_rs, (t + 1) * KV_TILE, a.Lk, nK, wave, lane);
+            stage_tile64<true>(V, a.v_rs, (t + 1) * KV_TILE, a.Lk, nK + TILE_BYTES, wave, lane);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        // ---- S^T = K . Q^T  (two 32-key blocks)
+        f32x16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
+            }
+        }
+        // ---- mask (tile-uniform test first), online softmax in log2 units
+        const int k0 = t * KV_TILE;
+        const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[kb][r] * LOG2E;
+                if (need_mask) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= a.Lk || (a.causal && key > qrow)) v = -INFINITY;
+                }
+                s[kb][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;      // fully masked so far: keep everything at 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_use);
+                s[kb][r] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+
+        // ---- O^T += V^T . P^T
+        const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
+        {
+            bf16x8_t vf[2][2];
+            tr_read_block<0>(vf, va0, va1);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const bf16x8_t pf = pack8(s[0], 8 * x);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+            }
+            tr_read_block<4096>(vf, va0, va1);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const bf16x8_t pf = pack8(s[1], 8 * x);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- epilogue
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qrow < a.Lq) {
+        unsigned short* O = reinterpret_cast<unsigned short*>(a.o) + (int64_t)b * a.o_bs + (int64_t)qrow * a.o_rs + h * HD;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int col = d * 32 + 8 * q4 + 4 * hh;
+                *reinterpret_cast<uint2*>(O + col) =
+                    make_uint2(pack_bf16x2(o[d][4 * q4] * inv_l, o[d][4 * q4 + 1] * inv_l),
+                               pack_bf16x2(o[d][4 * q4 + 2] * inv_l, o[d][4 * q4 + 3] * inv_l));
+            }
+        if (a.lse && hh == 0)
+            a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
+    }
+}
+
+static int check_strides(int64_t rs, const char* n) {
+    if (rs % 8 != 0) { dicow_set_error("attention: %s row stride must be a multiple of 8 elements", n); return 0; }
+    return 1;
+}
+
+extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
+    DICOW_REQUIRE(a && a->q && a->k && a->v && a->o, "attn_fwd: null operand");
+    DICOW_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0, "attn_fwd: empty problem");
+    DICOW_REQUIRE(a->H <= 65535 && a->B <= 65535, "attn_fwd: B/H too large for the grid");
+    if (!check_strides(a->q_rs, "q") || !check_strides(a->k_rs, "k") || !check_strides(a->v_rs, "v") ||
+        !check_strides(a->o_rs, "o")) return DICOW_ERR_INVALID;
+    DICOW_REQUIRE(a->q_bs % 8 == 0 && a->k_bs % 8 == 0 && a->v_bs % 8 == 0 && a->o_bs % 4 == 0, "attn_fwd: batch strides must keep 16-byte alignment");
+    dim3 grid(dicow_cdiv(a->Lq, 128), a->H, a->B);
+    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    DICOW_CHECK_LAUNCH("attn_fwd");
+    return DICOW_OK;
+}

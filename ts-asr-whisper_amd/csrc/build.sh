@@ -1,0 +1,20 @@
+#!/bin/bash
+# Build libdicow_hip.so for gfx950 in-tree (cross-compiles without a GPU).  Usage: build.sh [extra hipcc flags]
+set -e
+cd "$(dirname "$0")"
+OUT=../libdicow_hip.so
+SRCS=$(ls *.hip)
+mkdir -p build
+OBJS=""
+pids=""
+for s in $SRCS; do
+  o=build/${s%.hip}.o
+  OBJS="$OBJS $o"
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/dicow_hip.h -nt "$o" ]; then
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" "$@" &
+    pids="$pids $!"
+  fi
+done
+for p in $pids; do wait $p; done
+hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
+echo "built $(realpath $OUT)"

@@ -1,0 +1,400 @@
+// Fused FDDT (+pos-emb) + LayerNorm row kernels, forward and backward.  HBM-bound.
+//
+// Replaces (reference, /root/reference): src/models/dicow/FDDT.py:41-63, src/models/dicow/layers.py:73-77,
+// encoder.py:173-180,205-206 and the LayerNorm calls of HF WhisperEncoderLayer/DecoderLayer.
+//
+// Work decomposition ("column owner"): a block has D/4 threads (rounded up to a wave); thread `tid` owns the
+// four columns [4*tid, 4*tid+4) for EVERY row the block visits, so the 8 FDDT vectors + LayerNorm affine live
+// in registers (loaded once) and the parameter-gradient column sums accumulate in registers across rows.
+// Rows are visited R at a time (R independent 16-byte loads in flight per thread); row statistics use one
+// wave-shuffle + LDS reduction per R rows.  Algorithmic HBM bytes per row: fwd  D*(4 in + 4 out + 2 ln-out),
+// bwd  D*(4 h_in + 2 d_y + 4 g_res + 4 g_out + 2 g_out_bf16).
+#include "common.h"
+
+#define MAX_WAVES 16
+
+struct f4 { float x, y, z, w; };
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 ld4_bf16(const void* base, int64_t idx) {
+    uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4_bf16(void* base, int64_t idx, float4 v) {
+    uint2 u = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + idx) = u;
+}
+
+// Reference evaluation order, separate fp32 multiplies/adds (bit-exact vs the fp32 reference).
+__device__ __forceinline__ float fddt_diag_elem(float h, float w0, float b0, float w1, float b1, float w2, float b2,
+                                                float w3, float b3, float m0, float m1, float m2, float m3) {
+#pragma clang fp contract(off)
+    float t0 = (h * w0 + b0) * m0;
+    float t1 = (h * w1 + b1) * m1;
+    float t2 = (h * w2 + b2) * m2;
+    float t3 = (h * w3 + b3) * m3;
+    return ((t0 + t1) + t2) + t3;
+}
+__device__ __forceinline__ float fddt_bias_elem(float h, float b0, float b1, float b2, float b3, float m0, float m1,
+                                                float m2, float m3, int use) {
+#pragma clang fp contract(off)
+    if (use & 1) h = h + m0 * b0;
+    if (use & 2) h = h + m1 * b1;
+    if (use & 4) h = h + m2 * b2;
+    if (use & 8) h = h + m3 * b3;
+    return h;
+}
+
+#define F4_APPLY(dst, expr) do { dst.x = expr(x); dst.y = expr(y); dst.z = expr(z); dst.w = expr(w); } while (0)
+
+// block-wide sum of NV values per thread; result broadcast to all threads.  `red` is [MAX_WAVES][NV].
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float* red, int nwaves) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    if (nwaves == 1) return;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) red[wv * NV + i] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = 0.f;
+        for (int w = 0; w < nwaves; ++w) s += red[w * NV + i];
+        v[i] = s;
+    }
+}
+
+template <int R>
+__global__ void __launch_bounds__(1024) fddt_ln_fwd_kernel(const dicow_fddt_ln_fwd_args a) {
+    __shared__ float red[2][MAX_WAVES * R];
+    const int tid = threadIdx.x, col = tid * 4, D = a.D;
+    const bool act = col < D;
+    const int nwaves = blockDim.x >> 6;
+    const float4 one = make_float4(1, 1, 1, 1), zero = make_float4(0, 0, 0, 0);
+    float4 w[4], b[4], lnw = one, lnb = zero;
+    int use = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        w[c] = (a.mode == 1 && a.w[c] && act) ? ld4(a.w[c] + col) : one;
+        b[c] = (a.mode != 0 && a.b[c] && act) ? ld4(a.b[c] + col) : zero;
+        if (a.b[c]) use |= 1 << c;
+    }
+    const bool do_ln = a.ln_w != nullptr;
+    if (do_ln && act) { lnw = ld4(a.ln_w + col); lnb = ld4(a.ln_b + col); }
+    const float inv_d = 1.0f / (float)D;
+
+    for (int row0 = blockIdx.x * R; row0 < a.rows; row0 += gridDim.x * R) {
+        float4 x[R];
+        float m[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            const bool ok = act && row < a.rows;
+            const int64_t off = (int64_t)row * D + col;
+            x[r] = zero;
+            if (ok) x[r] = a.in_bf16 ? ld4_bf16(a.h_in, off) : ld4(reinterpret_cast<const float*>(a.h_in) + off);
+            if (a.mode != 0 && row < a.rows) {
+                const int bi = row / a.T, t = row - bi * a.T;
+                const float* mp = a.stno + (int64_t)bi * a.stno_bstride + t;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m[r][c] = mp[(int64_t)c * a.T];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m[r][c] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            if (a.mode == 1) {
+#define FD(e) fddt_diag_elem(x[r].e, w[0].e, b[0].e, w[1].e, b[1].e, w[2].e, b[2].e, w[3].e, b[3].e, m[r][0], m[r][1], m[r][2], m[r][3])
+                F4_APPLY(x[r], FD);
+#undef FD
+            } else if (a.mode == 2) {
+#define FB(e) fddt_bias_elem(x[r].e, b[0].e, b[1].e, b[2].e, b[3].e, m[r][0], m[r][1], m[r][2], m[r][3], use)
+                F4_APPLY(x[r], FB);
+#undef FB
+            }
+            if (a.pos && act && row < a.rows) {
+                const int t = row % a.T;
+                const float4 p = ld4(a.pos + (int64_t)t * D + col);
+                x[r].x += p.x; x[r].y += p.y; x[r].z += p.z; x[r].w += p.w;
+            }
+            if (a.h_out && act && row < a.rows) st4(a.h_out + (int64_t)row * D + col, x[r]);
+        }
+        if (!do_ln) continue;
+        float s[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) s[r] = act ? (x[r].x + x[r].y) + (x[r].z + x[r].w) : 0.f;
+        block_sum<R>(s, red[0], nwaves);
+        float mu[R], q[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            mu[r] = s[r] * inv_d;
+            const float dx = x[r].x - mu[r], dy = x[r].y - mu[r], dz = x[r].z - mu[r], dw = x[r].w - mu[r];
+            q[r] = act ? (dx * dx + dy * dy) + (dz * dz + dw * dw) : 0.f;
+        }
+        block_sum<R>(q, red[1], nwaves);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            if (row >= a.rows) continue;
+            const float rs = rsqrtf(q[r] * inv_d + a.eps);
+            if (tid == 0) {
+                if (a.mean) a.mean[row] = mu[r];
+                if (a.rstd) a.rstd[row] = rs;
+            }
+            if (!act) continue;
+            float4 y;
+            y.x = (x[r].x - mu[r]) * rs * lnw.x + lnb.x;
+            y.y = (x[r].y - mu[r]) * rs * lnw.y + lnb.y;
+            y.z = (x[r].z - mu[r]) * rs * lnw.z + lnb.z;
+            y.w = (x[r].w - mu[r]) * rs * lnw.w + lnb.w;
+            const int64_t off = (int64_t)row * D + col;
+            if (a.y_bf16) st4_bf16(a.y_bf16, off, y);
+            if (a.y_f32) st4(a.y_f32 + off, y);
+        }
+        // (the two __syncthreads inside block_sum order the LDS reuse across iterations)
+    }
+}
+
+static int pick_block(int D) {
+    int t = ((D / 4) + 63) / 64 * 64;
+    return t;
+}
+
+extern "C" int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream) {
+    DICOW_REQUIRE(a && a->h_in && a->rows > 0 && a->D > 0, "fddt_ln_fwd: null/empty input");
+    DICOW_REQUIRE(a->D % 4 == 0 && a->D <= 4096, "fddt_ln_fwd: D=%d must be a multiple of 4 and <= 4096", a->D);
+    DICOW_REQUIRE(a->mode >= 0 && a->mode <= 2, "fddt_ln_fwd: bad mode %d", a->mode);
+    DICOW_REQUIRE(a->mode == 0 || (a->stno && a->T > 0), "fddt_ln_fwd: mode %d needs stno and T", a->mode);
+    DICOW_REQUIRE(a->pos == nullptr || a->T > 0, "fddt_ln_fwd: pos needs T");
+    DICOW_REQUIRE((a->ln_w == nullptr) == (a->ln_b == nullptr), "fddt_ln_fwd: ln_w/ln_b must both be given");
+    DICOW_REQUIRE(a->ln_w || a->h_out, "fddt_ln_fwd: nothing to write");
+    const int R = 4;
+    const int block = pick_block(a->D);
+    int grid = dicow_cdiv(a->rows, R);
+    const int cap = 256 * (block <= 256 ? 8 : (block <= 512 ? 4 : 2));
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(fddt_ln_fwd_kernel<R>, dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+    DICOW_CHECK_LAUNCH("fddt_ln_fwd");
+    return DICOW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+__device__ __forceinline__ void atomic_add4(float* p, float4 v) {
+    atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+#define F4_FMA(acc, a_, b_) do { acc.x += (a_).x * (b_).x; acc.y += (a_).y * (b_).y; acc.z += (a_).z * (b_).z; acc.w += (a_).w * (b_).w; } while (0)
+#define F4_ADD(acc, a_) do { acc.x += (a_).x; acc.y += (a_).y; acc.z += (a_).z; acc.w += (a_).w; } while (0)
+
+template <int R>
+__global__ void __launch_bounds__(1024) fddt_ln_bwd_kernel(const dicow_fddt_ln_bwd_args a) {
+    __shared__ float red[2][MAX_WAVES * 2 * R];
+    const int tid = threadIdx.x, col = tid * 4, D = a.D;
+    const bool act = col < D;
+    const int nwaves = blockDim.x >> 6;
+    const float4 one = make_float4(1, 1, 1, 1), zero = make_float4(0, 0, 0, 0);
+    float4 w[4], b[4], lnw = one;
+    int use = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        w[c] = (a.mode == 1 && a.w[c] && act) ? ld4(a.w[c] + col) : one;
+        b[c] = (a.mode != 0 && a.b[c] && act) ? ld4(a.b[c] + col) : zero;
+        if (a.b[c]) use |= 1 << c;
+    }
+    const bool do_ln = a.ln_w != nullptr;
+    if (do_ln && act) lnw = ld4(a.ln_w + col);
+    const float inv_d = 1.0f / (float)D;
+    float4 acc_lnw = zero, acc_lnb = zero, acc_cs = zero, acc_dw[4], acc_db[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { acc_dw[c] = zero; acc_db[c] = zero; }
+
+    int it = 0;
+    for (int row0 = blockIdx.x * R; row0 < a.rows; row0 += gridDim.x * R, ++it) {
+        float4 hin[R], xh[R], dy[R];
+        float m[R][4], rs[R];
+        float sums[2 * R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            const bool ok = act && row < a.rows;
+            const int64_t off = (int64_t)row * D + col;
+            hin[r] = zero; dy[r] = zero; rs[r] = 0.f;
+            float mu = 0.f;
+            if (ok) hin[r] = a.in_bf16 ? ld4_bf16(a.h_in, off) : ld4(reinterpret_cast<const float*>(a.h_in) + off);
+            if (ok && do_ln) dy[r] = a.dy_f32 ? ld4(reinterpret_cast<const float*>(a.d_y) + off) : ld4_bf16(a.d_y, off);
+            if (do_ln && row < a.rows) { mu = a.mean[row]; rs[r] = a.rstd[row]; }
+            if (a.mode != 0 && row < a.rows) {
+                const int bi = row / a.T, t = row - bi * a.T;
+                const float* mp = a.stno + (int64_t)bi * a.stno_bstride + t;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m[r][c] = mp[(int64_t)c * a.T];
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) m[r][c] = 0.f;
+            }
+            // recompute x = FDDT(h_in) + pos exactly as the forward did
+            float4 x = hin[r];
+            if (a.mode == 1) {
+#define FD(e) fddt_diag_elem(x.e, w[0].e, b[0].e, w[1].e, b[1].e, w[2].e, b[2].e, w[3].e, b[3].e, m[r][0], m[r][1], m[r][2], m[r][3])
+                F4_APPLY(x, FD);
+#undef FD
+            } else if (a.mode == 2) {
+#define FB(e) fddt_bias_elem(x.e, b[0].e, b[1].e, b[2].e, b[3].e, m[r][0], m[r][1], m[r][2], m[r][3], use)
+                F4_APPLY(x, FB);
+#undef FB
+            }
+            if (a.pos && ok) {
+                const int t = row % a.T;
+                const float4 p = ld4(a.pos + (int64_t)t * D + col);
+                x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
+            }
+            xh[r].x = (x.x - mu) * rs[r]; xh[r].y = (x.y - mu) * rs[r];
+            xh[r].z = (x.z - mu) * rs[r]; xh[r].w = (x.w - mu) * rs[r];
+            // dxhat = dy * gamma
+            const float4 dxh = make_float4(dy[r].x * lnw.x, dy[r].y * lnw.y, dy[r].z * lnw.z, dy[r].w * lnw.w);
+            sums[2 * r] = ok ? (dxh.x + dxh.y) + (dxh.z + dxh.w) : 0.f;
+            sums[2 * r + 1] = ok ? (dxh.x * xh[r].x + dxh.y * xh[r].y) + (dxh.z * xh[r].z + dxh.w * xh[r].w) : 0.f;
+        }
+        if (do_ln) block_sum<2 * R>(sums, red[it & 1], nwaves);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            if (!(act && row < a.rows)) continue;
+            const int64_t off = (int64_t)row * D + col;
+            float4 g = a.g_res ? ld4(a.g_res + off) : zero;
+            if (do_ln) {
+                const float c1 = sums[2 * r] * inv_d, c2 = sums[2 * r + 1] * inv_d;
+                g.x += rs[r] * (dy[r].x * lnw.x - c1 - xh[r].x * c2);
+                g.y += rs[r] * (dy[r].y * lnw.y - c1 - xh[r].y * c2);
+                g.z += rs[r] * (dy[r].z * lnw.z - c1 - xh[r].z * c2);
+                g.w += rs[r] * (dy[r].w * lnw.w - c1 - xh[r].w * c2);
+                F4_FMA(acc_lnw, dy[r], xh[r]);
+                F4_ADD(acc_lnb, dy[r]);
+            }
+            float4 g0 = g;
+            if (a.mode == 1) {
+                float4 sc = zero;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float mc = m[r][c];
+                    sc.x += mc * w[c].x; sc.y += mc * w[c].y; sc.z += mc * w[c].z; sc.w += mc * w[c].w;
+                    const float4 mg = make_float4(mc * g.x, mc * g.y, mc * g.z, mc * g.w);
+                    F4_FMA(acc_dw[c], mg, hin[r]);
+                    F4_ADD(acc_db[c], mg);
+                }
+                g0 = make_float4(g.x * sc.x, g.y * sc.y, g.z * sc.z, g.w * sc.w);
+            } else if (a.mode == 2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float mc = m[r][c];
+                    const float4 mg = make_float4(mc * g.x, mc * g.y, mc * g.z, mc * g.w);
+                    F4_ADD(acc_db[c], mg);
+                }
+            }
+            F4_ADD(acc_cs, g0);
+            if (a.g_out) st4(a.g_out + off, g0);
+            if (a.g_out_bf16) st4_bf16(a.g_out_bf16, off, g0);
+        }
+    }
+    if (!act) return;
+    if (do_ln && a.dln_w) atomic_add4(a.dln_w + col, acc_lnw);
+    if (do_ln && a.dln_b) atomic_add4(a.dln_b + col, acc_lnb);
+    if (a.colsum_out) atomic_add4(a.colsum_out + col, acc_cs);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (a.mode == 1 && a.dw[c]) atomic_add4(a.dw[c] + col, acc_dw[c]);
+        if (a.mode != 0 && a.db[c]) atomic_add4(a.db[c] + col, acc_db[c]);
+    }
+}
+
+extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) {
+    DICOW_REQUIRE(a && a->h_in && a->rows > 0 && a->D > 0, "fddt_ln_bwd: null/empty input");
+    DICOW_REQUIRE(a->D % 4 == 0 && a->D <= 4096, "fddt_ln_bwd: D=%d must be a multiple of 4 and <= 4096", a->D);
+    DICOW_REQUIRE(a->mode >= 0 && a->mode <= 2, "fddt_ln_bwd: bad mode %d", a->mode);
+    DICOW_REQUIRE(a->mode == 0 || (a->stno && a->T > 0), "fddt_ln_bwd: mode %d needs stno and T", a->mode);
+    DICOW_REQUIRE(a->ln_w == nullptr || (a->mean && a->rstd && a->d_y), "fddt_ln_bwd: LayerNorm needs mean/rstd/d_y");
+    DICOW_REQUIRE(a->ln_w || a->g_res, "fddt_ln_bwd: no incoming gradient");
+    const int R = 4;
+    const int block = pick_block(a->D);
+    int grid = dicow_cdiv(a->rows, R);
+    const int cap = 256 * (block <= 256 ? 4 : 2);
+    if (grid > cap) grid = cap;
+    hipLaunchKernelGGL(fddt_ln_bwd_kernel<R>, dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+    DICOW_CHECK_LAUNCH("fddt_ln_bwd");
+    return DICOW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ full (DxD) FDDT combine
+__global__ void fddt_full_combine_fwd_kernel(const unsigned short* y4, const void* h_in, int in_bf16, const float* stno,
+                                             int64_t bstride, int use_mask, float* h_out, int rows, int T, int D) {
+    const int64_t n4 = (int64_t)rows * D / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i * 4;
+        const int row = (int)(e / D), col = (int)(e - (int64_t)row * D);
+        const int bi = row / T, t = row - bi * T;
+        const float* mp = stno + (int64_t)bi * bstride + t;
+        const float4 h = in_bf16 ? ld4_bf16(h_in, e) : ld4(reinterpret_cast<const float*>(h_in) + e);
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float mc = mp[(int64_t)c * T];
+            const float4 v = (use_mask >> c) & 1 ? ld4_bf16(y4, (int64_t)row * 4 * D + (int64_t)c * D + col) : h;
+            acc.x += v.x * mc; acc.y += v.y * mc; acc.z += v.z * mc; acc.w += v.w * mc;
+        }
+        st4(h_out + e, acc);
+    }
+}
+
+__global__ void fddt_full_combine_bwd_kernel(const float* g, const float* stno, int64_t bstride, int use_mask,
+                                             unsigned short* d_y4, float* dh_direct, int rows, int T, int D) {
+    const int64_t n4 = (int64_t)rows * D / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i * 4;
+        const int row = (int)(e / D), col = (int)(e - (int64_t)row * D);
+        const int bi = row / T, t = row - bi * T;
+        const float* mp = stno + (int64_t)bi * bstride + t;
+        const float4 gv = ld4(g + e);
+        float md = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float mc = mp[(int64_t)c * T];
+            if ((use_mask >> c) & 1) {
+                st4_bf16(d_y4, (int64_t)row * 4 * D + (int64_t)c * D + col,
+                         make_float4(gv.x * mc, gv.y * mc, gv.z * mc, gv.w * mc));
+            } else {
+                md += mc;
+            }
+        }
+        if (dh_direct) st4(dh_direct + e, make_float4(gv.x * md, gv.y * md, gv.z * md, gv.w * md));
+    }
+}
+
+extern "C" int dicow_fddt_full_combine_fwd(const void* y4, const void* h_in, int in_bf16, const float* stno,
+                                           int64_t stno_bstride, int use_mask, float* h_out, int rows, int T, int D,
+                                           void* stream) {
+    DICOW_REQUIRE(y4 && h_in && stno && h_out && rows > 0 && D % 4 == 0 && T > 0, "fddt_full_combine_fwd: bad args");
+    const int64_t n4 = (int64_t)rows * D / 4;
+    int grid = (int)((n4 + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(fddt_full_combine_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)y4, h_in, in_bf16, stno, stno_bstride, use_mask, h_out, rows, T, D);
+    DICOW_CHECK_LAUNCH("fddt_full_combine_fwd");
+    return DICOW_OK;
+}
+
+extern "C" int dicow_fddt_full_combine_bwd(const float* g, const float* stno, int64_t stno_bstride, int use_mask,
+                                           void* d_y4, float* dh_direct, int rows, int T, int D, void* stream) {
+    DICOW_REQUIRE(g && stno && d_y4 && rows > 0 && D % 4 == 0 && T > 0, "fddt_full_combine_bwd: bad args");
+    const int64_t n4 = (int64_t)rows * D / 4;
+    int grid = (int)((n4 + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(fddt_full_combine_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, stno,
+                       stno_bstride, use_mask, (unsigned short*)d_y4, dh_direct, rows, T, D);
+    DICOW_CHECK_LAUNCH("fddt_full_combine_bwd");
+    return DICOW_OK;
+}

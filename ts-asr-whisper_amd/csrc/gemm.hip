@@ -1,0 +1,394 @@
+// bf16 MFMA GEMMs for gfx950 (v_mfma_f32_32x32x16_bf16), LDS-staged with global_load_lds (16 B/lane DMA).
+//
+//   dicow_gemm_nt : C[M,N] = epi(A[M,K] . B[N,K]^T)       forward Linear / conv-as-GEMM and every dgrad
+//   dicow_gemm_tn : C[N1,N2] += sum_m A[m,N1] . B[m,N2]    every weight gradient
+//
+// Tile 128x128, K-step 64, 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA tiles of 32x32 (64 fp32
+// accumulators/lane).  Two LDS stages (2 x 32 KiB) -> 2 workgroups per CU; the next stage's DMA is in flight
+// while the current one is consumed (counted s_waitcnt vmcnt, raw s_barrier -- see cdna_hip_programming.md
+// "Pipelining across barriers").  LDS images are lane-linear (DMA constraint) so the bank-conflict swizzle is
+// applied to the per-lane SOURCE address and again on the fragment read (rule 21 of the guide).
+//
+// MFMA operand order is swapped (a = weight rows n, b = activation rows m) so that a lane's accumulator quad
+// holds 4 CONSECUTIVE n for one m: the epilogue then issues 8-byte (bf16) / 16-byte (fp32) row-major stores
+// and float4 bias / residual loads.
+#include "common.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define STAGE_BYTES (BM * BK * 2)          // 16 KiB per operand per stage
+#define NT_LDS_BYTES (4 * STAGE_BYTES)     // A0 B0 A1 B1
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)lds_dst, 16, 0, 0);
+}
+
+// grouped + XCD-aware tile order: consecutive tile ids share A/B panels; block b lands on XCD b % 8, so give
+// each XCD a contiguous chunk of the grouped order (bijective for any grid size).
+__device__ __forceinline__ void tile_coords(int ntm, int ntn, int& tm, int& tn) {
+    const int nwg = ntm * ntn;
+    const int bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    const int GM = 8;
+    const int per_group = GM * ntn;
+    const int group = id / per_group, rem = id - group * per_group;
+    const int first_m = group * GM;
+    const int gsize = (ntm - first_m) < GM ? (ntm - first_m) : GM;
+    tm = first_m + rem % gsize;
+    tn = rem / gsize;
+}
+
+// ------------------------------------------------------------------------------------------------ NT
+// LDS image of a [128 rows][64 k] bf16 tile: row stride 128 B; 16-B chunk c of row r stored at chunk
+// c ^ ((r >> 1) & 7)  (conflict-free for ds_read_b128 fragment reads, 16 lanes/row-group).
+__device__ __forceinline__ void nt_stage(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
+                                         int64_t lda, int64_t ldb, int M, int N, int m0, int n0, int k0, char* sA,
+                                         char* sB, int wave, int lane) {
+    const int rr = lane >> 3, p = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + rr;
+        const int c = p ^ ((row >> 1) & 7);
+        int gm = m0 + row; gm = gm < M ? gm : M - 1;
+        int gn = n0 + row; gn = gn < N ? gn : N - 1;
+        glds16(A + (int64_t)gm * lda + k0 + c * 8, sA + (wave * 4 + i) * 1024);
+        glds16(B + (int64_t)gn * ldb + k0 + c * 8, sB + (wave * 4 + i) * 1024);
+    }
+}
+
+__device__ __forceinline__ bf16x8_t lds_frag_nt(const char* s, int row, int c) {
+    return *reinterpret_cast<const bf16x8_t*>(s + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const dicow_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(ntm, ntn, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int bz = blockIdx.z;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
+    const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.K / BK;
+    nt_stage(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, 0, smem, smem + STAGE_BYTES, wave, lane);
+    for (int t = 0; t < nk; ++t) {
+        char* sA = smem + (t & 1) * 2 * STAGE_BYTES;
+        char* sB = sA + STAGE_BYTES;
+        if (t + 1 < nk) {
+            char* nA = smem + ((t + 1) & 1) * 2 * STAGE_BYTES;
+            nt_stage(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, (t + 1) * BK, nA, nA + STAGE_BYTES, wave, lane);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int c = kk * 2 + (lane >> 5);
+            bf16x8_t wf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[i] = lds_frag_nt(sB, wn * 64 + i * 32 + (lane & 31), c);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xf[j] = lds_frag_nt(sA, wm * 64 + j * 32 + (lane & 31), c);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- epilogue
+    const int flags = a.flags;
+    const int hh = lane >> 5;
+    unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)bz * a.strideC;
+    float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
+    unsigned short* aux = reinterpret_cast<unsigned short*>(a.aux);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * hh;
+                if (n >= a.N) continue;
+                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                if (flags & DICOW_EPI_BIAS) {
+                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+                }
+                if (flags & DICOW_EPI_SCALE_N) {
+                    if (n < a.scale_ncols) { v[0] *= a.scale; v[1] *= a.scale; v[2] *= a.scale; v[3] *= a.scale; }
+                }
+                if (flags & DICOW_EPI_GELU) {
+                    if (aux) {
+                        *reinterpret_cast<uint2*>(aux + (int64_t)m * a.ldaux + n) =
+                            make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                        // the activation is applied to the bf16-rounded pre-activation (AMP: fc1 output is bf16)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e]));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                }
+                if (flags & DICOW_EPI_GELU_BWD) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(aux + (int64_t)m * a.ldaux + n);
+                    v[0] *= gelu_erf_grad(__uint_as_float(u.x << 16));
+                    v[1] *= gelu_erf_grad(__uint_as_float(u.x & 0xffff0000u));
+                    v[2] *= gelu_erf_grad(__uint_as_float(u.y << 16));
+                    v[3] *= gelu_erf_grad(__uint_as_float(u.y & 0xffff0000u));
+                }
+                if (flags & DICOW_EPI_RESIDUAL) {
+                    const float4 rv = *reinterpret_cast<const float4*>(a.residual + (int64_t)m * a.ldr + n);
+                    // AMP: the Linear output is rounded to bf16 before the fp32 residual add
+                    v[0] = bf2f(f2bf(v[0])) + rv.x; v[1] = bf2f(f2bf(v[1])) + rv.y;
+                    v[2] = bf2f(f2bf(v[2])) + rv.z; v[3] = bf2f(f2bf(v[3])) + rv.w;
+                }
+                if (flags & DICOW_EPI_OUT_F32) {
+                    float* cp = Cf + (int64_t)m * a.ldc + n;
+                    if (flags & DICOW_EPI_ACCUM) {
+                        const float4 old = *reinterpret_cast<const float4*>(cp);
+                        v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+                    }
+                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    *reinterpret_cast<uint2*>(Cb + (int64_t)m * a.ldc + n) =
+                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+            }
+        }
+    }
+}
+
+extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
+    DICOW_REQUIRE(a && a->A && a->B && a->C, "gemm_nt: null operand");
+    DICOW_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
+    DICOW_REQUIRE(a->K % BK == 0, "gemm_nt: K=%d must be a multiple of %d (pad the operands)", a->K, BK);
+    DICOW_REQUIRE(a->N % 4 == 0 && a->ldc % 4 == 0, "gemm_nt: N=%d and ldc=%ld must be multiples of 4", a->N, (long)a->ldc);
+    DICOW_REQUIRE(a->lda % 8 == 0 && a->ldb % 8 == 0, "gemm_nt: lda/ldb must be multiples of 8 (16-byte rows)");
+    DICOW_REQUIRE(!(a->flags & DICOW_EPI_BIAS) || a->bias, "gemm_nt: BIAS without bias pointer");
+    DICOW_REQUIRE(!(a->flags & DICOW_EPI_RESIDUAL) || (a->residual && a->ldr % 4 == 0), "gemm_nt: RESIDUAL needs residual, ldr%%4==0");
+    DICOW_REQUIRE(!(a->flags & DICOW_EPI_GELU_BWD) || (a->aux && a->ldaux % 4 == 0), "gemm_nt: GELU_BWD needs aux");
+    DICOW_REQUIRE(!(a->flags & DICOW_EPI_ACCUM) || (a->flags & DICOW_EPI_OUT_F32), "gemm_nt: ACCUM needs OUT_F32");
+    DICOW_REQUIRE(!(a->aux) || a->ldaux % 4 == 0, "gemm_nt: ldaux must be a multiple of 4");
+    const int batch = a->batch > 0 ? a->batch : 1;
+    const int ntm = dicow_cdiv(a->M, BM), ntn = dicow_cdiv(a->N, BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3(ntm * ntn, 1, batch), dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
+    DICOW_CHECK_LAUNCH("gemm_nt");
+    return DICOW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ TN (weight gradients)
+// LDS image of a [64 m][128 n] bf16 tile: row stride 256 B; 16-B chunk c of row m stored at chunk
+// c ^ ((m & 3) << 2) (keeps the four rows of a ds_read_b64_tr_b16 block on distinct banks).
+#define TK 64
+#define TN_STAGE_BYTES (TK * 128 * 2)      // 16 KiB per operand per stage
+#define TN_LDS_BYTES (4 * TN_STAGE_BYTES)
+
+__device__ __forceinline__ void tn_stage(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
+                                         int64_t lda, int64_t ldb, int N1, int N2, int n1_0, int n2_0, int row_base,
+                                         int rows_valid, char* sA, char* sB, int wave, int lane) {
+    const int rr = lane >> 4, p = lane & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 4 + rr;
+        const int c = p ^ ((row & 3) << 2);
+        const int grow = row_base + (row < rows_valid ? row : rows_valid - 1);   // clamped (tail rows zeroed later)
+        int ca = n1_0 + c * 8; ca = ca + 8 <= N1 ? ca : N1 - 8;
+        int cb = n2_0 + c * 8; cb = cb + 8 <= N2 ? cb : N2 - 8;
+        glds16(A + (int64_t)grow * lda + ca, sA + (wave * 4 + i) * 1024);
+        glds16(B + (int64_t)grow * ldb + cb, sB + (wave * 4 + i) * 1024);
+    }
+}
+
+// ds_read_b64_tr_b16: each lane supplies the address of 4 contiguous bf16; within a 16-lane group the 16x4 block
+// is transposed so lane i receives element (i & 3) of lanes 4j + (i >> 2), j = 0..3  -- i.e. 4 consecutive ROWS of
+// one column (probe: profiles/r01_probe_gfx950.txt).  All 8 reads of one 16-deep k-step (2 operands x 2 column
+// blocks x rows {m..m+3, m+4..m+7}) and their wait are ONE asm statement so the compiler cannot touch the
+// destination registers before the data has landed (cdna_hip_programming.md section 5.7 item 1).
+__device__ __forceinline__ unsigned tn_tr_addr(const char* s, int m, int n) {
+    return (unsigned)(uintptr_t)(s + m * 256 + ((((n >> 3) ^ ((m & 3) << 2))) << 4) + ((n & 7) << 1));
+}
+template <int OFF>
+__device__ __forceinline__ void tn_read_kstep(bf16x8_t (&f2)[2], bf16x8_t (&f1)[2], unsigned b0, unsigned b1, unsigned a0,
+                                              unsigned a1) {
+    bf16x4_t r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %2, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %4, %10 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %6, %11 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(b0), "v"(b1), "v"(a0), "v"(a1), "i"(OFF), "i"(OFF + 1024)
+        : "memory");
+    f2[0] = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    f2[1] = __builtin_shufflevector(r2, r3, 0, 1, 2, 3, 4, 5, 6, 7);
+    f1[0] = __builtin_shufflevector(r4, r5, 0, 1, 2, 3, 4, 5, 6, 7);
+    f1[1] = __builtin_shufflevector(r6, r7, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const dicow_gemm_tn_args a, int tiles_per_batch, int total_tiles,
+                                                         int tiles_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt1 = (a.N1 + 127) / 128, nt2 = (a.N2 + 127) / 128;
+    int t1, t2;
+    tile_coords(nt1, nt2, t1, t2);
+    const int n1_0 = t1 * 128, n2_0 = t2 * 128;
+    const int kt0 = blockIdx.z * tiles_per_split;
+    int kt1 = kt0 + tiles_per_split; kt1 = kt1 < total_tiles ? kt1 : total_tiles;
+    if (kt0 >= kt1) return;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A);
+    const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B);
+    const int w1 = wave >> 1, w2 = wave & 1;
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue = [&](int kt, int buf) {
+        const int b = kt / tiles_per_batch, lt = kt - b * tiles_per_batch;
+        const int rv = (a.Mk - lt * TK) < TK ? (a.Mk - lt * TK) : TK;
+        char* sA = smem + buf * 2 * TN_STAGE_BYTES;
+        tn_stage(A + (int64_t)b * a.strideA, B + (int64_t)b * a.strideB, a.lda, a.ldb, a.N1, a.N2, n1_0, n2_0, lt * TK, rv,
+                 sA, sA + TN_STAGE_BYTES, wave, lane);
+    };
+
+    issue(kt0, 0);
+    // lane-constant parts of the transposing reads: group G -> 16-column block, u -> (row, 4-col) inside the block
+    const int G = lane >> 4, u = lane & 15;
+    const int tr_row = 8 * (G >> 1) + (u >> 2);          // + kk*16 (+4 for the second read)
+    const int tr_col = 16 * (G & 1) + 4 * (u & 3);       // + 32*blk + wave offset
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        char* sA = smem + buf * 2 * TN_STAGE_BYTES;
+        char* sB = sA + TN_STAGE_BYTES;
+        if (kt + 1 < kt1) {
+            issue(kt + 1, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {   // zero the rows of a partial contraction tile (the DMA fetched clamped duplicates there)
+            const int lt = kt % tiles_per_batch;
+            const int rv = (a.Mk - lt * TK) < TK ? (a.Mk - lt * TK) : TK;
+            if (rv < TK) {
+                for (int i = tid; i < (TK - rv) * 16; i += 256) {
+                    const int off = (rv + (i >> 4)) * 256 + (i & 15) * 16;
+                    *reinterpret_cast<uint4*>(sA + off) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(sB + off) = make_uint4(0, 0, 0, 0);
+                }
+                __syncthreads();
+            }
+        }
+        {
+            const unsigned b0 = tn_tr_addr(sB, tr_row, w2 * 64 + tr_col), b1 = tn_tr_addr(sB, tr_row, w2 * 64 + 32 + tr_col);
+            const unsigned a0 = tn_tr_addr(sA, tr_row, w1 * 64 + tr_col), a1 = tn_tr_addr(sA, tr_row, w1 * 64 + 32 + tr_col);
+            bf16x8_t f2[2], f1[2];
+#define TN_KSTEP(KK)                                                                                      \
+            tn_read_kstep<(KK) * 4096>(f2, f1, b0, b1, a0, a1);                                           \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[i], f1[j], acc[i][j], 0, 0, 0);
+            TN_KSTEP(0) TN_KSTEP(1) TN_KSTEP(2) TN_KSTEP(3)
+#undef TN_KSTEP
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- epilogue: C[n1][n2..n2+3] (+)= acc ; atomics when the contraction is split across blocks
+    const int hh = lane >> 5;
+    const bool use_atomic = gridDim.z > 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n1 = n1_0 + w1 * 64 + j * 32 + (lane & 31);
+        if (n1 >= a.N1) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n2 = n2_0 + w2 * 64 + i * 32 + 8 * q + 4 * hh;
+                if (n2 >= a.N2) continue;
+                float* cp = a.C + (int64_t)n1 * a.ldc + n2;
+                if (use_atomic) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(cp + e, acc[i][j][4 * q + e]);
+                } else {
+                    float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                    if (a.accumulate) {
+                        const float4 o = *reinterpret_cast<const float4*>(cp);
+                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                    }
+                    *reinterpret_cast<float4*>(cp) = v;
+                }
+            }
+        }
+    }
+}
+
+extern "C" int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream) {
+    DICOW_REQUIRE(a && a->A && a->B && a->C, "gemm_tn: null operand");
+    DICOW_REQUIRE(a->Mk > 0 && a->N1 >= 8 && a->N2 >= 8, "gemm_tn: empty problem");
+    DICOW_REQUIRE(a->N1 % 8 == 0 && a->N2 % 8 == 0, "gemm_tn: N1=%d, N2=%d must be multiples of 8", a->N1, a->N2);
+    DICOW_REQUIRE(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0, "gemm_tn: lda/ldb %% 8, ldc %% 4 required");
+    const int batch = a->batch > 0 ? a->batch : 1;
+    const int tpb = dicow_cdiv(a->Mk, TK);
+    const int total = tpb * batch;
+    const int nt = dicow_cdiv(a->N1, 128) * dicow_cdiv(a->N2, 128);
+    // split the contraction so that the grid has >= ~4 waves of workgroups (2 resident per CU)
+    int splits = (2048 + nt - 1) / nt;
+    if (splits > total / 4) splits = total / 4;
+    if (splits < 1) splits = 1;
+    int tps = dicow_cdiv(total, splits);
+    splits = dicow_cdiv(total, tps);
+    DICOW_REQUIRE(splits == 1 || a->accumulate, "gemm_tn: split contraction needs accumulate=1 (C pre-initialised)");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_kernel, dim3(nt, 1, splits), dim3(256), TN_LDS_BYTES, (hipStream_t)stream, *a, tpb, total, tps);
+    DICOW_CHECK_LAUNCH("gemm_tn");
+    return DICOW_OK;
+}

@@ -1,0 +1,187 @@
+"""Tensor-level wrappers over the C ABI (no autograd here; see ``functional.py`` / ``modeling.py``).
+
+Every wrapper validates device/dtype/contiguity, allocates outputs with torch (the library never
+allocates) and enqueues the HIP kernels on the current torch stream.
+"""
+import ctypes as C
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _req(t: torch.Tensor, dtype, name: str):
+    if not t.is_cuda:
+        raise L.DicowError(f"{name}: tensor must live on the GPU (no CPU fallback)")
+    if t.dtype != dtype:
+        raise L.DicowError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _arr4(ts):
+    a = (C.c_void_p * 4)()
+    for i, t in enumerate(ts):
+        a[i] = None if t is None else t.data_ptr()
+    return a
+
+
+# ------------------------------------------------------------------------------------------------ casts / packs
+def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _req(src, F32, "cast_bf16.src")
+    src = src.contiguous()
+    if out is None:
+        out = torch.empty(src.shape, dtype=BF16, device=src.device)
+    L.call("dicow_cast_f32_to_bf16", src.data_ptr(), out.data_ptr(), src.numel(), L.stream())
+    return out
+
+
+def cast_transpose_bf16(src: torch.Tensor, want_plain=True, want_t=True, out=None, out_t=None):
+    _req(src, F32, "cast_transpose.src")
+    assert src.dim() == 2 and src.is_contiguous()
+    R, Cc = src.shape
+    if want_plain and out is None:
+        out = torch.empty(R, Cc, dtype=BF16, device=src.device)
+    if want_t and out_t is None:
+        out_t = torch.empty(Cc, R, dtype=BF16, device=src.device)
+    L.call("dicow_cast_transpose_f32_to_bf16", src.data_ptr(), _p(out) if want_plain else None,
+           _p(out_t) if want_t else None, R, Cc, L.stream())
+    return out, out_t
+
+
+def conv_weight_pack(w: torch.Tensor, kpad: int, out=None) -> torch.Tensor:
+    _req(w, F32, "conv_weight_pack.w")
+    O, Cc, three = w.shape
+    assert three == 3 and w.is_contiguous()
+    if out is None:
+        out = torch.empty(O, kpad, dtype=BF16, device=w.device)
+    L.call("dicow_conv_weight_pack", w.data_ptr(), out.data_ptr(), O, Cc, kpad, L.stream())
+    return out
+
+
+def conv_weight_unpack_grad(g_packed: torch.Tensor, g_w: torch.Tensor):
+    O, Cc, _ = g_w.shape
+    L.call("dicow_conv_weight_unpack_grad", g_packed.data_ptr(), g_w.data_ptr(), O, Cc, g_packed.shape[1], L.stream())
+
+
+def mel_to_timemajor(mel: torch.Tensor, out=None) -> torch.Tensor:
+    _req(mel, F32, "mel_to_timemajor.mel")
+    mel = mel.contiguous()
+    B, M, Tin = mel.shape
+    if out is None:
+        out = torch.empty(B, Tin + 2, M, dtype=BF16, device=mel.device)
+    L.call("dicow_mel_to_timemajor", mel.data_ptr(), out.data_ptr(), B, M, Tin, L.stream())
+    return out
+
+
+def colsum_bf16(x: torch.Tensor, out: torch.Tensor):
+    """out[N] (fp32) += column sums of bf16 x [rows, N] (row stride x.stride(0))."""
+    _req(x, BF16, "colsum.x")
+    assert x.dim() == 2 and x.stride(1) == 1
+    L.call("dicow_colsum_bf16", x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], L.stream())
+
+
+def sum_over_batch(g: torch.Tensor, out: torch.Tensor):
+    B = g.shape[0]
+    L.call("dicow_sum_over_batch", g.data_ptr(), out.data_ptr(), B, g.numel() // B, L.stream())
+
+
+# ------------------------------------------------------------------------------------------------ FDDT + LayerNorm
+MODE_NONE, MODE_DIAG, MODE_BIAS = 0, 1, 2
+
+
+def fddt_ln_fwd(h_in, rows, D, *, mode=MODE_NONE, stno=None, stno_bstride=None, T=0, w=(None,) * 4, b=(None,) * 4,
+                pos=None, h_out=None, ln_w=None, ln_b=None, y_bf16=None, y_f32=None, mean=None, rstd=None, eps=1e-5):
+    a = L.FddtLnFwdArgs()
+    a.h_in, a.in_bf16, a.mode = h_in.data_ptr(), int(h_in.dtype == BF16), mode
+    a.stno = _p(stno)
+    a.stno_bstride = (4 * T) if stno_bstride is None else stno_bstride
+    a.w, a.b = _arr4(w), _arr4(b)
+    a.pos, a.h_out, a.ln_w, a.ln_b = _p(pos), _p(h_out), _p(ln_w), _p(ln_b)
+    a.y_bf16, a.y_f32, a.mean, a.rstd = _p(y_bf16), _p(y_f32), _p(mean), _p(rstd)
+    a.rows, a.T, a.D, a.eps = rows, T, D, eps
+    L.call_struct("dicow_fddt_ln_fwd", a)
+
+
+def fddt_ln_bwd(h_in, rows, D, *, mode=MODE_NONE, stno=None, stno_bstride=None, T=0, w=(None,) * 4, b=(None,) * 4,
+                pos=None, ln_w=None, mean=None, rstd=None, d_y=None, g_res=None, g_out=None, g_out_bf16=None,
+                dln_w=None, dln_b=None, dw=(None,) * 4, db=(None,) * 4, colsum_out=None):
+    a = L.FddtLnBwdArgs()
+    a.h_in, a.in_bf16, a.mode = h_in.data_ptr(), int(h_in.dtype == BF16), mode
+    a.stno = _p(stno)
+    a.stno_bstride = (4 * T) if stno_bstride is None else stno_bstride
+    a.w, a.b = _arr4(w), _arr4(b)
+    a.pos, a.ln_w, a.mean, a.rstd = _p(pos), _p(ln_w), _p(mean), _p(rstd)
+    a.d_y = _p(d_y)
+    a.dy_f32 = int(d_y is not None and d_y.dtype == F32)
+    a.g_res, a.g_out, a.g_out_bf16 = _p(g_res), _p(g_out), _p(g_out_bf16)
+    a.dln_w, a.dln_b = _p(dln_w), _p(dln_b)
+    a.dw, a.db = _arr4(dw), _arr4(db)
+    a.colsum_out = _p(colsum_out)
+    a.rows, a.T, a.D = rows, T, D
+    L.call_struct("dicow_fddt_ln_bwd", a)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residual=None, ldr=None, aux=None,
+            ldaux=None, flags=0, scale=1.0, scale_ncols=0, batch=1, strideA=0, strideB=0, strideC=0):
+    """C[M,N] = epilogue(A[M,K] @ B[N,K]^T).  Pointers + leading dimensions; see include/dicow_hip.h."""
+    a = L.GemmArgs()
+    a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
+    a.bias, a.residual, a.aux = _p(bias), _p(residual), _p(aux)
+    a.M, a.N, a.K = M, N, K
+    a.lda = K if lda is None else lda
+    a.ldb = K if ldb is None else ldb
+    a.ldc = N if ldc is None else ldc
+    a.ldr = N if ldr is None else ldr
+    a.ldaux = N if ldaux is None else ldaux
+    a.batch, a.strideA, a.strideB, a.strideC = batch, strideA, strideB, strideC
+    if C_out.dtype == F32:
+        flags |= L.EPI_OUT_F32
+    if bias is not None:
+        flags |= L.EPI_BIAS
+    if residual is not None:
+        flags |= L.EPI_RESIDUAL
+    a.flags, a.scale, a.scale_ncols = flags, scale, scale_ncols
+    L.call_struct("dicow_gemm_nt", a)
+
+
+def gemm_tn(A, B, C_out, Mk, N1, N2, *, lda=None, ldb=None, ldc=None, batch=1, strideA=0, strideB=0, accumulate=True):
+    """C[N1,N2] (+)= sum_m A[m,N1] * B[m,N2]  (fp32 C)."""
+    a = L.GemmTnArgs()
+    a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
+    a.Mk, a.N1, a.N2 = Mk, N1, N2
+    a.lda = N1 if lda is None else lda
+    a.ldb = N2 if ldb is None else ldb
+    a.ldc = N2 if ldc is None else ldc
+    a.batch, a.strideA, a.strideB, a.accumulate = batch, strideA, strideB, int(accumulate)
+    L.call_struct("dicow_gemm_tn", a)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _bs_rs(t, name):
+    # t: [B, L, H, 64] view (any batch/row stride)
+    assert t.dim() == 4 and t.shape[3] == 64 and t.stride(3) == 1 and t.stride(2) == 64, f"{name}: need [B,L,H,64] view"
+    return t.stride(0), t.stride(1)
+
+
+def attn_fwd(q, k, v, o, lse=None, causal=False):
+    """q [B,Lq,H,64], k/v [B,Lk,H,64] bf16 views; o like q; lse [B,H,Lq] fp32."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
+        _req(t, BF16, "attn_fwd." + n)
+    a = L.AttnFwdArgs()
+    a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _p(lse)
+    a.q_bs, a.q_rs = _bs_rs(q, "q")
+    a.k_bs, a.k_rs = _bs_rs(k, "k")
+    a.v_bs, a.v_rs = _bs_rs(v, "v")
+    a.o_bs, a.o_rs = _bs_rs(o, "o")
+    a.B, a.Lq, a.H = q.shape[0], q.shape[1], q.shape[2]
+    a.Lk, a.causal = k.shape[1], int(causal)
+    L.call_struct("dicow_attn_fwd", a)
