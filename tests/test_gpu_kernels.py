@@ -241,3 +241,39 @@ def test_attn_fwd(ops, B, H, Lq, Lk, causal):
     ops.attn_fwd(qd, kd, vd, o, lse, causal=causal)
     assert maxdiff(lse.cpu(), ref_lse) < 2e-3
     assert maxdiff(o.float().cpu(), ref_o) < 2e-2
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,causal", [(1, 2, 128, 64, False), (2, 3, 100, 100, False), (1, 2, 1500, 1500, False),
+                                             (2, 2, 77, 77, True), (1, 2, 300, 300, True), (2, 2, 50, 1500, False),
+                                             (1, 1, 200, 130, False)])
+def test_attn_bwd(ops, B, H, Lq, Lk, causal):
+    g = torch.Generator().manual_seed(B * 999 + Lq + 3 * Lk)
+    D = H * 64
+    qkv_q = _bf(torch.randn(B, Lq, 3 * D, generator=g) * 0.6)
+    qkv_k = _bf(torch.randn(B, Lk, 3 * D, generator=g) * 0.6)
+    d_o = _bf(torch.randn(B, Lq, H, 64, generator=g))
+    q = qkv_q[:, :, :D].view(B, Lq, H, 64).clone().requires_grad_(True)
+    k = qkv_k[:, :, D:2 * D].view(B, Lk, H, 64).clone().requires_grad_(True)
+    v = qkv_k[:, :, 2 * D:].view(B, Lk, H, 64).clone().requires_grad_(True)
+    s = torch.einsum("blhd,bmhd->bhlm", q.double(), k.double())
+    if causal:
+        s = s.masked_fill(~torch.ones(Lq, Lk, dtype=torch.bool).tril(), float("-inf"))
+    o_ref = torch.einsum("bhlm,bmhd->blhd", torch.softmax(s, -1), v.double())
+    (o_ref * d_o.double()).sum().backward()
+    dq_, dk_ = dev(qkv_q, torch.bfloat16), dev(qkv_k, torch.bfloat16)
+    qd = dq_[:, :, :D].view(B, Lq, H, 64)
+    kd = dk_[:, :, D:2 * D].view(B, Lk, H, 64)
+    vd = dk_[:, :, 2 * D:].view(B, Lk, H, 64)
+    o = torch.zeros(B, Lq, H, 64, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, Lq, device="cuda")
+    ops.attn_fwd(qd, kd, vd, o, lse, causal=causal)
+    gq = torch.zeros(B, Lq, 3 * D, dtype=torch.bfloat16, device="cuda")
+    gk = torch.zeros(B, Lk, 3 * D, dtype=torch.bfloat16, device="cuda")
+    delta = torch.empty(B, H, Lq, device="cuda")
+    ops.attn_bwd(qd, kd, vd, o, dev(d_o, torch.bfloat16), lse, delta,
+                 gq[:, :, :D].view(B, Lq, H, 64), gk[:, :, D:2 * D].view(B, Lk, H, 64), gk[:, :, 2 * D:].view(B, Lk, H, 64),
+                 causal=causal, dq_scale=0.5)
+    tol = lambda ref: 2e-2 * max(1.0, float(ref.abs().max()))
+    assert maxdiff(gq[:, :, :D].float().cpu().view(B, Lq, H, 64), 0.5 * q.grad) < tol(q.grad)
+    assert maxdiff(gk[:, :, D:2 * D].float().cpu().view(B, Lk, H, 64), k.grad) < tol(k.grad)
+    assert maxdiff(gk[:, :, 2 * D:].float().cpu().view(B, Lk, H, 64), v.grad) < tol(v.grad)

@@ -72,6 +72,7 @@ _SIGS = {
     "dicow_gemm_nt": [C.POINTER(GemmArgs), c_vp],
     "dicow_gemm_tn": [C.POINTER(GemmTnArgs), c_vp],
     "dicow_attn_fwd": [C.POINTER(AttnFwdArgs), c_vp],
+    "dicow_attn_bwd": [C.POINTER(AttnBwdArgs), c_vp],
 }
 
 

@@ -242,3 +242,348 @@ extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
     DICOW_CHECK_LAUNCH("attn_fwd");
     return DICOW_OK;
 }
+
+// ================================================================================================ backward
+// Three kernels (deterministic, no atomics):
+//   attn_delta_kernel : delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+//   attn_bwd_dq_kernel: per 128-query block, loop over key tiles   (S^T, dP^T, dQ^T += K^T . dS^T)
+//   attn_bwd_dkv_kernel: per 128-key block, loop over query tiles  (S, dP, dV^T += dO^T . P, dK^T += Q^T . dS)
+// All LDS tiles use the "universal" image U: 16-B chunk c of row r stored at c ^ rev3((r>>1)&7), which is
+// conflict-free both for ds_read_b128 row fragments and for ds_read_b64_tr_b16 column fragments.
+__device__ __forceinline__ int rev3(int x) { return ((x & 1) << 2) | (x & 2) | ((x >> 2) & 1); }
+__device__ __forceinline__ int uswz(int row, int c) { return row * 128 + ((c ^ rev3((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ void stage_tile64_u(const unsigned short* __restrict__ base, int64_t rs, int row0, int nrows,
+                                               char* lds, int wave, int lane) {
+    const int rr = lane >> 3, p = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + rr;
+        const int c = p ^ rev3((row >> 1) & 7);
+        int g = row0 + row; g = g < nrows ? g : nrows - 1;
+        glds16(base + (int64_t)g * rs + c * 8, lds + (wave * 2 + i) * 1024);
+    }
+}
+
+// lane base address of a transposing read on a U image: rows 4*half + (u>>2) (+8*sec), 16 columns of d-block dblk
+__device__ __forceinline__ unsigned tr_base_u(const char* s, int lane, int dblk, int sec) {
+    const int G = lane >> 4, u = lane & 15, hh = G >> 1;
+    const int row = 8 * sec + 4 * hh + (u >> 2);
+    const int c = (dblk * 4 + 2 * (G & 1) + ((u & 3) >> 1)) ^ rev3((row >> 1) & 7);
+    return (unsigned)(uintptr_t)(s + row * 128 + (c << 4) + ((u & 1) << 3));
+}
+
+// 8 transposing reads of one 32-row block (rows OFF/128 .. +31) x 64 columns; f[x][dblk], x = 16-row half
+template <int OFF>
+__device__ __forceinline__ void tr_read_block_u(bf16x8_t (&f)[2][2], unsigned a00, unsigned a01, unsigned a10, unsigned a11) {
+    // a{dblk}{sec}
+    bf16x4_t r0, r1, r2, r3, r4, r5, r6, r7;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %1, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %2, %10 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %3, %11 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "i"(OFF), "i"(OFF + 2048)
+        : "memory");
+    f[0][0] = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[0][1] = __builtin_shufflevector(r2, r3, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[1][0] = __builtin_shufflevector(r4, r5, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[1][1] = __builtin_shufflevector(r6, r7, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__global__ void attn_delta_kernel(const unsigned short* __restrict__ o, const unsigned short* __restrict__ d_o,
+                                  float* __restrict__ delta, int64_t o_bs, int64_t o_rs, int64_t do_bs, int64_t do_rs,
+                                  int B, int H, int Lq) {
+    // one 16-lane group per (b, q, h): 4 bf16 per lane
+    const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    const int64_t total = (int64_t)B * Lq * H;
+    float s = 0.f;
+    int b = 0, q = 0, h = 0;
+    if (gid < total) {
+        h = (int)(gid % H);
+        const int64_t bq = gid / H;
+        q = (int)(bq % Lq); b = (int)(bq / Lq);
+        const uint2 uo = *reinterpret_cast<const uint2*>(o + (int64_t)b * o_bs + (int64_t)q * o_rs + h * HD + sub * 4);
+        const uint2 ud = *reinterpret_cast<const uint2*>(d_o + (int64_t)b * do_bs + (int64_t)q * do_rs + h * HD + sub * 4);
+        s = __uint_as_float(uo.x << 16) * __uint_as_float(ud.x << 16) +
+            __uint_as_float(uo.x & 0xffff0000u) * __uint_as_float(ud.x & 0xffff0000u) +
+            __uint_as_float(uo.y << 16) * __uint_as_float(ud.y << 16) +
+            __uint_as_float(uo.y & 0xffff0000u) * __uint_as_float(ud.y & 0xffff0000u);
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (gid < total && sub == 0) delta[((int64_t)b * H + h) * Lq + q] = s;
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+__global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bwd_args a) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];      // K0 V0 K1 V1 (U images)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128;
+    const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
+    const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
+    const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
+    const unsigned short* dO = reinterpret_cast<const unsigned short*>(a.d_o) + (int64_t)b * a.do_bs + h * HD;
+
+    const int qrow = q0 + wave * 32 + (lane & 31);
+    const int qrow_c = qrow < a.Lq ? qrow : a.Lq - 1;
+    bf16x8_t qf[4], dof[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        qf[kk] = *reinterpret_cast<const bf16x8_t*>(Q + (int64_t)qrow_c * a.q_rs + kk * 16 + hh * 8);
+        dof[kk] = *reinterpret_cast<const bf16x8_t*>(dO + (int64_t)qrow_c * a.do_rs + kk * 16 + hh * 8);
+    }
+    const int64_t stat = ((int64_t)b * a.H + h) * a.Lq + qrow_c;
+    const float lse2 = a.lse[stat] * LOG2E;
+    const float dlt = a.delta[stat];
+
+    f32x16_t dq[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+
+    int kv_end = a.Lk;
+    if (a.causal) kv_end = q0 + 128 < a.Lk ? q0 + 128 : a.Lk;
+    const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
+
+    stage_tile64_u(K, a.k_rs, 0, a.Lk, smem, wave, lane);
+    stage_tile64_u(V, a.v_rs, 0, a.Lk, smem + TILE_BYTES, wave, lane);
+    for (int t = 0; t < nt; ++t) {
+        char* sK = smem + (t & 1) * 2 * TILE_BYTES;
+        char* sV = sK + TILE_BYTES;
+        if (t + 1 < nt) {
+            char* nK = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+            stage_tile64_u(K, a.k_rs, (t + 1) * KV_TILE, a.Lk, nK, wave, lane);
+            stage_tile64_u(V, a.v_rs, (t + 1) * KV_TILE, a.Lk, nK + TILE_BYTES, wave, lane);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        const int k0 = t * KV_TILE;
+        const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
+        f32x16_t ds[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16_t s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + uswz(kb * 32 + (lane & 31), kk * 2 + hh));
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + uswz(kb * 32 + (lane & 31), kk * 2 + hh));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float p = __builtin_amdgcn_exp2f(s[r] * LOG2E - lse2);
+                if (need_mask) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= a.Lk || (a.causal && key > qrow)) p = 0.f;
+                }
+                ds[kb][r] = p * (dp[r] - dlt);
+            }
+        }
+        // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
+        const unsigned k00 = tr_base_u(sK, lane, 0, 0), k01 = tr_base_u(sK, lane, 0, 1);
+        const unsigned k10 = tr_base_u(sK, lane, 1, 0), k11 = tr_base_u(sK, lane, 1, 1);
+        {
+            bf16x8_t ktf[2][2];
+            tr_read_block_u<0>(ktf, k00, k01, k10, k11);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const bf16x8_t pf = pack8(ds[0], 8 * x);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[x][d], pf, dq[d], 0, 0, 0);
+            }
+            tr_read_block_u<4096>(ktf, k00, k01, k10, k11);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const bf16x8_t pf = pack8(ds[1], 8 * x);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[x][d], pf, dq[d], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (qrow < a.Lq) {
+        unsigned short* DQ = reinterpret_cast<unsigned short*>(a.dq) + (int64_t)b * a.dq_bs + (int64_t)qrow * a.dq_rs + h * HD;
+        const float sc = a.dq_scale;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int col = d * 32 + 8 * q4 + 4 * hh;
+                *reinterpret_cast<uint2*>(DQ + col) =
+                    make_uint2(pack_bf16x2(dq[d][4 * q4] * sc, dq[d][4 * q4 + 1] * sc),
+                               pack_bf16x2(dq[d][4 * q4 + 2] * sc, dq[d][4 * q4 + 3] * sc));
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+// lse / delta of a 64-query tile -> LDS (one 4-byte DMA per lane; waves 0/2 fetch lse, waves 1/3 delta, so every wave
+// issues the same number of VMEM ops and one counted vmcnt serves all)
+__device__ __forceinline__ void stage_stats64(const float* lse, const float* delta, int q0, int Lq, char* dst, int wave, int lane) {
+    int q = q0 + lane; q = q < Lq ? q : Lq - 1;
+    const float* src = (wave & 1) ? delta + q : lse + q;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + (wave & 1) * 256), 4, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_bwd_args a) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 1024];   // Q0 dO0 Q1 dO1 (U images) + lse/delta x2
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int kblk0 = blockIdx.x * 128;
+    const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
+    const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
+    const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
+    const unsigned short* dO = reinterpret_cast<const unsigned short*>(a.d_o) + (int64_t)b * a.do_bs + h * HD;
+    const float* lse = a.lse + ((int64_t)b * a.H + h) * a.Lq;
+    const float* delta = a.delta + ((int64_t)b * a.H + h) * a.Lq;
+
+    // this wave's 32 keys as B operands (column = key, k-slots = d)
+    const int key = kblk0 + wave * 32 + (lane & 31);
+    const int key_c = key < a.Lk ? key : a.Lk - 1;
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = *reinterpret_cast<const bf16x8_t*>(K + (int64_t)key_c * a.k_rs + kk * 16 + hh * 8);
+        vf[kk] = *reinterpret_cast<const bf16x8_t*>(V + (int64_t)key_c * a.v_rs + kk * 16 + hh * 8);
+    }
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+
+    const int t0 = a.causal ? (kblk0 / KV_TILE) : 0;                 // query tiles entirely before the key block see none of it
+    const int nt = (a.Lq + KV_TILE - 1) / KV_TILE;
+    if (t0 < nt) {
+        stage_tile64_u(Q, a.q_rs, t0 * KV_TILE, a.Lq, smem, wave, lane);
+        stage_tile64_u(dO, a.do_rs, t0 * KV_TILE, a.Lq, smem + TILE_BYTES, wave, lane);
+        stage_stats64(lse, delta, t0 * KV_TILE, a.Lq, smem + 4 * TILE_BYTES, wave, lane);
+    }
+    for (int t = t0; t < nt; ++t) {
+        char* sQ = smem + ((t - t0) & 1) * 2 * TILE_BYTES;
+        char* sdO = sQ + TILE_BYTES;
+        if (t + 1 < nt) {
+            char* nQ = smem + ((t - t0 + 1) & 1) * 2 * TILE_BYTES;
+            stage_tile64_u(Q, a.q_rs, (t + 1) * KV_TILE, a.Lq, nQ, wave, lane);
+            stage_tile64_u(dO, a.do_rs, (t + 1) * KV_TILE, a.Lq, nQ + TILE_BYTES, wave, lane);
+            stage_stats64(lse, delta, (t + 1) * KV_TILE, a.Lq, smem + 4 * TILE_BYTES + ((t - t0 + 1) & 1) * 512, wave, lane);
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+
+        const int qt0 = t * KV_TILE;
+        const float* sStat = reinterpret_cast<const float*>(smem + 4 * TILE_BYTES + ((t - t0) & 1) * 512);
+        const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + 128 > a.Lk) || (a.causal && (kblk0 + wave * 32 + 31 > qt0));
+        const unsigned q00 = tr_base_u(sQ, lane, 0, 0), q01 = tr_base_u(sQ, lane, 0, 1);
+        const unsigned q10 = tr_base_u(sQ, lane, 1, 0), q11 = tr_base_u(sQ, lane, 1, 1);
+        const unsigned o00 = tr_base_u(sdO, lane, 0, 0), o01 = tr_base_u(sdO, lane, 0, 1);
+        const unsigned o10 = tr_base_u(sdO, lane, 1, 0), o11 = tr_base_u(sdO, lane, 1, 1);
+#define DKV_QBLOCK(QB)                                                                                                  \
+        {                                                                                                               \
+            f32x16_t s, dp;                                                                                             \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }                                 \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(sQ + uswz((QB) * 32 + (lane & 31), kk * 2 + hh)); \
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(sdO + uswz((QB) * 32 + (lane & 31), kk * 2 + hh)); \
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);                                    \
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
+            }                                                                                                           \
+            f32x16_t pv, dsv;                                                                                           \
+            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                          \
+                const int qb = qt0 + (QB) * 32 + 8 * q4 + 4 * hh;                                                       \
+                const float4 lv = *reinterpret_cast<const float4*>(sStat + (QB) * 32 + 8 * q4 + 4 * hh);                 \
+                const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 64 + (QB) * 32 + 8 * q4 + 4 * hh);          \
+                const float l4[4] = {lv.x, lv.y, lv.z, lv.w};                                                           \
+                const float d4[4] = {dv4.x, dv4.y, dv4.z, dv4.w};                                                       \
+                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                         \
+                    const int r = 4 * q4 + e;                                                                           \
+                    float p = __builtin_amdgcn_exp2f((s[r] - l4[e]) * LOG2E);                                           \
+                    if (need_mask) {                                                                                    \
+                        const int qq = qb + e;                                                                          \
+                        if (qq >= a.Lq || key >= a.Lk || (a.causal && key > qq)) p = 0.f;                               \
+                    }                                                                                                   \
+                    pv[r] = p;                                                                                          \
+                    dsv[r] = p * (dp[r] - d4[e]);                                                                       \
+                }                                                                                                       \
+            }                                                                                                           \
+            bf16x8_t qtf[2][2], dotf[2][2];                                                                             \
+            tr_read_block_u<(QB) * 4096>(dotf, o00, o01, o10, o11);                                                     \
+            tr_read_block_u<(QB) * 4096>(qtf, q00, q01, q10, q11);                                                      \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                             \
+                const bf16x8_t pf = pack8(pv, 8 * x);                                                                   \
+                const bf16x8_t df = pack8(dsv, 8 * x);                                                                  \
+                _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                         \
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[x][d], pf, dv[d], 0, 0, 0);                    \
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[x][d], df, dk[d], 0, 0, 0);                     \
+                }                                                                                                       \
+            }                                                                                                           \
+        }
+        DKV_QBLOCK(0)
+        DKV_QBLOCK(1)
+#undef DKV_QBLOCK
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    if (key < a.Lk) {
+        unsigned short* DK = reinterpret_cast<unsigned short*>(a.dk) + (int64_t)b * a.dk_bs + (int64_t)key * a.dk_rs + h * HD;
+        unsigned short* DV = reinterpret_cast<unsigned short*>(a.dv) + (int64_t)b * a.dv_bs + (int64_t)key * a.dv_rs + h * HD;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int col = d * 32 + 8 * q4 + 4 * hh;
+                *reinterpret_cast<uint2*>(DK + col) = make_uint2(pack_bf16x2(dk[d][4 * q4], dk[d][4 * q4 + 1]),
+                                                                 pack_bf16x2(dk[d][4 * q4 + 2], dk[d][4 * q4 + 3]));
+                *reinterpret_cast<uint2*>(DV + col) = make_uint2(pack_bf16x2(dv[d][4 * q4], dv[d][4 * q4 + 1]),
+                                                                 pack_bf16x2(dv[d][4 * q4 + 2], dv[d][4 * q4 + 3]));
+            }
+    }
+}
+
+extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
+    DICOW_REQUIRE(a && a->q && a->k && a->v && a->o && a->d_o && a->lse && a->delta && a->dq && a->dk && a->dv,
+                  "attn_bwd: null operand");
+    DICOW_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0, "attn_bwd: empty problem");
+    const int64_t rs[] = {a->q_rs, a->k_rs, a->v_rs, a->o_rs, a->do_rs, a->dq_rs, a->dk_rs, a->dv_rs,
+                          a->q_bs, a->k_bs, a->v_bs, a->o_bs, a->do_bs, a->dq_bs, a->dk_bs, a->dv_bs};
+    for (int i = 0; i < 16; ++i) DICOW_REQUIRE(rs[i] % 4 == 0, "attn_bwd: strides must keep 8-byte alignment");
+    DICOW_REQUIRE(a->q_rs % 8 == 0 && a->k_rs % 8 == 0 && a->v_rs % 8 == 0 && a->do_rs % 8 == 0, "attn_bwd: q/k/v/dO row strides %% 8");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t groups = (int64_t)a->B * a->Lq * a->H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, st,
+                       (const unsigned short*)a->o, (const unsigned short*)a->d_o, a->delta, a->o_bs, a->o_rs, a->do_bs,
+                       a->do_rs, a->B, a->H, a->Lq);
+    DICOW_CHECK_LAUNCH("attn_delta");
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(dicow_cdiv(a->Lq, 128), a->H, a->B), dim3(256), 0, st, *a);
+    DICOW_CHECK_LAUNCH("attn_bwd_dq");
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(dicow_cdiv(a->Lk, 128), a->H, a->B), dim3(256), 0, st, *a);
+    DICOW_CHECK_LAUNCH("attn_bwd_dkv");
+    return DICOW_OK;
+}

@@ -185,3 +185,22 @@ def attn_fwd(q, k, v, o, lse=None, causal=False):
     a.B, a.Lq, a.H = q.shape[0], q.shape[1], q.shape[2]
     a.Lk, a.causal = k.shape[1], int(causal)
     L.call_struct("dicow_attn_fwd", a)
+
+
+def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0):
+    """Backward of attn_fwd.  All [B,L,H,64] bf16 views; lse/delta [B,H,Lq] fp32 (delta is workspace)."""
+    a = L.AttnBwdArgs()
+    a.q, a.k, a.v, a.o, a.d_o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr()
+    a.lse, a.delta = lse.data_ptr(), delta.data_ptr()
+    a.dq, a.dk, a.dv = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    a.q_bs, a.q_rs = _bs_rs(q, "q")
+    a.k_bs, a.k_rs = _bs_rs(k, "k")
+    a.v_bs, a.v_rs = _bs_rs(v, "v")
+    a.o_bs, a.o_rs = _bs_rs(o, "o")
+    a.do_bs, a.do_rs = _bs_rs(d_o, "d_o")
+    a.dq_bs, a.dq_rs = _bs_rs(dq, "dq")
+    a.dk_bs, a.dk_rs = _bs_rs(dk, "dk")
+    a.dv_bs, a.dv_rs = _bs_rs(dv, "dv")
+    a.B, a.Lq, a.H = q.shape[0], q.shape[1], q.shape[2]
+    a.Lk, a.causal, a.dq_scale = k.shape[1], int(causal), dq_scale
+    L.call_struct("dicow_attn_bwd", a)
