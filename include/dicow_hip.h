@@ -40,12 +40,13 @@ const char* dicow_last_error(void);
 /* ------------------------------------------------------------------------------------------------ casts
  * AMP weight preparation (configs/base.yaml:49 `bf16: true`): fp32 master -> bf16 compute copies.      */
 int dicow_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream);
-/* [R,C] fp32 -> bf16 [R,C] (dst, may be NULL) and bf16 [C,R] (dst_t, may be NULL): the transposed copy is the
- * dgrad operand of every Linear. */
-int dicow_cast_transpose_f32_to_bf16(const float* src, void* dst, void* dst_t, int R, int C, void* stream);
-/* Conv1d weight [O,C,3] fp32 -> bf16 [O,Kpad], k = tap*C + c (tap-major), zero padded to Kpad >= 3C:
- * the GEMM view of conv1/conv2 (encoder.py:167-168). */
-int dicow_conv_weight_pack(const float* w, void* dst, int O, int C, int Kpad, void* stream);
+/* [R,C] fp32 -> bf16 [R,C] (dst, row stride ld; may be NULL) and bf16 [C,R] (dst_t, row stride ld_t; may be NULL):
+ * the transposed copy is the dgrad operand of every Linear; the strides let q/k/v land in one fused [3D,D] / [D,3D]. */
+int dicow_cast_transpose_f32_to_bf16(const float* src, void* dst, int64_t ld, void* dst_t, int64_t ld_t, int R, int C,
+                                     void* stream);
+/* Conv1d weight [O,C,3] fp32 -> bf16 [O,Kpad] (dst) and its transpose [Kpad,O] (dst_t; either may be NULL),
+ * k = tap*C + c (tap-major), zero padded to Kpad >= 3C: the GEMM view of conv1/conv2 (encoder.py:167-168). */
+int dicow_conv_weight_pack(const float* w, void* dst, void* dst_t, int O, int C, int Kpad, void* stream);
 /* inverse mapping for the weight gradient: [O,Kpad] fp32 (tap-major) accumulated into [O,C,3] fp32 */
 int dicow_conv_weight_unpack_grad(const float* g_packed, float* g_w, int O, int C, int Kpad, void* stream);
 /* input_features [B,M,Tin] fp32 -> time-major bf16 [B, Tin+2, M], rows 0 and Tin+1 zero (conv padding=1). */
@@ -137,7 +138,7 @@ typedef struct {
     const float* bias; const float* residual; void* aux;
     int M, N, K;
     int64_t lda, ldb, ldc, ldr, ldaux;
-    int batch; int64_t strideA, strideB, strideC;   /* grid.z batches (conv stem: per-utterance strided views) */
+    int batch; int64_t strideA, strideB, strideC, strideAux;   /* grid.z batches (conv stem: per-utterance strided views) */
     int flags; float scale; int scale_ncols;
 } dicow_gemm_args;
 int dicow_gemm_nt(const dicow_gemm_args* a, void* stream);
@@ -176,6 +177,52 @@ typedef struct {
     float dq_scale;                                 /* head_dim^-0.5 folded into dq (gradient of the pre-scale) */
 } dicow_attn_bwd_args;
 int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------ loss
+ * Fused log-softmax + cross-entropy on the LM-head logits (bf16 [rows, ld], V valid columns).
+ * Hard-label fallback (src/models/dicow/modeling_dicow.py:310-323): CE(ignore_index=-100) for `labels` and
+ * `upp_labels`, per-token min; caller divides loss_sum by rows (mean over ALL positions).
+ * Soft-label loss (modeling_dicow.py:95-144, soft != 0): rows whose label is a timestamp token use the Gaussian-
+ * smoothed target ts_w[ts_index[label], :] scattered at ts_ids (:35-93); both losses masked by labels != -100;
+ * caller divides loss_sum by max(count, 1).
+ * Backward: d_logits = grad_scale[0] * (softmax - target of the argmin branch) in bf16 (grad_scale on device so
+ * that no host sync is needed for the 1/count normalisation).                                                  */
+typedef struct {
+    const void* logits; int64_t ld; int rows; int V;
+    const int64_t* labels; const int64_t* upp_labels;   /* [rows]; upp_labels may be NULL */
+    int soft;
+    const int32_t* ts_index;                            /* [V] timestamp row of a token id, -1 if none (NULL: no smoothing) */
+    const int32_t* ts_ids;                              /* [n_ts] sorted timestamp token ids */
+    const float* ts_w;                                  /* [n_ts, n_ts] row-normalised Gaussian weights */
+    int n_ts;
+    float* lse; float* row_loss; int32_t* choice;       /* [rows] outputs of fwd, inputs of bwd */
+    float* loss_sum; float* count;                      /* scalars, ACCUMULATED (zero them first) */
+    void* d_logits;                                     /* bwd: bf16 [rows, ld] (pad columns written as 0) */
+} dicow_ce_args;
+int dicow_ce_loss_fwd(const dicow_ce_args* a, void* stream);
+int dicow_ce_loss_bwd(const dicow_ce_args* a, const float* grad_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ decoder embedding
+ * h[b,l,:] = embed_tokens[ids[b,l]] + embed_positions[l]   (HF:modeling_whisper.py:737,754-762), fp32.     */
+int dicow_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float* out, int B, int Lq, int D, void* stream);
+/* d_tok[ids] += g (atomics), d_pos[l] += sum_b g[b,l]; either output may be NULL (frozen). */
+int dicow_embed_bwd(const int64_t* ids, const float* g, float* d_tok, float* d_pos, int B, int Lq, int D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ conv-stem backward helpers
+ * out = g * gelu'(pre)   (bf16, elementwise): gradient through the GELU after conv2 (encoder.py:168).     */
+int dicow_gelu_bwd_bf16(const void* g, const void* pre, void* out, int64_t n, void* stream);
+/* col2im of the conv2 (k=3,s=2,p=1) input gradient + GELU' of conv1 (encoder.py:167):
+ *   dA2 bf16 [B, T2, 3*C] (tap-major im2col gradient)  ->  d_pre1 bf16 [B, 2*T2, C] = gelu'(pre1) * scatter-add */
+int dicow_conv2_col2im_gelu_bwd(const void* dA2, const void* pre1, void* d_pre1, int B, int T2, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ optimizer
+ * Fused AdamW + global-norm clipping on flat fp32 regions (src/models/containers.py:100-114 two param groups;
+ * HF Trainer max_grad_norm 1.0).  dicow_sumsq_f32 accumulates sum(x^2) into out[0]; dicow_adamw_f32 applies
+ *   g' = g * min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6));  decoupled weight decay; bias-corrected moments.   */
+int dicow_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
+int dicow_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, const float* gnorm_sq, float max_norm, void* stream);
 
 #ifdef __cplusplus
 }

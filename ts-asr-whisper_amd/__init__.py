@@ -8,5 +8,8 @@ There is NO CPU fallback: every op raises if the HIP library is missing or the t
 on a GPU.  The CPU oracle lives in ``oracle/`` and is test infrastructure only.
 """
 from . import _lib  # noqa: F401
+from .config import DiCoWConfig, PRESETS  # noqa: F401
+from .modeling import (FDDT, DiCoWEncoder, DiCoW, DiCoWForConditionalGeneration, SpeakerCommunicationBlock,  # noqa: F401
+                       shift_tokens_right, build_ts_tables)
 
-__all__ = ["_lib"]
+__all__ = ["DiCoWConfig", "FDDT", "DiCoWEncoder", "DiCoW", "DiCoWForConditionalGeneration", "SpeakerCommunicationBlock"]

@@ -28,7 +28,7 @@ class GemmArgs(C.Structure):
     _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("bias", c_vp), ("residual", c_vp), ("aux", c_vp),
                 ("M", c_i), ("N", c_i), ("K", c_i),
                 ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("ldr", c_i64), ("ldaux", c_i64),
-                ("batch", c_i), ("strideA", c_i64), ("strideB", c_i64), ("strideC", c_i64),
+                ("batch", c_i), ("strideA", c_i64), ("strideB", c_i64), ("strideC", c_i64), ("strideAux", c_i64),
                 ("flags", c_i), ("scale", c_f), ("scale_ncols", c_i)]
 
 
@@ -54,13 +54,20 @@ class AttnBwdArgs(C.Structure):
                 ("B", c_i), ("H", c_i), ("Lq", c_i), ("Lk", c_i), ("causal", c_i), ("dq_scale", c_f)]
 
 
+class CeArgs(C.Structure):
+    _fields_ = [("logits", c_vp), ("ld", c_i64), ("rows", c_i), ("V", c_i), ("labels", c_vp), ("upp_labels", c_vp),
+                ("soft", c_i), ("ts_index", c_vp), ("ts_ids", c_vp), ("ts_w", c_vp), ("n_ts", c_i),
+                ("lse", c_vp), ("row_loss", c_vp), ("choice", c_vp), ("loss_sum", c_vp), ("count", c_vp),
+                ("d_logits", c_vp)]
+
+
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_SCALE_N, EPI_GELU_BWD, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 
 # name -> argtypes ; every function returns int
 _SIGS = {
     "dicow_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
-    "dicow_cast_transpose_f32_to_bf16": [c_vp, c_vp, c_vp, c_i, c_i, c_vp],
-    "dicow_conv_weight_pack": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "dicow_cast_transpose_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp],
+    "dicow_conv_weight_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_conv_weight_unpack_grad": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_mel_to_timemajor": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_colsum_bf16": [c_vp, c_i64, c_vp, c_i, c_i, c_vp],
@@ -73,6 +80,14 @@ _SIGS = {
     "dicow_gemm_tn": [C.POINTER(GemmTnArgs), c_vp],
     "dicow_attn_fwd": [C.POINTER(AttnFwdArgs), c_vp],
     "dicow_attn_bwd": [C.POINTER(AttnBwdArgs), c_vp],
+    "dicow_ce_loss_fwd": [C.POINTER(CeArgs), c_vp],
+    "dicow_ce_loss_bwd": [C.POINTER(CeArgs), c_vp, c_vp],
+    "dicow_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "dicow_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "dicow_gelu_bwd_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
+    "dicow_conv2_col2im_gelu_bwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "dicow_sumsq_f32": [c_vp, c_i64, c_vp, c_vp],
+    "dicow_adamw_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_f, c_vp],
 }
 
 

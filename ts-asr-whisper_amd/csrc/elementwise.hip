@@ -38,7 +38,7 @@ extern "C" int dicow_cast_f32_to_bf16(const float* src, void* dst, int64_t n, vo
 
 // [R,C] fp32 -> bf16 [R,C] and bf16 [C,R]; 64x64 tiles through LDS so that both stores are coalesced.
 __global__ void cast_transpose_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
-                                      unsigned short* __restrict__ dst_t, int R, int C) {
+                                      unsigned short* __restrict__ dst_t, int R, int C, int64_t ld, int64_t ld_t) {
     __shared__ unsigned short tile[64][66];
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 256 threads: 4 rows per pass
@@ -47,7 +47,7 @@ __global__ void cast_transpose_kernel(const float* __restrict__ src, unsigned sh
         unsigned short v = 0;
         if (r < R && c < C) {
             v = f2bfbits(src[(int64_t)r * C + c]);
-            if (dst) dst[(int64_t)r * C + c] = v;
+            if (dst) dst[(int64_t)r * ld + c] = v;
         }
         tile[i][tx] = v;
     }
@@ -55,21 +55,24 @@ __global__ void cast_transpose_kernel(const float* __restrict__ src, unsigned sh
     if (!dst_t) return;
     for (int i = ty; i < 64; i += 4) {
         const int c = c0 + i, r = r0 + tx;
-        if (r < R && c < C) dst_t[(int64_t)c * R + r] = tile[tx][i];
+        if (r < R && c < C) dst_t[(int64_t)c * ld_t + r] = tile[tx][i];
     }
 }
 
-extern "C" int dicow_cast_transpose_f32_to_bf16(const float* src, void* dst, void* dst_t, int R, int C, void* stream) {
+extern "C" int dicow_cast_transpose_f32_to_bf16(const float* src, void* dst, int64_t ld, void* dst_t, int64_t ld_t, int R,
+                                                int C, void* stream) {
     DICOW_REQUIRE(src && (dst || dst_t) && R > 0 && C > 0, "cast_transpose: bad args");
+    DICOW_REQUIRE((!dst || ld >= C) && (!dst_t || ld_t >= R), "cast_transpose: leading dimensions too small");
     dim3 grid(dicow_cdiv(C, 64), dicow_cdiv(R, 64));
     hipLaunchKernelGGL(cast_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, src, (unsigned short*)dst,
-                       (unsigned short*)dst_t, R, C);
+                       (unsigned short*)dst_t, R, C, ld, ld_t);
     DICOW_CHECK_LAUNCH("cast_transpose");
     return DICOW_OK;
 }
 
 // Conv1d weight [O,C,3] -> [O,Kpad] with k = tap*C + c
-__global__ void conv_weight_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst, int O, int C, int Kpad) {
+__global__ void conv_weight_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst,
+                                        unsigned short* __restrict__ dst_t, int O, int C, int Kpad) {
     const int64_t n = (int64_t)O * Kpad;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const int o = (int)(i / Kpad), k = (int)(i - (int64_t)o * Kpad);
@@ -78,15 +81,17 @@ __global__ void conv_weight_pack_kernel(const float* __restrict__ w, unsigned sh
             const int tap = k / C, c = k - tap * C;
             v = w[((int64_t)o * C + c) * 3 + tap];
         }
-        dst[i] = f2bfbits(v);
+        if (dst) dst[i] = f2bfbits(v);
+        if (dst_t) dst_t[(int64_t)k * O + o] = f2bfbits(v);
     }
 }
 
-extern "C" int dicow_conv_weight_pack(const float* w, void* dst, int O, int C, int Kpad, void* stream) {
-    DICOW_REQUIRE(w && dst && O > 0 && C > 0 && Kpad >= 3 * C, "conv_weight_pack: bad args");
+extern "C" int dicow_conv_weight_pack(const float* w, void* dst, void* dst_t, int O, int C, int Kpad, void* stream) {
+    DICOW_REQUIRE(w && (dst || dst_t) && O > 0 && C > 0 && Kpad >= 3 * C, "conv_weight_pack: bad args");
     const int64_t n = (int64_t)O * Kpad;
     int grid = (int)((n + 255) / 256); if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(conv_weight_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)dst, O, C, Kpad);
+    hipLaunchKernelGGL(conv_weight_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, (unsigned short*)dst,
+                       (unsigned short*)dst_t, O, C, Kpad);
     DICOW_CHECK_LAUNCH("conv_weight_pack");
     return DICOW_OK;
 }
@@ -179,5 +184,175 @@ extern "C" int dicow_sum_over_batch(const float* g, float* out, int B, int64_t T
     int grid = (int)((TD / 4 + 255) / 256); if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(sum_over_batch_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, out, B, TD);
     DICOW_CHECK_LAUNCH("sum_over_batch");
+    return DICOW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder embedding
+__global__ void embed_fwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ tok, const float* __restrict__ pos,
+                                 float* __restrict__ out, int Lq, int D) {
+    const int row = blockIdx.x;                   // b*Lq + l
+    const int l = row % Lq;
+    const int64_t id = ids[row];
+    const float4* t = reinterpret_cast<const float4*>(tok + id * D);
+    const float4* p = reinterpret_cast<const float4*>(pos + (int64_t)l * D);
+    float4* o = reinterpret_cast<float4*>(out + (int64_t)row * D);
+    for (int i = threadIdx.x; i < D / 4; i += blockDim.x) {
+        const float4 a = t[i], b = p[i];
+        o[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+}
+
+extern "C" int dicow_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float* out, int B, int Lq, int D, void* stream) {
+    DICOW_REQUIRE(ids && tok && pos && out && B > 0 && Lq > 0 && D % 4 == 0, "embed_fwd: bad args");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(B * Lq), dim3(256), 0, (hipStream_t)stream, ids, tok, pos, out, Lq, D);
+    DICOW_CHECK_LAUNCH("embed_fwd");
+    return DICOW_OK;
+}
+
+__global__ void embed_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ g, float* __restrict__ d_tok,
+                                 float* __restrict__ d_pos, int Lq, int D) {
+    const int row = blockIdx.x;
+    const int l = row % Lq;
+    const int64_t id = ids[row];
+    const float* gr = g + (int64_t)row * D;
+    for (int i = threadIdx.x; i < D; i += blockDim.x) {
+        const float v = gr[i];
+        if (d_tok) atomicAdd(d_tok + id * D + i, v);
+        if (d_pos) atomicAdd(d_pos + (int64_t)l * D + i, v);
+    }
+}
+
+extern "C" int dicow_embed_bwd(const int64_t* ids, const float* g, float* d_tok, float* d_pos, int B, int Lq, int D, void* stream) {
+    DICOW_REQUIRE(ids && g && B > 0 && Lq > 0 && D > 0, "embed_bwd: bad args");
+    if (!d_tok && !d_pos) return DICOW_OK;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(B * Lq), dim3(256), 0, (hipStream_t)stream, ids, g, d_tok, d_pos, Lq, D);
+    DICOW_CHECK_LAUNCH("embed_bwd");
+    return DICOW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ conv-stem backward helpers
+__global__ void gelu_bwd_bf16_kernel(const unsigned short* __restrict__ g, const unsigned short* __restrict__ pre,
+                                     unsigned short* __restrict__ out, int64_t n) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint2 a = reinterpret_cast<const uint2*>(g)[i], b = reinterpret_cast<const uint2*>(pre)[i];
+        const float r0 = __uint_as_float(a.x << 16) * gelu_erf_grad(__uint_as_float(b.x << 16));
+        const float r1 = __uint_as_float(a.x & 0xffff0000u) * gelu_erf_grad(__uint_as_float(b.x & 0xffff0000u));
+        const float r2 = __uint_as_float(a.y << 16) * gelu_erf_grad(__uint_as_float(b.y << 16));
+        const float r3 = __uint_as_float(a.y & 0xffff0000u) * gelu_erf_grad(__uint_as_float(b.y & 0xffff0000u));
+        reinterpret_cast<uint2*>(out)[i] = make_uint2(pack_bf16x2(r0, r1), pack_bf16x2(r2, r3));
+    }
+}
+
+extern "C" int dicow_gelu_bwd_bf16(const void* g, const void* pre, void* out, int64_t n, void* stream) {
+    DICOW_REQUIRE(g && pre && out && n > 0 && n % 4 == 0, "gelu_bwd_bf16: bad args (n %% 4)");
+    int grid = (int)((n / 4 + 255) / 256); if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(gelu_bwd_bf16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)g,
+                       (const unsigned short*)pre, (unsigned short*)out, n);
+    DICOW_CHECK_LAUNCH("gelu_bwd_bf16");
+    return DICOW_OK;
+}
+
+// padded time index p = s + 1 (s = conv1 output frame); im2col row t of conv2 covers padded rows 2t, 2t+1, 2t+2 (taps 0,1,2)
+__global__ void conv2_col2im_gelu_bwd_kernel(const unsigned short* __restrict__ dA2, const unsigned short* __restrict__ pre1,
+                                             unsigned short* __restrict__ d_pre1, int T2, int C) {
+    const int b = blockIdx.y, s = blockIdx.x;                      // s in [0, 2*T2)
+    const int p = s + 1;
+    const unsigned short* base = dA2 + (int64_t)b * T2 * 3 * C;
+    const unsigned short* src0 = nullptr; const unsigned short* src1 = nullptr;
+    if (p & 1) {
+        const int t = (p - 1) >> 1;
+        if (t < T2) src0 = base + (int64_t)t * 3 * C + C;          // tap 1
+    } else {
+        const int t = p >> 1;
+        if (t < T2) src0 = base + (int64_t)t * 3 * C;              // tap 0
+        if (t - 1 >= 0) src1 = base + (int64_t)(t - 1) * 3 * C + 2 * C;   // tap 2
+    }
+    const int64_t off = ((int64_t)b * 2 * T2 + s) * C;
+    for (int c = threadIdx.x * 2; c < C; c += blockDim.x * 2) {
+        float g0 = 0.f, g1 = 0.f;
+        if (src0) { const unsigned u = *reinterpret_cast<const unsigned*>(src0 + c); g0 += __uint_as_float(u << 16); g1 += __uint_as_float(u & 0xffff0000u); }
+        if (src1) { const unsigned u = *reinterpret_cast<const unsigned*>(src1 + c); g0 += __uint_as_float(u << 16); g1 += __uint_as_float(u & 0xffff0000u); }
+        const unsigned pu = *reinterpret_cast<const unsigned*>(pre1 + off + c);
+        g0 *= gelu_erf_grad(__uint_as_float(pu << 16));
+        g1 *= gelu_erf_grad(__uint_as_float(pu & 0xffff0000u));
+        *reinterpret_cast<unsigned*>(d_pre1 + off + c) = pack_bf16x2(g0, g1);
+    }
+}
+
+extern "C" int dicow_conv2_col2im_gelu_bwd(const void* dA2, const void* pre1, void* d_pre1, int B, int T2, int C, void* stream) {
+    DICOW_REQUIRE(dA2 && pre1 && d_pre1 && B > 0 && T2 > 0 && C % 2 == 0, "conv2_col2im_gelu_bwd: bad args");
+    hipLaunchKernelGGL(conv2_col2im_gelu_bwd_kernel, dim3(2 * T2, B), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)dA2, (const unsigned short*)pre1, (unsigned short*)d_pre1, T2, C);
+    DICOW_CHECK_LAUNCH("conv2_col2im_gelu_bwd");
+    return DICOW_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ optimizer
+__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = reinterpret_cast<const float4*>(x)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int dicow_sumsq_f32(const float* x, int64_t n, float* out, void* stream) {
+    DICOW_REQUIRE(x && out && n > 0, "sumsq_f32: bad args");
+    int grid = (int)((n / 4 + 255) / 256); if (grid < 1) grid = 1; if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, out);
+    DICOW_CHECK_LAUNCH("sumsq_f32");
+    return DICOW_OK;
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                             const float* __restrict__ gnorm_sq, float max_norm) {
+    float clip = 1.f;
+    if (gnorm_sq && max_norm > 0.f) {
+        const float c = max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f);
+        clip = c < 1.f ? c : 1.f;
+    }
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
+        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gr = ga[e] * clip;
+            pa[e] *= 1.f - lr * wd;
+            ma[e] = b1 * ma[e] + (1.f - b1) * gr;
+            va[e] = b2 * va[e] + (1.f - b2) * gr * gr;
+            const float denom = sqrtf(va[e]) / sqrtf(bc2) + eps;
+            pa[e] -= (lr / bc1) * (ma[e] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+    }
+    for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gr = g[i] * clip;
+        float pv = p[i] * (1.f - lr * wd);
+        const float mv = b1 * m[i] + (1.f - b1) * gr, vv2 = b2 * v[i] + (1.f - b2) * gr * gr;
+        pv -= (lr / bc1) * (mv / (sqrtf(vv2) / sqrtf(bc2) + eps));
+        p[i] = pv; m[i] = mv; v[i] = vv2;
+    }
+}
+
+extern "C" int dicow_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int step, const float* gnorm_sq, float max_norm, void* stream) {
+    DICOW_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adamw_f32: bad args");
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    int grid = (int)((n / 4 + 255) / 256); if (grid < 1) grid = 1; if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2, gnorm_sq, max_norm);
+    DICOW_CHECK_LAUNCH("adamw_f32");
     return DICOW_OK;
 }

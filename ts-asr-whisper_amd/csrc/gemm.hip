@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const dicow_gemm_args a
     const int hh = lane >> 5;
     unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)bz * a.strideC;
     float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
-    unsigned short* aux = reinterpret_cast<unsigned short*>(a.aux);
+    unsigned short* aux = reinterpret_cast<unsigned short*>(a.aux) + (int64_t)bz * a.strideAux;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int m = m0 + wm * 64 + j * 32 + (lane & 31);

@@ -1,0 +1,653 @@
+"""Forward / backward orchestration of the DiCoW encoder and Whisper decoder over the HIP C ABI.
+
+No torch compute kernels on the hot path: torch is used for device memory (``torch.empty``), streams, and a
+handful of tiny integer / scalar ops.  Every arithmetic step is a ``libdicow_hip.so`` entry point (``ops.py``).
+
+Precision policy = the reference's ``bf16: true`` AMP recipe (configs/base.yaml:49): bf16 GEMM /
+attention operands and outputs, fp32 accumulation, fp32 LayerNorm / FDDT / residual stream / loss, fp32 master
+parameters and gradients.
+
+Reference structure followed (paths under /root/reference): encoder.py:140-246 (stem, initial FDDT, positions,
+per-layer FDDT + optional speaker-communication block + WhisperEncoderLayer, final LayerNorm),
+layers.py:145-193 (SCB), HF modeling_whisper.py WhisperEncoderLayer / WhisperDecoderLayer / WhisperAttention,
+modeling_dicow.py:248-338 (shift, tied LM head, losses).
+"""
+from types import SimpleNamespace as NS
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+CLS = ("silence_linear", "target_linear", "non_target_linear", "overlap_linear")     # stno channel order S,T,N,O
+
+
+def _e(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
+
+
+def _ceil(a, b):
+    return (a + b - 1) // b * b
+
+
+class GradSink:
+    """fp32 gradient buffers for a set of parameters, allocated as ONE zeroed flat buffer (wgrad GEMMs and
+    column reductions accumulate into it).  ``get(p)`` returns None for parameters that do not require grad."""
+
+    def __init__(self, params, dev, extra_rows=None):
+        self.index = {}
+        off = 0
+        extra_rows = extra_rows or {}
+        for p in params:
+            if p is None or not p.requires_grad or id(p) in self.index:
+                continue
+            n = p.numel() + extra_rows.get(id(p), 0)
+            self.index[id(p)] = (off, p.shape, p.numel())
+            off += _ceil(n, 64)
+        self.flat = torch.zeros(max(off, 1), dtype=F32, device=dev)
+
+    def get(self, p):
+        if p is None or id(p) not in self.index:
+            return None
+        off, shape, n = self.index[id(p)]
+        return self.flat[off:off + n].view(shape)
+
+    def raw(self, p, n):
+        off, _, _ = self.index[id(p)]
+        return self.flat[off:off + n]
+
+
+# ------------------------------------------------------------------------------------------------ weight preparation
+class LinW:
+    """bf16 compute copies of one Linear: w [N,K] (forward), wt [K,N] (dgrad), fp32 bias."""
+    __slots__ = ("w", "wt", "b", "N", "K")
+
+
+def prep_linear(weights, biases, dev, need_t=True, n_pad=None, scale_info=None):
+    """Fuse several Linear weights [N_i, K] (same K) into one bf16 [sum N_i, K] (+ transposed copy)."""
+    K = weights[0].shape[1]
+    Ns = [w.shape[0] for w in weights]
+    N = sum(Ns)
+    Np = N if n_pad is None else n_pad
+    lw = LinW()
+    lw.N, lw.K = Np, K
+    lw.w = torch.zeros(Np, K, dtype=BF16, device=dev) if Np != N else _e((Np, K), BF16, dev)
+    lw.wt = (torch.zeros(K, Np, dtype=BF16, device=dev) if Np != N else _e((K, Np), BF16, dev)) if need_t else None
+    off = 0
+    for w, n in zip(weights, Ns):
+        ops.cast_transpose_bf16(w.detach(), out=lw.w[off:off + n], out_t=None if lw.wt is None else lw.wt[:, off:off + n],
+                                ld=K, ld_t=Np)
+        off += n
+    if biases is None or all(b is None for b in biases):
+        lw.b = None
+    else:
+        parts = [(b.detach() if b is not None else torch.zeros(n, dtype=F32, device=dev)) for b, n in zip(biases, Ns)]
+        lw.b = parts[0] if len(parts) == 1 else torch.cat(parts)
+    return lw
+
+
+def prep_attention(att, dev, fuse_qkv=True):
+    a = NS()
+    if fuse_qkv:
+        a.qkv = prep_linear([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight],
+                            [att.q_proj.bias, None, att.v_proj.bias], dev)
+    else:
+        a.q = prep_linear([att.q_proj.weight], [att.q_proj.bias], dev)
+        a.kv = prep_linear([att.k_proj.weight, att.v_proj.weight], [None, att.v_proj.bias], dev)
+    a.o = prep_linear([att.out_proj.weight], [att.out_proj.bias], dev)
+    return a
+
+
+def fddt_ptrs(fddt, cfg):
+    """(mode, w[4], b[4]) raw parameter tensors of an FDDT module in S,T,N,O order; disabled classes -> None."""
+    if fddt is None:
+        return ops.MODE_NONE, (None,) * 4, (None,) * 4
+    w, b = [], []
+    for c in CLS:
+        m = getattr(fddt, c, None)
+        if fddt.bias_only:
+            w.append(None)
+            b.append(None if m is None else m)
+        else:
+            w.append(None if m is None else m.weight)
+            b.append(None if m is None else m.bias)
+    return (ops.MODE_BIAS if fddt.bias_only else ops.MODE_DIAG), tuple(w), tuple(b)
+
+
+# ------------------------------------------------------------------------------------------------ building blocks
+def linear_fwd(x, lw, M, out_dtype=BF16, residual=None, gelu_aux=None, flags=0, scale=1.0, scale_ncols=0, out=None):
+    dev = x.device
+    if out is None:
+        out = _e((M, lw.N), out_dtype, dev)
+    ops.gemm_nt(x, lw.w, out, M, lw.N, lw.K, bias=lw.b, residual=residual, aux=gelu_aux,
+                flags=flags | (L.EPI_GELU if gelu_aux is not None else 0), scale=scale, scale_ncols=scale_ncols)
+    return out
+
+
+def linear_dgrad(dy, lw, M, aux=None, out=None, out_dtype=BF16, accumulate=False, dy_cols=None):
+    """dx[M,K] = dy[M,N] @ W[N,K]  (NT GEMM against the transposed copy); optional GELU' epilogue."""
+    N = lw.N if dy_cols is None else dy_cols
+    if out is None:
+        out = _e((M, lw.K), out_dtype, dy.device)
+    flags = (L.EPI_GELU_BWD if aux is not None else 0) | (L.EPI_ACCUM if accumulate else 0)
+    ops.gemm_nt(dy, lw.wt, out, M, lw.K, N, lda=dy.stride(0), ldb=lw.wt.stride(0), aux=aux, flags=flags)
+    return out
+
+
+def linear_wgrad(dy, x, gw, M, n_rows=None):
+    """dW[N,K] += dy[M,N]^T @ x[M,K]; dy/x may be column slices (strided)."""
+    if gw is None:
+        return
+    N = dy.shape[1] if n_rows is None else n_rows
+    ops.gemm_tn(dy, x, gw, M, N, x.shape[1], lda=dy.stride(0), ldb=x.stride(0), ldc=gw.stride(0))
+
+
+def bias_grad(dy, gb):
+    if gb is not None:
+        ops.colsum_bf16(dy, gb)
+
+
+def heads(t, B, Lx, H):
+    """[B*L, >=H*64] column slice -> [B, L, H, 64] strided view."""
+    return t.as_strided((B, Lx, H, 64), (Lx * t.stride(0), t.stride(0), 64, 1), t.storage_offset())
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+class EncoderEngine:
+    def __init__(self, enc):
+        self.enc = enc
+        self.cfg = enc.config
+
+    # -- bf16 weight copies (once per optimizer step)
+    def prepare(self):
+        enc, cfg = self.enc, self.cfg
+        dev = enc.conv1.weight.device
+        D, M = cfg.d_model, cfg.num_mel_bins
+        W = NS()
+        W.k1 = _ceil(3 * M, 64)
+        W.conv1, W.conv1_t = ops.conv_weight_pack(enc.conv1.weight.detach(), W.k1, want_t=True)
+        W.conv2, W.conv2_t = ops.conv_weight_pack(enc.conv2.weight.detach(), 3 * D, want_t=True)
+        W.layers = []
+        for lyr in enc.layers:
+            w = NS()
+            w.att = prep_attention(lyr.self_attn, dev)
+            w.fc1 = prep_linear([lyr.fc1.weight], [lyr.fc1.bias], dev)
+            w.fc2 = prep_linear([lyr.fc2.weight], [lyr.fc2.bias], dev)
+            W.layers.append(w)
+        W.scb = []
+        if cfg.use_enrollments and cfg.scb_layers:
+            for blk in enc.ca_enrolls:
+                s = NS()
+                s.att = prep_attention(blk.cae.cross_attn, dev, fuse_qkv=False)
+                s.f0 = prep_linear([blk.cae.ffn[0].weight], [blk.cae.ffn[0].bias], dev)
+                s.f3 = prep_linear([blk.cae.ffn[3].weight], [blk.cae.ffn[3].bias], dev)
+                W.scb.append(s)
+        self.W = W
+        return W
+
+    def _fddt_full_fwd(self, fddt, h_in, stno, bstride, rows, T, D, h_out):
+        raise L.DicowError("full (D x D) FDDT inside the fused encoder path is not wired yet; use fddt_is_diagonal=True "
+                           "or the standalone FDDT module")
+
+    # -- forward
+    def forward(self, input_features, stno_mask, enrollments=None, need_grad=True):
+        enc, cfg, W = self.enc, self.cfg, self.W
+        dev = input_features.device
+        if enrollments is not None:                      # encoder.py:152-154: interleave mixture / enrollment rows
+            input_features = torch.stack((input_features, enrollments["input_features"].to(dev)), dim=1).flatten(0, 1)
+            stno_mask = torch.stack((stno_mask, enrollments["stno_mask"].to(dev)), dim=1).flatten(0, 1)
+        B, M, Tin = input_features.shape
+        T, D, H, F_ = cfg.max_source_positions, cfg.d_model, cfg.encoder_attention_heads, cfg.encoder_ffn_dim
+        if Tin != 2 * T:
+            raise ValueError(f"Whisper expects the mel input features to be of length {2 * T}, but found {Tin}. "
+                             f"Make sure to pad the input mel features to {2 * T}.")
+        stno = stno_mask.to(device=dev, dtype=F32).contiguous()
+        S = NS(B0=B, T=T, stno=stno, layers=[], scb=[])
+        # ---- conv stem as two GEMMs over time-major views (encoder.py:167-170)
+        xt = torch.zeros(B * (Tin + 2) * M + W.k1, dtype=BF16, device=dev)        # + slack for the K padding reads
+        ops.mel_to_timemajor(input_features.to(F32), out=xt)
+        g1p = _e((B, Tin + 2, D), BF16, dev)
+        g1p[:, 0].zero_()
+        g1p[:, Tin + 1].zero_()
+        pre1 = _e((B, Tin, D), BF16, dev)
+        ops.gemm_nt(xt, W.conv1, g1p[:, 1:], Tin, D, W.k1, lda=M, bias=enc.conv1.bias.detach(), aux=pre1, flags=L.EPI_GELU,
+                    batch=B, strideA=(Tin + 2) * M, strideC=(Tin + 2) * D, strideAux=Tin * D)
+        x2 = _e((B * T, D), BF16, dev)
+        pre2 = _e((B * T, D), BF16, dev)
+        ops.gemm_nt(g1p, W.conv2, x2, T, D, 3 * D, lda=2 * D, bias=enc.conv2.bias.detach(), aux=pre2, flags=L.EPI_GELU,
+                    batch=B, strideA=(Tin + 2) * D, strideC=T * D, strideAux=T * D)
+        S.xt, S.g1p, S.pre1, S.pre2, S.x2 = xt, g1p, pre1, pre2, x2
+        # ---- initial FDDT + positions (encoder.py:173-180)
+        rows = B * T
+        pos = enc.embed_positions.weight
+        init_fddt = enc.initial_fddt if (cfg.use_fddt and cfg.use_pre_pos_fddt) else None
+        mode, fw, fb = fddt_ptrs(init_fddt, cfg)
+        h = _e((rows, D), F32, dev)
+        ops.fddt_ln_fwd(x2, rows, D, mode=mode, stno=stno, T=T, w=fw, b=fb, pos=pos.detach(), h_out=h)
+        bstride = 4 * T
+        Bc = B
+        for i, lyr in enumerate(enc.layers):
+            w = W.layers[i]
+            Ls = NS(h_in=h, B=Bc, bstride=bstride)
+            rows = Bc * T
+            fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None
+            mode, fw, fb = fddt_ptrs(fd, cfg)
+            use_scb = cfg.use_enrollments and cfg.scb_layers is not None and i < cfg.scb_layers
+            xln = _e((rows, D), BF16, dev)
+            mean, rstd = _e((rows,), F32, dev), _e((rows,), F32, dev)
+            ln = lyr.self_attn_layer_norm
+            if not use_scb:
+                hp = _e((rows, D), F32, dev) if mode != ops.MODE_NONE else h
+                ops.fddt_ln_fwd(h, rows, D, mode=mode, stno=stno, stno_bstride=bstride, T=T, w=fw, b=fb,
+                                h_out=hp if mode != ops.MODE_NONE else None, ln_w=ln.weight.detach(),
+                                ln_b=ln.bias.detach(), y_bf16=xln, mean=mean, rstd=rstd)
+            else:                                    # FDDT, then the speaker-communication block, then LayerNorm
+                hf = _e((rows, D), F32, dev) if mode != ops.MODE_NONE else h
+                if mode != ops.MODE_NONE:
+                    ops.fddt_ln_fwd(h, rows, D, mode=mode, stno=stno, stno_bstride=bstride, T=T, w=fw, b=fb, h_out=hf)
+                hs, scb_s = self._scb_fwd(i, hf, Bc, T)
+                Ls.scb = scb_s
+                Ls.hf = hf
+                if i == cfg.scb_layers - 1:          # drop the enrollment rows (encoder.py:210-213): even rows only
+                    Bc = Bc // 2
+                    rows = Bc * T
+                    hs = hs.view(Bc, 2, T, D)[:, 0].contiguous().view(rows, D)
+                    bstride = 8 * T
+                    xln = _e((rows, D), BF16, dev)
+                    mean, rstd = _e((rows,), F32, dev), _e((rows,), F32, dev)
+                    Ls.dropped = True
+                hp = hs
+                ops.fddt_ln_fwd(hs, rows, D, mode=ops.MODE_NONE, ln_w=ln.weight.detach(), ln_b=ln.bias.detach(),
+                                y_bf16=xln, mean=mean, rstd=rstd)
+            Ls.rows, Ls.B_after, Ls.hp, Ls.xln, Ls.mean, Ls.rstd = rows, Bc, hp, xln, mean, rstd
+            # ---- self-attention (HF WhisperAttention; q pre-scaled in the projection epilogue)
+            qkv = linear_fwd(xln, w.att.qkv, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+            o = _e((rows, D), BF16, dev)
+            lse = _e((Bc, H, T), F32, dev)
+            ops.attn_fwd(heads(qkv[:, :D], Bc, T, H), heads(qkv[:, D:2 * D], Bc, T, H), heads(qkv[:, 2 * D:], Bc, T, H),
+                         heads(o, Bc, T, H), lse)
+            h2 = linear_fwd(o, w.att.o, rows, out_dtype=F32, residual=hp)
+            # ---- feed-forward
+            ln2 = lyr.final_layer_norm
+            xln2 = _e((rows, D), BF16, dev)
+            mean2, rstd2 = _e((rows,), F32, dev), _e((rows,), F32, dev)
+            ops.fddt_ln_fwd(h2, rows, D, mode=ops.MODE_NONE, ln_w=ln2.weight.detach(), ln_b=ln2.bias.detach(), y_bf16=xln2,
+                            mean=mean2, rstd=rstd2)
+            u = _e((rows, F_), BF16, dev)
+            a = linear_fwd(xln2, w.fc1, rows, gelu_aux=u)
+            h = linear_fwd(a, w.fc2, rows, out_dtype=F32, residual=h2)
+            Ls.qkv, Ls.o, Ls.lse, Ls.h2, Ls.xln2, Ls.mean2, Ls.rstd2, Ls.u, Ls.a = qkv, o, lse, h2, xln2, mean2, rstd2, u, a
+            S.layers.append(Ls)
+        rows = Bc * T
+        S.h_last, S.B_out, S.bstride_out = h, Bc, bstride
+        enc_out = _e((rows, D), F32, dev)
+        enc_bf = _e((rows, D), BF16, dev)
+        S.meanf, S.rstdf = _e((rows,), F32, dev), _e((rows,), F32, dev)
+        ops.fddt_ln_fwd(h, rows, D, mode=ops.MODE_NONE, ln_w=enc.layer_norm.weight.detach(), ln_b=enc.layer_norm.bias.detach(),
+                        y_bf16=enc_bf, y_f32=enc_out, mean=S.meanf, rstd=S.rstdf)
+        S.enc_bf = enc_bf
+        return enc_out.view(Bc, T, D), S
+
+    # -- speaker communication block (layers.py:145-193) on interleaved rows: even = mixture, odd = enrollment
+    def _scb_fwd(self, i, hf, Bc, T):
+        enc, cfg = self.enc, self.cfg
+        w = self.W.scb[i]
+        blk = enc.ca_enrolls[i].cae
+        D, H, F_ = cfg.d_model, cfg.encoder_attention_heads, cfg.encoder_ffn_dim
+        dev = hf.device
+        rows = Bc * T
+        Bp = Bc // 2
+        rp = Bp * T
+        hb = ops.cast_bf16(hf)                                              # [rows, D] bf16 (GEMM operand)
+        h4 = hb.view(Bp, 2, T, D)
+        q_in = h4[:, 0].contiguous().view(rp, D)                            # mixture rows
+        kv_in = h4[:, 1].contiguous().view(rp, D)                           # enrollment rows
+        q = linear_fwd(q_in, w.att.q, rp, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+        kv = linear_fwd(kv_in, w.att.kv, rp)
+        o = _e((rp, D), BF16, dev)
+        lse = _e((Bp, H, T), F32, dev)
+        ops.attn_fwd(heads(q, Bp, T, H), heads(kv[:, :D], Bp, T, H), heads(kv[:, D:], Bp, T, H), heads(o, Bp, T, H), lse)
+        cat = _e((rp, 2 * D), BF16, dev)                                    # [attn_output | q]  (layers.py:161)
+        ops.gemm_nt(o, w.att.o.w, cat, rp, D, D, ldc=2 * D, bias=w.att.o.b)
+        cat[:, D:].copy_(q_in)
+        u = _e((rp, F_), BF16, dev)
+        a = linear_fwd(cat, w.f0, rp, gelu_aux=u)
+        upd = linear_fwd(a, w.f3, rp)                                       # bf16 [rp, D]
+        gate = torch.tanh(blk.cross_gate.gate.detach())
+        out = hf.clone()
+        o4 = out.view(Bp, 2, T, D)
+        o4[:, 0].add_(upd.view(Bp, T, D).float() * gate)
+        s = NS(q_in=q_in, kv_in=kv_in, q=q, kv=kv, o=o, lse=lse, cat=cat, u=u, a=a, upd=upd, Bp=Bp)
+        return out, s
+
+    def _scb_bwd(self, i, s, g, G, T):
+        """g: fp32 grad wrt SCB output [rows, D] (interleaved).  Returns grad wrt SCB input (fp32, same shape)."""
+        enc, cfg = self.enc, self.cfg
+        w = self.W.scb[i]
+        blk = enc.ca_enrolls[i].cae
+        D, H, F_ = cfg.d_model, cfg.encoder_attention_heads, cfg.encoder_ffn_dim
+        Bp, rp = s.Bp, s.Bp * T
+        dev = g.device
+        g4 = g.view(Bp, 2, T, D)
+        gq = g4[:, 0]                                                        # grad of q_out
+        gate_p = blk.cross_gate.gate
+        tg = torch.tanh(gate_p.detach())
+        ggate = G.get(gate_p)
+        if ggate is not None:
+            ggate.add_(((gq * s.upd.view(Bp, T, D).float()).sum() * (1 - tg * tg)).reshape(-1))
+        d_upd = (gq * tg).to(BF16).contiguous().view(rp, D)
+        bias_grad(d_upd, G.get(blk.ffn[3].bias))
+        linear_wgrad(d_upd, s.a, G.get(blk.ffn[3].weight), rp)
+        d_u = linear_dgrad(d_upd, w.f3, rp, aux=s.u)
+        bias_grad(d_u, G.get(blk.ffn[0].bias))
+        linear_wgrad(d_u, s.cat, G.get(blk.ffn[0].weight), rp)
+        d_cat = linear_dgrad(d_u, w.f0, rp)                                  # [rp, 2D]
+        d_attn = d_cat[:, :D]
+        att = blk.cross_attn
+        bias_grad(d_attn, G.get(att.out_proj.bias))
+        linear_wgrad(d_attn, s.o, G.get(att.out_proj.weight), rp)
+        d_o = _e((rp, D), BF16, dev)
+        ops.gemm_nt(d_attn, w.att.o.wt, d_o, rp, D, D, lda=2 * D)
+        dq = _e((rp, D), BF16, dev)
+        dkv = _e((rp, 2 * D), BF16, dev)
+        delta = _e((Bp, H, T), F32, dev)
+        ops.attn_bwd(heads(s.q, Bp, T, H), heads(s.kv[:, :D], Bp, T, H), heads(s.kv[:, D:], Bp, T, H), heads(s.o, Bp, T, H),
+                     heads(d_o, Bp, T, H), s.lse, delta, heads(dq, Bp, T, H), heads(dkv[:, :D], Bp, T, H),
+                     heads(dkv[:, D:], Bp, T, H), dq_scale=0.125)
+        bias_grad(dq, G.get(att.q_proj.bias))
+        bias_grad(dkv[:, D:], G.get(att.v_proj.bias))
+        linear_wgrad(dq, s.q_in, G.get(att.q_proj.weight), rp)
+        linear_wgrad(dkv[:, :D], s.kv_in, G.get(att.k_proj.weight), rp)
+        linear_wgrad(dkv[:, D:], s.kv_in, G.get(att.v_proj.weight), rp)
+        d_qin = linear_dgrad(dq, w.att.q, rp, out_dtype=F32)
+        d_kvin = linear_dgrad(dkv, w.att.kv, rp, out_dtype=F32)
+        gin = g.clone()
+        gi4 = gin.view(Bp, 2, T, D)
+        gi4[:, 0].add_(d_qin.view(Bp, T, D)).add_(d_cat[:, D:].float().view(Bp, T, D))
+        gi4[:, 1].add_(d_kvin.view(Bp, T, D))
+        return gin
+
+    # -- backward
+    def backward(self, S, d_enc, G):
+        """d_enc: fp32 [B_out*T, D] gradient wrt encoder_last_hidden_state.  Accumulates parameter grads into G."""
+        enc, cfg, W = self.enc, self.cfg, self.W
+        dev = d_enc.device
+        T, D, H, F_ = S.T, cfg.d_model, cfg.encoder_attention_heads, cfg.encoder_ffn_dim
+        rows = S.B_out * T
+        nl = len(enc.layers)
+        g = _e((rows, D), F32, dev)
+        gb = _e((rows, D), BF16, dev)
+        last = enc.layers[nl - 1]
+        ops.fddt_ln_bwd(S.h_last, rows, D, mode=ops.MODE_NONE, ln_w=enc.layer_norm.weight.detach(), mean=S.meanf, rstd=S.rstdf,
+                        d_y=d_enc.contiguous(), g_out=g, g_out_bf16=gb, dln_w=G.get(enc.layer_norm.weight),
+                        dln_b=G.get(enc.layer_norm.bias), colsum_out=G.get(last.fc2.bias))
+        for i in range(nl - 1, -1, -1):
+            lyr, w, Ls = enc.layers[i], W.layers[i], S.layers[i]
+            rows, Bc = Ls.rows, Ls.B_after
+            # ---- FFN backward
+            linear_wgrad(gb, Ls.a, G.get(lyr.fc2.weight), rows)
+            d_u = linear_dgrad(gb, w.fc2, rows, aux=Ls.u)
+            bias_grad(d_u, G.get(lyr.fc1.bias))
+            linear_wgrad(d_u, Ls.xln2, G.get(lyr.fc1.weight), rows)
+            d_xln2 = linear_dgrad(d_u, w.fc1, rows)
+            g2 = _e((rows, D), F32, dev)
+            g2b = _e((rows, D), BF16, dev)
+            ln2 = lyr.final_layer_norm
+            ops.fddt_ln_bwd(Ls.h2, rows, D, mode=ops.MODE_NONE, ln_w=ln2.weight.detach(), mean=Ls.mean2, rstd=Ls.rstd2,
+                            d_y=d_xln2, g_res=g, g_out=g2, g_out_bf16=g2b, dln_w=G.get(ln2.weight), dln_b=G.get(ln2.bias),
+                            colsum_out=G.get(lyr.self_attn.out_proj.bias))
+            # ---- attention backward
+            att = lyr.self_attn
+            linear_wgrad(g2b, Ls.o, G.get(att.out_proj.weight), rows)
+            d_o = linear_dgrad(g2b, w.att.o, rows)
+            d_qkv = _e((rows, 3 * D), BF16, dev)
+            delta = _e((Bc, H, T), F32, dev)
+            qkv = Ls.qkv
+            ops.attn_bwd(heads(qkv[:, :D], Bc, T, H), heads(qkv[:, D:2 * D], Bc, T, H), heads(qkv[:, 2 * D:], Bc, T, H),
+                         heads(Ls.o, Bc, T, H), heads(d_o, Bc, T, H), Ls.lse, delta, heads(d_qkv[:, :D], Bc, T, H),
+                         heads(d_qkv[:, D:2 * D], Bc, T, H), heads(d_qkv[:, 2 * D:], Bc, T, H), dq_scale=0.125)
+            bias_grad(d_qkv[:, :D], G.get(att.q_proj.bias))
+            bias_grad(d_qkv[:, 2 * D:], G.get(att.v_proj.bias))
+            linear_wgrad(d_qkv[:, :D], Ls.xln, G.get(att.q_proj.weight), rows)
+            linear_wgrad(d_qkv[:, D:2 * D], Ls.xln, G.get(att.k_proj.weight), rows)
+            linear_wgrad(d_qkv[:, 2 * D:], Ls.xln, G.get(att.v_proj.weight), rows)
+            d_xln = linear_dgrad(d_qkv, w.att.qkv, rows)
+            # ---- LayerNorm1 (+ SCB) + FDDT backward; the column sum of the result is the previous fc2's bias grad
+            fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None
+            mode, fw, fb = fddt_ptrs(fd, cfg)
+            dw = tuple(G.get(x) for x in fw)
+            db = tuple(G.get(x) for x in fb)
+            ln = lyr.self_attn_layer_norm
+            prev_b2 = G.get(enc.layers[i - 1].fc2.bias) if i > 0 else None
+            rows_in = Ls.B * T
+            g0 = _e((rows_in, D), F32, dev)
+            g0b = _e((rows_in, D), BF16, dev) if i > 0 else None
+            if not hasattr(Ls, "scb"):
+                ops.fddt_ln_bwd(Ls.h_in, rows, D, mode=mode, stno=S.stno, stno_bstride=Ls.bstride, T=T, w=fw, b=fb,
+                                ln_w=ln.weight.detach(), mean=Ls.mean, rstd=Ls.rstd, d_y=d_xln, g_res=g2, g_out=g0,
+                                g_out_bf16=g0b, dln_w=G.get(ln.weight), dln_b=G.get(ln.bias), dw=dw, db=db,
+                                colsum_out=prev_b2)
+            else:
+                gs = _e((rows, D), F32, dev)
+                ops.fddt_ln_bwd(Ls.hp, rows, D, mode=ops.MODE_NONE, ln_w=ln.weight.detach(), mean=Ls.mean, rstd=Ls.rstd,
+                                d_y=d_xln, g_res=g2, g_out=gs, dln_w=G.get(ln.weight), dln_b=G.get(ln.bias))
+                if getattr(Ls, "dropped", False):    # re-interleave: enrollment rows receive zero gradient
+                    full = torch.zeros(rows_in, D, dtype=F32, device=dev)
+                    full.view(Ls.B // 2, 2, T, D)[:, 0].copy_(gs.view(Ls.B // 2, T, D))
+                    gs = full
+                gin = self._scb_bwd(i, Ls.scb, gs, G, T)
+                ops.fddt_ln_bwd(Ls.h_in, rows_in, D, mode=mode, stno=S.stno, stno_bstride=Ls.bstride, T=T, w=fw, b=fb,
+                                g_res=gin, g_out=g0, g_out_bf16=g0b, dw=dw, db=db, colsum_out=prev_b2)
+            g, gb = g0, g0b
+        # ---- positions + initial FDDT + conv stem (encoder.py:167-180)
+        B, Tin, M = S.B0, 2 * T, cfg.num_mel_bins
+        rows = B * T
+        gpos = G.get(enc.embed_positions.weight)
+        if gpos is not None:
+            ops.sum_over_batch(g, gpos)
+        conv_train = enc.conv1.weight.requires_grad or enc.conv2.weight.requires_grad or enc.conv1.bias.requires_grad
+        init_fddt = enc.initial_fddt if (cfg.use_fddt and cfg.use_pre_pos_fddt) else None
+        mode, fw, fb = fddt_ptrs(init_fddt, cfg)
+        dw = tuple(G.get(x) for x in fw)
+        db = tuple(G.get(x) for x in fb)
+        if not conv_train and all(x is None for x in dw + db):
+            return
+        d_x2 = _e((rows, D), BF16, dev)
+        ops.fddt_ln_bwd(S.x2, rows, D, mode=mode, stno=S.stno, T=T, w=fw, b=fb, g_res=g, g_out_bf16=d_x2, dw=dw, db=db)
+        if not conv_train:
+            return
+        d_pre2 = _e((rows, D), BF16, dev)
+        ops.gelu_bwd_bf16(d_x2, S.pre2, d_pre2)
+        bias_grad(d_pre2, G.get(enc.conv2.bias))
+        gw2 = G.get(enc.conv2.weight)
+        if gw2 is not None:
+            tmp = torch.zeros(D, 3 * D, dtype=F32, device=dev)
+            ops.gemm_tn(d_pre2, S.g1p, tmp, T, D, 3 * D, lda=D, ldb=2 * D, batch=B, strideA=T * D, strideB=(Tin + 2) * D)
+            ops.conv_weight_unpack_grad(tmp, gw2)
+        dA2 = _e((rows, 3 * D), BF16, dev)
+        ops.gemm_nt(d_pre2, W.conv2_t, dA2, rows, 3 * D, D)
+        d_pre1 = _e((B, Tin, D), BF16, dev)
+        ops.conv2_col2im_gelu_bwd(dA2, S.pre1, d_pre1, B, T, D)
+        bias_grad(d_pre1.view(B * Tin, D), G.get(enc.conv1.bias))
+        gw1 = G.get(enc.conv1.weight)
+        if gw1 is not None:
+            tmp = torch.zeros(D, W.k1, dtype=F32, device=dev)
+            ops.gemm_tn(d_pre1, S.xt, tmp, Tin, D, W.k1, lda=D, ldb=M, batch=B, strideA=Tin * D, strideB=(Tin + 2) * M)
+            ops.conv_weight_unpack_grad(tmp, gw1)
+
+
+# ------------------------------------------------------------------------------------------------ decoder + LM head + loss
+class DecoderEngine:
+    def __init__(self, model):
+        self.model = model                      # DiCoWForConditionalGeneration
+        self.cfg = model.config
+
+    def prepare(self):
+        dec, cfg = self.model.model.decoder, self.cfg
+        dev = dec.embed_tokens.weight.device
+        W = NS(layers=[])
+        for lyr in dec.layers:
+            w = NS()
+            w.sa = prep_attention(lyr.self_attn, dev)
+            w.ca = prep_attention(lyr.encoder_attn, dev, fuse_qkv=False)
+            w.fc1 = prep_linear([lyr.fc1.weight], [lyr.fc1.bias], dev)
+            w.fc2 = prep_linear([lyr.fc2.weight], [lyr.fc2.bias], dev)
+            W.layers.append(w)
+        W.vpad = _ceil(cfg.vocab_size, 128)
+        W.head = prep_linear([self.model.proj_out.weight], None, dev, n_pad=W.vpad)
+        self.W = W
+        return W
+
+    def forward(self, enc_bf, B, T, decoder_input_ids, labels, upp_labels, ts=None):
+        model, cfg, W = self.model, self.cfg, self.W
+        dec = model.model.decoder
+        dev = enc_bf.device
+        D, H, F_ = cfg.d_model, cfg.decoder_attention_heads, cfg.decoder_ffn_dim
+        Lq = decoder_input_ids.shape[1]
+        if Lq > cfg.max_target_positions:
+            raise ValueError(f"decoder length {Lq} exceeds max_target_positions {cfg.max_target_positions}")
+        rows = B * Lq
+        S = NS(B=B, T=T, Lq=Lq, ids=decoder_input_ids.contiguous(), layers=[], enc_bf=enc_bf)
+        h = _e((rows, D), F32, dev)
+        ops.embed_fwd(S.ids, dec.embed_tokens.weight.detach(), dec.embed_positions.weight.detach(), h)
+        for i, lyr in enumerate(dec.layers):
+            w = W.layers[i]
+            Ls = NS(h_in=h)
+            # causal self-attention
+            ln = lyr.self_attn_layer_norm
+            Ls.x1, Ls.m1, Ls.r1 = _e((rows, D), BF16, dev), _e((rows,), F32, dev), _e((rows,), F32, dev)
+            ops.fddt_ln_fwd(h, rows, D, ln_w=ln.weight.detach(), ln_b=ln.bias.detach(), y_bf16=Ls.x1, mean=Ls.m1, rstd=Ls.r1)
+            Ls.qkv = linear_fwd(Ls.x1, w.sa.qkv, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+            Ls.o1, Ls.lse1 = _e((rows, D), BF16, dev), _e((B, H, Lq), F32, dev)
+            ops.attn_fwd(heads(Ls.qkv[:, :D], B, Lq, H), heads(Ls.qkv[:, D:2 * D], B, Lq, H), heads(Ls.qkv[:, 2 * D:], B, Lq, H),
+                         heads(Ls.o1, B, Lq, H), Ls.lse1, causal=True)
+            Ls.h2 = linear_fwd(Ls.o1, w.sa.o, rows, out_dtype=F32, residual=h)
+            # cross-attention over the encoder output
+            ln = lyr.encoder_attn_layer_norm
+            Ls.x2, Ls.m2, Ls.r2 = _e((rows, D), BF16, dev), _e((rows,), F32, dev), _e((rows,), F32, dev)
+            ops.fddt_ln_fwd(Ls.h2, rows, D, ln_w=ln.weight.detach(), ln_b=ln.bias.detach(), y_bf16=Ls.x2, mean=Ls.m2, rstd=Ls.r2)
+            Ls.q = linear_fwd(Ls.x2, w.ca.q, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+            Ls.kv = linear_fwd(enc_bf, w.ca.kv, B * T)
+            Ls.o2, Ls.lse2 = _e((rows, D), BF16, dev), _e((B, H, Lq), F32, dev)
+            ops.attn_fwd(heads(Ls.q, B, Lq, H), heads(Ls.kv[:, :D], B, T, H), heads(Ls.kv[:, D:], B, T, H), heads(Ls.o2, B, Lq, H),
+                         Ls.lse2)
+            Ls.h3 = linear_fwd(Ls.o2, w.ca.o, rows, out_dtype=F32, residual=Ls.h2)
+            # feed-forward
+            ln = lyr.final_layer_norm
+            Ls.x3, Ls.m3, Ls.r3 = _e((rows, D), BF16, dev), _e((rows,), F32, dev), _e((rows,), F32, dev)
+            ops.fddt_ln_fwd(Ls.h3, rows, D, ln_w=ln.weight.detach(), ln_b=ln.bias.detach(), y_bf16=Ls.x3, mean=Ls.m3, rstd=Ls.r3)
+            Ls.u = _e((rows, F_), BF16, dev)
+            Ls.a = linear_fwd(Ls.x3, w.fc1, rows, gelu_aux=Ls.u)
+            h = linear_fwd(Ls.a, w.fc2, rows, out_dtype=F32, residual=Ls.h3)
+            S.layers.append(Ls)
+        S.h_last = h
+        S.xf, S.mf, S.rf = _e((rows, D), BF16, dev), _e((rows,), F32, dev), _e((rows,), F32, dev)
+        ops.fddt_ln_fwd(h, rows, D, ln_w=dec.layer_norm.weight.detach(), ln_b=dec.layer_norm.bias.detach(), y_bf16=S.xf,
+                        mean=S.mf, rstd=S.rf)
+        logits = _e((rows, W.vpad), BF16, dev)
+        ops.gemm_nt(S.xf, W.head.w, logits, rows, W.vpad, D)
+        S.logits = logits
+        loss = None
+        if labels is not None:
+            S.labels = labels.contiguous().view(-1)
+            S.upp = None if upp_labels is None else upp_labels.contiguous().view(-1)
+            S.lse, S.row_loss = _e((rows,), F32, dev), _e((rows,), F32, dev)
+            S.choice = _e((rows,), torch.int32, dev)
+            S.acc = torch.zeros(2, dtype=F32, device=dev)               # [loss_sum, count]
+            S.soft = ts is not None
+            S.ce = ops.ce_args(logits, W.vpad, rows, cfg.vocab_size, S.labels, S.upp, S.soft, ts, S.lse, S.row_loss, S.choice,
+                               S.acc[0:1], S.acc[1:2])
+            ops.ce_loss_fwd(S.ce)
+            if S.soft:                                                   # modeling_dicow.py:144
+                S.denom = S.acc[1].clamp(min=1.0)
+            else:                                                        # modeling_dicow.py:318-323 (.mean() over all positions)
+                S.denom = torch.full((), float(rows), dtype=F32, device=dev)
+            loss = S.acc[0] / S.denom
+        return loss, logits.view(B, Lq, W.vpad)[:, :, :cfg.vocab_size], S
+
+    def backward(self, S, grad_loss, G, need_d_enc=True, d_logits_ext=None):
+        """Returns d_enc fp32 [B*T, D] (or None)."""
+        model, cfg, W = self.model, self.cfg, self.W
+        dec = model.model.decoder
+        dev = S.logits.device
+        D, H, F_ = cfg.d_model, cfg.decoder_attention_heads, cfg.decoder_ffn_dim
+        B, T, Lq = S.B, S.T, S.Lq
+        rows = B * Lq
+        d_logits = _e((rows, W.vpad), BF16, dev)
+        scale = (grad_loss.to(F32) / S.denom).reshape(1)
+        S.ce.d_logits = d_logits.data_ptr()
+        ops.ce_loss_bwd(S.ce, scale)
+        # tied LM head (modeling_dicow.py:302): d_x = d_logits @ E ; dE += d_logits^T @ x
+        ge = G.get(model.proj_out.weight)
+        if ge is not None:
+            ops.gemm_tn(d_logits, S.xf, G.raw(model.proj_out.weight, W.vpad * D).view(W.vpad, D), rows, W.vpad, D)
+        d_xf = linear_dgrad(d_logits, W.head, rows)
+        g = _e((rows, D), F32, dev)
+        gb = _e((rows, D), BF16, dev)
+        nl = len(dec.layers)
+        ops.fddt_ln_bwd(S.h_last, rows, D, ln_w=dec.layer_norm.weight.detach(), mean=S.mf, rstd=S.rf, d_y=d_xf, g_out=g,
+                        g_out_bf16=gb, dln_w=G.get(dec.layer_norm.weight), dln_b=G.get(dec.layer_norm.bias),
+                        colsum_out=G.get(dec.layers[nl - 1].fc2.bias))
+        d_enc = torch.zeros(B * T, D, dtype=F32, device=dev) if need_d_enc else None
+        for i in range(nl - 1, -1, -1):
+            lyr, w, Ls = dec.layers[i], W.layers[i], S.layers[i]
+            # FFN
+            linear_wgrad(gb, Ls.a, G.get(lyr.fc2.weight), rows)
+            d_u = linear_dgrad(gb, w.fc2, rows, aux=Ls.u)
+            bias_grad(d_u, G.get(lyr.fc1.bias))
+            linear_wgrad(d_u, Ls.x3, G.get(lyr.fc1.weight), rows)
+            d_x3 = linear_dgrad(d_u, w.fc1, rows)
+            g3, g3b = _e((rows, D), F32, dev), _e((rows, D), BF16, dev)
+            ln = lyr.final_layer_norm
+            ops.fddt_ln_bwd(Ls.h3, rows, D, ln_w=ln.weight.detach(), mean=Ls.m3, rstd=Ls.r3, d_y=d_x3, g_res=g, g_out=g3,
+                            g_out_bf16=g3b, dln_w=G.get(ln.weight), dln_b=G.get(ln.bias),
+                            colsum_out=G.get(lyr.encoder_attn.out_proj.bias))
+            # cross-attention
+            att = lyr.encoder_attn
+            linear_wgrad(g3b, Ls.o2, G.get(att.out_proj.weight), rows)
+            d_o2 = linear_dgrad(g3b, w.ca.o, rows)
+            dq = _e((rows, D), BF16, dev)
+            dkv = _e((B * T, 2 * D), BF16, dev)
+            delta = _e((B, H, Lq), F32, dev)
+            ops.attn_bwd(heads(Ls.q, B, Lq, H), heads(Ls.kv[:, :D], B, T, H), heads(Ls.kv[:, D:], B, T, H), heads(Ls.o2, B, Lq, H),
+                         heads(d_o2, B, Lq, H), Ls.lse2, delta, heads(dq, B, Lq, H), heads(dkv[:, :D], B, T, H),
+                         heads(dkv[:, D:], B, T, H), dq_scale=0.125)
+            bias_grad(dq, G.get(att.q_proj.bias))
+            bias_grad(dkv[:, D:], G.get(att.v_proj.bias))
+            linear_wgrad(dq, Ls.x2, G.get(att.q_proj.weight), rows)
+            linear_wgrad(dkv[:, :D], S.enc_bf, G.get(att.k_proj.weight), B * T)
+            linear_wgrad(dkv[:, D:], S.enc_bf, G.get(att.v_proj.weight), B * T)
+            if need_d_enc:
+                linear_dgrad(dkv, w.ca.kv, B * T, out=d_enc, accumulate=True)
+            d_x2 = linear_dgrad(dq, w.ca.q, rows)
+            g2, g2b = _e((rows, D), F32, dev), _e((rows, D), BF16, dev)
+            ln = lyr.encoder_attn_layer_norm
+            ops.fddt_ln_bwd(Ls.h2, rows, D, ln_w=ln.weight.detach(), mean=Ls.m2, rstd=Ls.r2, d_y=d_x2, g_res=g3, g_out=g2,
+                            g_out_bf16=g2b, dln_w=G.get(ln.weight), dln_b=G.get(ln.bias),
+                            colsum_out=G.get(lyr.self_attn.out_proj.bias))
+            # causal self-attention
+            att = lyr.self_attn
+            linear_wgrad(g2b, Ls.o1, G.get(att.out_proj.weight), rows)
+            d_o1 = linear_dgrad(g2b, w.sa.o, rows)
+            d_qkv = _e((rows, 3 * D), BF16, dev)
+            qkv = Ls.qkv
+            ops.attn_bwd(heads(qkv[:, :D], B, Lq, H), heads(qkv[:, D:2 * D], B, Lq, H), heads(qkv[:, 2 * D:], B, Lq, H),
+                         heads(Ls.o1, B, Lq, H), heads(d_o1, B, Lq, H), Ls.lse1, delta, heads(d_qkv[:, :D], B, Lq, H),
+                         heads(d_qkv[:, D:2 * D], B, Lq, H), heads(d_qkv[:, 2 * D:], B, Lq, H), causal=True, dq_scale=0.125)
+            bias_grad(d_qkv[:, :D], G.get(att.q_proj.bias))
+            bias_grad(d_qkv[:, 2 * D:], G.get(att.v_proj.bias))
+            linear_wgrad(d_qkv[:, :D], Ls.x1, G.get(att.q_proj.weight), rows)
+            linear_wgrad(d_qkv[:, D:2 * D], Ls.x1, G.get(att.k_proj.weight), rows)
+            linear_wgrad(d_qkv[:, 2 * D:], Ls.x1, G.get(att.v_proj.weight), rows)
+            d_x1 = linear_dgrad(d_qkv, w.sa.qkv, rows)
+            g1, g1b = _e((rows, D), F32, dev), _e((rows, D), BF16, dev)
+            ln = lyr.self_attn_layer_norm
+            ops.fddt_ln_bwd(Ls.h_in, rows, D, ln_w=ln.weight.detach(), mean=Ls.m1, rstd=Ls.r1, d_y=d_x1, g_res=g2, g_out=g1,
+                            g_out_bf16=g1b, dln_w=G.get(ln.weight), dln_b=G.get(ln.bias),
+                            colsum_out=G.get(dec.layers[i - 1].fc2.bias) if i > 0 else None)
+            g, gb = g1, g1b
+        gt, gp = G.get(dec.embed_tokens.weight), G.get(dec.embed_positions.weight)
+        if gt is not None or gp is not None:
+            ops.embed_bwd(S.ids, g, gt, gp, D)
+        return d_enc

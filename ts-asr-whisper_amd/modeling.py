@@ -1,0 +1,554 @@
+"""Drop-in module surface of the reference's DiCoW model, backed by the HIP engine.
+
+Mirrors (reference, /root/reference/src/models/dicow): ``FDDT`` (FDDT.py:6-63), ``DiCoWEncoder`` (encoder.py:10-246),
+``DiCoW`` / ``DiCoWForConditionalGeneration`` (modeling_dicow.py:146-357) -- same constructor arguments, forward
+keyword arguments, returned fields (``.loss``, ``.logits``, ``.encoder_last_hidden_state``) and state-dict keys
+(SURVEY.md section 8b), so ``model(**batch)`` / ``loss.backward()`` callers (HF Trainer, the reference's
+``src/train.py``) work unchanged.  The ``nn.Module`` tree only HOLDS parameters (fp32 masters); all arithmetic runs
+in ``engine.py`` -> ``libdicow_hip.so``.  Modules refuse CPU tensors: there is no fallback path.
+"""
+import math
+import re
+from collections import OrderedDict
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import _lib as L
+from . import ops
+from .config import DiCoWConfig
+from .engine import EncoderEngine, DecoderEngine, GradSink, fddt_ptrs, CLS
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+class ModelOutput(OrderedDict):
+    """Attribute + index access like HF's ModelOutput (None fields are skipped when indexing by position)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __getitem__(self, k):
+        if isinstance(k, int):
+            return [v for v in self.values() if v is not None][k]
+        return super().__getitem__(k)
+
+    def to_tuple(self):
+        return tuple(v for v in self.values() if v is not None)
+
+
+# ------------------------------------------------------------------------------------------------ parameter holders
+class DiagonalLinear(nn.Module):
+    """out = x * weight (+ bias): parameters of one diagonal FDDT class (reference layers.py:49-77)."""
+
+    def __init__(self, d_model, bias=True, init_eye_val=0.0, fddt_init=None):
+        super().__init__()
+        self.init_eye_val, self.fddt_init = init_eye_val, fddt_init
+        self.weight = nn.Parameter(torch.empty(d_model))
+        self.bias = nn.Parameter(torch.zeros(d_model)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            bound = math.sqrt(3.0 / self.weight.numel())
+            self.weight.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.zero_()
+            if self.fddt_init == "non-disturbing":
+                self.weight.fill_(1.0)
+            elif self.fddt_init == "suppressive":
+                self.weight.fill_(self.init_eye_val)
+
+
+class DenseLinear(nn.Linear):
+    """Full D x D FDDT class / SCB feed-forward Linear with the reference's initialisation modes (layers.py:7-47)."""
+
+    def __init__(self, in_f, out_f, bias=True, init_eye_val=0.0, fddt_init=None, init_fun=None):
+        self.init_eye_val, self.fddt_init, self.init_fun = init_eye_val, fddt_init, init_fun
+        super().__init__(in_f, out_f, bias=bias)
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            if getattr(self, "init_fun", None) is not None:
+                self.init_fun(self)
+                return
+            nn.init.xavier_uniform_(self.weight)
+            if self.bias is not None:
+                nn.init.zeros_(self.bias)
+            mode = getattr(self, "fddt_init", None)
+            if mode in ("non-disturbing", "suppressive"):
+                val = 1.0 if mode == "non-disturbing" else self.init_eye_val
+                eye = torch.zeros_like(self.weight)
+                n = min(self.weight.shape)
+                eye[:n, :n] = val * torch.eye(n)
+                self.weight.copy_(eye)
+
+
+def _init_first_half_identity(m):          # layers.py:95-106
+    nn.init.xavier_uniform_(m.weight, gain=1e-1)
+    h = m.weight.shape[1] // 2
+    m.weight.data[:h, :h] += torch.eye(h)
+    m.bias.data.zero_()
+
+
+def _init_first_embeds_identity(m):        # layers.py:109-117
+    nn.init.xavier_uniform_(m.weight, gain=1e-1)
+    m.weight.data[:, :m.weight.shape[0]] += torch.eye(m.weight.shape[0])
+    m.bias.data.zero_()
+
+
+class Gate(nn.Module):
+    def __init__(self, items, init_val=0.0):
+        super().__init__()
+        self.init_val = init_val
+        self.gate = nn.Parameter(torch.full((items,), init_val))
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            self.gate.fill_(self.init_val)
+
+
+class Attention(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.k_proj = nn.Linear(d, d, bias=False)
+        self.v_proj = nn.Linear(d, d)
+        self.q_proj = nn.Linear(d, d)
+        self.out_proj = nn.Linear(d, d)
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.self_attn = Attention(d)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, f)
+        self.fc2 = nn.Linear(f, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, d, f):
+        super().__init__()
+        self.self_attn = Attention(d)
+        self.self_attn_layer_norm = nn.LayerNorm(d)
+        self.encoder_attn = Attention(d)
+        self.encoder_attn_layer_norm = nn.LayerNorm(d)
+        self.fc1 = nn.Linear(d, f)
+        self.fc2 = nn.Linear(f, d)
+        self.final_layer_norm = nn.LayerNorm(d)
+
+
+class CrossAttentionEnrollBlock(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        d, f = config.d_model, config.encoder_ffn_dim
+        self.cross_attn = Attention(d)
+        self.cross_gate = Gate(1, init_val=0.0)
+        self.ffn = nn.Sequential(DenseLinear(2 * d, f, init_fun=_init_first_half_identity), nn.GELU(), nn.Dropout(0.0),
+                                 DenseLinear(f, d, init_fun=_init_first_embeds_identity), nn.Dropout(0.0))
+
+
+class SpeakerCommunicationBlock(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.streams = 2
+        self.cae = CrossAttentionEnrollBlock(config)
+
+
+def _require_cuda(t, what):
+    if not t.is_cuda:
+        raise L.DicowError(f"{what}: tensors must be on the GPU -- the MI355X path has no CPU fallback "
+                           "(the CPU oracle under oracle/ is test infrastructure only)")
+
+
+def _param_sig(params):
+    return tuple((p.data_ptr(), p._version) for p in params)
+
+
+# ------------------------------------------------------------------------------------------------ FDDT module
+class _FDDTFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, hidden, stno, *params):
+        _require_cuda(hidden, "FDDT")
+        B, T, D = hidden.shape
+        h = hidden.contiguous()
+        if h.dtype not in (F32, BF16):
+            h = h.to(F32)
+        st = stno.to(device=h.device, dtype=F32).contiguous()
+        mode, w, b = fddt_ptrs(mod, None)
+        out = torch.empty(B, T, D, dtype=F32, device=h.device)
+        ops.fddt_ln_fwd(h, B * T, D, mode=mode, stno=st, T=T, w=tuple(None if x is None else x.detach() for x in w),
+                        b=tuple(None if x is None else x.detach() for x in b), h_out=out)
+        ctx.mod, ctx.h, ctx.st, ctx.params = mod, h, st, params
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mod, h, st = ctx.mod, ctx.h, ctx.st
+        B, T, D = h.shape
+        G = GradSink(ctx.params, h.device)
+        mode, w, b = fddt_ptrs(mod, None)
+        gh = torch.empty(B, T, D, dtype=F32, device=h.device)
+        ops.fddt_ln_bwd(h, B * T, D, mode=mode, stno=st, T=T, w=tuple(None if x is None else x.detach() for x in w),
+                        b=tuple(None if x is None else x.detach() for x in b), g_res=g.contiguous().to(F32), g_out=gh,
+                        dw=tuple(G.get(x) for x in w), db=tuple(G.get(x) for x in b))
+        return (None, gh.to(ctx.h.dtype) if ctx.h.dtype != F32 else gh, None) + tuple(G.get(p) for p in ctx.params)
+
+
+class FDDT(nn.Module):
+    """Frame-level diarization-dependent transformation; signature of reference FDDT.py:7-8."""
+
+    def __init__(self, d_model, non_target_rate=0.01, fddt_init=None, is_diagonal=False, bias_only=False, use_silence=True,
+                 use_target=True, use_overlap=True, use_non_target=True):
+        super().__init__()
+
+        def make(val):
+            if bias_only:
+                return nn.Parameter(torch.zeros(d_model))
+            if is_diagonal:
+                return DiagonalLinear(d_model, bias=True, fddt_init=fddt_init, init_eye_val=val)
+            return DenseLinear(d_model, d_model, bias=True, fddt_init=fddt_init, init_eye_val=val)
+
+        if use_target:
+            self.target_linear = make(1.0)
+        if use_non_target:
+            self.non_target_linear = make(non_target_rate)
+        if use_overlap:
+            self.overlap_linear = make(1.0)
+        if use_silence:
+            self.silence_linear = make(non_target_rate)
+        self.use_silence, self.use_target, self.use_overlap, self.use_non_target = use_silence, use_target, use_overlap, use_non_target
+        self.bias_only, self.is_diagonal, self.d_model = bias_only, is_diagonal or bias_only, d_model
+
+    def forward(self, hidden_states, stno_mask):
+        if not self.is_diagonal:
+            return self._forward_full(hidden_states, stno_mask)
+        params = [p for p in self.parameters()]
+        return _FDDTFn.apply(self, hidden_states, stno_mask, *params)
+
+    # full D x D variant (FDDT.py:13-16): one GEMM [rows,D] x [D,4D] + masked combine
+    def _forward_full(self, hidden_states, stno_mask):
+        params = [p for p in self.parameters()]
+        return _FDDTFullFn.apply(self, hidden_states, stno_mask, *params)
+
+
+class _FDDTFullFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, hidden, stno, *params):
+        _require_cuda(hidden, "FDDT")
+        B, T, D = hidden.shape
+        if D % 64 != 0:
+            raise L.DicowError("full FDDT needs d_model % 64 == 0")
+        dev = hidden.device
+        h = hidden.contiguous().to(F32)
+        st = stno.to(device=dev, dtype=F32).contiguous()
+        rows = B * T
+        hb = ops.cast_bf16(h)
+        Wc = torch.zeros(4 * D, D, dtype=BF16, device=dev)
+        Wct = torch.zeros(D, 4 * D, dtype=BF16, device=dev)
+        bias = torch.zeros(4 * D, dtype=F32, device=dev)
+        use = 0
+        for c, name in enumerate(CLS):
+            m = getattr(mod, name, None)
+            if m is not None:
+                use |= 1 << c
+                ops.cast_transpose_bf16(m.weight.detach(), out=Wc[c * D:(c + 1) * D], out_t=Wct[:, c * D:(c + 1) * D], ld=D, ld_t=4 * D)
+                bias[c * D:(c + 1) * D] = m.bias.detach()
+        y4 = torch.empty(rows, 4 * D, dtype=BF16, device=dev)
+        ops.gemm_nt(hb, Wc, y4, rows, 4 * D, D, bias=bias)
+        out = torch.empty(B, T, D, dtype=F32, device=dev)
+        L.call("dicow_fddt_full_combine_fwd", y4.data_ptr(), h.data_ptr(), 0, st.data_ptr(), 4 * T, use, out.data_ptr(), rows, T, D, L.stream())
+        ctx.mod, ctx.hb, ctx.st, ctx.Wct, ctx.use, ctx.params, ctx.shape = mod, hb, st, Wct, use, params, (B, T, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        mod, hb, st, Wct, use = ctx.mod, ctx.hb, ctx.st, ctx.Wct, ctx.use
+        B, T, D = ctx.shape
+        rows, dev = B * T, hb.device
+        g = g.contiguous().to(F32)
+        G = GradSink(ctx.params, dev)
+        d_y4 = torch.zeros(rows, 4 * D, dtype=BF16, device=dev)
+        gh = torch.empty(B, T, D, dtype=F32, device=dev)
+        L.call("dicow_fddt_full_combine_bwd", g.data_ptr(), st.data_ptr(), 4 * T, use, d_y4.data_ptr(), gh.data_ptr(), rows, T, D, L.stream())
+        ops.gemm_nt(d_y4, Wct, gh, rows, D, 4 * D, flags=L.EPI_ACCUM)
+        for c, name in enumerate(CLS):
+            m = getattr(mod, name, None)
+            if m is None:
+                continue
+            sl = d_y4[:, c * D:(c + 1) * D]
+            if G.get(m.bias) is not None:
+                ops.colsum_bf16(sl, G.get(m.bias))
+            if G.get(m.weight) is not None:
+                ops.gemm_tn(sl, hb, G.get(m.weight), rows, D, D, lda=4 * D, ldb=D, ldc=D)
+        return (None, gh, None) + tuple(G.get(p) for p in ctx.params)
+
+
+# ------------------------------------------------------------------------------------------------ encoder
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc, input_features, stno, enrollments, *params):
+        eng = enc._engine()
+        out, S = eng.forward(input_features, stno, enrollments)
+        ctx.enc, ctx.S, ctx.params = enc, S, params
+        enc._last_state = S
+        return out
+
+    @staticmethod
+    def backward(ctx, d_enc):
+        enc, S = ctx.enc, ctx.S
+        G = GradSink(ctx.params, d_enc.device)
+        D = enc.config.d_model
+        enc._engine(prepare=False).backward(S, d_enc.contiguous().view(-1, D).to(F32), G)
+        hook = getattr(enc, "_grad_ready_hook", None)
+        if hook is not None:
+            hook(G)
+        return (None, None, None, None) + tuple(G.get(p) for p in ctx.params)
+
+
+class DiCoWEncoder(nn.Module):
+    def __init__(self, config: DiCoWConfig):
+        super().__init__()
+        self.config = config
+        d, f = config.d_model, config.encoder_ffn_dim
+        self.conv1 = nn.Conv1d(config.num_mel_bins, d, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv1d(d, d, kernel_size=3, stride=2, padding=1)
+        self.embed_positions = nn.Embedding(config.max_source_positions, d)
+        self.embed_positions.requires_grad_(False)
+        self.layers = nn.ModuleList([EncoderLayer(d, f) for _ in range(config.encoder_layers)])
+        self.layer_norm = nn.LayerNorm(d)
+        self.ctc_weight = config.ctc_weight
+        if config.ctc_weight > 0.0:
+            raise NotImplementedError("the CTC auxiliary branch (ctc_weight > 0) is a 'next' row (SURVEY.md section 8 f2)")
+        if config.use_fddt:
+            def mk(rate):
+                return FDDT(d_model=d, non_target_rate=rate, fddt_init=config.fddt_init, is_diagonal=config.fddt_is_diagonal,
+                            bias_only=config.fddt_bias_only, use_silence=config.fddt_use_silence,
+                            use_target=config.fddt_use_target, use_overlap=config.fddt_use_overlap,
+                            use_non_target=config.fddt_use_non_target)
+            self.fddts = nn.ModuleList([mk(1.0) for _ in range(config.num_fddts)])
+            if config.use_pre_pos_fddt:
+                self.initial_fddt = mk(config.non_target_fddt_value)
+        if config.use_enrollments and config.scb_layers is not None:
+            self.ca_enrolls = nn.ModuleList([SpeakerCommunicationBlock(config) for _ in range(config.scb_layers)])
+        if config.use_fddt and not (config.fddt_is_diagonal or config.fddt_bias_only):
+            raise NotImplementedError("full (D x D) FDDT is available as the standalone FDDT module; the fused encoder "
+                                      "path implements the recipe's diagonal and bias-only variants")
+        self._eng = None
+        self._sig = None
+
+    def _engine(self, prepare=True):
+        if self._eng is None:
+            self._eng = EncoderEngine(self)
+        if prepare:
+            sig = _param_sig(list(self.parameters()))
+            if sig != self._sig:
+                self._eng.prepare()
+                self._sig = sig
+        return self._eng
+
+    def get_max_len(self):
+        return self.config.max_source_positions * 2
+
+    def forward(self, input_features, attention_mask=None, head_mask=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, stno_mask=None, return_logits=False, enrollments=None):
+        _require_cuda(input_features, "DiCoWEncoder")
+        if return_logits:
+            raise NotImplementedError("return_logits (CTC head) is a 'next' row (SURVEY.md section 8 f2)")
+        if stno_mask is None:
+            raise ValueError("stno_mask is required")
+        params = list(self.parameters())
+        out = _EncoderFn.apply(self, input_features, stno_mask, enrollments, *params)
+        if return_dict is False:
+            return (out,)
+        return ModelOutput(last_hidden_state=out, hidden_states=None, attentions=None)
+
+
+# ------------------------------------------------------------------------------------------------ decoder
+class WhisperDecoder(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        d = config.d_model
+        self.embed_tokens = nn.Embedding(config.vocab_size, d, padding_idx=config.pad_token_id)
+        self.embed_positions = nn.Embedding(config.max_target_positions, d)
+        self.layers = nn.ModuleList([DecoderLayer(d, config.decoder_ffn_dim) for _ in range(config.decoder_layers)])
+        self.layer_norm = nn.LayerNorm(d)
+
+
+class DiCoW(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.encoder = DiCoWEncoder(config)
+        self.decoder = WhisperDecoder(config)
+
+    def get_encoder(self):
+        return self.encoder
+
+
+def shift_tokens_right(input_ids, pad_token_id, decoder_start_token_id):
+    out = input_ids.new_zeros(input_ids.shape)
+    out[:, 1:] = input_ids[:, :-1].clone()
+    out[:, 0] = decoder_start_token_id
+    out.masked_fill_(out == -100, pad_token_id)
+    return out
+
+
+class _DecoderLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, enc_out, dec_ids, labels, upp_labels, *params):
+        eng = model._engine()
+        B, T, D = enc_out.shape
+        enc_bf = ops.cast_bf16(enc_out.contiguous().to(F32)).view(B * T, D)
+        loss, logits, S = eng.forward(enc_bf, B, T, dec_ids, labels, upp_labels, ts=model._ts_tables)
+        ctx.model, ctx.S, ctx.params = model, S, params
+        ctx.need_enc = enc_out.requires_grad
+        ctx.mark_non_differentiable(logits)
+        if loss is None:
+            loss = torch.zeros((), device=enc_out.device)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_logits):
+        model, S = ctx.model, ctx.S
+        dev = g_loss.device
+        Wv = model._engine(prepare=False).W
+        p_emb = model.model.decoder.embed_tokens.weight
+        extra = {id(p_emb): (Wv.vpad - model.config.vocab_size) * model.config.d_model}
+        G = GradSink(ctx.params, dev, extra_rows=extra)
+        d_enc = model._engine(prepare=False).backward(S, g_loss, G, need_d_enc=ctx.need_enc)
+        if d_enc is not None:
+            d_enc = d_enc.view(S.B, S.T, -1)
+        return (None, d_enc, None, None, None) + tuple(G.get(p) for p in ctx.params)
+
+
+class DiCoWForConditionalGeneration(nn.Module):
+    config_class = DiCoWConfig
+
+    def __init__(self, config: DiCoWConfig):
+        super().__init__()
+        self.config = config
+        self.model = DiCoW(config)
+        self.proj_out = nn.Linear(config.d_model, config.vocab_size, bias=False)
+        self.tokenizer = None
+        self.soft_label_creator = None
+        self._ts_tables = None
+        self.generation_config = None
+        self._eng = None
+        self._sig = None
+        self.apply(self._init_weights)
+        self.tie_weights()
+
+    # -- initialisation (HF Whisper init_std 0.02 + the reference's FDDT / gate / SCB schemes)
+    def _init_weights(self, m):
+        if isinstance(m, (DiagonalLinear, DenseLinear, Gate)):
+            m.reset_parameters()
+        elif isinstance(m, (nn.Linear, nn.Conv1d)):
+            nn.init.normal_(m.weight, mean=0.0, std=0.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.Embedding):
+            nn.init.normal_(m.weight, mean=0.0, std=0.02)
+            if m.padding_idx is not None:
+                with torch.no_grad():
+                    m.weight[m.padding_idx].zero_()
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.ones_(m.weight)
+            nn.init.zeros_(m.bias)
+        if isinstance(m, DiCoWEncoder):
+            with torch.no_grad():
+                m.embed_positions.weight.copy_(sinusoids(*m.embed_positions.weight.shape))
+
+    def tie_weights(self):
+        self.proj_out.weight = self.model.decoder.embed_tokens.weight
+
+    def post_init(self):
+        self.tie_weights()
+
+    def get_encoder(self):
+        return self.model.encoder
+
+    def get_decoder(self):
+        return self.model.decoder
+
+    def get_output_embeddings(self):
+        return self.proj_out
+
+    def set_tokenizer(self, tokenizer):
+        """Enables the soft-label (timestamp-smoothed) loss, as reference modeling_dicow.py:237-240."""
+        self.tokenizer = tokenizer
+        self._ts_tables = build_ts_tables(tokenizer.get_vocab(), self.config.vocab_size,
+                                          self.model.decoder.embed_tokens.weight.device)
+        self.soft_label_creator = self._ts_tables is not None or True
+
+    def _engine(self, prepare=True):
+        if self._eng is None:
+            self._eng = DecoderEngine(self)
+        if prepare:
+            sig = _param_sig(list(self.model.decoder.parameters()))
+            if sig != self._sig:
+                self._eng.prepare()
+                self._sig = sig
+        return self._eng
+
+    def forward(self, input_features=None, attention_mask=None, stno_mask=None, decoder_input_ids=None,
+                decoder_attention_mask=None, head_mask=None, decoder_head_mask=None, cross_attn_head_mask=None,
+                encoder_outputs=None, past_key_values=None, decoder_inputs_embeds=None, decoder_position_ids=None,
+                labels=None, upp_labels=None, use_cache=None, output_attentions=None, output_hidden_states=None,
+                return_dict=None, cache_position=None, forced_decoder_ids=None, enrollments=None):
+        cfg = self.config
+        if labels is not None and decoder_input_ids is None and decoder_inputs_embeds is None:
+            decoder_input_ids = shift_tokens_right(labels, cfg.pad_token_id, cfg.decoder_start_token_id)
+        if decoder_inputs_embeds is not None or past_key_values is not None:
+            raise NotImplementedError("decoder_inputs_embeds / KV-cache decoding are outside the training-step path")
+        if encoder_outputs is None:
+            _require_cuda(input_features, "DiCoWForConditionalGeneration")
+            enc_out = self.model.encoder(input_features, stno_mask=stno_mask, enrollments=enrollments).last_hidden_state
+        else:
+            enc_out = encoder_outputs[0]
+        if decoder_input_ids is None:
+            raise ValueError("either labels or decoder_input_ids must be given")
+        dev = enc_out.device
+        dec_ids = decoder_input_ids.to(dev)
+        lab = None if labels is None else labels.to(dev)
+        upp = None if upp_labels is None else upp_labels.to(dev)
+        if self._ts_tables is not None and self._ts_tables["ids"].device != dev:
+            self._ts_tables = {k: v.to(dev) for k, v in self._ts_tables.items()}
+        params = list(self.model.decoder.parameters())
+        loss, logits = _DecoderLossFn.apply(self, enc_out, dec_ids, lab, upp, *params)
+        if labels is None:
+            loss = None
+        if return_dict is False:
+            return tuple(x for x in (loss, logits, enc_out) if x is not None)
+        return ModelOutput(loss=loss, logits=logits, past_key_values=None, decoder_hidden_states=None,
+                           decoder_attentions=None, cross_attentions=None, encoder_last_hidden_state=enc_out,
+                           encoder_hidden_states=None, encoder_attentions=None)
+
+
+def sinusoids(length, channels, max_timescale=10000.0):
+    inc = math.log(max_timescale) / (channels // 2 - 1)
+    inv = torch.exp(-inc * torch.arange(channels // 2))
+    t = torch.arange(length)[:, None] * inv[None, :]
+    return torch.cat([t.sin(), t.cos()], dim=1)
+
+
+def build_ts_tables(vocab, vocab_size, device, sigma=0.08):
+    """Timestamp smoothing tables for the soft-label loss: sorted timestamp ids, row-normalised Gaussian
+    weights over them, and the token-id -> timestamp-row lookup (what reference modeling_dicow.py:35-93 keeps as a
+    dense [n_ts, V] matrix)."""
+    pat = re.compile(r"<\|(\d+\.\d+)\|>")
+    pairs = sorted((tid, float(mt.group(1))) for tok, tid in vocab.items() for mt in [pat.match(tok)] if mt)
+    if not pairs:
+        return None
+    ids = torch.tensor([p[0] for p in pairs], dtype=torch.int32)
+    times = torch.tensor([p[1] for p in pairs], dtype=torch.float32)
+    w = torch.exp(-((times[:, None] - times[None, :]) ** 2) / (2 * sigma ** 2))
+    w = w / w.sum(dim=1, keepdim=True)
+    index = torch.full((max(vocab_size, int(ids.max()) + 1),), -1, dtype=torch.int32)
+    index[ids.long()] = torch.arange(len(pairs), dtype=torch.int32)
+    return {"ids": ids.to(device), "w": w.contiguous().to(device), "index": index.to(device)}

@@ -43,27 +43,26 @@ def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     return out
 
 
-def cast_transpose_bf16(src: torch.Tensor, want_plain=True, want_t=True, out=None, out_t=None):
+def cast_transpose_bf16(src: torch.Tensor, out=None, out_t=None, ld=None, ld_t=None):
+    """fp32 [R,C] -> bf16 `out` [R,C] (row stride ld) and/or `out_t` [C,R] (row stride ld_t); either may be None."""
     _req(src, F32, "cast_transpose.src")
     assert src.dim() == 2 and src.is_contiguous()
     R, Cc = src.shape
-    if want_plain and out is None:
-        out = torch.empty(R, Cc, dtype=BF16, device=src.device)
-    if want_t and out_t is None:
-        out_t = torch.empty(Cc, R, dtype=BF16, device=src.device)
-    L.call("dicow_cast_transpose_f32_to_bf16", src.data_ptr(), _p(out) if want_plain else None,
-           _p(out_t) if want_t else None, R, Cc, L.stream())
+    L.call("dicow_cast_transpose_f32_to_bf16", src.data_ptr(), _p(out), Cc if ld is None else ld, _p(out_t),
+           R if ld_t is None else ld_t, R, Cc, L.stream())
     return out, out_t
 
 
-def conv_weight_pack(w: torch.Tensor, kpad: int, out=None) -> torch.Tensor:
+def conv_weight_pack(w: torch.Tensor, kpad: int, out=None, out_t=None, want_t=False):
     _req(w, F32, "conv_weight_pack.w")
     O, Cc, three = w.shape
     assert three == 3 and w.is_contiguous()
     if out is None:
         out = torch.empty(O, kpad, dtype=BF16, device=w.device)
-    L.call("dicow_conv_weight_pack", w.data_ptr(), out.data_ptr(), O, Cc, kpad, L.stream())
-    return out
+    if want_t and out_t is None:
+        out_t = torch.empty(kpad, O, dtype=BF16, device=w.device)
+    L.call("dicow_conv_weight_pack", w.data_ptr(), out.data_ptr(), _p(out_t), O, Cc, kpad, L.stream())
+    return (out, out_t) if want_t else out
 
 
 def conv_weight_unpack_grad(g_packed: torch.Tensor, g_w: torch.Tensor):
@@ -131,7 +130,7 @@ def fddt_ln_bwd(h_in, rows, D, *, mode=MODE_NONE, stno=None, stno_bstride=None, 
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residual=None, ldr=None, aux=None,
-            ldaux=None, flags=0, scale=1.0, scale_ncols=0, batch=1, strideA=0, strideB=0, strideC=0):
+            ldaux=None, flags=0, scale=1.0, scale_ncols=0, batch=1, strideA=0, strideB=0, strideC=0, strideAux=0):
     """C[M,N] = epilogue(A[M,K] @ B[N,K]^T).  Pointers + leading dimensions; see include/dicow_hip.h."""
     a = L.GemmArgs()
     a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
@@ -142,7 +141,7 @@ def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, re
     a.ldc = N if ldc is None else ldc
     a.ldr = N if ldr is None else ldr
     a.ldaux = N if ldaux is None else ldaux
-    a.batch, a.strideA, a.strideB, a.strideC = batch, strideA, strideB, strideC
+    a.batch, a.strideA, a.strideB, a.strideC, a.strideAux = batch, strideA, strideB, strideC, strideAux
     if C_out.dtype == F32:
         flags |= L.EPI_OUT_F32
     if bias is not None:
@@ -204,3 +203,50 @@ def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0
     a.B, a.Lq, a.H = q.shape[0], q.shape[1], q.shape[2]
     a.Lk, a.causal, a.dq_scale = k.shape[1], int(causal), dq_scale
     L.call_struct("dicow_attn_bwd", a)
+
+
+# ------------------------------------------------------------------------------------------------ loss / embedding / misc
+def ce_args(logits, ld, rows, V, labels, upp_labels, soft, ts, lse, row_loss, choice, loss_sum, count, d_logits=None):
+    a = L.CeArgs()
+    a.logits, a.ld, a.rows, a.V = logits.data_ptr(), ld, rows, V
+    a.labels, a.upp_labels, a.soft = labels.data_ptr(), _p(upp_labels), int(soft)
+    if ts is not None:
+        a.ts_index, a.ts_ids, a.ts_w, a.n_ts = ts["index"].data_ptr(), ts["ids"].data_ptr(), ts["w"].data_ptr(), ts["ids"].numel()
+    a.lse, a.row_loss, a.choice = lse.data_ptr(), row_loss.data_ptr(), choice.data_ptr()
+    a.loss_sum, a.count, a.d_logits = loss_sum.data_ptr(), count.data_ptr(), _p(d_logits)
+    return a
+
+
+def ce_loss_fwd(a):
+    L.call_struct("dicow_ce_loss_fwd", a)
+
+
+def ce_loss_bwd(a, grad_scale):
+    L.check(L.lib().dicow_ce_loss_bwd(C.byref(a), grad_scale.data_ptr(), L.stream()), "dicow_ce_loss_bwd")
+
+
+def embed_fwd(ids, tok, pos, out):
+    B, Lq = ids.shape
+    L.call("dicow_embed_fwd", ids.data_ptr(), tok.data_ptr(), pos.data_ptr(), out.data_ptr(), B, Lq, tok.shape[1], L.stream())
+
+
+def embed_bwd(ids, g, d_tok, d_pos, D):
+    B, Lq = ids.shape
+    L.call("dicow_embed_bwd", ids.data_ptr(), g.data_ptr(), _p(d_tok), _p(d_pos), B, Lq, D, L.stream())
+
+
+def gelu_bwd_bf16(g, pre, out):
+    L.call("dicow_gelu_bwd_bf16", g.data_ptr(), pre.data_ptr(), out.data_ptr(), g.numel(), L.stream())
+
+
+def conv2_col2im_gelu_bwd(dA2, pre1, d_pre1, B, T2, Cc):
+    L.call("dicow_conv2_col2im_gelu_bwd", dA2.data_ptr(), pre1.data_ptr(), d_pre1.data_ptr(), B, T2, Cc, L.stream())
+
+
+def sumsq(x, out):
+    L.call("dicow_sumsq_f32", x.data_ptr(), x.numel(), out.data_ptr(), L.stream())
+
+
+def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0):
+    L.call("dicow_adamw_f32", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, wd,
+           step, _p(gnorm_sq), max_norm, L.stream())
