@@ -445,7 +445,7 @@ class EncoderEngine:
         rows = B * T
         gpos = G.get(enc.embed_positions.weight)
         if gpos is not None:
-            ops.sum_over_batch(g, gpos)
+            ops.sum_over_batch(g.view(B, T * D), gpos)
         conv_train = enc.conv1.weight.requires_grad or enc.conv2.weight.requires_grad or enc.conv1.bias.requires_grad
         init_fddt = enc.initial_fddt if (cfg.use_fddt and cfg.use_pre_pos_fddt) else None
         mode, fw, fb = fddt_ptrs(init_fddt, cfg)
