@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Benchmark of the DiCoW training step on MI355X (contract: see the task description / DESIGN.md "Measurement").
+
+    python bench.py --gpus 1 --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = forward + backward + gradient all-reduce + clip + AdamW on one synthetic batch of 30 s clips
+(whisper-large-v3-turbo dims, per-GPU batch 16, decoder frozen, L=128: BASELINE.json configs[2]/[3]); inputs are
+resident in HBM before the timed region.  Prints ONE JSON line (rank 0) with the metric, the roofline of the
+dominant kernel (live HIP-event timing of every launch of it inside the timed region) and the CPU baseline
+(the oracle timed on the host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="whisper-large-v3-turbo")
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
+    ap.add_argument("--labels", type=int, default=128)
+    ap.add_argument("--se", action="store_true", help="SE-DiCoW (enrollment cross-attention, scb_layers=8), config 5")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="turbo-b1")
+    return ap.parse_args()
+
+
+class KernelTimer:
+    """HIP-event bracket around every launch of selected C-ABI entry points (events on the launch stream)."""
+
+    def __init__(self, ops_mod, names):
+        self.ops, self.names, self.rec, self.orig, self.on = ops_mod, names, {n: [] for n in names}, {}, False
+
+    def install(self):
+        for n in self.names:
+            fn = getattr(self.ops, n)
+            self.orig[n] = fn
+
+            def wrapped(*a, __fn=fn, __n=n, **kw):
+                if not self.on:
+                    return __fn(*a, **kw)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = __fn(*a, **kw)
+                e.record()
+                self.rec[__n].append((s, e, self.work(__n, a, kw)))
+                return r
+            setattr(self.ops, n, wrapped)
+        import ts_asr_whisper_amd.engine as eng      # engine calls through the module attribute `ops.<name>`
+        assert eng.ops is self.ops
+
+    @staticmethod
+    def work(name, a, kw):
+        if name == "gemm_nt":
+            return 2.0 * a[3] * a[4] * a[5] * kw.get("batch", 1)
+        if name == "gemm_tn":
+            return 2.0 * a[3] * a[4] * a[5] * kw.get("batch", 1)
+        return 0.0
+
+    def summary(self, name):
+        rec = self.rec[name]
+        if not rec:
+            return None
+        ms = [s.elapsed_time(e) for s, e, _ in rec]
+        fl = [w for _, _, w in rec]
+        return {"launches": len(rec), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms), "flops": sum(fl),
+                "tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12 if sum(ms) > 0 else 0.0}
+
+
+def cpu_baseline(cfg_name, labels):
+    """Oracle (kind "port") timed on the host cores: fwd+bwd of whisper-large-v3-turbo dims, B=1 (bounded sample)."""
+    import amd_pkg
+    pkg = amd_pkg.load()
+    from oracle import dicow_oracle as O
+    cfg = pkg.DiCoWConfig.preset(cfg_name, use_pre_pos_fddt=True, non_target_fddt_value=0.5)
+    ocfg = O.OracleConfig(**{k: getattr(cfg, k) for k in O.OracleConfig.__dataclass_fields__ if hasattr(cfg, k)})
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    p = O.init_state(ocfg, seed=0)
+    for n, t in p.items():
+        if "decoder" not in n and n != "proj_out.weight" and t.is_floating_point():
+            t.requires_grad_(True)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, cfg.num_mel_bins, 3000, generator=g).clamp_(-1.5, 1.5)
+    st = torch.softmax(torch.randn(1, 4, 1500, generator=g), 1)
+    lab = torch.randint(0, 50257, (1, labels), generator=g)
+    times = []
+    for it in range(2):
+        t0 = time.time()
+        out = O.model_forward(p, ocfg, x, st, lab, lab)
+        out["loss"].backward()
+        times.append(time.time() - t0)
+        for t in p.values():
+            t.grad = None
+        if sum(times) > 40:
+            break
+    best = min(times)
+    return {"value": 1.0 / best, "unit": "utt/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (plain PyTorch fp32 restatement) fwd+bwd, {cfg_name} dims, B=1, L={labels}, {len(times)} steps, "
+                      f"best {best:.2f} s, host has {cores} logical cores"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    import amd_pkg
+    pkg = amd_pkg.load()
+    from ts_asr_whisper_amd import ops
+    from ts_asr_whisper_amd.trainer import TrainStep
+    from ts_asr_whisper_amd.data import synthetic_batch
+
+    over = dict(use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True, fddt_init="suppressive", non_target_fddt_value=0.5)
+    if a.se:
+        over.update(use_enrollments=True, scb_layers=8)
+    cfg = pkg.DiCoWConfig.preset(a.model, **over)
+    torch.manual_seed(0)
+    model = pkg.DiCoWForConditionalGeneration(cfg).cuda()
+    model.tie_weights()
+    prefixes = ("model.encoder.fddts", "model.encoder.initial_fddt") + (("model.encoder.ca_enrolls",) if a.se else ())
+    ts = TrainStep(model, lr=2e-6, fddt_lr_multiplier=100.0, max_grad_norm=1.0, warmup_steps=2000, max_steps=40000,
+                   preheat_prefixes=prefixes)
+    batches = [synthetic_batch(cfg, a.batch, a.labels, seed=1000 + rank * 17 + i, mixed_length=a.se, enrollments=a.se)
+               for i in range(2)]
+    timer = KernelTimer(ops, ["gemm_nt", "gemm_tn"])
+    timer.install()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        loss = ts.step(batches[i % 2])
+    sync()
+    timer.on = True
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = ts.step(batches[i % 2])
+    sync()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ms = dt / a.steps * 1e3
+    utts = a.batch * world * a.steps / dt
+    nt, tn = timer.summary("gemm_nt"), timer.summary("gemm_tn")
+    peak = 2500.0
+    out = {
+        "metric": f"train utterances/sec (30 s clips) {a.model} DiCoW" if not a.se else
+                  "train utterances/sec (30 s clips) SE-DiCoW large-v3-turbo",
+        "value": round(utts, 3), "unit": "utt/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (random-init weights, N(0,1) mel clamped to [-1.5,1.5], 3-speaker STNO process, random labels)",
+        "config": {"workload": f"{a.model} DiCoW fine-tune step, per-GPU batch {a.batch}, L={a.labels}, decoder frozen, "
+                               f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}",
+                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "trainable_params": ts.store.n_trainable},
+        "loss": float(loss),
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA 32x32x16; forward Linear/conv + dgrad)",
+                     "achieved": round(nt["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(nt["tflops"] / peak, 4),
+                     "traffic": None, "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // a.steps,
+                     "share_of_step": round(nt["total_ms"] / (dt * 1e3), 3)},
+        "kernels": {"gemm_tn_kernel": {"tflops": round(tn["tflops"], 1), "frac": round(tn["tflops"] / peak, 4),
+                                       "share_of_step": round(tn["total_ms"] / (dt * 1e3), 3)}},
+        "step_tflops": round((6.99 if not a.se else 10.7) * utts, 1),
+    }
+    out["step_mfma_frac"] = round(out["step_tflops"] / peak, 4)
+    if not a.no_cpu_baseline and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(a.model, a.labels)
+        except Exception as ex:      # the bench line must still be printed
+            out["cpu_baseline"] = {"value": None, "unit": "utt/s", "cores": 0, "kind": "port", "sample": f"failed: {ex!r}"}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

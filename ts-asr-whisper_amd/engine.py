@@ -32,15 +32,19 @@ def _ceil(a, b):
 
 
 class GradSink:
-    """fp32 gradient buffers for a set of parameters, allocated as ONE zeroed flat buffer (wgrad GEMMs and
-    column reductions accumulate into it).  ``get(p)`` returns None for parameters that do not require grad."""
+    """fp32 gradient buffers for a set of parameters.  Parameters that carry a persistent ``_direct_grad`` view (set
+    by trainer.FlatStore) are accumulated into directly; the others get ONE zeroed flat buffer whose views are
+    returned to autograd.  ``get(p)`` returns None for parameters that do not require grad."""
 
     def __init__(self, params, dev, extra_rows=None):
-        self.index = {}
+        self.index, self.direct = {}, {}
         off = 0
         extra_rows = extra_rows or {}
         for p in params:
-            if p is None or not p.requires_grad or id(p) in self.index:
+            if p is None or not p.requires_grad or id(p) in self.index or id(p) in self.direct:
+                continue
+            if getattr(p, "_direct_grad", None) is not None and extra_rows.get(id(p), 0) == 0:
+                self.direct[id(p)] = p._direct_grad
                 continue
             n = p.numel() + extra_rows.get(id(p), 0)
             self.index[id(p)] = (off, p.shape, p.numel())
@@ -48,10 +52,18 @@ class GradSink:
         self.flat = torch.zeros(max(off, 1), dtype=F32, device=dev)
 
     def get(self, p):
-        if p is None or id(p) not in self.index:
+        if p is None:
+            return None
+        if id(p) in self.direct:
+            return self.direct[id(p)]
+        if id(p) not in self.index:
             return None
         off, shape, n = self.index[id(p)]
         return self.flat[off:off + n].view(shape)
+
+    def result(self, p):
+        """What autograd should receive for p: None when the gradient was accumulated in place."""
+        return None if (p is None or id(p) in self.direct) else self.get(p)
 
     def raw(self, p, n):
         off, _, _ = self.index[id(p)]
@@ -382,6 +394,8 @@ class EncoderEngine:
         ops.fddt_ln_bwd(S.h_last, rows, D, mode=ops.MODE_NONE, ln_w=enc.layer_norm.weight.detach(), mean=S.meanf, rstd=S.rstdf,
                         d_y=d_enc.contiguous(), g_out=g, g_out_bf16=gb, dln_w=G.get(enc.layer_norm.weight),
                         dln_b=G.get(enc.layer_norm.bias), colsum_out=G.get(last.fc2.bias))
+        hook = getattr(enc, "_segment_hook", None) or (lambda name: None)
+        hook("final_ln")
         for i in range(nl - 1, -1, -1):
             lyr, w, Ls = enc.layers[i], W.layers[i], S.layers[i]
             rows, Bc = Ls.rows, Ls.B_after
@@ -440,6 +454,14 @@ class EncoderEngine:
                 ops.fddt_ln_bwd(Ls.h_in, rows_in, D, mode=mode, stno=S.stno, stno_bstride=Ls.bstride, T=T, w=fw, b=fb,
                                 g_res=gin, g_out=g0, g_out_bf16=g0b, dw=dw, db=db, colsum_out=prev_b2)
             g, gb = g0, g0b
+            hook(f"layer{i}")
+        self._stem_backward(S, g, G)
+        hook("stem")
+
+    def _stem_backward(self, S, g, G):
+        enc, cfg, W = self.enc, self.cfg, self.W
+        dev = g.device
+        T, D = S.T, cfg.d_model
         # ---- positions + initial FDDT + conv stem (encoder.py:167-180)
         B, Tin, M = S.B0, 2 * T, cfg.num_mel_bins
         rows = B * T

@@ -197,7 +197,7 @@ class _FDDTFn(torch.autograd.Function):
         ops.fddt_ln_bwd(h, B * T, D, mode=mode, stno=st, T=T, w=tuple(None if x is None else x.detach() for x in w),
                         b=tuple(None if x is None else x.detach() for x in b), g_res=g.contiguous().to(F32), g_out=gh,
                         dw=tuple(G.get(x) for x in w), db=tuple(G.get(x) for x in b))
-        return (None, gh.to(ctx.h.dtype) if ctx.h.dtype != F32 else gh, None) + tuple(G.get(p) for p in ctx.params)
+        return (None, gh.to(ctx.h.dtype) if ctx.h.dtype != F32 else gh, None) + tuple(G.result(p) for p in ctx.params)
 
 
 class FDDT(nn.Module):
@@ -286,7 +286,7 @@ class _FDDTFullFn(torch.autograd.Function):
                 ops.colsum_bf16(sl, G.get(m.bias))
             if G.get(m.weight) is not None:
                 ops.gemm_tn(sl, hb, G.get(m.weight), rows, D, D, lda=4 * D, ldb=D, ldc=D)
-        return (None, gh, None) + tuple(G.get(p) for p in ctx.params)
+        return (None, gh, None) + tuple(G.result(p) for p in ctx.params)
 
 
 # ------------------------------------------------------------------------------------------------ encoder
@@ -305,10 +305,7 @@ class _EncoderFn(torch.autograd.Function):
         G = GradSink(ctx.params, d_enc.device)
         D = enc.config.d_model
         enc._engine(prepare=False).backward(S, d_enc.contiguous().view(-1, D).to(F32), G)
-        hook = getattr(enc, "_grad_ready_hook", None)
-        if hook is not None:
-            hook(G)
-        return (None, None, None, None) + tuple(G.get(p) for p in ctx.params)
+        return (None, None, None, None) + tuple(G.result(p) for p in ctx.params)
 
 
 class DiCoWEncoder(nn.Module):
@@ -407,7 +404,7 @@ class _DecoderLossFn(torch.autograd.Function):
         enc_bf = ops.cast_bf16(enc_out.contiguous().to(F32)).view(B * T, D)
         loss, logits, S = eng.forward(enc_bf, B, T, dec_ids, labels, upp_labels, ts=model._ts_tables)
         ctx.model, ctx.S, ctx.params = model, S, params
-        ctx.need_enc = enc_out.requires_grad
+        ctx.need_enc = ctx.needs_input_grad[1]
         ctx.mark_non_differentiable(logits)
         if loss is None:
             loss = torch.zeros((), device=enc_out.device)
@@ -424,7 +421,10 @@ class _DecoderLossFn(torch.autograd.Function):
         d_enc = model._engine(prepare=False).backward(S, g_loss, G, need_d_enc=ctx.need_enc)
         if d_enc is not None:
             d_enc = d_enc.view(S.B, S.T, -1)
-        return (None, d_enc, None, None, None) + tuple(G.get(p) for p in ctx.params)
+        hook = getattr(model, "_segment_hook", None)
+        if hook is not None:
+            hook("decoder")
+        return (None, d_enc, None, None, None) + tuple(G.result(p) for p in ctx.params)
 
 
 class DiCoWForConditionalGeneration(nn.Module):

@@ -1,0 +1,193 @@
+"""Training-step driver for the DiCoW hot path: flat parameter/gradient store, fused AdamW + clipping, data parallel.
+
+The repository's counterpart of the reference harness (SURVEY.md section 8b last row): batch dict -> ``model(**batch)`` ->
+``loss.backward()`` -> global-norm clip 1.0 -> AdamW with the two parameter groups of reference
+src/models/containers.py:100-114 (base lr; ``prefixes_to_preheat`` parameters lr x fddt_lr_multiplier, weight decay 0)
+-> cosine/linear-warmup schedule (configs/train/dicow_v3.yaml:66-68), keyword freezing (containers.py:80-97,
+dicow_v3.yaml:6-7: every parameter whose name contains "decoder" is frozen).
+
+Data parallel (reference: torchrun + DDP/NCCL, scripts/submit_slurm.sh:34): one process per GPU, full replica, disjoint
+minibatch; trainable gradients live in ONE flat fp32 buffer laid out in backward-completion order, so that each encoder
+layer's slice is all-reduced (RCCL over xGMI, ``torch.distributed`` backend "nccl") on a side HIP stream as soon as that
+layer's backward has been enqueued, overlapped with the remaining backward.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .engine import GradSink
+
+F32 = torch.float32
+
+
+def freeze_by_keyword(model, frozen_keywords=("decoder",)):
+    """reference containers.py:80-90: requires_grad = not any(keyword in name)."""
+    for n, p in model.named_parameters():
+        p.requires_grad_(not any(k in n for k in frozen_keywords))
+    model.tie_weights()
+
+
+def _backward_order(model):
+    """Trainable encoder parameters grouped in the order their gradients complete during backward."""
+    enc = model.model.encoder
+    groups = []
+    groups.append(("final_ln", list(enc.layer_norm.parameters())))
+    nl = len(enc.layers)
+    for i in range(nl - 1, -1, -1):
+        ps = list(enc.layers[i].parameters())
+        if hasattr(enc, "fddts") and i < len(enc.fddts):
+            ps += list(enc.fddts[i].parameters())
+        if hasattr(enc, "ca_enrolls") and i < len(enc.ca_enrolls):
+            ps += list(enc.ca_enrolls[i].parameters())
+        groups.append((f"layer{i}", ps))
+    tail = []
+    if hasattr(enc, "initial_fddt"):
+        tail += list(enc.initial_fddt.parameters())
+    tail += [enc.embed_positions.weight] + list(enc.conv2.parameters()) + list(enc.conv1.parameters())
+    groups.append(("stem", tail))
+    return groups
+
+
+class FlatStore:
+    """Flat fp32 parameter / gradient / Adam-moment buffers for the trainable parameters.
+
+    ``p.data`` and ``p.grad`` become views into the flat buffers; the engine accumulates gradients directly into
+    ``p.grad`` (``p._direct_grad``), so autograd performs no extra accumulation pass and the fused optimizer and the
+    bucketed all-reduce work on contiguous memory."""
+
+    def __init__(self, model, preheat_prefixes=("model.encoder.fddts", "model.encoder.initial_fddt")):
+        names = {id(p): n for n, p in model.named_parameters()}
+        dev = next(model.parameters()).device
+        self.segments = []            # (name, start, end) per backward group
+        self.runs = []                # (start, end, is_preheat) contiguous optimizer runs
+        entries, off, seen = [], 0, set()
+        grouped = _backward_order(model)
+        enc_ids = {id(p) for _, ps in grouped for p in ps}
+        rest = [p for p in model.parameters() if p.requires_grad and id(p) not in enc_ids]
+        if rest:
+            grouped = [("decoder", rest)] + grouped      # decoder grads complete first (its backward runs first)
+        for gname, ps in grouped:
+            start = off
+            for p in ps:
+                if not p.requires_grad or id(p) in seen:
+                    continue
+                seen.add(id(p))
+                n = p.numel()
+                pre = any(names[id(p)].startswith(pp) for pp in preheat_prefixes)
+                entries.append((p, off, n, pre))
+                off += (n + 63) // 64 * 64
+            if off > start:
+                self.segments.append((gname, start, off))
+        self.numel = off
+        self.params = torch.zeros(off, dtype=F32, device=dev)
+        self.grads = torch.zeros(off, dtype=F32, device=dev)
+        self.exp_avg = torch.zeros(off, dtype=F32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=F32, device=dev)
+        self.entries = entries
+        for p, o, n, pre in entries:
+            self.params[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.params[o:o + n].view(p.shape)
+            p.grad = self.grads[o:o + n].view(p.shape)
+            p._direct_grad = p.grad
+            pad_end = o + (n + 63) // 64 * 64
+            if self.runs and self.runs[-1][2] == pre and self.runs[-1][1] == o:
+                self.runs[-1] = (self.runs[-1][0], pad_end, pre)
+            else:
+                self.runs.append((o, pad_end, pre))
+        self.n_trainable = sum(n for _, _, n, _ in entries)
+
+    def zero_grad(self):
+        self.grads.zero_()
+
+
+class FusedAdamW:
+    """Two-group AdamW + global-norm clipping in fused HIP kernels over the FlatStore (no host synchronisation)."""
+
+    def __init__(self, store, lr=2e-6, fddt_lr_multiplier=100.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                 max_grad_norm=1.0, warmup_steps=0, max_steps=0, schedule="cosine"):
+        self.s, self.lr, self.mult, self.betas, self.eps, self.wd = store, lr, fddt_lr_multiplier, betas, eps, weight_decay
+        self.max_norm, self.warmup, self.max_steps, self.schedule = max_grad_norm, warmup_steps, max_steps, schedule
+        self.t = 0
+        self.gnorm_sq = torch.zeros(1, dtype=F32, device=store.params.device)
+
+    def lr_at(self, t):
+        if self.warmup and t <= self.warmup:
+            return self.lr * t / max(1, self.warmup)
+        if self.schedule == "cosine" and self.max_steps > self.warmup:
+            prog = min(1.0, (t - self.warmup) / (self.max_steps - self.warmup))
+            return self.lr * 0.5 * (1.0 + math.cos(math.pi * prog))
+        return self.lr
+
+    def step(self, trainable_runs=None):
+        s = self.s
+        self.t += 1
+        lr = self.lr_at(self.t)
+        self.gnorm_sq.zero_()
+        ops.sumsq(s.grads, self.gnorm_sq)
+        for a, b, pre in (trainable_runs or s.runs):
+            ops.adamw(s.params[a:b], s.grads[a:b], s.exp_avg[a:b], s.exp_avg_sq[a:b], lr * (self.mult if pre else 1.0),
+                      self.betas[0], self.betas[1], self.eps, self.wd, self.t, gnorm_sq=self.gnorm_sq, max_norm=self.max_norm)
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce on a side stream, one bucket per backward segment of the FlatStore."""
+
+    def __init__(self, store, process_group=None):
+        self.s = store
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
+        self.seg = {name: (a, b) for name, a, b in store.segments}
+        self.pending = []
+
+    def segment_ready(self, name):
+        """Called right after the segment's backward kernels have been enqueued on the current stream."""
+        if self.world == 1 or name not in self.seg:
+            return
+        a, b = self.seg[name]
+        if self.stream is None:                       # CPU / gloo tests: synchronous
+            buf = self.s.grads[a:b]
+            dist.all_reduce(buf, group=self.pg)
+            buf.div_(self.world)
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(self.stream):
+            self.stream.wait_event(ev)
+            buf = self.s.grads[a:b]
+            dist.all_reduce(buf, group=self.pg)
+            buf.div_(self.world)
+
+    def finish(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+class TrainStep:
+    """model + FlatStore + FusedAdamW (+ GradReducer): ``loss = step(batch)``."""
+
+    def __init__(self, model, lr=2e-6, fddt_lr_multiplier=100.0, weight_decay=0.0, max_grad_norm=1.0, warmup_steps=0,
+                 max_steps=0, frozen_keywords=("decoder",), preheat_prefixes=("model.encoder.fddts", "model.encoder.initial_fddt"),
+                 process_group=None):
+        self.model = model
+        freeze_by_keyword(model, frozen_keywords)
+        self.store = FlatStore(model, preheat_prefixes)
+        self.opt = FusedAdamW(self.store, lr, fddt_lr_multiplier, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
+                              warmup_steps=warmup_steps, max_steps=max_steps)
+        self.reducer = GradReducer(self.store, process_group)
+        model.model.encoder._segment_hook = self.reducer.segment_ready
+        model._segment_hook = self.reducer.segment_ready
+
+    def step(self, batch):
+        self.store.zero_grad()
+        out = self.model(**batch)
+        out.loss.backward()
+        self.reducer.finish()
+        self.opt.step()
+        # the fused optimizer writes through raw pointers (no torch version bump): invalidate the bf16 weight copies
+        self.model.model.encoder._sig = None
+        if any(p.requires_grad for p in self.model.model.decoder.parameters()):
+            self.model._sig = None
+        return out.loss.detach()
