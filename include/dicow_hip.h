@@ -51,8 +51,10 @@ int dicow_conv_weight_pack(const float* w, void* dst, void* dst_t, int O, int C,
 int dicow_conv_weight_unpack_grad(const float* g_packed, float* g_w, int O, int C, int Kpad, void* stream);
 /* input_features [B,M,Tin] fp32 -> time-major bf16 [B, Tin+2, M], rows 0 and Tin+1 zero (conv padding=1). */
 int dicow_mel_to_timemajor(const float* mel, void* dst, int B, int M, int Tin, void* stream);
-/* column sums of a bf16 [rows, N] matrix accumulated (+=) into fp32 out[N] (bias gradients). */
-int dicow_colsum_bf16(const void* x, int64_t ld, float* out, int rows, int N, void* stream);
+/* column sums of a bf16 [rows, N] matrix accumulated (+=) into fp32 out[N] (bias gradients).  Two-stage (partials in
+ * the caller's workspace, then a reduce pass): fp32 L2 atomics are ~20x slower than that on gfx950. */
+int64_t dicow_colsum_ws_bytes(int rows, int N);
+int dicow_colsum_bf16(const void* x, int64_t ld, float* out, int rows, int N, void* ws, int64_t ws_bytes, void* stream);
 /* out[t,:] += sum_b g[b,t,:]   (gradient of encoder.embed_positions, encoder.py:177-179) */
 int dicow_sum_over_batch(const float* g, float* out, int B, int64_t TD, void* stream);
 
@@ -92,7 +94,8 @@ int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream);
  *   g0  = FDDTBackward(g)  (diag: g * sum_c m_c w_c ; bias-only / mode 0: g)
  * and the column reductions  dln_w += sum_r d_y*xhat, dln_b += sum_r d_y,
  *   dw[c] += sum_r m_c*h_in*g, db[c] += sum_r m_c*g, colsum_out += sum_r g0  (bias grad of the producing Linear).
- * All parameter-gradient outputs are fp32 and ACCUMULATED with atomics (NULL = not needed).             */
+ * All parameter-gradient outputs are fp32 and ACCUMULATED (+=, NULL = not needed) by a deterministic two-stage
+ * reduction through the caller's workspace (no atomics).                                                */
 typedef struct {
     const void* h_in; int in_bf16; int mode;
     const float* stno; int64_t stno_bstride;
@@ -110,7 +113,9 @@ typedef struct {
     float* colsum_out;
     float* dpos_rows;        /* unused, reserved */
     int rows, T, D;
+    void* ws; int64_t ws_bytes;   /* workspace for the per-workgroup partial column sums (dicow_fddt_ln_bwd_ws_bytes) */
 } dicow_fddt_ln_bwd_args;
+int64_t dicow_fddt_ln_bwd_ws_bytes(int rows, int D);
 int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream);
 
 /* Full (D x D) FDDT combine: y4 = h @ [W_S;W_T;W_N;W_O]^T (bf16 [rows,4D], from dicow_gemm_nt with bias) ->
@@ -143,15 +148,22 @@ typedef struct {
 } dicow_gemm_args;
 int dicow_gemm_nt(const dicow_gemm_args* a, void* stream);
 
-/* C[N1,N2] (+)= sum_m A[m,N1] * B[m,N2]  (fp32 C): every weight gradient dW = dY^T X.  Split over m
- * across grid.z with fp32 atomics.  Requirements: N1 % 8 == 0, N2 % 8 == 0, lda/ldb % 8 == 0.          */
+/* C[N1,N2] (+)= sum_m A[m,N1] * B[m,N2]  (fp32 C): every weight gradient dW = dY^T X.  When the output has too few
+ * tiles to fill the chip the contraction is split over grid.z; the splits write fp32 partials to the caller's
+ * workspace (dicow_gemm_tn_ws_bytes) and a reduce pass adds them into C -- deterministic, no atomics.
+ * Requirements: N1 % 8 == 0, N2 % 8 == 0, lda/ldb % 8 == 0.                                              */
 typedef struct {
     const void* A; const void* B; float* C;
     int Mk, N1, N2;
     int64_t lda, ldb, ldc;
     int batch; int64_t strideA, strideB;            /* extra contraction batches (conv views) */
-    int accumulate;                                 /* 0: C must be pre-zeroed by the caller as well (atomics) */
+    int accumulate;                                 /* 1: C += result, 0: C = result */
+    float* C_seg[2];                                /* optional row segments: rows [seg_rows, 2*seg_rows) of the logical C */
+    int seg_rows;                                   /* go to C_seg[0], rows [2*seg_rows, ..) to C_seg[1] (q/k/v weight grads
+                                                       from ONE GEMM over the fused d_qkv); 0 = single C */
+    void* ws; int64_t ws_bytes;                     /* workspace for split partials */
 } dicow_gemm_tn_args;
+int64_t dicow_gemm_tn_ws_bytes(const dicow_gemm_tn_args* a);
 int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ attention

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
     """include/dicow_hip.h is the ABI: every function it declares must be exported by the built library and bound."""
     from ts_asr_whisper_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "dicow_hip.h")).read()
-    declared = set(re.findall(r"^(?:int|const char\*)\s+(dicow_\w+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(dicow_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 25
     assert declared == set(_lib.declared_symbols())
     lib = _lib.lib()                       # raises loudly if the .so has not been built

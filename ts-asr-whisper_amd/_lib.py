@@ -21,7 +21,7 @@ class FddtLnBwdArgs(C.Structure):
                 ("w", c_vp * 4), ("b", c_vp * 4), ("pos", c_vp), ("ln_w", c_vp), ("mean", c_vp), ("rstd", c_vp),
                 ("d_y", c_vp), ("dy_f32", c_i), ("g_res", c_vp), ("g_out", c_vp), ("g_out_bf16", c_vp),
                 ("dln_w", c_vp), ("dln_b", c_vp), ("dw", c_vp * 4), ("db", c_vp * 4), ("colsum_out", c_vp),
-                ("dpos_rows", c_vp), ("rows", c_i), ("T", c_i), ("D", c_i)]
+                ("dpos_rows", c_vp), ("rows", c_i), ("T", c_i), ("D", c_i), ("ws", c_vp), ("ws_bytes", c_i64)]
 
 
 class GemmArgs(C.Structure):
@@ -35,7 +35,8 @@ class GemmArgs(C.Structure):
 class GemmTnArgs(C.Structure):
     _fields_ = [("A", c_vp), ("B", c_vp), ("C", c_vp), ("Mk", c_i), ("N1", c_i), ("N2", c_i),
                 ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64),
-                ("batch", c_i), ("strideA", c_i64), ("strideB", c_i64), ("accumulate", c_i)]
+                ("batch", c_i), ("strideA", c_i64), ("strideB", c_i64), ("accumulate", c_i),
+                ("C_seg", c_vp * 2), ("seg_rows", c_i), ("ws", c_vp), ("ws_bytes", c_i64)]
 
 
 class AttnFwdArgs(C.Structure):
@@ -70,7 +71,7 @@ _SIGS = {
     "dicow_conv_weight_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_conv_weight_unpack_grad": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_mel_to_timemajor": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
-    "dicow_colsum_bf16": [c_vp, c_i64, c_vp, c_i, c_i, c_vp],
+    "dicow_colsum_bf16": [c_vp, c_i64, c_vp, c_i, c_i, c_vp, c_i64, c_vp],
     "dicow_sum_over_batch": [c_vp, c_vp, c_i, c_i64, c_vp],
     "dicow_fddt_ln_fwd": [C.POINTER(FddtLnFwdArgs), c_vp],
     "dicow_fddt_ln_bwd": [C.POINTER(FddtLnBwdArgs), c_vp],
@@ -109,12 +110,23 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = at
             fn.restype = c_i
+        for name, at in _SIGS64.items():
+            fn = getattr(l, name)
+            fn.argtypes = at
+            fn.restype = c_i64
         _lib = l
     return _lib
 
 
+_SIGS64 = {   # functions returning int64_t (workspace sizes)
+    "dicow_colsum_ws_bytes": [c_i, c_i],
+    "dicow_fddt_ln_bwd_ws_bytes": [c_i, c_i],
+    "dicow_gemm_tn_ws_bytes": [C.POINTER(GemmTnArgs)],
+}
+
+
 def declared_symbols():
-    return ["dicow_abi_version", "dicow_last_error"] + list(_SIGS)
+    return ["dicow_abi_version", "dicow_last_error"] + list(_SIGS) + list(_SIGS64)
 
 
 def check(rc, what):

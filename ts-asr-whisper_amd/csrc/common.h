@@ -50,8 +50,32 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// Wave-wide sum with DPP (VALU lane shuffles, no LDS traffic): quad swaps, half-row / row mirrors, then the
+// row-broadcast steps; the total lands in lane 63 and is returned wave-uniform through v_readlane.
+// (__shfl_xor lowers to ds_bpermute_b32: ~6 dependent LDS round trips per reduction, measured 2x slower kernels.)
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    int x;
+#define DPP_ADD(ctrl, rmask) \
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false); v += __int_as_float(x);
+    DPP_ADD(0xB1, 0xf)    // quad_perm [1,0,3,2]
+    DPP_ADD(0x4E, 0xf)    // quad_perm [2,3,0,1]
+    DPP_ADD(0x141, 0xf)   // row_half_mirror
+    DPP_ADD(0x140, 0xf)   // row_mirror        -> every lane holds its 16-lane row sum
+    DPP_ADD(0x142, 0xa)   // row_bcast15 into rows 1,3
+    DPP_ADD(0x143, 0xc)   // row_bcast31 into rows 2,3 -> lane 63 holds the wave sum
+#undef DPP_ADD
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// ---- two-stage (workspace) reductions instead of fp32 atomics: L2 float atomics sustain only ~130 GB/s on gfx950
+// (measured: every extra split of a 26 MB weight gradient cost ~0.2 ms), a plain partial write + reduce pass is 20x cheaper.
+// out[j] += sum_p part[p*stride + j], j < n          (defined in elementwise.hip)
+int dicow_launch_reduce_parts(const float* part, int nparts, int64_t stride, float* out, int64_t n, hipStream_t st);
+// out[k][j] += sum_p part[p*stride + k*kstride + j] for k < nout (<= 11; NULL outputs skipped), ONE launch
+int dicow_launch_reduce_multi(const float* part, int nparts, int64_t stride, int64_t kstride, float* const* outs, int nout,
+                              int64_t n, hipStream_t st);

@@ -144,27 +144,100 @@ extern "C" int dicow_mel_to_timemajor(const float* mel, void* dst, int B, int M,
     return DICOW_OK;
 }
 
-// column sums of bf16 [rows,N] (ld) += into fp32 out[N]; block = 256 threads owning 256*2 columns, rows strided by grid.y
-__global__ void colsum_bf16_kernel(const unsigned short* __restrict__ x, int64_t ld, float* __restrict__ out, int rows, int N) {
+// ---- partial-sum reductions --------------------------------------------------------------------------------------
+// few, long partials (split weight gradients): one float4 column per thread
+__global__ void reduce_parts_wide_kernel(const float* __restrict__ part, int nparts, int64_t stride, float* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 s = reinterpret_cast<float4*>(out)[i];
+        for (int p = 0; p < nparts; ++p) {
+            const float4 v = reinterpret_cast<const float4*>(part + (int64_t)p * stride)[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+}
+// many, short partials (column sums over hundreds of workgroups): 16 columns x 16 partial-lanes per block;
+// blockIdx.y selects one of up to 11 outputs whose partials are interleaved [part][k][n] (fddt_ln_bwd)
+struct reduce_multi_args { float* out[11]; };
+__global__ void reduce_parts_tall_kernel(const float* __restrict__ part, int nparts, int64_t stride, int64_t kstride,
+                                         reduce_multi_args outs, int64_t n) {
+    __shared__ float red[16][17];
+    float* out = outs.out[blockIdx.y];
+    if (!out) return;
+    part += (int64_t)blockIdx.y * kstride;
+    const int c = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int64_t j = (int64_t)blockIdx.x * 16 + c;
+    float s = 0.f;
+    if (j < n) {
+        int p = pl;
+        for (; p + 48 < nparts; p += 64) {
+            const float a0 = part[(int64_t)p * stride + j], a1 = part[(int64_t)(p + 16) * stride + j];
+            const float a2 = part[(int64_t)(p + 32) * stride + j], a3 = part[(int64_t)(p + 48) * stride + j];
+            s += (a0 + a1) + (a2 + a3);
+        }
+        for (; p < nparts; p += 16) s += part[(int64_t)p * stride + j];
+    }
+    red[pl][c] = s;
+    __syncthreads();
+    if (pl == 0 && j < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][c];
+        out[j] += t;
+    }
+}
+
+int dicow_launch_reduce_multi(const float* part, int nparts, int64_t stride, int64_t kstride, float* const* outs, int nout,
+                              int64_t n, hipStream_t st) {
+    reduce_multi_args ra;
+    for (int k = 0; k < 11; ++k) ra.out[k] = k < nout ? outs[k] : nullptr;
+    hipLaunchKernelGGL(reduce_parts_tall_kernel, dim3((unsigned)((n + 15) / 16), nout), dim3(256), 0, st, part, nparts, stride,
+                       kstride, ra, n);
+    DICOW_CHECK_LAUNCH("reduce_parts_multi");
+    return DICOW_OK;
+}
+
+int dicow_launch_reduce_parts(const float* part, int nparts, int64_t stride, float* out, int64_t n, hipStream_t st) {
+    if (nparts <= 16 && n % 4 == 0 && stride % 4 == 0) {
+        int grid = (int)((n / 4 + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+        hipLaunchKernelGGL(reduce_parts_wide_kernel, dim3(grid), dim3(256), 0, st, part, nparts, stride, out, n / 4);
+    } else {
+        float* outs[1] = {out};
+        return dicow_launch_reduce_multi(part, nparts, stride, 0, outs, 1, n, st);
+    }
+    DICOW_CHECK_LAUNCH("reduce_parts");
+    return DICOW_OK;
+}
+
+// column sums of bf16 [rows,N] (ld) += into fp32 out[N]: stage 1 = per-(column pair, row slice) partials, stage 2 = reduce
+__global__ void colsum_bf16_kernel(const unsigned short* __restrict__ x, int64_t ld, float* __restrict__ part, int rows, int N) {
     const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (c >= N) return;
     float s0 = 0.f, s1 = 0.f;
-    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
+    const int r1 = (int)(((int64_t)rows * (blockIdx.y + 1)) / gridDim.y);
+    for (int r = (int)(((int64_t)rows * blockIdx.y) / gridDim.y); r < r1; ++r) {
         const unsigned u = *reinterpret_cast<const unsigned*>(x + (int64_t)r * ld + c);
         s0 += __uint_as_float(u << 16);
         s1 += __uint_as_float(u & 0xffff0000u);
     }
-    atomicAdd(out + c, s0);
-    if (c + 1 < N) atomicAdd(out + c + 1, s1);
+    *reinterpret_cast<float2*>(part + (int64_t)blockIdx.y * N + c) = make_float2(s0, s1);
 }
 
-extern "C" int dicow_colsum_bf16(const void* x, int64_t ld, float* out, int rows, int N, void* stream) {
-    DICOW_REQUIRE(x && out && rows > 0 && N > 0 && N % 2 == 0 && ld % 2 == 0, "colsum_bf16: bad args (N, ld must be even)");
+static int colsum_slices(int rows, int N) {
     const int gx = dicow_cdiv(N, 512);
-    int gy = 2048 / gx; if (gy < 1) gy = 1; if (gy > rows) gy = rows;
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ld, out, rows, N);
+    int gy = 2048 / gx; if (gy < 1) gy = 1; if (gy > rows) gy = rows; if (gy > 512) gy = 512;
+    return gy;
+}
+
+extern "C" int64_t dicow_colsum_ws_bytes(int rows, int N) { return (int64_t)colsum_slices(rows, N) * N * 4; }
+
+extern "C" int dicow_colsum_bf16(const void* x, int64_t ld, float* out, int rows, int N, void* ws, int64_t ws_bytes, void* stream) {
+    DICOW_REQUIRE(x && out && rows > 0 && N > 0 && N % 2 == 0 && ld % 2 == 0, "colsum_bf16: bad args (N, ld must be even)");
+    const int gx = dicow_cdiv(N, 512), gy = colsum_slices(rows, N);
+    DICOW_REQUIRE(ws && ws_bytes >= (int64_t)gy * N * 4, "colsum_bf16: workspace too small (need %ld bytes)", (long)gy * N * 4);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const unsigned short*)x, ld, (float*)ws, rows, N);
     DICOW_CHECK_LAUNCH("colsum_bf16");
-    return DICOW_OK;
+    return dicow_launch_reduce_parts((const float*)ws, gy, N, out, N, (hipStream_t)stream);
 }
 
 __global__ void sum_over_batch_kernel(const float* __restrict__ g, float* __restrict__ out, int B, int64_t TD) {

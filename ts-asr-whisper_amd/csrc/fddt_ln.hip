@@ -9,6 +9,7 @@
 // Rows are visited R at a time (R independent 16-byte loads in flight per thread); row statistics use one
 // wave-shuffle + LDS reduction per R rows.  Algorithmic HBM bytes per row: fwd  D*(4 in + 4 out + 2 ln-out),
 // bwd  D*(4 h_in + 2 d_y + 4 g_res + 4 g_out + 2 g_out_bf16).
+#include <stdlib.h>
 #include "common.h"
 
 #define MAX_WAVES 16
@@ -54,7 +55,7 @@ template <int NV>
 __device__ __forceinline__ void block_sum(float (&v)[NV], float* red, int nwaves) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+    for (int i = 0; i < NV; ++i) v[i] = wave_sum_dpp(v[i]);
     if (nwaves == 1) return;
     if (lane == 0) {
 #pragma unroll
@@ -69,9 +70,46 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red, int nwaves
     }
 }
 
+// Chan/Welford combination of (count, mean, M2) so that mean and variance need ONE block-wide reduction (one barrier)
+// without the E[x^2]-mean^2 cancellation.
+__device__ __forceinline__ void wf_combine(float& n, float& mu, float& m2, float nb, float mub, float m2b) {
+    const float nt = n + nb;
+    if (nt > 0.f) {
+        const float d = mub - mu, f = nb / nt;
+        mu += d * f;
+        m2 += m2b + d * d * n * f;
+        n = nt;
+    }
+}
 template <int R>
-__global__ void __launch_bounds__(1024) fddt_ln_fwd_kernel(const dicow_fddt_ln_fwd_args a) {
-    __shared__ float red[2][MAX_WAVES * R];
+__device__ __forceinline__ void block_welford(float (&n)[R], float (&mu)[R], float (&m2)[R], float* red, int nwaves) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float nb = __shfl_xor(n[r], o, 64), mb = __shfl_xor(mu[r], o, 64), qb = __shfl_xor(m2[r], o, 64);
+            wf_combine(n[r], mu[r], m2[r], nb, mb, qb);
+        }
+    }
+    if (nwaves == 1) return;
+    if (lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) { red[(wv * R + r) * 3] = n[r]; red[(wv * R + r) * 3 + 1] = mu[r]; red[(wv * R + r) * 3 + 2] = m2[r]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        float tn = 0.f, tm = 0.f, tq = 0.f;
+        for (int w = 0; w < nwaves; ++w)
+            wf_combine(tn, tm, tq, red[(w * R + r) * 3], red[(w * R + r) * 3 + 1], red[(w * R + r) * 3 + 2]);
+        n[r] = tn; mu[r] = tm; m2[r] = tq;
+    }
+}
+
+template <int R, int MAXT>
+__global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_fwd_args a) {
+    __shared__ float red[2][MAX_WAVES * R * 3];
     const int tid = threadIdx.x, col = tid * 4, D = a.D;
     const bool act = col < D;
     const int nwaves = blockDim.x >> 6;
@@ -128,14 +166,14 @@ __global__ void __launch_bounds__(1024) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
             if (a.h_out && act && row < a.rows) st4(a.h_out + (int64_t)row * D + col, x[r]);
         }
         if (!do_ln) continue;
-        float s[R];
+        float sm[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) s[r] = act ? (x[r].x + x[r].y) + (x[r].z + x[r].w) : 0.f;
-        block_sum<R>(s, red[0], nwaves);
+        for (int r = 0; r < R; ++r) sm[r] = act ? (x[r].x + x[r].y) + (x[r].z + x[r].w) : 0.f;
+        block_sum<R>(sm, red[0], nwaves);
         float mu[R], q[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            mu[r] = s[r] * inv_d;
+            mu[r] = sm[r] * inv_d;
             const float dx = x[r].x - mu[r], dy = x[r].y - mu[r], dz = x[r].z - mu[r], dw = x[r].w - mu[r];
             q[r] = act ? (dx * dx + dy * dy) + (dz * dz + dw * dw) : 0.f;
         }
@@ -159,8 +197,20 @@ __global__ void __launch_bounds__(1024) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
             if (a.y_bf16) st4_bf16(a.y_bf16, off, y);
             if (a.y_f32) st4(a.y_f32 + off, y);
         }
-        // (the two __syncthreads inside block_sum order the LDS reuse across iterations)
+        // (the two barriers inside block_sum order the LDS reuse across iterations)
     }
+}
+
+// resident workgroups per CU for a row kernel (occupancy API, cached): the grid is sized to exactly fill the chip
+// once and every workgroup strides over rows, so no partial tail wave runs at low occupancy.
+template <typename K>
+static int resident_grid(K kernel, int block, int* cache) {
+    if (*cache == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) nb = 1;
+        *cache = nb;
+    }
+    return 256 * *cache;
 }
 
 static int pick_block(int D) {
@@ -179,22 +229,24 @@ extern "C" int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream) 
     const int R = 4;
     const int block = pick_block(a->D);
     int grid = dicow_cdiv(a->rows, R);
-    const int cap = 256 * (block <= 256 ? 8 : (block <= 512 ? 4 : 2));
+    static int occ[17] = {0};
+    const int cap = block <= 512 ? resident_grid(fddt_ln_fwd_kernel<R, 512>, block, &occ[block / 64])
+                                 : resident_grid(fddt_ln_fwd_kernel<R, 1024>, block, &occ[block / 64]);
     if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(fddt_ln_fwd_kernel<R>, dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+    if (block <= 512)
+        hipLaunchKernelGGL((fddt_ln_fwd_kernel<R, 512>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+    else
+        hipLaunchKernelGGL((fddt_ln_fwd_kernel<R, 1024>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("fddt_ln_fwd");
     return DICOW_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-__device__ __forceinline__ void atomic_add4(float* p, float4 v) {
-    atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
-}
 #define F4_FMA(acc, a_, b_) do { acc.x += (a_).x * (b_).x; acc.y += (a_).y * (b_).y; acc.z += (a_).z * (b_).z; acc.w += (a_).w * (b_).w; } while (0)
 #define F4_ADD(acc, a_) do { acc.x += (a_).x; acc.y += (a_).y; acc.z += (a_).z; acc.w += (a_).w; } while (0)
 
-template <int R>
-__global__ void __launch_bounds__(1024) fddt_ln_bwd_kernel(const dicow_fddt_ln_bwd_args a) {
+template <int R, int MAXT>
+__global__ void __launch_bounds__(MAXT) fddt_ln_bwd_kernel(const dicow_fddt_ln_bwd_args a) {
     __shared__ float red[2][MAX_WAVES * 2 * R];
     const int tid = threadIdx.x, col = tid * 4, D = a.D;
     const bool act = col < D;
@@ -217,7 +269,7 @@ __global__ void __launch_bounds__(1024) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
 
     int it = 0;
     for (int row0 = blockIdx.x * R; row0 < a.rows; row0 += gridDim.x * R, ++it) {
-        float4 hin[R], xh[R], dy[R];
+        float4 hin[R], xh[R], dy[R], gr[R];
         float m[R][4], rs[R];
         float sums[2 * R];
 #pragma unroll
@@ -229,6 +281,7 @@ __global__ void __launch_bounds__(1024) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
             float mu = 0.f;
             if (ok) hin[r] = a.in_bf16 ? ld4_bf16(a.h_in, off) : ld4(reinterpret_cast<const float*>(a.h_in) + off);
             if (ok && do_ln) dy[r] = a.dy_f32 ? ld4(reinterpret_cast<const float*>(a.d_y) + off) : ld4_bf16(a.d_y, off);
+            gr[r] = (ok && a.g_res) ? ld4(a.g_res + off) : zero;      // issued with the other loads, ahead of the reduction
             if (do_ln && row < a.rows) { mu = a.mean[row]; rs[r] = a.rstd[row]; }
             if (a.mode != 0 && row < a.rows) {
                 const int bi = row / a.T, t = row - bi * a.T;
@@ -268,7 +321,7 @@ __global__ void __launch_bounds__(1024) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
             const int row = row0 + r;
             if (!(act && row < a.rows)) continue;
             const int64_t off = (int64_t)row * D + col;
-            float4 g = a.g_res ? ld4(a.g_res + off) : zero;
+            float4 g = gr[r];
             if (do_ln) {
                 const float c1 = sums[2 * r] * inv_d, c2 = sums[2 * r + 1] * inv_d;
                 g.x += rs[r] * (dy[r].x * lnw.x - c1 - xh[r].x * c2);
@@ -304,15 +357,26 @@ __global__ void __launch_bounds__(1024) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
         }
     }
     if (!act) return;
-    if (do_ln && a.dln_w) atomic_add4(a.dln_w + col, acc_lnw);
-    if (do_ln && a.dln_b) atomic_add4(a.dln_b + col, acc_lnb);
-    if (a.colsum_out) atomic_add4(a.colsum_out + col, acc_cs);
+    // per-workgroup partial column sums -> workspace [block][11][D]; reduced by dicow_launch_reduce_parts (no atomics)
+    float* part = reinterpret_cast<float*>(a.ws) + (int64_t)blockIdx.x * 11 * D + col;
+    if (do_ln && a.dln_w) st4(part + 0 * D, acc_lnw);
+    if (do_ln && a.dln_b) st4(part + 1 * D, acc_lnb);
+    if (a.colsum_out) st4(part + 2 * D, acc_cs);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        if (a.mode == 1 && a.dw[c]) atomic_add4(a.dw[c] + col, acc_dw[c]);
-        if (a.mode != 0 && a.db[c]) atomic_add4(a.db[c] + col, acc_db[c]);
+        if (a.mode == 1 && a.dw[c]) st4(part + (3 + c) * D, acc_dw[c]);
+        if (a.mode != 0 && a.db[c]) st4(part + (7 + c) * D, acc_db[c]);
     }
 }
+
+static int bwd_grid(int rows, int D) {
+    const int block = ((D / 4) + 63) / 64 * 64;
+    int grid = (rows + 3) / 4;
+    const int cap = 256 * (block <= 256 ? 4 : 2);
+    return grid > cap ? cap : grid;
+}
+
+extern "C" int64_t dicow_fddt_ln_bwd_ws_bytes(int rows, int D) { return (int64_t)bwd_grid(rows, D) * 11 * D * 4; }
 
 extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) {
     DICOW_REQUIRE(a && a->h_in && a->rows > 0 && a->D > 0, "fddt_ln_bwd: null/empty input");
@@ -323,11 +387,26 @@ extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) 
     DICOW_REQUIRE(a->ln_w || a->g_res, "fddt_ln_bwd: no incoming gradient");
     const int R = 4;
     const int block = pick_block(a->D);
-    int grid = dicow_cdiv(a->rows, R);
-    const int cap = 256 * (block <= 256 ? 4 : 2);
-    if (grid > cap) grid = cap;
-    hipLaunchKernelGGL(fddt_ln_bwd_kernel<R>, dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+    const int grid = bwd_grid(a->rows, a->D);
+    const int D = a->D;
+    float* outs[11] = {a->ln_w ? a->dln_w : nullptr, a->ln_w ? a->dln_b : nullptr, a->colsum_out,
+                       a->mode == 1 ? a->dw[0] : nullptr, a->mode == 1 ? a->dw[1] : nullptr, a->mode == 1 ? a->dw[2] : nullptr,
+                       a->mode == 1 ? a->dw[3] : nullptr, a->mode != 0 ? a->db[0] : nullptr, a->mode != 0 ? a->db[1] : nullptr,
+                       a->mode != 0 ? a->db[2] : nullptr, a->mode != 0 ? a->db[3] : nullptr};
+    bool any = false;
+    for (int k = 0; k < 11; ++k) any = any || outs[k];
+    DICOW_REQUIRE(!any || (a->ws && a->ws_bytes >= (int64_t)grid * 11 * D * 4),
+                  "fddt_ln_bwd: workspace too small (need %ld bytes)", (long)grid * 11 * D * 4);
+    static const int r_env = getenv("DICOW_ROW_R") ? atoi(getenv("DICOW_ROW_R")) : 2;
+    if (block <= 512 && r_env == 4)
+        hipLaunchKernelGGL((fddt_ln_bwd_kernel<4, 512>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+    else if (block <= 512)
+        hipLaunchKernelGGL((fddt_ln_bwd_kernel<2, 512>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+    else
+        hipLaunchKernelGGL((fddt_ln_bwd_kernel<2, 1024>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("fddt_ln_bwd");
+    if (any) return dicow_launch_reduce_multi(reinterpret_cast<const float*>(a->ws), grid, (int64_t)11 * D, D, outs, 11, D,
+                                              (hipStream_t)stream);
     return DICOW_OK;
 }
 

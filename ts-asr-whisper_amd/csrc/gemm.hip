@@ -12,6 +12,7 @@
 // MFMA operand order is swapped (a = weight rows n, b = activation rows m) so that a lane's accumulator quad
 // holds 4 CONSECUTIVE n for one m: the epilogue then issues 8-byte (bf16) / 16-byte (fp32) row-major stores
 // and float4 bias / residual loads.
+#include <stdlib.h>
 #include "common.h"
 
 #define BM 128
@@ -237,10 +238,11 @@ __device__ __forceinline__ void tn_stage(const unsigned short* __restrict__ A, c
 __device__ __forceinline__ unsigned tn_tr_addr(const char* s, int m, int n) {
     return (unsigned)(uintptr_t)(s + m * 256 + ((((n >> 3) ^ ((m & 3) << 2))) << 4) + ((n & 7) << 1));
 }
+struct tn_frag_t { bf16x4_t r0, r1, r2, r3, r4, r5, r6, r7; };
+
+// issue the 8 transposing reads of k-step OFF/4096 (no wait: they stay in flight behind the previous step's MFMAs)
 template <int OFF>
-__device__ __forceinline__ void tn_read_kstep(bf16x8_t (&f2)[2], bf16x8_t (&f1)[2], unsigned b0, unsigned b1, unsigned a0,
-                                              unsigned a1) {
-    bf16x4_t r0, r1, r2, r3, r4, r5, r6, r7;
+__device__ __forceinline__ void tn_issue(tn_frag_t& f, unsigned b0, unsigned b1, unsigned a0, unsigned a1) {
     asm volatile(
         "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
         "ds_read_b64_tr_b16 %1, %8 offset:%13\n\t"
@@ -249,15 +251,29 @@ __device__ __forceinline__ void tn_read_kstep(bf16x8_t (&f2)[2], bf16x8_t (&f1)[
         "ds_read_b64_tr_b16 %4, %10 offset:%12\n\t"
         "ds_read_b64_tr_b16 %5, %10 offset:%13\n\t"
         "ds_read_b64_tr_b16 %6, %11 offset:%12\n\t"
-        "ds_read_b64_tr_b16 %7, %11 offset:%13\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7)
+        "ds_read_b64_tr_b16 %7, %11 offset:%13"
+        : "=&v"(f.r0), "=&v"(f.r1), "=&v"(f.r2), "=&v"(f.r3), "=&v"(f.r4), "=&v"(f.r5), "=&v"(f.r6), "=&v"(f.r7)
         : "v"(b0), "v"(b1), "v"(a0), "v"(a1), "i"(OFF), "i"(OFF + 1024)
         : "memory");
-    f2[0] = __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7);
-    f2[1] = __builtin_shufflevector(r2, r3, 0, 1, 2, 3, 4, 5, 6, 7);
-    f1[0] = __builtin_shufflevector(r4, r5, 0, 1, 2, 3, 4, 5, 6, 7);
-    f1[1] = __builtin_shufflevector(r6, r7, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// wait until at most N LDS reads are outstanding; names the fragment registers so that no consumer is scheduled
+// above the wait and the compiler never touches them in between (cdna_hip_programming.md section 5.7 form (ii))
+template <int N>
+__device__ __forceinline__ void tn_wait(tn_frag_t& f) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(f.r0), "+v"(f.r1), "+v"(f.r2), "+v"(f.r3), "+v"(f.r4), "+v"(f.r5), "+v"(f.r6), "+v"(f.r7)
+                 : "i"(N)
+                 : "memory");
+}
+__device__ __forceinline__ void tn_mfma(f32x16_t (&acc)[2][2], const tn_frag_t& f) {
+    const bf16x8_t f20 = __builtin_shufflevector(f.r0, f.r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8_t f21 = __builtin_shufflevector(f.r2, f.r3, 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8_t f10 = __builtin_shufflevector(f.r4, f.r5, 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8_t f11 = __builtin_shufflevector(f.r6, f.r7, 0, 1, 2, 3, 4, 5, 6, 7);
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f20, f10, acc[0][0], 0, 0, 0);
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f20, f11, acc[0][1], 0, 0, 0);
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f21, f10, acc[1][0], 0, 0, 0);
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f21, f11, acc[1][1], 0, 0, 0);
 }
 
 __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const dicow_gemm_tn_args a, int tiles_per_batch, int total_tiles,
@@ -324,22 +340,28 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const dicow_gemm_tn_arg
         {
             const unsigned b0 = tn_tr_addr(sB, tr_row, w2 * 64 + tr_col), b1 = tn_tr_addr(sB, tr_row, w2 * 64 + 32 + tr_col);
             const unsigned a0 = tn_tr_addr(sA, tr_row, w1 * 64 + tr_col), a1 = tn_tr_addr(sA, tr_row, w1 * 64 + 32 + tr_col);
-            bf16x8_t f2[2], f1[2];
-#define TN_KSTEP(KK)                                                                                      \
-            tn_read_kstep<(KK) * 4096>(f2, f1, b0, b1, a0, a1);                                           \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
-                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                             \
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[i], f1[j], acc[i][j], 0, 0, 0);
-            TN_KSTEP(0) TN_KSTEP(1) TN_KSTEP(2) TN_KSTEP(3)
-#undef TN_KSTEP
+            tn_frag_t fa, fb;
+            tn_issue<0>(fa, b0, b1, a0, a1);
+            tn_issue<4096>(fb, b0, b1, a0, a1);
+            tn_wait<8>(fa);
+            tn_mfma(acc, fa);
+            tn_issue<8192>(fa, b0, b1, a0, a1);
+            tn_wait<8>(fb);
+            tn_mfma(acc, fb);
+            tn_issue<12288>(fb, b0, b1, a0, a1);
+            tn_wait<8>(fa);
+            tn_mfma(acc, fa);
+            tn_wait<0>(fb);
+            tn_mfma(acc, fb);
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
 
-    // ---- epilogue: C[n1][n2..n2+3] (+)= acc ; atomics when the contraction is split across blocks
+    // ---- epilogue: C[n1][n2..n2+3] (+)= acc; a split contraction writes fp32 partials [split][N1][N2] to the workspace
     const int hh = lane >> 5;
-    const bool use_atomic = gridDim.z > 1;
+    const bool to_ws = gridDim.z > 1;
+    float* wsz = reinterpret_cast<float*>(a.ws) + (int64_t)blockIdx.z * a.N1 * a.N2;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n1 = n1_0 + w1 * 64 + j * 32 + (lane & 31);
@@ -350,21 +372,64 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const dicow_gemm_tn_arg
             for (int q = 0; q < 4; ++q) {
                 const int n2 = n2_0 + w2 * 64 + i * 32 + 8 * q + 4 * hh;
                 if (n2 >= a.N2) continue;
-                float* cp = a.C + (int64_t)n1 * a.ldc + n2;
-                if (use_atomic) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) atomicAdd(cp + e, acc[i][j][4 * q + e]);
-                } else {
-                    float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                    if (a.accumulate) {
-                        const float4 o = *reinterpret_cast<const float4*>(cp);
-                        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                    }
-                    *reinterpret_cast<float4*>(cp) = v;
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (to_ws) {
+                    *reinterpret_cast<float4*>(wsz + (int64_t)n1 * a.N2 + n2) = v;
+                    continue;
                 }
+                float* cp;
+                if (a.seg_rows > 0 && n1 >= a.seg_rows) {
+                    const int sg = n1 / a.seg_rows;
+                    cp = a.C_seg[sg - 1] + (int64_t)(n1 - sg * a.seg_rows) * a.ldc + n2;
+                } else {
+                    cp = a.C + (int64_t)n1 * a.ldc + n2;
+                }
+                if (a.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(cp);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                *reinterpret_cast<float4*>(cp) = v;
             }
         }
     }
+}
+
+// C[r][:] (+)= sum_z ws[z][row0 + r][:]   for r < nrows   (ldc may exceed N2)
+__global__ void tn_reduce_kernel(const float* __restrict__ ws, int splits, int64_t zstride, int row0, int nrows, int N2,
+                                 float* __restrict__ C, int64_t ldc, int accumulate) {
+    const int n24 = N2 >> 2;
+    const int64_t total = (int64_t)nrows * n24;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / n24), c4 = (int)(i - (int64_t)r * n24);
+        float* cp = C + (int64_t)r * ldc + c4 * 4;
+        float4 s = accumulate ? *reinterpret_cast<const float4*>(cp) : make_float4(0, 0, 0, 0);
+        const float* wp = ws + (int64_t)(row0 + r) * N2 + c4 * 4;
+        for (int z = 0; z < splits; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(wp + (int64_t)z * zstride);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(cp) = s;
+    }
+}
+
+static void tn_plan(const dicow_gemm_tn_args* a, int& tpb, int& total, int& nt, int& splits, int& tps) {
+    const int batch = a->batch > 0 ? a->batch : 1;
+    tpb = dicow_cdiv(a->Mk, TK);
+    total = tpb * batch;
+    nt = dicow_cdiv(a->N1, 128) * dicow_cdiv(a->N2, 128);
+    // ~2 resident workgroups per CU: split the contraction only when the output has too few tiles to fill the chip
+    splits = nt >= 384 ? 1 : (640 + nt - 1) / nt;
+    if (splits > total / 8) splits = total / 8;
+    if (const char* ev = getenv("DICOW_TN_SPLITS")) splits = atoi(ev);        // tuning knob (tools/bench_gemm.py)
+    if (splits < 1) splits = 1;
+    tps = dicow_cdiv(total, splits);
+    splits = dicow_cdiv(total, tps);
+}
+
+extern "C" int64_t dicow_gemm_tn_ws_bytes(const dicow_gemm_tn_args* a) {
+    int tpb, total, nt, splits, tps;
+    tn_plan(a, tpb, total, nt, splits, tps);
+    return splits > 1 ? (int64_t)splits * a->N1 * a->N2 * 4 : 0;
 }
 
 extern "C" int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream) {
@@ -372,17 +437,12 @@ extern "C" int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream) {
     DICOW_REQUIRE(a->Mk > 0 && a->N1 >= 8 && a->N2 >= 8, "gemm_tn: empty problem");
     DICOW_REQUIRE(a->N1 % 8 == 0 && a->N2 % 8 == 0, "gemm_tn: N1=%d, N2=%d must be multiples of 8", a->N1, a->N2);
     DICOW_REQUIRE(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0, "gemm_tn: lda/ldb %% 8, ldc %% 4 required");
-    const int batch = a->batch > 0 ? a->batch : 1;
-    const int tpb = dicow_cdiv(a->Mk, TK);
-    const int total = tpb * batch;
-    const int nt = dicow_cdiv(a->N1, 128) * dicow_cdiv(a->N2, 128);
-    // split the contraction so that the grid has >= ~4 waves of workgroups (2 resident per CU)
-    int splits = (2048 + nt - 1) / nt;
-    if (splits > total / 4) splits = total / 4;
-    if (splits < 1) splits = 1;
-    int tps = dicow_cdiv(total, splits);
-    splits = dicow_cdiv(total, tps);
-    DICOW_REQUIRE(splits == 1 || a->accumulate, "gemm_tn: split contraction needs accumulate=1 (C pre-initialised)");
+    DICOW_REQUIRE(a->seg_rows == 0 || (a->seg_rows % 128 == 0 && a->N1 <= 3 * a->seg_rows && a->C_seg[0] &&
+                                        (a->N1 <= 2 * a->seg_rows || a->C_seg[1])), "gemm_tn: bad C segments");
+    int tpb, total, nt, splits, tps;
+    tn_plan(a, tpb, total, nt, splits, tps);
+    DICOW_REQUIRE(splits == 1 || (a->ws && a->ws_bytes >= (int64_t)splits * a->N1 * a->N2 * 4),
+                  "gemm_tn: workspace too small (need %ld bytes)", (long)splits * a->N1 * a->N2 * 4);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
@@ -390,5 +450,18 @@ extern "C" int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream) {
     }
     hipLaunchKernelGGL(gemm_tn_kernel, dim3(nt, 1, splits), dim3(256), TN_LDS_BYTES, (hipStream_t)stream, *a, tpb, total, tps);
     DICOW_CHECK_LAUNCH("gemm_tn");
+    if (splits > 1) {
+        const int nseg = a->seg_rows > 0 ? dicow_cdiv(a->N1, a->seg_rows) : 1;
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int row0 = sg * (a->seg_rows > 0 ? a->seg_rows : 0);
+            const int nrows = a->seg_rows > 0 ? ((a->N1 - row0) < a->seg_rows ? (a->N1 - row0) : a->seg_rows) : a->N1;
+            float* C = sg == 0 ? a->C : a->C_seg[sg - 1];
+            const int64_t tot4 = (int64_t)nrows * (a->N2 / 4);
+            int grid = (int)((tot4 + 255) / 256); if (grid > 4096) grid = 4096;
+            hipLaunchKernelGGL(tn_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)a->ws, splits,
+                               (int64_t)a->N1 * a->N2, row0, nrows, a->N2, C, a->ldc, a->accumulate);
+            DICOW_CHECK_LAUNCH("tn_reduce");
+        }
+    }
     return DICOW_OK;
 }

@@ -155,6 +155,16 @@ def linear_wgrad(dy, x, gw, M, n_rows=None):
     ops.gemm_tn(dy, x, gw, M, N, x.shape[1], lda=dy.stride(0), ldb=x.stride(0), ldc=gw.stride(0))
 
 
+def qkv_wgrad(d_qkv, x, gq, gk, gv, M, D):
+    """Weight gradients of the fused q/k/v projection from ONE TN GEMM (C rows segmented over the three tensors)."""
+    if gq is not None and gk is not None and gv is not None and D % 128 == 0:
+        ops.gemm_tn(d_qkv, x, gq, M, 3 * D, D, lda=d_qkv.stride(0), ldb=x.stride(0), ldc=D, C_seg=(gk, gv), seg_rows=D)
+        return
+    linear_wgrad(d_qkv[:, :D], x, gq, M)
+    linear_wgrad(d_qkv[:, D:2 * D], x, gk, M)
+    linear_wgrad(d_qkv[:, 2 * D:], x, gv, M)
+
+
 def bias_grad(dy, gb):
     if gb is not None:
         ops.colsum_bf16(dy, gb)
@@ -423,9 +433,7 @@ class EncoderEngine:
                          heads(d_qkv[:, D:2 * D], Bc, T, H), heads(d_qkv[:, 2 * D:], Bc, T, H), dq_scale=0.125)
             bias_grad(d_qkv[:, :D], G.get(att.q_proj.bias))
             bias_grad(d_qkv[:, 2 * D:], G.get(att.v_proj.bias))
-            linear_wgrad(d_qkv[:, :D], Ls.xln, G.get(att.q_proj.weight), rows)
-            linear_wgrad(d_qkv[:, D:2 * D], Ls.xln, G.get(att.k_proj.weight), rows)
-            linear_wgrad(d_qkv[:, 2 * D:], Ls.xln, G.get(att.v_proj.weight), rows)
+            qkv_wgrad(d_qkv, Ls.xln, G.get(att.q_proj.weight), G.get(att.k_proj.weight), G.get(att.v_proj.weight), rows, D)
             d_xln = linear_dgrad(d_qkv, w.att.qkv, rows)
             # ---- LayerNorm1 (+ SCB) + FDDT backward; the column sum of the result is the previous fc2's bias grad
             fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None

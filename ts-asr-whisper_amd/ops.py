@@ -26,6 +26,20 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_WS = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    """Persistent per-device scratch for the two-stage reductions (the library never allocates).  Kernels that use
+    it are stream-ordered on the current stream, so one buffer per device suffices."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    t = _WS.get(key)
+    if t is None or t.numel() < nbytes:
+        t = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = t
+    return t
+
+
 def _arr4(ts):
     a = (C.c_void_p * 4)()
     for i, t in enumerate(ts):
@@ -84,7 +98,9 @@ def colsum_bf16(x: torch.Tensor, out: torch.Tensor):
     """out[N] (fp32) += column sums of bf16 x [rows, N] (row stride x.stride(0))."""
     _req(x, BF16, "colsum.x")
     assert x.dim() == 2 and x.stride(1) == 1
-    L.call("dicow_colsum_bf16", x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], L.stream())
+    ws = workspace(L.lib().dicow_colsum_ws_bytes(x.shape[0], x.shape[1]), x.device)
+    L.call("dicow_colsum_bf16", x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], x.shape[1], ws.data_ptr(), ws.numel(),
+           L.stream())
 
 
 def sum_over_batch(g: torch.Tensor, out: torch.Tensor):
@@ -125,6 +141,8 @@ def fddt_ln_bwd(h_in, rows, D, *, mode=MODE_NONE, stno=None, stno_bstride=None, 
     a.dw, a.db = _arr4(dw), _arr4(db)
     a.colsum_out = _p(colsum_out)
     a.rows, a.T, a.D = rows, T, D
+    ws = workspace(L.lib().dicow_fddt_ln_bwd_ws_bytes(rows, D), h_in.device)
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     L.call_struct("dicow_fddt_ln_bwd", a)
 
 
@@ -152,7 +170,8 @@ def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, re
     L.call_struct("dicow_gemm_nt", a)
 
 
-def gemm_tn(A, B, C_out, Mk, N1, N2, *, lda=None, ldb=None, ldc=None, batch=1, strideA=0, strideB=0, accumulate=True):
+def gemm_tn(A, B, C_out, Mk, N1, N2, *, lda=None, ldb=None, ldc=None, batch=1, strideA=0, strideB=0, accumulate=True,
+            C_seg=None, seg_rows=0):
     """C[N1,N2] (+)= sum_m A[m,N1] * B[m,N2]  (fp32 C)."""
     a = L.GemmTnArgs()
     a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
@@ -161,6 +180,14 @@ def gemm_tn(A, B, C_out, Mk, N1, N2, *, lda=None, ldb=None, ldc=None, batch=1, s
     a.ldb = N2 if ldb is None else ldb
     a.ldc = N2 if ldc is None else ldc
     a.batch, a.strideA, a.strideB, a.accumulate = batch, strideA, strideB, int(accumulate)
+    if C_seg is not None:
+        for i, t in enumerate(C_seg):
+            a.C_seg[i] = t.data_ptr()
+        a.seg_rows = seg_rows
+    need = L.lib().dicow_gemm_tn_ws_bytes(C.byref(a))
+    if need:
+        ws = workspace(need, C_out.device)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     L.call_struct("dicow_gemm_tn", a)
 
 
