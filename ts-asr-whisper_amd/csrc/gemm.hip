@@ -62,11 +62,27 @@ __device__ __forceinline__ void nt_stage(const unsigned short* __restrict__ A, c
     }
 }
 
+// one (A,B) pair of the four DMA instruction pairs of a stage: lets the k-loop spread the DMA issue between its MFMA
+// groups -- a burst of 8 back-to-back DMAs per wave fills the CU's vector-memory queue and BLOCKS the in-order wave
+// at issue, which serialises fill and compute (measured: step time = fill + MFMA instead of max(fill, MFMA)).
+__device__ __forceinline__ void nt_stage_part(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
+                                              int64_t lda, int64_t ldb, int M, int N, int m0, int n0, int k0, char* sA,
+                                              char* sB, int wave, int lane, int i) {
+    const int rr = lane >> 3, p = lane & 7;
+    const int row = (wave * 4 + i) * 8 + rr;
+    const int c = p ^ ((row >> 1) & 7);
+    int gm = m0 + row; gm = gm < M ? gm : M - 1;
+    int gn = n0 + row; gn = gn < N ? gn : N - 1;
+    glds16(A + (int64_t)gm * lda + k0 + c * 8, sA + (wave * 4 + i) * 1024);
+    glds16(B + (int64_t)gn * ldb + k0 + c * 8, sB + (wave * 4 + i) * 1024);
+}
+
 __device__ __forceinline__ bf16x8_t lds_frag_nt(const char* s, int row, int c) {
     return *reinterpret_cast<const bf16x8_t*>(s + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
 }
 
-__global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const dicow_gemm_args a) {
+template <int STAGES, bool PRIO>
+__global__ void __launch_bounds__(256, STAGES == 2 ? 2 : 4) gemm_nt_kernel(const dicow_gemm_args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -88,11 +104,15 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const dicow_gemm_args a
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = a.K / BK;
-    nt_stage(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, 0, smem, smem + STAGE_BYTES, wave, lane);
+    if (STAGES == 2) nt_stage(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, 0, smem, smem + STAGE_BYTES, wave, lane);
     for (int t = 0; t < nk; ++t) {
-        char* sA = smem + (t & 1) * 2 * STAGE_BYTES;
+        char* sA = smem + (STAGES == 2 ? (t & 1) * 2 * STAGE_BYTES : 0);
         char* sB = sA + STAGE_BYTES;
-        if (t + 1 < nk) {
+        if (STAGES == 1) {
+            // single LDS stage (32 KiB): 4 workgroups per CU hide each other's load / barrier phases
+            nt_stage(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, t * BK, sA, sB, wave, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (t + 1 < nk) {
             char* nA = smem + ((t + 1) & 1) * 2 * STAGE_BYTES;
             nt_stage(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, (t + 1) * BK, nA, nA + STAGE_BYTES, wave, lane);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -101,6 +121,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const dicow_gemm_args a
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             const int c = kk * 2 + (lane >> 5);
@@ -115,6 +136,7 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const dicow_gemm_args a
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -184,6 +206,163 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(const dicow_gemm_args a
     }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, 256x256 tile
+// 512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 (M) x 64 (N) = 4x2 MFMA tiles (128 fp32 accumulators/lane).
+// Twice the arithmetic intensity of the 128x128 kernel (128 flop per LDS-staged byte): at ~0.7 PFLOP/s the small
+// tile already pulls ~11 TB/s through L2 -> LDS.  Two 64 KiB stages (128 KiB of the CU's 160 KiB LDS), one workgroup
+// per CU with two waves per SIMD.
+#define NT256_STAGE (2 * 256 * BK * 2)       // A + B = 64 KiB
+#define NT256_LDS (2 * NT256_STAGE)
+
+template <typename T> struct epi_store;
+
+__device__ __forceinline__ void nt_epilogue_quad(const dicow_gemm_args& a, int flags, float (&v)[4], int m, int n,
+                                                 unsigned short* Cb, float* Cf, unsigned short* aux) {
+    if (flags & DICOW_EPI_BIAS) {
+        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+    if (flags & DICOW_EPI_SCALE_N) {
+        if (n < a.scale_ncols) { v[0] *= a.scale; v[1] *= a.scale; v[2] *= a.scale; v[3] *= a.scale; }
+    }
+    if (flags & DICOW_EPI_GELU) {
+        if (aux) {
+            *reinterpret_cast<uint2*>(aux + (int64_t)m * a.ldaux + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e]));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (flags & DICOW_EPI_GELU_BWD) {
+        const uint2 u = *reinterpret_cast<const uint2*>(aux + (int64_t)m * a.ldaux + n);
+        v[0] *= gelu_erf_grad(__uint_as_float(u.x << 16));
+        v[1] *= gelu_erf_grad(__uint_as_float(u.x & 0xffff0000u));
+        v[2] *= gelu_erf_grad(__uint_as_float(u.y << 16));
+        v[3] *= gelu_erf_grad(__uint_as_float(u.y & 0xffff0000u));
+    }
+    if (flags & DICOW_EPI_RESIDUAL) {
+        const float4 rv = *reinterpret_cast<const float4*>(a.residual + (int64_t)m * a.ldr + n);
+        v[0] = bf2f(f2bf(v[0])) + rv.x; v[1] = bf2f(f2bf(v[1])) + rv.y;
+        v[2] = bf2f(f2bf(v[2])) + rv.z; v[3] = bf2f(f2bf(v[3])) + rv.w;
+    }
+    if (flags & DICOW_EPI_OUT_F32) {
+        float* cp = Cf + (int64_t)m * a.ldc + n;
+        if (flags & DICOW_EPI_ACCUM) {
+            const float4 old = *reinterpret_cast<const float4*>(cp);
+            v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+        }
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        *reinterpret_cast<uint2*>(Cb + (int64_t)m * a.ldc + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+}
+
+template <int ABL>   // ablation: 0 = real kernel, 1 = no DMA after the first tile, 2 = no MFMA, 3 = no LDS fragment reads
+__global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256;
+    int tm, tn;
+    tile_coords(ntm, ntn, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int bz = blockIdx.z;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
+    const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
+    const int wm = wave >> 2, wn = wave & 3;          // wave tile: rows m [wm*128, +128), cols n [wn*64, +64)
+
+    f32x16_t acc[2][4];                               // [n block i][m block j]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.K / BK;
+    // stage image: [A 256 rows x 128 B][B 256 rows x 128 B]; the 8 waves x 4 instructions cover 32 x 8 rows each
+    nt_stage(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, 0, smem, smem + 256 * 128, wave, lane);
+    // Software pipeline (one barrier per k-step, MFMA work on both sides of it):
+    //   * fragment reads run one 16-deep k-slice ahead of the MFMAs that consume them (two register sets f0/f1);
+    //   * the LAST slice's MFMAs of tile t are issued AFTER the barrier that opens tile t+1, so the matrix pipe has
+    //     work while the first fragment reads of the new tile are in flight (the barrier only needs those fragments
+    //     to have left LDS, which lgkmcnt(0) guarantees);
+    //   * the DMA of tile t+2 is issued right after that barrier, two instruction pairs per slice, and gets ~3/4 of
+    //     a k-step to land.
+    // sched_group_barrier pins [reads][DMA][8 MFMA] per slice (hipcc otherwise sinks the reads behind the MFMAs).
+    bf16x8_t wf0[2], xf0[4], wf1[2], xf1[4];
+#define LDFRAG(WF, XF, KK)                                                                                   \
+    {                                                                                                        \
+        const int c_ = (KK) * 2 + (lane >> 5);                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) WF[i] = lds_frag_nt(sB, wn * 64 + i * 32 + (lane & 31), c_);  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) XF[j] = lds_frag_nt(sA, wm * 128 + j * 32 + (lane & 31), c_); \
+    }
+#define DOMFMA(WF, XF)                                                                                       \
+    if (ABL == 2) { _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(XF[j]), "v"(WF[j & 1])); } \
+    else { _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < 2; ++i)              \
+               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0); }
+#define DMA2(I0) if (MORE) { nt_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, (t + 1) * BK, nA, nA + 256 * 128, wave, lane, I0); \
+                             nt_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, (t + 1) * BK, nA, nA + 256 * 128, wave, lane, I0 + 1); }
+#define SCHED(NREAD, NDMA, NMFMA)                                                                            \
+    __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);                                                   \
+    __builtin_amdgcn_sched_group_barrier(0x020, NDMA, 0);                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
+    // KSTEP(MORE, FIRST): tile t is in stage t&1; on entry (unless FIRST) f1 holds slice 3 of tile t-1
+#define KSTEP(MORE_, FIRST_)                                                                                 \
+    {                                                                                                        \
+        constexpr bool MORE = MORE_;                                                                         \
+        char* sA = smem + (t & 1) * NT256_STAGE;                                                             \
+        char* sB = sA + 256 * 128;                                                                           \
+        char* nA = smem + ((t + 1) & 1) * NT256_STAGE;                                                       \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        asm volatile("" ::: "memory");                                                                       \
+        LDFRAG(wf0, xf0, 0) DMA2(0)                                                                          \
+        if (!(FIRST_)) { DOMFMA(wf1, xf1) }                                                                  \
+        SCHED(6, MORE ? 4 : 0, (FIRST_) ? 0 : 8)                                                             \
+        LDFRAG(wf1, xf1, 1) DMA2(2) DOMFMA(wf0, xf0) SCHED(6, MORE ? 4 : 0, 8)                                \
+        LDFRAG(wf0, xf0, 2) DOMFMA(wf1, xf1) SCHED(6, 0, 8)                                                  \
+        LDFRAG(wf1, xf1, 3) DOMFMA(wf0, xf0) SCHED(6, 0, 8)                                                  \
+    }
+    int t = 0;
+    if (nk == 1) {
+        KSTEP(false, true)
+    } else {
+        if (ABL == 1) KSTEP(false, true) else KSTEP(true, true)
+        for (t = 1; t + 1 < nk; ++t) {
+            if (ABL == 1) KSTEP(false, false) else KSTEP(true, false)
+        }
+        KSTEP(false, false)
+    }
+    DOMFMA(wf1, xf1)          // slice 3 of the last tile
+#undef KSTEP
+#undef SCHED
+#undef LDFRAG
+#undef DOMFMA
+#undef DMA2
+    const int flags = a.flags;
+    const int hh = lane >> 5;
+    unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)bz * a.strideC;
+    float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
+    unsigned short* aux = a.aux ? reinterpret_cast<unsigned short*>(a.aux) + (int64_t)bz * a.strideAux : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 128 + j * 32 + (lane & 31);
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * hh;
+                if (n >= a.N) continue;
+                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                nt_epilogue_quad(a, flags, v, m, n, Cb, Cf, aux);
+            }
+        }
+    }
+}
+
 extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     DICOW_REQUIRE(a && a->A && a->B && a->C, "gemm_nt: null operand");
     DICOW_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -199,10 +378,33 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     const int ntm = dicow_cdiv(a->M, BM), ntn = dicow_cdiv(a->N, BN);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(ntm * ntn, 1, batch), dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
+    static const int variant = getenv("DICOW_NT_VARIANT") ? atoi(getenv("DICOW_NT_VARIANT")) : 0;     // tuning knob
+    static bool attr256 = false;
+    if (!attr256) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+        attr256 = true;
+    }
+    // the 256x256 kernel wins once it can put ~one workgroup on every CU; smaller problems keep the 128x128 tiles
+    const bool big = (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
+    if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
+        const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
+        if (variant == 5) hipLaunchKernelGGL(gemm_nt256_kernel<1>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
+        else if (variant == 6) hipLaunchKernelGGL(gemm_nt256_kernel<2>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
+        else hipLaunchKernelGGL(gemm_nt256_kernel<0>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
+        DICOW_CHECK_LAUNCH("gemm_nt256");
+        return DICOW_OK;
+    }
+    const dim3 grid(ntm * ntn, 1, batch);
+    if (variant == 1) hipLaunchKernelGGL((gemm_nt_kernel<1, false>), grid, dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, *a);
+    else if (variant == 2) hipLaunchKernelGGL((gemm_nt_kernel<2, true>), grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
+    else if (variant == 3) hipLaunchKernelGGL((gemm_nt_kernel<1, true>), grid, dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<2, false>), grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("gemm_nt");
     return DICOW_OK;
 }
