@@ -228,6 +228,15 @@ int dicow_gelu_bwd_bf16(const void* g, const void* pre, void* out, int64_t n, vo
  *   dA2 bf16 [B, T2, 3*C] (tap-major im2col gradient)  ->  d_pre1 bf16 [B, 2*T2, C] = gelu'(pre1) * scatter-add */
 int dicow_conv2_col2im_gelu_bwd(const void* dA2, const void* pre1, void* d_pre1, int B, int T2, int C, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ log-mel front end
+ * Whisper features on the GPU (reference call site src/data/local_datasets.py:208-214 -> HF feature_extraction_whisper.py
+ * :135-165): wave fp32 [B, n_samples] (padded to a multiple of 30 s) -> out fp32 [B, M, n_samples/160].
+ * tw_cos/tw_sin: [400, 201] hann-window-folded DFT tables, fb: [201, M] slaney mel filterbank (host-built once,
+ * ts-asr-whisper_amd/features.py). */
+int64_t dicow_logmel_ws_bytes(int B, int n_samples);
+int dicow_logmel(const float* wave, int B, int n_samples, const float* tw_cos, const float* tw_sin, const float* fb, int M,
+                 float* out, void* ws, int64_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ optimizer
  * Fused AdamW + global-norm clipping on flat fp32 regions (src/models/containers.py:100-114 two param groups;
  * HF Trainer max_grad_norm 1.0).  dicow_sumsq_f32 accumulates sum(x^2) into out[0]; dicow_adamw_f32 applies

@@ -277,3 +277,24 @@ def test_attn_bwd(ops, B, H, Lq, Lk, causal):
     assert maxdiff(gq[:, :, :D].float().cpu().view(B, Lq, H, 64), 0.5 * q.grad) < tol(q.grad)
     assert maxdiff(gk[:, :, D:2 * D].float().cpu().view(B, Lk, H, 64), k.grad) < tol(k.grad)
     assert maxdiff(gk[:, :, 2 * D:].float().cpu().view(B, Lk, H, 64), v.grad) < tol(v.grad)
+
+
+# ------------------------------------------------------------------------------------------------ log-mel (golden F2)
+def test_logmel_vs_reference_golden(ops):
+    import numpy as np
+    from ts_asr_whisper_amd import features
+    z = load_golden("f2_logmel")
+    for i in range(int(z["n_cases"])):
+        wave = z[f"wave_{i}"].astype(np.float32) / 32768.0
+        padded, am = features.pad_to_30s([wave])
+        got = features.log_mel(padded.cuda(), int(z[f"mels_{i}"])).cpu()[0]
+        ref = T(z, f"feat_{i}")
+        assert got.shape == ref.shape
+        assert int(am.sum()) == int(z[f"attn_sum_{i}"])
+        # reference: fp32 torch.stft; HF quotes 1e-5 between its own numpy/torch paths
+        assert maxdiff(got, ref) < 3e-4, maxdiff(got, ref)
+    # batch of two clips, second longer than 30 s -> 60 s padding
+    w2 = [np.random.default_rng(0).standard_normal(16000 * 31).astype(np.float32) * 0.1, wave]
+    padded, am = features.pad_to_30s(w2)
+    out = features.log_mel(padded.cuda(), 80)
+    assert out.shape == (2, 80, 6000) and torch.isfinite(out).all()

@@ -81,3 +81,10 @@ def test_config_rejects_unsupported():
         pkg.DiCoWConfig(d_model=100, encoder_attention_heads=2, decoder_attention_heads=2)
     with pytest.raises(ValueError):
         pkg.DiCoWConfig(dropout=0.1)
+
+
+def test_product_mel_filterbank_matches_oracle():
+    from ts_asr_whisper_amd import features
+    from oracle import logmel as ol
+    for m in (80, 128):
+        assert np.allclose(features.mel_filter_bank(m), ol.mel_filter_bank(m), atol=1e-12)

@@ -87,6 +87,7 @@ _SIGS = {
     "dicow_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_gelu_bwd_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "dicow_conv2_col2im_gelu_bwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "dicow_logmel": [c_vp, c_i, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp],
     "dicow_sumsq_f32": [c_vp, c_i64, c_vp, c_vp],
     "dicow_adamw_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_f, c_vp],
 }
@@ -122,6 +123,7 @@ _SIGS64 = {   # functions returning int64_t (workspace sizes)
     "dicow_colsum_ws_bytes": [c_i, c_i],
     "dicow_fddt_ln_bwd_ws_bytes": [c_i, c_i],
     "dicow_gemm_tn_ws_bytes": [C.POINTER(GemmTnArgs)],
+    "dicow_logmel_ws_bytes": [c_i, c_i],
 }
 
 
