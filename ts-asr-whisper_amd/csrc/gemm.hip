@@ -596,6 +596,180 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const dicow_gemm_tn_arg
     }
 }
 
+// ------------------------------------------------------------------------------------------------ TN, 256x256 tile
+// Same pipeline as gemm_nt256_kernel (8 waves, 2 x 64 KiB stages, one barrier per 64-deep contraction step, fragments
+// one k-slice ahead, last slice's MFMAs after the barrier, DMA spread two instruction pairs per slice); fragments come
+// from ds_read_b64_tr_b16.  LDS image per operand: [64 m][256 n] bf16, 512-B rows, chunk c of row m at c ^ ((m&3)<<2).
+#define TN256_OP (TK * 256 * 2)              // 32 KiB per operand per stage
+#define TN256_STAGE (2 * TN256_OP)
+#define TN256_LDS (2 * TN256_STAGE)
+
+__device__ __forceinline__ void tn256_stage_part(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
+                                                 int64_t lda, int64_t ldb, int N1, int N2, int n1_0, int n2_0, int row_base,
+                                                 int rows_valid, char* sA, char* sB, int wave, int lane, int i) {
+    const int q = wave * 4 + i;                       // DMA instruction index: rows 2q, 2q+1 (1 KiB)
+    const int row = 2 * q + (lane >> 5), p = lane & 31;
+    const int c = p ^ ((row & 3) << 2);
+    const int grow = row_base + (row < rows_valid ? row : rows_valid - 1);
+    int ca = n1_0 + c * 8; ca = ca + 8 <= N1 ? ca : N1 - 8;
+    int cb = n2_0 + c * 8; cb = cb + 8 <= N2 ? cb : N2 - 8;
+    glds16(A + (int64_t)grow * lda + ca, sA + q * 1024);
+    glds16(B + (int64_t)grow * ldb + cb, sB + q * 1024);
+}
+__device__ __forceinline__ unsigned tn256_tr_addr(const char* s, int m, int n) {
+    return (unsigned)(uintptr_t)(s + m * 512 + ((((n >> 3) ^ ((m & 3) << 2))) << 4) + ((n & 7) << 1));
+}
+struct tn256_frag_t { bf16x4_t r[12]; };
+template <int OFF>
+__device__ __forceinline__ void tn256_issue(tn256_frag_t& f, const unsigned (&ad)[6]) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %12 offset:%18\n\t"  "ds_read_b64_tr_b16 %1, %12 offset:%19\n\t"
+        "ds_read_b64_tr_b16 %2, %13 offset:%18\n\t"  "ds_read_b64_tr_b16 %3, %13 offset:%19\n\t"
+        "ds_read_b64_tr_b16 %4, %14 offset:%18\n\t"  "ds_read_b64_tr_b16 %5, %14 offset:%19\n\t"
+        "ds_read_b64_tr_b16 %6, %15 offset:%18\n\t"  "ds_read_b64_tr_b16 %7, %15 offset:%19\n\t"
+        "ds_read_b64_tr_b16 %8, %16 offset:%18\n\t"  "ds_read_b64_tr_b16 %9, %16 offset:%19\n\t"
+        "ds_read_b64_tr_b16 %10, %17 offset:%18\n\t" "ds_read_b64_tr_b16 %11, %17 offset:%19"
+        : "=&v"(f.r[0]), "=&v"(f.r[1]), "=&v"(f.r[2]), "=&v"(f.r[3]), "=&v"(f.r[4]), "=&v"(f.r[5]), "=&v"(f.r[6]), "=&v"(f.r[7]),
+          "=&v"(f.r[8]), "=&v"(f.r[9]), "=&v"(f.r[10]), "=&v"(f.r[11])
+        : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "i"(OFF), "i"(OFF + 2048)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tn256_wait(tn256_frag_t& f) {
+    asm volatile("s_waitcnt lgkmcnt(%12)"
+                 : "+v"(f.r[0]), "+v"(f.r[1]), "+v"(f.r[2]), "+v"(f.r[3]), "+v"(f.r[4]), "+v"(f.r[5]), "+v"(f.r[6]), "+v"(f.r[7]),
+                   "+v"(f.r[8]), "+v"(f.r[9]), "+v"(f.r[10]), "+v"(f.r[11])
+                 : "i"(N)
+                 : "memory");
+}
+// r[0..3]: the two n2 blocks (lo,hi each); r[4..11]: the four n1 blocks
+__device__ __forceinline__ void tn256_mfma(f32x16_t (&acc)[2][4], const tn256_frag_t& f) {
+    bf16x8_t f2[2], f1[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) f2[i] = __builtin_shufflevector(f.r[2 * i], f.r[2 * i + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f1[j] = __builtin_shufflevector(f.r[4 + 2 * j], f.r[5 + 2 * j], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[i], f1[j], acc[i][j], 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_args a, int tiles_per_batch, int total_tiles,
+                                                            int tiles_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt1 = (a.N1 + 255) / 256, nt2 = (a.N2 + 255) / 256;
+    int t1, t2;
+    tile_coords(nt1, nt2, t1, t2);
+    const int n1_0 = t1 * 256, n2_0 = t2 * 256;
+    const int kt0 = blockIdx.z * tiles_per_split;
+    int kt1 = kt0 + tiles_per_split; kt1 = kt1 < total_tiles ? kt1 : total_tiles;
+    if (kt0 >= kt1) return;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A);
+    const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B);
+    const int w1 = wave >> 2, w2 = wave & 3;          // wave tile: n1 [w1*128, +128), n2 [w2*64, +64)
+
+    f32x16_t acc[2][4];                               // [n2 block i][n1 block j]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int G = lane >> 4, u = lane & 15;
+    const int tr_row = 8 * (G >> 1) + (u >> 2);
+    const int tr_col = 16 * (G & 1) + 4 * (u & 3);
+    auto dma2 = [&](int kt, int i0) {                 // two DMA instruction pairs of contraction tile kt
+        const int b = kt / tiles_per_batch, lt = kt - b * tiles_per_batch;
+        const int rv = (a.Mk - lt * TK) < TK ? (a.Mk - lt * TK) : TK;
+        char* sA = smem + ((kt - kt0) & 1) * TN256_STAGE;
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            tn256_stage_part(A + (int64_t)b * a.strideA, B + (int64_t)b * a.strideB, a.lda, a.ldb, a.N1, a.N2, n1_0, n2_0,
+                             lt * TK, rv, sA, sA + TN256_OP, wave, lane, i0 + e);
+    };
+    dma2(kt0, 0);
+    dma2(kt0, 2);
+    tn256_frag_t f0, f1;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        char* sA = smem + ((kt - kt0) & 1) * TN256_STAGE;
+        char* sB = sA + TN256_OP;
+        const bool more = kt + 1 < kt1, first = kt == kt0;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        {   // zero the rows of a partial contraction tile (the DMA fetched clamped duplicates there)
+            const int lt = kt % tiles_per_batch;
+            const int rv = (a.Mk - lt * TK) < TK ? (a.Mk - lt * TK) : TK;
+            if (rv < TK) {
+                for (int i = tid; i < (TK - rv) * 32; i += 512) {
+                    const int off = (rv + (i >> 5)) * 512 + (i & 31) * 16;
+                    *reinterpret_cast<uint4*>(sA + off) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<uint4*>(sB + off) = make_uint4(0, 0, 0, 0);
+                }
+                __syncthreads();
+            }
+        }
+        unsigned ad[6];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) ad[i] = tn256_tr_addr(sB, tr_row, w2 * 64 + i * 32 + tr_col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ad[2 + j] = tn256_tr_addr(sA, tr_row, w1 * 128 + j * 32 + tr_col);
+        tn256_issue<0>(f0, ad);
+        if (more) dma2(kt + 1, 0);
+        if (!first) tn256_mfma(acc, f1);              // slice 3 of the previous tile (landed before the barrier)
+        tn256_issue<8192>(f1, ad);
+        if (more) dma2(kt + 1, 2);
+        tn256_wait<12>(f0);
+        tn256_mfma(acc, f0);
+        tn256_issue<16384>(f0, ad);
+        tn256_wait<12>(f1);
+        tn256_mfma(acc, f1);
+        tn256_issue<24576>(f1, ad);
+        tn256_wait<12>(f0);
+        tn256_mfma(acc, f0);
+    }
+    tn256_wait<0>(f1);
+    tn256_mfma(acc, f1);
+
+    const int hh = lane >> 5;
+    const bool to_ws = gridDim.z > 1;
+    float* wsz = reinterpret_cast<float*>(a.ws) + (int64_t)blockIdx.z * a.N1 * a.N2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n1 = n1_0 + w1 * 128 + j * 32 + (lane & 31);
+        if (n1 >= a.N1) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n2 = n2_0 + w2 * 64 + i * 32 + 8 * q + 4 * hh;
+                if (n2 >= a.N2) continue;
+                float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                if (to_ws) {
+                    *reinterpret_cast<float4*>(wsz + (int64_t)n1 * a.N2 + n2) = v;
+                    continue;
+                }
+                float* cp;
+                if (a.seg_rows > 0 && n1 >= a.seg_rows) {
+                    const int sg = n1 / a.seg_rows;
+                    cp = a.C_seg[sg - 1] + (int64_t)(n1 - sg * a.seg_rows) * a.ldc + n2;
+                } else {
+                    cp = a.C + (int64_t)n1 * a.ldc + n2;
+                }
+                if (a.accumulate) {
+                    const float4 o = *reinterpret_cast<const float4*>(cp);
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                *reinterpret_cast<float4*>(cp) = v;
+            }
+        }
+    }
+}
+
 // C[r][:] (+)= sum_z ws[z][row0 + r][:]   for r < nrows   (ldc may exceed N2)
 __global__ void tn_reduce_kernel(const float* __restrict__ ws, int splits, int64_t zstride, int row0, int nrows, int N2,
                                  float* __restrict__ C, int64_t ldc, int accumulate) {
@@ -614,23 +788,37 @@ __global__ void tn_reduce_kernel(const float* __restrict__ ws, int splits, int64
     }
 }
 
-static void tn_plan(const dicow_gemm_tn_args* a, int& tpb, int& total, int& nt, int& splits, int& tps) {
+// Tile size + contraction split: minimise  flops / (rate * grid-quantisation efficiency) + split-reduction traffic.
+static void tn_plan(const dicow_gemm_tn_args* a, int& tpb, int& total, int& nt, int& splits, int& tps, int& tile) {
     const int batch = a->batch > 0 ? a->batch : 1;
     tpb = dicow_cdiv(a->Mk, TK);
     total = tpb * batch;
-    nt = dicow_cdiv(a->N1, 128) * dicow_cdiv(a->N2, 128);
-    // ~2 resident workgroups per CU: split the contraction only when the output has too few tiles to fill the chip
-    splits = nt >= 384 ? 1 : (640 + nt - 1) / nt;
-    if (splits > total / 8) splits = total / 8;
-    if (const char* ev = getenv("DICOW_TN_SPLITS")) splits = atoi(ev);        // tuning knob (tools/bench_gemm.py)
+    const double flops = 2.0 * a->Mk * batch * (double)a->N1 * a->N2;
+    const double cbytes = 4.0 * a->N1 * a->N2;
+    double best = 1e30;
+    tile = 128; splits = 1; nt = 1;
+    for (int tl = 128; tl <= 256; tl += 128) {
+        if (tl == 256 && (a->N1 < 256 || a->N2 < 256)) continue;
+        const int n = dicow_cdiv(a->N1, tl) * dicow_cdiv(a->N2, tl);
+        const int slots = tl == 256 ? 256 : 512;               // resident workgroups on the chip
+        const double rate = tl == 256 ? 0.85e15 : 0.69e15;
+        for (int sp = 1; sp <= 16 && sp <= (total / 8 > 1 ? total / 8 : 1); ++sp) {
+            const int blocks = n * sp;
+            const double eff = (double)blocks / (slots * ((blocks + slots - 1) / slots));
+            const double tsec = flops / (rate * eff) + (sp > 1 ? (sp + 2) * cbytes / 4.0e12 + 4e-6 : 0.0);
+            if (tsec < best) { best = tsec; tile = tl; splits = sp; nt = n; }
+        }
+    }
+    if (const char* ev = getenv("DICOW_TN_SPLITS")) splits = atoi(ev);        // tuning knobs (tools/bench_gemm.py)
+    if (const char* ev = getenv("DICOW_TN_TILE")) { tile = atoi(ev); nt = dicow_cdiv(a->N1, tile) * dicow_cdiv(a->N2, tile); }
     if (splits < 1) splits = 1;
     tps = dicow_cdiv(total, splits);
     splits = dicow_cdiv(total, tps);
 }
 
 extern "C" int64_t dicow_gemm_tn_ws_bytes(const dicow_gemm_tn_args* a) {
-    int tpb, total, nt, splits, tps;
-    tn_plan(a, tpb, total, nt, splits, tps);
+    int tpb, total, nt, splits, tps, tile;
+    tn_plan(a, tpb, total, nt, splits, tps, tile);
     return splits > 1 ? (int64_t)splits * a->N1 * a->N2 * 4 : 0;
 }
 
@@ -641,16 +829,20 @@ extern "C" int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream) {
     DICOW_REQUIRE(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0, "gemm_tn: lda/ldb %% 8, ldc %% 4 required");
     DICOW_REQUIRE(a->seg_rows == 0 || (a->seg_rows % 128 == 0 && a->N1 <= 3 * a->seg_rows && a->C_seg[0] &&
                                         (a->N1 <= 2 * a->seg_rows || a->C_seg[1])), "gemm_tn: bad C segments");
-    int tpb, total, nt, splits, tps;
-    tn_plan(a, tpb, total, nt, splits, tps);
+    int tpb, total, nt, splits, tps, tile;
+    tn_plan(a, tpb, total, nt, splits, tps, tile);
     DICOW_REQUIRE(splits == 1 || (a->ws && a->ws_bytes >= (int64_t)splits * a->N1 * a->N2 * 4),
                   "gemm_tn: workspace too small (need %ld bytes)", (long)splits * a->N1 * a->N2 * 4);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(nt, 1, splits), dim3(256), TN_LDS_BYTES, (hipStream_t)stream, *a, tpb, total, tps);
+    if (tile == 256)
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3(nt, 1, splits), dim3(512), TN256_LDS, (hipStream_t)stream, *a, tpb, total, tps);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel, dim3(nt, 1, splits), dim3(256), TN_LDS_BYTES, (hipStream_t)stream, *a, tpb, total, tps);
     DICOW_CHECK_LAUNCH("gemm_tn");
     if (splits > 1) {
         const int nseg = a->seg_rows > 0 ? dicow_cdiv(a->N1, a->seg_rows) : 1;
