@@ -80,6 +80,53 @@ __device__ __forceinline__ unsigned tr_base(const char* s, int lane, int dblk) {
     return (unsigned)(uintptr_t)(s + row * 128 + (c << 4) + ((u & 1) << 3));
 }
 
+// ---- split issue / wait forms of the transposing reads: the 8 reads of a 32-row block are issued EARLY (before the
+// MFMAs / softmax that do not depend on them) and waited for right before their first consumer; the wait names the
+// destination registers ("+v") so that no consumer is scheduled above it (cdna_hip_programming.md section 5.7 form (ii)).
+struct tr8_t { bf16x4_t r0, r1, r2, r3, r4, r5, r6, r7; };
+template <int OFF>   // V-style image (forward): a0/a1 = d-block bases
+__device__ __forceinline__ void tr_issue_v(tr8_t& t, unsigned a0, unsigned a1) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %2, %9 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %5, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %6, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %7, %9 offset:%13"
+        : "=&v"(t.r0), "=&v"(t.r1), "=&v"(t.r2), "=&v"(t.r3), "=&v"(t.r4), "=&v"(t.r5), "=&v"(t.r6), "=&v"(t.r7)
+        : "v"(a0), "v"(a1), "i"(OFF), "i"(OFF + 1024), "i"(OFF + 2048), "i"(OFF + 3072)
+        : "memory");
+}
+template <int OFF>   // U image (backward): a{dblk}{sec}
+__device__ __forceinline__ void tr_issue_u(tr8_t& t, unsigned a00, unsigned a01, unsigned a10, unsigned a11) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %1, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %2, %10 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %3, %11 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %5, %9 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %6, %10 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %7, %11 offset:%13"
+        : "=&v"(t.r0), "=&v"(t.r1), "=&v"(t.r2), "=&v"(t.r3), "=&v"(t.r4), "=&v"(t.r5), "=&v"(t.r6), "=&v"(t.r7)
+        : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "i"(OFF), "i"(OFF + 2048)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tr_wait(tr8_t& t) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(t.r0), "+v"(t.r1), "+v"(t.r2), "+v"(t.r3), "+v"(t.r4), "+v"(t.r5), "+v"(t.r6), "+v"(t.r7)
+                 : "i"(N) : "memory");
+}
+__device__ __forceinline__ void tr_pack(bf16x8_t (&f)[2][2], const tr8_t& t) {       // f[x][dblk]
+    f[0][0] = __builtin_shufflevector(t.r0, t.r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[0][1] = __builtin_shufflevector(t.r2, t.r3, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[1][0] = __builtin_shufflevector(t.r4, t.r5, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[1][1] = __builtin_shufflevector(t.r6, t.r7, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
 __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& s, int r0) {
     bf16x8_t o;
     unsigned* ou = reinterpret_cast<unsigned*>(&o);
@@ -146,6 +193,11 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
             }
         }
+        // V^T fragments for both 32-key blocks: issued now, consumed after the softmax
+        const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
+        tr8_t tv0, tv1;
+        tr_issue_v<0>(tv0, va0, va1);
+        tr_issue_v<4096>(tv1, va0, va1);
         // ---- mask (tile-uniform test first), online softmax in log2 units
         const int k0 = t * KV_TILE;
         const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
@@ -183,17 +235,18 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
             for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
 
         // ---- O^T += V^T . P^T
-        const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
         {
             bf16x8_t vf[2][2];
-            tr_read_block<0>(vf, va0, va1);
+            tr_wait<8>(tv0);
+            tr_pack(vf, tv0);
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 const bf16x8_t pf = pack8(s[0], 8 * x);
 #pragma unroll
                 for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
             }
-            tr_read_block<4096>(vf, va0, va1);
+            tr_wait<0>(tv1);
+            tr_pack(vf, tv1);
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 const bf16x8_t pf = pack8(s[1], 8 * x);
@@ -375,6 +428,12 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
 
         const int k0 = t * KV_TILE;
         const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
+        // K^T fragments for the dQ product: issued now, consumed after S / dP / dS
+        const unsigned k00 = tr_base_u(sK, lane, 0, 0), k01 = tr_base_u(sK, lane, 0, 1);
+        const unsigned k10 = tr_base_u(sK, lane, 1, 0), k11 = tr_base_u(sK, lane, 1, 1);
+        tr8_t tk0, tk1;
+        tr_issue_u<0>(tk0, k00, k01, k10, k11);
+        tr_issue_u<4096>(tk1, k00, k01, k10, k11);
         f32x16_t ds[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
@@ -399,18 +458,18 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
             }
         }
         // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
-        const unsigned k00 = tr_base_u(sK, lane, 0, 0), k01 = tr_base_u(sK, lane, 0, 1);
-        const unsigned k10 = tr_base_u(sK, lane, 1, 0), k11 = tr_base_u(sK, lane, 1, 1);
         {
             bf16x8_t ktf[2][2];
-            tr_read_block_u<0>(ktf, k00, k01, k10, k11);
+            tr_wait<0>(tk0);      // (the compiler-scheduled K/V row reads above share the LDS queue: drain it)
+            tr_pack(ktf, tk0);
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 const bf16x8_t pf = pack8(ds[0], 8 * x);
 #pragma unroll
                 for (int d = 0; d < 2; ++d) dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[x][d], pf, dq[d], 0, 0, 0);
             }
-            tr_read_block_u<4096>(ktf, k00, k01, k10, k11);
+            tr_wait<0>(tk1);
+            tr_pack(ktf, tk1);
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
                 const bf16x8_t pf = pack8(ds[1], 8 * x);
@@ -506,6 +565,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
         const unsigned o10 = tr_base_u(sdO, lane, 1, 0), o11 = tr_base_u(sdO, lane, 1, 1);
 #define DKV_QBLOCK(QB)                                                                                                  \
         {                                                                                                               \
+            tr8_t tdo, tq;                                                                                              \
+            tr_issue_u<(QB) * 4096>(tdo, o00, o01, o10, o11);                                                           \
+            tr_issue_u<(QB) * 4096>(tq, q00, q01, q10, q11);                                                            \
             f32x16_t s, dp;                                                                                             \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }                                 \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
@@ -533,8 +595,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
                 }                                                                                                       \
             }                                                                                                           \
             bf16x8_t qtf[2][2], dotf[2][2];                                                                             \
-            tr_read_block_u<(QB) * 4096>(dotf, o00, o01, o10, o11);                                                     \
-            tr_read_block_u<(QB) * 4096>(qtf, q00, q01, q10, q11);                                                      \
+            tr_wait<0>(tdo);                                                                                            \
+            tr_wait<0>(tq);                                                                                             \
+            tr_pack(dotf, tdo);                                                                                         \
+            tr_pack(qtf, tq);                                                                                           \
             _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                             \
                 const bf16x8_t pf = pack8(pv, 8 * x);                                                                   \
                 const bf16x8_t df = pack8(dsv, 8 * x);                                                                  \

@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_arg
     // sched_group_barrier pins [reads][DMA][8 MFMA] per slice (hipcc otherwise sinks the reads behind the MFMAs).
     bf16x8_t wf0[2], xf0[4], wf1[2], xf1[4];
 #define LDFRAG(WF, XF, KK)                                                                                   \
-    {                                                                                                        \
+    if (ABL != 3 || t == 0) {                                                                                \
         const int c_ = (KK) * 2 + (lane >> 5);                                                               \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) WF[i] = lds_frag_nt(sB, wn * 64 + i * 32 + (lane & 31), c_);  \
         _Pragma("unroll") for (int j = 0; j < 4; ++j) XF[j] = lds_frag_nt(sA, wm * 128 + j * 32 + (lane & 31), c_); \
@@ -315,7 +315,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_arg
         char* sA = smem + (t & 1) * NT256_STAGE;                                                             \
         char* sB = sA + 256 * 128;                                                                           \
         char* nA = smem + ((t + 1) & 1) * NT256_STAGE;                                                       \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
+        if (ABL == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                     \
         __builtin_amdgcn_s_barrier();                                                                        \
         asm volatile("" ::: "memory");                                                                       \
         LDFRAG(wf0, xf0, 0) DMA2(0)                                                                          \
@@ -329,9 +330,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_arg
     if (nk == 1) {
         KSTEP(false, true)
     } else {
-        if (ABL == 1) KSTEP(false, true) else KSTEP(true, true)
+        if (ABL == 1 || ABL == 3) KSTEP(false, true) else KSTEP(true, true)
         for (t = 1; t + 1 < nk; ++t) {
-            if (ABL == 1) KSTEP(false, false) else KSTEP(true, false)
+            if (ABL == 1 || ABL == 3) KSTEP(false, false) else KSTEP(true, false)
         }
         KSTEP(false, false)
     }
@@ -388,6 +389,8 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
         attr256 = true;
     }
     // the 256x256 kernel wins once it can put ~one workgroup on every CU; smaller problems keep the 128x128 tiles
@@ -396,6 +399,8 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
         const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
         if (variant == 5) hipLaunchKernelGGL(gemm_nt256_kernel<1>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
         else if (variant == 6) hipLaunchKernelGGL(gemm_nt256_kernel<2>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
+        else if (variant == 7) hipLaunchKernelGGL(gemm_nt256_kernel<3>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
+        else if (variant == 8) hipLaunchKernelGGL(gemm_nt256_kernel<4>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
         else hipLaunchKernelGGL(gemm_nt256_kernel<0>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
         DICOW_CHECK_LAUNCH("gemm_nt256");
         return DICOW_OK;

@@ -12,6 +12,7 @@ layer's slice is all-reduced (RCCL over xGMI, ``torch.distributed`` backend "ncc
 layer's backward has been enqueued, overlapped with the remaining backward.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -138,13 +139,16 @@ class GradReducer:
         self.s = store
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
+        # DICOW_FORCE_REDUCE=1 exercises the bucketed side-stream all-reduce even with a single rank (smoke test of
+        # the RCCL code path on a 1-GPU box)
+        self.force = os.environ.get("DICOW_FORCE_REDUCE") == "1" and dist.is_initialized()
+        self.stream = torch.cuda.Stream() if ((self.world > 1 or self.force) and torch.cuda.is_available()) else None
         self.seg = {name: (a, b) for name, a, b in store.segments}
         self.pending = []
 
     def segment_ready(self, name):
         """Called right after the segment's backward kernels have been enqueued on the current stream."""
-        if self.world == 1 or name not in self.seg:
+        if (self.world == 1 and not self.force) or name not in self.seg:
             return
         a, b = self.seg[name]
         if self.stream is None:                       # CPU / gloo tests: synchronous
