@@ -61,6 +61,11 @@ class OracleConfig:
     use_enrollments: bool = False
     scb_layers: Optional[int] = None
     ctc_weight: float = 0.0
+    additional_self_attention_layer: bool = False
+    pre_ctc_sub_sample: bool = False
+    remove_timestamps_from_ctc: bool = False
+    ctc_loss_reduction: str = "mean"
+    eos_token_id: int = 50257
 
     @property
     def n_fddts(self):
@@ -311,13 +316,89 @@ def soft_loss(logits: T, labels: T, upp_labels: Optional[T], ts) -> T:
     return torch.minimum(lo, up).sum() / mask.sum().clamp(min=1)
 
 
+# --------------------------------------------------------------------------- CTC auxiliary branch
+def conv1d_k3s2_nobias(x: T, w: T, emu: bool) -> T:
+    """[B,T,D] time-major in/out, kernel 3 stride 2 padding 1, no bias (encoder.py:26-41)."""
+    y = conv1d_k3(x.transpose(1, 2), w, torch.zeros(w.shape[0]), 2, emu)
+    return y.transpose(1, 2)
+
+
+def ctc_logits(p: Dict[str, T], cfg: OracleConfig, enc: T, emu: bool = False) -> T:
+    """get_enc_logits (modeling_dicow.py:242-246) -> possibly_update_last_hidden_states (encoder.py:87-106)."""
+    e = "model.encoder."
+    h = enc
+    if cfg.additional_self_attention_layer:
+        # the attention output REPLACES the hidden states (no residual, no LayerNorm): encoder.py:95-101
+        h = attention(h, h, p, e + "additional_self_attention_layer.", cfg.encoder_attention_heads, False, emu)
+    if cfg.pre_ctc_sub_sample:
+        h = conv1d_k3s2_nobias(h, p[e + "subsample_conv1.weight"], emu)
+        h = conv1d_k3s2_nobias(h, p[e + "subsample_conv2.weight"], emu)
+    return linear(h, p[e + "lm_head.weight"], None, emu)
+
+
+def ctc_prepare_labels(labels: T, cfg: OracleConfig, prefix_tokens) -> T:
+    """modeling_dicow.py:328-333 + encoder.py:111-113."""
+    lab = labels.clone()
+    for tok in prefix_tokens:
+        if bool((lab[:, 0] == tok).all()):
+            lab = lab[:, 1:]
+    lab[lab == cfg.eos_token_id] = -100
+    if cfg.remove_timestamps_from_ctc:
+        first_task_token = cfg.vocab_size - 30 * 50 - 1 - 6
+        rows = [r[r < first_task_token] for r in lab]
+        width = max(int(r.numel()) for r in rows)
+        out = lab.new_full((len(rows), max(width, 1)), -100)
+        for i, r in enumerate(rows):
+            out[i, :r.numel()] = r
+        lab = out
+    return lab
+
+
+def ctc_loss(logits: T, labels: T, reduction: str = "mean") -> T:
+    """Plain log-domain CTC forward algorithm (blank = last class, zero_infinity=True), as
+    torch.nn.functional.ctc_loss is called at encoder.py:119-134.  logits [B,T,C], labels [B,L] (-100 padded)."""
+    B, Tn, C = logits.shape
+    blank = C - 1
+    lp = logits.float() - _lse_and_pick(logits.float(), None)[..., None]
+    tl = (labels >= 0).sum(-1)
+    Lmax = max(int(tl.max()), 1)
+    ext = labels.new_full((B, 2 * Lmax + 1), blank)
+    ext[:, 1::2] = labels[:, :Lmax].clamp(min=0)
+    S = 2 * tl + 1
+    neg = -1e30                      # finite "minus infinity": keeps autograd free of inf * 0 = NaN
+    idx = torch.arange(2 * Lmax + 1)[None, :]
+    valid = idx < S[:, None]
+    skip = torch.zeros_like(valid)
+    skip[:, 2:] = (ext[:, 2:] != blank) & (ext[:, 2:] != ext[:, :-2])
+    g = lp.gather(2, ext[:, None, :].expand(B, Tn, -1))                 # [B,T,S]
+    alpha = torch.full((B, 2 * Lmax + 1), neg)
+    alpha[:, 0] = g[:, 0, 0]
+    alpha[:, 1] = torch.where(tl > 0, g[:, 0, 1], torch.full((B,), neg)) if 2 * Lmax + 1 > 1 else alpha[:, 1]
+    for t in range(1, Tn):
+        a1 = torch.cat([torch.full((B, 1), neg), alpha[:, :-1]], 1)
+        a2 = torch.cat([torch.full((B, 2), neg), alpha[:, :-2]], 1)
+        a2 = torch.where(skip, a2, torch.full_like(a2, neg))
+        msafe = torch.maximum(torch.maximum(alpha, a1), a2).detach()
+        alpha = msafe + torch.log(torch.exp(alpha - msafe) + torch.exp(a1 - msafe) + torch.exp(a2 - msafe)) + g[:, t]
+        alpha = alpha.clamp(min=neg)
+        alpha = torch.where(valid, alpha, torch.full_like(alpha, neg))
+    last = alpha.gather(1, (S - 1)[:, None]).squeeze(1)
+    prev = torch.where(tl > 0, alpha.gather(1, (S - 2).clamp(min=0)[:, None]).squeeze(1), torch.full((B,), neg))
+    msafe = torch.maximum(last, prev).detach()
+    nll = -(msafe + torch.log(torch.exp(last - msafe) + torch.exp(prev - msafe)))
+    nll = torch.where(nll > 1e29, torch.zeros_like(nll), nll)            # zero_infinity
+    if reduction == "mean":
+        return (nll / tl.clamp(min=1).float()).mean()
+    return nll.sum() if reduction == "sum" else nll
+
+
 # --------------------------------------------------------------------------- whole model
 
 def model_forward(p: Dict[str, T], cfg: OracleConfig, input_features: T, stno_mask: T, labels: T,
                   upp_labels: Optional[T] = None, enrollments=None, ts=None, emu: bool = False,
-                  collect=None):
-    """DiCoWForConditionalGeneration.forward (modeling_dicow.py:248-354), ctc_weight == 0.
-    Returns dict(loss, logits, encoder_last_hidden_state)."""
+                  collect=None, prefix_tokens=()):
+    """DiCoWForConditionalGeneration.forward (modeling_dicow.py:248-354) incl. the CTC branch (:326-336).
+    Returns dict(loss, logits, encoder_last_hidden_state[, ctc_loss, dec_loss])."""
     enc = encoder_forward(p, cfg, input_features, stno_mask, enrollments, emu, collect)
     dec_in = shift_tokens_right(labels, cfg.pad_token_id, cfg.decoder_start_token_id)
     hdec = decoder_forward(p, cfg, dec_in, enc, emu)
@@ -326,7 +407,13 @@ def model_forward(p: Dict[str, T], cfg: OracleConfig, input_features: T, stno_ma
         loss = soft_loss(logits, labels, upp_labels, ts)
     else:
         loss = hard_loss(logits, labels, upp_labels)
-    return {"loss": loss, "logits": logits, "encoder_last_hidden_state": enc}
+    out = {"loss": loss, "logits": logits, "encoder_last_hidden_state": enc}
+    if cfg.ctc_weight > 0.0:
+        enc_logits = ctc_logits(p, cfg, enc, emu)
+        c = ctc_loss(enc_logits, ctc_prepare_labels(labels, cfg, prefix_tokens), cfg.ctc_loss_reduction)
+        out.update(dec_loss=loss, ctc_loss=c, enc_logits=enc_logits)
+        out["loss"] = (1 - cfg.ctc_weight) * loss + cfg.ctc_weight * c
+    return out
 
 
 def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> T:

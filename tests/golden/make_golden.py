@@ -220,7 +220,8 @@ def small_cfg(**over):
     return DiCoWConfig(**kw)
 
 
-CFG_KEYS = ["vocab_size", "num_mel_bins", "d_model", "encoder_layers", "encoder_attention_heads", "decoder_layers",
+CFG_KEYS = ["additional_self_attention_layer", "pre_ctc_sub_sample", "remove_timestamps_from_ctc", "ctc_loss_reduction",
+            "eos_token_id", "vocab_size", "num_mel_bins", "d_model", "encoder_layers", "encoder_attention_heads", "decoder_layers",
             "decoder_attention_heads", "encoder_ffn_dim", "decoder_ffn_dim", "max_source_positions",
             "max_target_positions", "pad_token_id", "decoder_start_token_id", "use_fddt", "fddt_is_diagonal",
             "fddt_bias_only", "fddt_use_silence", "fddt_use_target", "fddt_use_overlap", "fddt_use_non_target",
@@ -381,9 +382,42 @@ def f6_scb():
     save("f6_scb", **arrs)
 
 
+# ----------------------------------------------------------------------------- F10: CTC auxiliary branch (recipe default)
+def f10_ctc():
+    cfg = small_cfg(vocab_size=2048, pad_token_id=2000, bos_token_id=2000, eos_token_id=2000, decoder_start_token_id=2001,
+                    ctc_weight=0.3, pre_ctc_sub_sample=True, additional_self_attention_layer=True,
+                    remove_timestamps_from_ctc=True, encoder_layers=1, decoder_layers=1)
+    torch.manual_seed(4)
+    model = DiCoWForConditionalGeneration(cfg).eval()
+    randomize_(model, 10)
+    tok = StubTokenizer(cfg.vocab_size, 600, 100)        # timestamps at 600..699 (>= first_task_token 541: removed from CTC)
+    tok.prefix_tokens = [2001]
+    model.set_tokenizer(tok)
+    x, st, lab, upp = make_inputs(cfg, B=3, L=12, seed=90, ts_range=(600, 100))
+    lab[2, 5:] = -100
+    upp[2, 5:] = -100
+    lab[0, 7] = lab[0, 8]                               # a repeated token (CTC needs the blank between repeats)
+    upp[0, 7] = upp[0, 8]
+    lab[1, 8] = 2000                                    # an eos inside the labels -> ignored by CTC
+    upp[1, 8] = 2000
+    batch = dict(input_features=x, stno_mask=st, labels=lab, upp_labels=upp)
+    out = run_model(model, batch)
+    out.loss.backward()
+    enc_logits = model.get_enc_logits(out.encoder_last_hidden_state)
+    arrs = {"cfg": np.array(repr(cfg_dict(cfg))), "x": x, "stno": st, "labels": lab, "upp_labels": upp, "loss": out.loss,
+            "logits": out.logits, "enc": out.encoder_last_hidden_state, "enc_logits": enc_logits,
+            "ts_start": np.array(600), "ts_n": np.array(100), "prefix": np.array([2001])}
+    for n, p in model.state_dict().items():
+        arrs["p." + n] = p
+    for n, p in model.named_parameters():
+        if p.grad is not None and ("encoder" in n) and n != "proj_out.weight":
+            arrs["g." + n] = p.grad
+    save("f10_ctc", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10"]
     fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
-           "f8": f8_se}
+           "f8": f8_se, "f10": f10_ctc}
     for w in which:
         fns[w]()

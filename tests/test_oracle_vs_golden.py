@@ -168,3 +168,27 @@ def test_f5_encoder_full_length():
     assert maxdiff(enc[:, :48], T(z, "enc_head")) < 3e-4
     assert maxdiff(enc[:, -48:], T(z, "enc_tail")) < 3e-4
     assert maxdiff(enc.mean(-1), T(z, "enc_mean")) < 1e-4
+
+
+def test_f10_ctc_branch():
+    """CTC auxiliary branch (recipe default ctc_weight 0.3): extra self-attention, two stride-2 convs, lm_head, CTC loss."""
+    z = load_golden("f10_ctc")
+    cfg = golden_cfg(z)
+    p = golden_params(z, requires_grad=True)
+    vocab = {f"tok{i}": i for i in range(cfg.vocab_size)}
+    for j in range(int(z["ts_n"])):
+        vocab.pop(f"tok{int(z['ts_start']) + j}")
+        vocab[f"<|{0.02 * j:.2f}|>"] = int(z["ts_start"]) + j
+    ts = O.build_ts_smoothing(vocab)
+    out = O.model_forward(p, cfg, T(z, "x"), T(z, "stno"), T(z, "labels"), T(z, "upp_labels"), ts=ts,
+                          prefix_tokens=[int(v) for v in z["prefix"]])
+    assert maxdiff(out["enc_logits"], T(z, "enc_logits")) < 3e-4
+    assert abs(float(out["loss"]) - float(z["loss"])) < 2e-5
+    out["loss"].backward()
+    n = 0
+    for k in z.files:
+        if k.startswith("g."):
+            ref = T(z, k)
+            assert maxdiff(p[k[2:]].grad, ref) < 1e-5 + 2e-3 * float(ref.abs().max()), k
+            n += 1
+    assert n > 30
