@@ -31,6 +31,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--labels", type=int, default=128)
     ap.add_argument("--se", action="store_true", help="SE-DiCoW (enrollment cross-attention, scb_layers=8), config 5")
+    ap.add_argument("--ctc", action="store_true", help="recipe CTC auxiliary branch (ctc_weight 0.3, subsample, extra attention)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="turbo-b1")
     return ap.parse_args()
@@ -130,6 +131,8 @@ def main():
     over = dict(use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True, fddt_init="suppressive", non_target_fddt_value=0.5)
     if a.se:
         over.update(use_enrollments=True, scb_layers=8)
+    if a.ctc:
+        over.update(ctc_weight=0.3, pre_ctc_sub_sample=True, additional_self_attention_layer=True, remove_timestamps_from_ctc=True)
     cfg = pkg.DiCoWConfig.preset(a.model, **over)
     torch.manual_seed(0)
     model = pkg.DiCoWForConditionalGeneration(cfg).cuda()
@@ -177,10 +180,10 @@ def main():
         "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic (random-init weights, N(0,1) mel clamped to [-1.5,1.5], 3-speaker STNO process, random labels)",
         "config": {"workload": f"{a.model} DiCoW fine-tune step, per-GPU batch {a.batch}, L={a.labels}, decoder frozen, "
-                               f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}",
+                               f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}{', CTC 0.3' if a.ctc else ''}",
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "trainable_params": ts.store.n_trainable},
         "loss": float(loss),
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel (bf16 MFMA 32x32x16; forward Linear/conv + dgrad)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel / gemm_nt_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
                      "achieved": round(nt["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(nt["tflops"] / peak, 4),
                      "traffic": None, "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // a.steps,
                      "share_of_step": round(nt["total_ms"] / (dt * 1e3), 3)},

@@ -215,6 +215,26 @@ typedef struct {
 int dicow_ce_loss_fwd(const dicow_ce_args* a, void* stream);
 int dicow_ce_loss_bwd(const dicow_ce_args* a, const float* grad_scale, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ CTC auxiliary loss
+ * torch.nn.functional.ctc_loss as called at src/models/dicow/encoder.py:108-135 on the encoder logits
+ * (modeling_dicow.py:242-246, 326-336): bf16 logits [B, Tn, ld] with C = vocab+1 valid classes, blank = C-1,
+ * labels [B, Lc] int64 with the valid targets as a prefix (-100 padded), zero_infinity, reduction "mean":
+ * loss_sum accumulates sum_b nll_b / max(len_b, 1) (caller divides by B).  alpha/beta: workspace [B, Tn, 2*Lc+1] each.
+ * Backward: d_logits = grad_scale[0] / (B * max(len_b,1)) * (softmax - label posterior), bf16, pad columns zero.   */
+typedef struct {
+    const void* logits; int64_t ld; int B, Tn, C;
+    const int64_t* labels; int Lc; int blank;
+    float* lse;                  /* [B*Tn] */
+    float* alpha; float* beta;   /* [B, Tn, Smax] fp32 log-domain */
+    int Smax;                    /* 2*Lc + 1 (<= 1024) */
+    float* nll; float* tlen;     /* [B] */
+    float* loss_sum;             /* scalar, ACCUMULATED */
+    void* d_logits;              /* bwd */
+} dicow_ctc_args;
+int64_t dicow_ctc_ws_bytes(int B, int Tn, int Lc);
+int dicow_ctc_loss_fwd(const dicow_ctc_args* a, void* stream);
+int dicow_ctc_loss_bwd(const dicow_ctc_args* a, const float* grad_scale, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ decoder embedding
  * h[b,l,:] = embed_tokens[ids[b,l]] + embed_positions[l]   (HF:modeling_whisper.py:737,754-762), fp32.     */
 int dicow_embed_fwd(const int64_t* ids, const float* tok, const float* pos, float* out, int B, int Lq, int D, void* stream);
@@ -225,7 +245,8 @@ int dicow_embed_bwd(const int64_t* ids, const float* g, float* d_tok, float* d_p
  * out = g * gelu'(pre)   (bf16, elementwise): gradient through the GELU after conv2 (encoder.py:168).     */
 int dicow_gelu_bwd_bf16(const void* g, const void* pre, void* out, int64_t n, void* stream);
 /* col2im of the conv2 (k=3,s=2,p=1) input gradient + GELU' of conv1 (encoder.py:167):
- *   dA2 bf16 [B, T2, 3*C] (tap-major im2col gradient)  ->  d_pre1 bf16 [B, 2*T2, C] = gelu'(pre1) * scatter-add */
+ *   dA2 bf16 [B, T2, 3*C] (tap-major im2col gradient)  ->  d_pre1 bf16 [B, 2*T2, C] = gelu'(pre1) * scatter-add
+ * pre1 == NULL: plain col2im (the activation-free CTC subsample convs, encoder.py:26-41). */
 int dicow_conv2_col2im_gelu_bwd(const void* dA2, const void* pre1, void* d_pre1, int B, int T2, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ log-mel front end

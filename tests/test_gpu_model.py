@@ -28,7 +28,9 @@ def pkg():
 
 def build_model(pkg, z, requires_grad=True):
     d = ast.literal_eval(str(z["cfg"]))
-    cfg = pkg.DiCoWConfig(**d, bos_token_id=d["pad_token_id"], eos_token_id=d["pad_token_id"])
+    d.setdefault("bos_token_id", d["pad_token_id"])
+    d.setdefault("eos_token_id", d["pad_token_id"])
+    cfg = pkg.DiCoWConfig(**d)
     model = pkg.DiCoWForConditionalGeneration(cfg)
     sd = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
     missing, unexpected = model.load_state_dict(sd, strict=True), None     # identical key surface to the reference
@@ -180,3 +182,28 @@ def test_cpu_tensors_are_refused(pkg):
     m = pkg.FDDT(128, is_diagonal=True)
     with pytest.raises(Exception):
         m(torch.randn(1, 4, 128), torch.rand(1, 4, 4))
+
+
+def test_f10_ctc_branch(pkg):
+    """Recipe-default CTC auxiliary branch vs the reference golden (fp32) -- loss and every encoder gradient."""
+    z = load_golden("f10_ctc")
+    model, cfg = build_model(pkg, z)
+
+    class Tok:
+        prefix_tokens = [int(v) for v in z["prefix"]]
+
+        def get_vocab(self):
+            v = {f"tok{i}": i for i in range(cfg.vocab_size)}
+            for j in range(int(z["ts_n"])):
+                v.pop(f"tok{int(z['ts_start']) + j}")
+                v[f"<|{0.02 * j:.2f}|>"] = int(z["ts_start"]) + j
+            return v
+
+    model.set_tokenizer(Tok())
+    out = model(input_features=T(z, "x").cuda(), stno_mask=T(z, "stno").cuda(), labels=T(z, "labels").cuda(),
+                upp_labels=T(z, "upp_labels").cuda())
+    assert abs(float(out.loss) - float(z["loss"])) < 3e-2
+    out.loss.backward()
+    ref = {k[2:]: T(z, k) for k in z.files if k.startswith("g.")}
+    worst = _check_grads(model, ref, tol_rel=8e-2, min_checked=30)
+    print("worst CTC-model grad rel err:", worst)

@@ -62,6 +62,12 @@ class CeArgs(C.Structure):
                 ("d_logits", c_vp)]
 
 
+class CtcArgs(C.Structure):
+    _fields_ = [("logits", c_vp), ("ld", c_i64), ("B", c_i), ("Tn", c_i), ("C", c_i), ("labels", c_vp), ("Lc", c_i),
+                ("blank", c_i), ("lse", c_vp), ("alpha", c_vp), ("beta", c_vp), ("Smax", c_i), ("nll", c_vp), ("tlen", c_vp),
+                ("loss_sum", c_vp), ("d_logits", c_vp)]
+
+
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_SCALE_N, EPI_GELU_BWD, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 
 # name -> argtypes ; every function returns int
@@ -83,6 +89,8 @@ _SIGS = {
     "dicow_attn_bwd": [C.POINTER(AttnBwdArgs), c_vp],
     "dicow_ce_loss_fwd": [C.POINTER(CeArgs), c_vp],
     "dicow_ce_loss_bwd": [C.POINTER(CeArgs), c_vp, c_vp],
+    "dicow_ctc_loss_fwd": [C.POINTER(CtcArgs), c_vp],
+    "dicow_ctc_loss_bwd": [C.POINTER(CtcArgs), c_vp, c_vp],
     "dicow_embed_fwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_gelu_bwd_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
@@ -124,6 +132,7 @@ _SIGS64 = {   # functions returning int64_t (workspace sizes)
     "dicow_fddt_ln_bwd_ws_bytes": [c_i, c_i],
     "dicow_gemm_tn_ws_bytes": [C.POINTER(GemmTnArgs)],
     "dicow_logmel_ws_bytes": [c_i, c_i],
+    "dicow_ctc_ws_bytes": [c_i, c_i, c_i],
 }
 
 

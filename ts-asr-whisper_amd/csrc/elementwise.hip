@@ -346,15 +346,17 @@ __global__ void conv2_col2im_gelu_bwd_kernel(const unsigned short* __restrict__ 
         float g0 = 0.f, g1 = 0.f;
         if (src0) { const unsigned u = *reinterpret_cast<const unsigned*>(src0 + c); g0 += __uint_as_float(u << 16); g1 += __uint_as_float(u & 0xffff0000u); }
         if (src1) { const unsigned u = *reinterpret_cast<const unsigned*>(src1 + c); g0 += __uint_as_float(u << 16); g1 += __uint_as_float(u & 0xffff0000u); }
-        const unsigned pu = *reinterpret_cast<const unsigned*>(pre1 + off + c);
-        g0 *= gelu_erf_grad(__uint_as_float(pu << 16));
-        g1 *= gelu_erf_grad(__uint_as_float(pu & 0xffff0000u));
+        if (pre1) {
+            const unsigned pu = *reinterpret_cast<const unsigned*>(pre1 + off + c);
+            g0 *= gelu_erf_grad(__uint_as_float(pu << 16));
+            g1 *= gelu_erf_grad(__uint_as_float(pu & 0xffff0000u));
+        }
         *reinterpret_cast<unsigned*>(d_pre1 + off + c) = pack_bf16x2(g0, g1);
     }
 }
 
 extern "C" int dicow_conv2_col2im_gelu_bwd(const void* dA2, const void* pre1, void* d_pre1, int B, int T2, int C, void* stream) {
-    DICOW_REQUIRE(dA2 && pre1 && d_pre1 && B > 0 && T2 > 0 && C % 2 == 0, "conv2_col2im_gelu_bwd: bad args");
+    DICOW_REQUIRE(dA2 && d_pre1 && B > 0 && T2 > 0 && C % 2 == 0, "conv2_col2im_gelu_bwd: bad args");
     hipLaunchKernelGGL(conv2_col2im_gelu_bwd_kernel, dim3(2 * T2, B), dim3(256), 0, (hipStream_t)stream,
                        (const unsigned short*)dA2, (const unsigned short*)pre1, (unsigned short*)d_pre1, T2, C);
     DICOW_CHECK_LAUNCH("conv2_col2im_gelu_bwd");

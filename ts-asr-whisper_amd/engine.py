@@ -681,3 +681,140 @@ class DecoderEngine:
         if gt is not None or gp is not None:
             ops.embed_bwd(S.ids, g, gt, gp, D)
         return d_enc
+
+
+# ------------------------------------------------------------------------------------------------ CTC auxiliary branch
+class CtcEngine:
+    """get_enc_logits + CTC loss of the reference (modeling_dicow.py:242-246,326-336; encoder.py:87-135):
+    optional extra self-attention (its output REPLACES the hidden states), two activation-free stride-2 convolutions
+    (as GEMMs over overlapping time-major views), lm_head over vocab+1 classes, CTC loss with blank = vocab."""
+
+    def __init__(self, enc):
+        self.enc = enc
+        self.cfg = enc.config
+
+    def prepare(self):
+        enc, cfg = self.enc, self.cfg
+        dev = enc.lm_head.weight.device
+        D = cfg.d_model
+        W = NS()
+        W.att = prep_attention(enc.additional_self_attention_layer, dev) if hasattr(enc, "additional_self_attention_layer") else None
+        if hasattr(enc, "subsample_conv1"):
+            W.c1, W.c1_t = ops.conv_weight_pack(enc.subsample_conv1.weight.detach(), 3 * D, want_t=True)
+            W.c2, W.c2_t = ops.conv_weight_pack(enc.subsample_conv2.weight.detach(), 3 * D, want_t=True)
+        W.cpad = _ceil(cfg.vocab_size + 1, 128)
+        W.head = prep_linear([enc.lm_head.weight], None, dev, n_pad=W.cpad)
+        self.W = W
+        return W
+
+    def forward(self, enc_bf, B, T, labels):
+        enc, cfg, W = self.enc, self.cfg, self.W
+        dev = enc_bf.device
+        D, H = cfg.d_model, cfg.encoder_attention_heads
+        rows = B * T
+        S = NS(B=B, T=T, enc_bf=enc_bf)
+        sub = hasattr(enc, "subsample_conv1")
+        if sub and T % 4 != 0:
+            raise L.DicowError("pre_ctc_sub_sample needs max_source_positions % 4 == 0")
+        h = enc_bf
+        hpad = None
+        if W.att is not None:
+            S.qkv = linear_fwd(enc_bf, W.att.qkv, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+            S.o, S.lse_a = _e((rows, D), BF16, dev), _e((B, H, T), F32, dev)
+            ops.attn_fwd(heads(S.qkv[:, :D], B, T, H), heads(S.qkv[:, D:2 * D], B, T, H), heads(S.qkv[:, 2 * D:], B, T, H),
+                         heads(S.o, B, T, H), S.lse_a)
+            if sub:                                   # write the projection straight into the zero-padded conv input
+                hpad = _e((B, T + 2, D), BF16, dev)
+                hpad[:, 0].zero_()
+                hpad[:, T + 1].zero_()
+                ops.gemm_nt(S.o, W.att.o.w, hpad[:, 1:], T, D, D, bias=W.att.o.b, batch=B, strideA=T * D, strideC=(T + 2) * D)
+            else:
+                h = linear_fwd(S.o, W.att.o, rows)
+        elif sub:
+            hpad = torch.zeros(B, T + 2, D, dtype=BF16, device=dev)
+            hpad[:, 1:T + 1].copy_(enc_bf.view(B, T, D))
+        Tn = T
+        if sub:
+            T1, T2 = T // 2, T // 4
+            c1pad = _e((B, T1 + 2, D), BF16, dev)
+            c1pad[:, 0].zero_()
+            c1pad[:, T1 + 1].zero_()
+            ops.gemm_nt(hpad, W.c1, c1pad[:, 1:], T1, D, 3 * D, lda=2 * D, batch=B, strideA=(T + 2) * D, strideC=(T1 + 2) * D)
+            h = _e((B * T2, D), BF16, dev)
+            ops.gemm_nt(c1pad, W.c2, h, T2, D, 3 * D, lda=2 * D, batch=B, strideA=(T1 + 2) * D, strideC=T2 * D)
+            S.hpad, S.c1pad, S.T1 = hpad, c1pad, T1
+            Tn = T2
+        S.h, S.Tn = h, Tn
+        Cc = cfg.vocab_size + 1
+        logits = _e((B * Tn, W.cpad), BF16, dev)
+        ops.gemm_nt(h, W.head.w, logits, B * Tn, W.cpad, D)
+        S.logits = logits
+        lab = labels.contiguous()
+        Lc = lab.shape[1]
+        S.lse, S.nll, S.tlen = _e((B * Tn,), F32, dev), _e((B,), F32, dev), _e((B,), F32, dev)
+        Smax = 2 * Lc + 1
+        S.ab = _e((2, B, Tn, Smax), F32, dev)
+        S.acc = torch.zeros(1, dtype=F32, device=dev)
+        S.labels = lab
+        S.ctc = ops.ctc_args(logits, W.cpad, B, Tn, Cc, lab, S.lse, S.ab[0], S.ab[1], S.nll, S.tlen, S.acc)
+        ops.ctc_loss_fwd(S.ctc)
+        if cfg.ctc_loss_reduction != "mean":
+            raise L.DicowError("only ctc_loss_reduction='mean' (reference default) is implemented")
+        return S.acc[0] / B, S
+
+    def backward(self, S, grad_loss, G):
+        """Returns d_enc fp32 [B*T, D]."""
+        enc, cfg, W = self.enc, self.cfg, self.W
+        dev = S.logits.device
+        D, H = cfg.d_model, cfg.encoder_attention_heads
+        B, T, Tn = S.B, S.T, S.Tn
+        rows = B * T
+        d_logits = _e((B * Tn, W.cpad), BF16, dev)
+        S.ctc.d_logits = d_logits.data_ptr()
+        ops.ctc_loss_bwd(S.ctc, grad_loss.to(F32).reshape(1))
+        glm = G.get(enc.lm_head.weight)
+        if glm is not None:
+            tmp = torch.zeros(W.cpad, D, dtype=F32, device=dev)          # vocab+1 is not a multiple of 8: padded rows
+            ops.gemm_tn(d_logits, S.h, tmp, B * Tn, W.cpad, D)
+            glm.add_(tmp[:cfg.vocab_size + 1])
+        d_h = linear_dgrad(d_logits, W.head, B * Tn)                     # bf16 [B*Tn, D]
+        sub = hasattr(enc, "subsample_conv1")
+        if sub:
+            T1 = S.T1
+            # subsample_conv2 backward
+            g2 = G.get(enc.subsample_conv2.weight)
+            if g2 is not None:
+                tmp = torch.zeros(D, 3 * D, dtype=F32, device=dev)
+                ops.gemm_tn(d_h, S.c1pad, tmp, Tn, D, 3 * D, lda=D, ldb=2 * D, batch=B, strideA=Tn * D, strideB=(T1 + 2) * D)
+                ops.conv_weight_unpack_grad(tmp, g2)
+            dA = _e((B * Tn, 3 * D), BF16, dev)
+            ops.gemm_nt(d_h, W.c2_t, dA, B * Tn, 3 * D, D)
+            d_c1 = _e((B, T1, D), BF16, dev)
+            ops.conv2_col2im_gelu_bwd(dA, None, d_c1, B, Tn, D)
+            # subsample_conv1 backward
+            g1 = G.get(enc.subsample_conv1.weight)
+            if g1 is not None:
+                tmp = torch.zeros(D, 3 * D, dtype=F32, device=dev)
+                ops.gemm_tn(d_c1, S.hpad, tmp, T1, D, 3 * D, lda=D, ldb=2 * D, batch=B, strideA=T1 * D, strideB=(T + 2) * D)
+                ops.conv_weight_unpack_grad(tmp, g1)
+            dA1 = _e((B * T1, 3 * D), BF16, dev)
+            ops.gemm_nt(d_c1.view(B * T1, D), W.c1_t, dA1, B * T1, 3 * D, D)
+            d_hid = _e((B, T, D), BF16, dev)
+            ops.conv2_col2im_gelu_bwd(dA1, None, d_hid, B, T1, D)
+            d_h = d_hid.view(rows, D)
+        if W.att is None:
+            return d_h.float()
+        att = enc.additional_self_attention_layer
+        bias_grad(d_h, G.get(att.out_proj.bias))
+        linear_wgrad(d_h, S.o, G.get(att.out_proj.weight), rows)
+        d_o = linear_dgrad(d_h, W.att.o, rows)
+        d_qkv = _e((rows, 3 * D), BF16, dev)
+        delta = _e((B, H, T), F32, dev)
+        qkv = S.qkv
+        ops.attn_bwd(heads(qkv[:, :D], B, T, H), heads(qkv[:, D:2 * D], B, T, H), heads(qkv[:, 2 * D:], B, T, H),
+                     heads(S.o, B, T, H), heads(d_o, B, T, H), S.lse_a, delta, heads(d_qkv[:, :D], B, T, H),
+                     heads(d_qkv[:, D:2 * D], B, T, H), heads(d_qkv[:, 2 * D:], B, T, H), dq_scale=0.125)
+        bias_grad(d_qkv[:, :D], G.get(att.q_proj.bias))
+        bias_grad(d_qkv[:, 2 * D:], G.get(att.v_proj.bias))
+        qkv_wgrad(d_qkv, S.enc_bf, G.get(att.q_proj.weight), G.get(att.k_proj.weight), G.get(att.v_proj.weight), rows, D)
+        return linear_dgrad(d_qkv, W.att.qkv, rows, out_dtype=F32)

@@ -18,7 +18,7 @@ from torch import nn
 from . import _lib as L
 from . import ops
 from .config import DiCoWConfig
-from .engine import EncoderEngine, DecoderEngine, GradSink, fddt_ptrs, CLS
+from .engine import EncoderEngine, DecoderEngine, CtcEngine, GradSink, fddt_ptrs, CLS
 
 F32, BF16 = torch.float32, torch.bfloat16
 
@@ -320,8 +320,17 @@ class DiCoWEncoder(nn.Module):
         self.layers = nn.ModuleList([EncoderLayer(d, f) for _ in range(config.encoder_layers)])
         self.layer_norm = nn.LayerNorm(d)
         self.ctc_weight = config.ctc_weight
-        if config.ctc_weight > 0.0:
-            raise NotImplementedError("the CTC auxiliary branch (ctc_weight > 0) is a 'next' row (SURVEY.md section 8 f2)")
+        if config.ctc_weight > 0.0:                      # CTC auxiliary branch (reference encoder.py:15-44)
+            if config.additional_layer:
+                raise NotImplementedError("additional_layer (a full extra encoder layer before the CTC head) is not "
+                                          "implemented; the recipe uses additional_self_attention_layer")
+            if config.additional_self_attention_layer:
+                self.additional_self_attention_layer = Attention(d)
+            if config.pre_ctc_sub_sample:
+                self.subsample_conv1 = nn.Conv1d(d, d, kernel_size=3, stride=2, padding=1, bias=False)
+                self.subsample_conv2 = nn.Conv1d(d, d, kernel_size=3, stride=2, padding=1, bias=False)
+            self.lm_head = nn.Linear(d, config.vocab_size + 1, bias=False)
+        self.first_task_token = config.vocab_size - 30 * 50 - 1 - 6
         if config.use_fddt:
             def mk(rate):
                 return FDDT(d_model=d, non_target_rate=rate, fddt_init=config.fddt_init, is_diagonal=config.fddt_is_diagonal,
@@ -338,12 +347,30 @@ class DiCoWEncoder(nn.Module):
                                       "path implements the recipe's diagonal and bias-only variants")
         self._eng = None
         self._sig = None
+        self._ctc_eng = None
+        self._ctc_sig = None
+
+    _CTC_PREFIXES = ("additional_self_attention_layer.", "subsample_conv", "lm_head.")
+
+    def ctc_parameters(self):
+        return [p for n, p in self.named_parameters() if n.startswith(self._CTC_PREFIXES)]
+
+    def _ctc_engine(self, prepare=True):
+        if self._ctc_eng is None:
+            self._ctc_eng = CtcEngine(self)
+        if prepare:
+            sig = _param_sig(self.ctc_parameters())
+            if sig != self._ctc_sig:
+                self._ctc_eng.prepare()
+                self._ctc_sig = sig
+        return self._ctc_eng
 
     def _engine(self, prepare=True):
         if self._eng is None:
             self._eng = EncoderEngine(self)
         if prepare:
-            sig = _param_sig(list(self.parameters()))
+            ctc_ids = {id(p) for p in self.ctc_parameters()} if self.ctc_weight > 0.0 else set()
+            sig = _param_sig([p for p in self.parameters() if id(p) not in ctc_ids])
             if sig != self._sig:
                 self._eng.prepare()
                 self._sig = sig
@@ -359,11 +386,58 @@ class DiCoWEncoder(nn.Module):
             raise NotImplementedError("return_logits (CTC head) is a 'next' row (SURVEY.md section 8 f2)")
         if stno_mask is None:
             raise ValueError("stno_mask is required")
-        params = list(self.parameters())
+        ctc_ids = {id(p) for p in self.ctc_parameters()} if self.ctc_weight > 0.0 else set()
+        params = [p for p in self.parameters() if id(p) not in ctc_ids]
         out = _EncoderFn.apply(self, input_features, stno_mask, enrollments, *params)
         if return_dict is False:
             return (out,)
         return ModelOutput(last_hidden_state=out, hidden_states=None, attentions=None)
+
+
+class _CtcFn(torch.autograd.Function):
+    """CTC auxiliary loss on the encoder output (reference modeling_dicow.py:326-336)."""
+
+    @staticmethod
+    def forward(ctx, enc, enc_out, ctc_labels, *params):
+        eng = enc._ctc_engine()
+        B, T, D = enc_out.shape
+        enc_bf = ops.cast_bf16(enc_out.contiguous().to(F32)).view(B * T, D)
+        loss, S = eng.forward(enc_bf, B, T, ctc_labels)
+        ctx.enc, ctx.S, ctx.params = enc, S, params
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        enc, S = ctx.enc, ctx.S
+        G = GradSink(ctx.params, g_loss.device)
+        d_enc = enc._ctc_engine(prepare=False).backward(S, g_loss, G)
+        hook = getattr(enc, "_segment_hook", None)
+        if hook is not None:
+            hook("ctc")
+        return (None, d_enc.view(S.B, S.T, -1), None) + tuple(G.result(p) for p in ctx.params)
+
+
+def prepare_ctc_labels(labels, config, prefix_tokens, first_task_token):
+    """Label preparation of the CTC branch: strip decoder prefix tokens shared by the whole batch, eos -> -100
+    (reference modeling_dicow.py:328-333), optionally drop timestamp/task tokens and re-pad (encoder.py:111-113)."""
+    lab = labels.clone()
+    for tok in prefix_tokens:
+        if bool((lab[:, 0] == tok).all()):
+            lab = lab[:, 1:]
+    lab[lab == config.eos_token_id] = -100
+    if config.remove_timestamps_from_ctc:
+        keep = lab < first_task_token                      # also keeps the -100 padding, like the reference
+        order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)
+        lab = torch.gather(lab, 1, order)
+        cnt = keep.sum(dim=1, keepdim=True)
+        lab = torch.where(torch.arange(lab.shape[1], device=lab.device)[None, :] < cnt, lab, torch.full_like(lab, -100))
+        lab = lab[:, :max(int(cnt.max()), 1)]
+    if int(lab.max()) >= config.vocab_size:
+        raise ValueError(f"Label values must be <= vocab_size: {config.vocab_size}")
+    # CTC expects the valid targets as a prefix: move any interior -100 behind them
+    valid = lab >= 0
+    order = torch.argsort((~valid).to(torch.int8), dim=1, stable=True)
+    return torch.gather(lab, 1, order).contiguous()
 
 
 # ------------------------------------------------------------------------------------------------ decoder
@@ -443,6 +517,14 @@ class DiCoWForConditionalGeneration(nn.Module):
         self._sig = None
         self.apply(self._init_weights)
         self.tie_weights()
+        # reference checkpoints saved after set_tokenizer() carry the dense [n_ts, V] smoothing buffer
+        # (modeling_dicow.py:33); this implementation rebuilds compact tables from the tokenizer instead
+        self._register_load_state_dict_pre_hook(self._drop_soft_label_buffer)
+
+    @staticmethod
+    def _drop_soft_label_buffer(state_dict, prefix, *args):
+        for k in [k for k in state_dict if k.startswith(prefix + "soft_label_creator.")]:
+            state_dict.pop(k)
 
     # -- initialisation (HF Whisper init_std 0.02 + the reference's FDDT / gate / SCB schemes)
     def _init_weights(self, m):
@@ -472,6 +554,9 @@ class DiCoWForConditionalGeneration(nn.Module):
 
     def get_encoder(self):
         return self.model.encoder
+
+    def get_enc_logits(self, hidden_states):
+        raise NotImplementedError("get_enc_logits is used by CTC-rescored decoding (out of the training path)")
 
     def get_decoder(self):
         return self.model.decoder
@@ -523,6 +608,12 @@ class DiCoWForConditionalGeneration(nn.Module):
         loss, logits = _DecoderLossFn.apply(self, enc_out, dec_ids, lab, upp, *params)
         if labels is None:
             loss = None
+        elif cfg.ctc_weight > 0.0:                         # modeling_dicow.py:326-336
+            enc = self.model.encoder
+            prefix = getattr(self.tokenizer, "prefix_tokens", []) if self.tokenizer is not None else []
+            ctc_lab = prepare_ctc_labels(lab, cfg, prefix, enc.first_task_token)
+            ctc_loss = _CtcFn.apply(enc, enc_out, ctc_lab, *enc.ctc_parameters())
+            loss = (1 - cfg.ctc_weight) * loss + cfg.ctc_weight * ctc_loss
         if return_dict is False:
             return tuple(x for x in (loss, logits, enc_out) if x is not None)
         return ModelOutput(loss=loss, logits=logits, past_key_values=None, decoder_hidden_states=None,

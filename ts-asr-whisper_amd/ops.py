@@ -267,7 +267,24 @@ def gelu_bwd_bf16(g, pre, out):
 
 
 def conv2_col2im_gelu_bwd(dA2, pre1, d_pre1, B, T2, Cc):
-    L.call("dicow_conv2_col2im_gelu_bwd", dA2.data_ptr(), pre1.data_ptr(), d_pre1.data_ptr(), B, T2, Cc, L.stream())
+    L.call("dicow_conv2_col2im_gelu_bwd", dA2.data_ptr(), _p(pre1), d_pre1.data_ptr(), B, T2, Cc, L.stream())
+
+
+def ctc_args(logits, ld, B, Tn, Cc, labels, lse, alpha, beta, nll, tlen, loss_sum):
+    a = L.CtcArgs()
+    a.logits, a.ld, a.B, a.Tn, a.C = logits.data_ptr(), ld, B, Tn, Cc
+    a.labels, a.Lc, a.blank = labels.data_ptr(), labels.shape[1], Cc - 1
+    a.lse, a.alpha, a.beta, a.Smax = lse.data_ptr(), alpha.data_ptr(), beta.data_ptr(), 2 * labels.shape[1] + 1
+    a.nll, a.tlen, a.loss_sum = nll.data_ptr(), tlen.data_ptr(), loss_sum.data_ptr()
+    return a
+
+
+def ctc_loss_fwd(a):
+    L.call_struct("dicow_ctc_loss_fwd", a)
+
+
+def ctc_loss_bwd(a, grad_scale):
+    L.check(L.lib().dicow_ctc_loss_bwd(C.byref(a), grad_scale.data_ptr(), L.stream()), "dicow_ctc_loss_bwd")
 
 
 def sumsq(x, out):

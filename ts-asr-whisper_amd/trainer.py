@@ -34,6 +34,11 @@ def _backward_order(model):
     """Trainable encoder parameters grouped in the order their gradients complete during backward."""
     enc = model.model.encoder
     groups = []
+    ctc_ids = set()
+    if getattr(enc, "ctc_weight", 0.0) > 0.0:
+        ctc = enc.ctc_parameters()
+        ctc_ids = {id(p) for p in ctc}
+        groups.append(("ctc", ctc))                        # the CTC branch's backward runs before the encoder's
     groups.append(("final_ln", list(enc.layer_norm.parameters())))
     nl = len(enc.layers)
     for i in range(nl - 1, -1, -1):
