@@ -364,6 +364,119 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_arg
     }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, 256x256, staggered
+// Same tile / wave grid as gemm_nt256_kernel, but the contraction advances in 32-deep PHASES through a 4-stage LDS ring
+// (4 x 32 KiB) and the two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run ONE PHASE APART: in barrier
+// interval I group 0 works on phase I and group 1 on phase I-1.  While one group sits in its LDS-read / barrier
+// bubble the other group's MFMAs keep the SIMD's matrix pipe busy (the lock-step kernel loses ~45 % of the pipe
+// there).  DMA of phase I+2 is issued in interval I (its stage was last read in interval I-1) and has two intervals
+// to land; waits are counted (vmcnt(4) keeps the newest group in flight).
+#define NTS_STAGE (2 * 256 * 64)             // A 16 KiB + B 16 KiB (32-deep)
+#define NTS_LDS (4 * NTS_STAGE)
+
+__device__ __forceinline__ void nts_stage_part(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
+                                               int64_t lda, int64_t ldb, int M, int N, int m0, int n0, int k0, char* sA,
+                                               char* sB, int wave, int lane, int i) {
+    const int q = wave * 2 + i;                       // DMA instruction index: 16 rows x 64 B
+    const int row = q * 16 + (lane >> 2), p = lane & 3;
+    const int c = p ^ ((row >> 3) & 3);
+    int gm = m0 + row; gm = gm < M ? gm : M - 1;
+    int gn = n0 + row; gn = gn < N ? gn : N - 1;
+    glds16(A + (int64_t)gm * lda + k0 + c * 8, sA + q * 1024);
+    glds16(B + (int64_t)gn * ldb + k0 + c * 8, sB + q * 1024);
+}
+__device__ __forceinline__ bf16x8_t lds_frag_nts(const char* s, int row, int c) {
+    return *reinterpret_cast<const bf16x8_t*>(s + row * 64 + ((c ^ ((row >> 3) & 3)) << 4));
+}
+
+__global__ void __launch_bounds__(512, 2) gemm_nt256s_kernel(const dicow_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256;
+    int tm, tn;
+    tile_coords(ntm, ntn, tm, tn);
+    const int m0 = tm * 256, n0 = tn * 256;
+    const int bz = blockIdx.z;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
+    const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
+    const int wm = wave >> 2, wn = wave & 3;          // wm doubles as the stagger group
+    const int grp = wm;
+
+    f32x16_t acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int P = a.K / 32;
+    bf16x8_t wf0[2], xf0[4], wf1[2], xf1[4];
+#define NTS_LD(WF, XF, SA, SB, KK)                                                                           \
+    {                                                                                                        \
+        const int c_ = (KK) * 2 + (lane >> 5);                                                               \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) WF[i] = lds_frag_nts(SB, wn * 64 + i * 32 + (lane & 31), c_);  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) XF[j] = lds_frag_nts(SA, wm * 128 + j * 32 + (lane & 31), c_); \
+    }
+#define NTS_MFMA(WF, XF)                                                                                     \
+    { _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < 2; ++i)            \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0); }
+    auto dma = [&](int ph) {
+        char* sA = smem + (ph & 3) * NTS_STAGE;
+        nts_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, ph * 32, sA, sA + 256 * 64, wave, lane, 0);
+        nts_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, ph * 32, sA, sA + 256 * 64, wave, lane, 1);
+    };
+    dma(0);
+    if (P > 1) dma(1);
+    bool pending = false;                             // f1 holds the second slice of the previous phase
+    for (int I = 0; I <= P; ++I) {
+        if (I + 1 < P) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (I + 2 < P) dma(I + 2);
+        const int ph = I - grp;
+        if (ph >= 0 && ph < P) {
+            const char* sA = smem + (ph & 3) * NTS_STAGE;
+            const char* sB = sA + 256 * 64;
+            NTS_LD(wf0, xf0, sA, sB, 0)
+            if (pending) NTS_MFMA(wf1, xf1)
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            NTS_LD(wf1, xf1, sA, sB, 1)
+            NTS_MFMA(wf0, xf0)
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+            pending = true;
+        }
+    }
+    if (pending) NTS_MFMA(wf1, xf1)
+#undef NTS_LD
+#undef NTS_MFMA
+
+    const int flags = a.flags;
+    const int hh = lane >> 5;
+    unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)bz * a.strideC;
+    float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
+    unsigned short* aux = a.aux ? reinterpret_cast<unsigned short*>(a.aux) + (int64_t)bz * a.strideAux : nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 128 + j * 32 + (lane & 31);
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * hh;
+                if (n >= a.N) continue;
+                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                nt_epilogue_quad(a, flags, v, m, n, Cb, Cf, aux);
+            }
+        }
+    }
+}
+
 extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     DICOW_REQUIRE(a && a->A && a->B && a->C, "gemm_nt: null operand");
     DICOW_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
@@ -386,6 +499,7 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     static const int variant = getenv("DICOW_NT_VARIANT") ? atoi(getenv("DICOW_NT_VARIANT")) : 0;     // tuning knob
     static bool attr256 = false;
     if (!attr256) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NTS_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
@@ -397,7 +511,8 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     const bool big = (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
         const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
-        if (variant == 5) hipLaunchKernelGGL(gemm_nt256_kernel<1>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
+        if (variant == 9) hipLaunchKernelGGL(gemm_nt256s_kernel, g256, dim3(512), NTS_LDS, (hipStream_t)stream, *a);
+        else if (variant == 5) hipLaunchKernelGGL(gemm_nt256_kernel<1>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
         else if (variant == 6) hipLaunchKernelGGL(gemm_nt256_kernel<2>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
         else if (variant == 7) hipLaunchKernelGGL(gemm_nt256_kernel<3>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
         else if (variant == 8) hipLaunchKernelGGL(gemm_nt256_kernel<4>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
