@@ -55,7 +55,7 @@ class KernelTimer:
                 s.record()
                 r = __fn(*a, **kw)
                 e.record()
-                self.rec[__n].append((s, e, self.work(__n, a, kw)))
+                self.rec[__n].append((s, e, self.work(__n, a, kw), self.key(__n, a, kw)))
                 return r
             setattr(self.ops, n, wrapped)
         import ts_asr_whisper_amd.engine as eng      # engine calls through the module attribute `ops.<name>`
@@ -69,12 +69,28 @@ class KernelTimer:
             return 2.0 * a[3] * a[4] * a[5] * kw.get("batch", 1)
         return 0.0
 
+    @staticmethod
+    def key(name, a, kw):
+        epi = "+".join(k for k in ("bias", "residual", "aux") if kw.get(k) is not None)
+        return (a[3], a[4], a[5], kw.get("batch", 1), kw.get("flags", 0), epi, str(a[2].dtype).replace("torch.", ""))
+
+    def breakdown(self, name, steps):
+        """per (shape, epilogue) totals, for `DICOW_BENCH_BREAKDOWN=1 python bench.py` (stderr)"""
+        agg = {}
+        for s, e, w, k in self.rec[name]:
+            t = agg.setdefault(k, [0, 0.0, 0.0])
+            t[0] += 1; t[1] += s.elapsed_time(e); t[2] += w
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        for k, (n, ms, fl) in rows:
+            print(f"  {name} M{k[0]} N{k[1]} K{k[2]} batch{k[3]} flags{k[4]} [{k[5]}] {k[6]}: {n // steps}/step, "
+                  f"{ms / steps:.3f} ms/step, {ms / n:.4f} ms each, {fl / ms / 1e9:.0f} TF", file=sys.stderr)
+
     def summary(self, name):
         rec = self.rec[name]
         if not rec:
             return None
-        ms = [s.elapsed_time(e) for s, e, _ in rec]
-        fl = [w for _, _, w in rec]
+        ms = [r[0].elapsed_time(r[1]) for r in rec]
+        fl = [r[2] for r in rec]
         return {"launches": len(rec), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms), "flops": sum(fl),
                 "tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12 if sum(ms) > 0 else 0.0}
 
@@ -172,6 +188,9 @@ def main():
     ms = dt / a.steps * 1e3
     utts = a.batch * world * a.steps / dt
     nt, tn = timer.summary("gemm_nt"), timer.summary("gemm_tn")
+    if os.environ.get("DICOW_BENCH_BREAKDOWN"):
+        timer.breakdown("gemm_nt", a.steps)
+        timer.breakdown("gemm_tn", a.steps)
     peak = 2500.0
     out = {
         "metric": f"train utterances/sec (30 s clips) {a.model} DiCoW" if not a.se else

@@ -138,6 +138,9 @@ int dicow_fddt_full_combine_bwd(const float* g, const float* stno, int64_t stno_
 #define DICOW_EPI_SCALE_N  16    /* columns n < scale_ncols multiplied by scale AFTER bias (q * head_dim^-0.5) */
 #define DICOW_EPI_GELU_BWD 32    /* C = acc * gelu'(aux[m,n])  (aux = saved pre-activation, bf16) */
 #define DICOW_EPI_ACCUM    64    /* C += result (fp32 C only) */
+#define DICOW_EPI_GELU_DAUX 128  /* with GELU: aux receives gelu'(pre-activation) (bf16) instead of the pre-activation,  */
+                                 /* so that the backward GEMM needs one multiply (MUL_AUX) and no transcendental    */
+#define DICOW_EPI_MUL_AUX  256   /* C = acc * aux[m,n]  (aux = saved gelu' from GELU_DAUX, bf16)                      */
 typedef struct {
     const void* A; const void* B; void* C;
     const float* bias; const float* residual; void* aux;

@@ -147,39 +147,72 @@ def test_gemm_nt_plain(ops, M, N, K):
     assert maxdiff(Cb.float().cpu(), ref) < 1e-2 * max(1.0, float(ref.abs().max()))
 
 
-def test_gemm_nt_epilogues(ops):
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (6100, 2244, 128)])     # 128x128 tiles / persistent 256x256 kernel
+def test_gemm_nt_epilogues(ops, M, N, K):
     from ts_asr_whisper_amd import _lib as L
-    M, N, K = 300, 256, 192
     g = torch.Generator().manual_seed(5)
     A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * K ** -0.5)
     bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
     Ad, Bd = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
     base = A @ B.t() + bias
-    # bias + q-scale on the first 128 columns
+    nq = (N // 8) * 4
+    # bias only (bf16 out)
+    C0 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(Ad, Bd, C0, M, N, K, bias=dev(bias))
+    assert maxdiff(C0.float().cpu(), base) < 3e-2
+    # bias + q-scale on the first nq columns
     C1 = torch.empty(M, N, device="cuda")
-    ops.gemm_nt(Ad, Bd, C1, M, N, K, bias=dev(bias), flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=128)
-    ref = base.clone(); ref[:, :128] *= 0.125
+    ops.gemm_nt(Ad, Bd, C1, M, N, K, bias=dev(bias), flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=nq)
+    ref = base.clone(); ref[:, :nq] *= 0.125
     assert maxdiff(C1.cpu(), ref) < 2e-4
+    C1b = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(Ad, Bd, C1b, M, N, K, bias=dev(bias), flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=nq)
+    assert maxdiff(C1b.float().cpu(), ref) < 3e-2
     # bias + GELU with saved pre-activation
     C2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     aux = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     ops.gemm_nt(Ad, Bd, C2, M, N, K, bias=dev(bias), aux=aux, flags=L.EPI_GELU)
-    assert maxdiff(aux.float().cpu(), base) < 2e-2
-    assert maxdiff(C2.float().cpu(), O.gelu_erf(_bf(base))) < 2e-2
+    assert maxdiff(aux.float().cpu(), base) < 3e-2
+    assert maxdiff(C2.float().cpu(), O.gelu_erf(_bf(base))) < 3e-2
     # bias + residual (fp32 out); the Linear output is bf16-rounded before the add (AMP)
     C3 = torch.empty(M, N, device="cuda")
     ops.gemm_nt(Ad, Bd, C3, M, N, K, bias=dev(bias), residual=dev(res))
-    assert maxdiff(C3.cpu(), _bf(base) + res) < 2e-2
-    # GELU backward: C = acc * gelu'(aux)
+    assert maxdiff(C3.cpu(), _bf(base) + res) < 3e-2
+    # GELU backward from the saved pre-activation: C = acc * gelu'(aux)
     C4 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     ops.gemm_nt(Ad, Bd, C4, M, N, K, aux=aux, flags=L.EPI_GELU_BWD)
     u = aux.float().cpu().requires_grad_(True)
     O.gelu_erf(u).sum().backward()
-    assert maxdiff(C4.float().cpu(), (A @ B.t()) * u.grad) < 3e-2
+    assert maxdiff(C4.float().cpu(), (A @ B.t()) * u.grad) < 4e-2
+    # bias + GELU saving the derivative instead (MLP path), then the one-multiply backward epilogue
+    C6 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    daux = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(Ad, Bd, C6, M, N, K, bias=dev(bias), aux=daux, flags=L.EPI_GELU | L.EPI_GELU_DAUX)
+    ub = _bf(base).requires_grad_(True)
+    O.gelu_erf(ub).sum().backward()
+    assert maxdiff(C6.float().cpu(), O.gelu_erf(_bf(base))) < 3e-2
+    # the pre-activation itself is only bf16-accurate, so compare gelu' where it is taken at the kernel's own rounding
+    assert (daux.float().cpu() - ub.grad).abs().mean() < 2e-3 and maxdiff(daux.float().cpu(), ub.grad) < 3e-2
+    C7 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(Ad, Bd, C7, M, N, K, aux=daux, flags=L.EPI_MUL_AUX)
+    assert maxdiff(C7.float().cpu(), (A @ B.t()) * daux.float().cpu()) < 4e-2
     # accumulate
     C5 = dev(res.clone())
     ops.gemm_nt(Ad, Bd, C5, M, N, K, flags=L.EPI_ACCUM)
     assert maxdiff(C5.cpu(), res + A @ B.t()) < 2e-4
+
+
+def test_gelu_device_accuracy(ops):
+    """The A&S-7.1.26 GELU used by the epilogues against float64 erf: |err| < 1e-6 before the bf16 rounding."""
+    from ts_asr_whisper_amd import _lib as L
+    # identity GEMM: A = x (bf16) as a [M, 64] block against B = I (64x64) reproduces x in the accumulator
+    x = _bf(torch.linspace(-9, 9, 256 * 64).view(256, 64))
+    eye = torch.eye(64)
+    C = torch.empty(256, 64, device="cuda")
+    ops.gemm_nt(dev(x, torch.bfloat16), dev(eye, torch.bfloat16), C, 256, 64, 64, flags=L.EPI_GELU)
+    xd = x.double()
+    ref = xd * 0.5 * (1 + torch.erf(xd / 2 ** 0.5))
+    assert maxdiff(C.cpu().double(), ref) < 1e-6
 
 
 def test_gemm_nt_batched_strided_conv_view(ops):

@@ -1,0 +1,53 @@
+// Measures the shader clock the chip actually sustains under an all-CU MFMA load (power management lowers it well below
+// the 2.4 GHz peak), so that MFMA-bound kernels can be judged against the attainable rate, not the datasheet one.
+//   hipcc --offload-arch=gfx950 -O3 tools/probe_clock.hip -o tools/probe_clock && tools/probe_clock
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+template <int NACC>
+__global__ void __launch_bounds__(256) mfma_loop(float* out, long long* clk, int iters) {
+    f32x16_t acc[NACC];
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    bf16x8_t a, b;
+    for (int r = 0; r < 8; ++r) { a[r] = (short)(0x3f80 + threadIdx.x); b[r] = (short)(0x3f00 + r); }
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    float s = 0.f;
+    for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = w1 - w0; }
+}
+
+int main() {
+    const int blocks = 256, iters = 20000;
+    float* out; long long* clk;
+    hipMalloc(&out, blocks * 256 * 4); hipMalloc(&clk, blocks * 16);
+    std::vector<long long> h(2 * blocks);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    int wall_khz = 0; hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, 0);
+    printf("wall clock rate %d kHz\n", wall_khz);
+    for (int rep = 0; rep < 3; ++rep) {
+        for (int nb : {256, 32, 1}) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(mfma_loop<8>, dim3(nb), dim3(256), 0, 0, out, clk, iters);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(h.data(), clk, nb * 16, hipMemcpyDeviceToHost);
+            double cyc = 0, wall = 0; for (int i = 0; i < nb; ++i) { cyc += h[2 * i]; wall += h[2 * i + 1]; }
+            cyc /= nb; wall /= nb;
+            const double secs = wall / (wall_khz * 1e3);
+            const double flops = (double)nb * 4 * iters * 8 * 32768.0;
+            printf("blocks %3d: %.3f ms  shader clk %.3f GHz (s_memtime) | cycles/MFMA %.2f | %.1f TF (%.0f%% of 2500)\n", nb, ms,
+                   cyc / secs * 1e-9, cyc / (iters * 8.0), flops / (ms * 1e-3) * 1e-12, flops / (ms * 1e-3) * 1e-12 / 25.0);
+        }
+    }
+    return 0;
+}

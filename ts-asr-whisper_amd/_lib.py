@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdicow_hip.so")
+LIB_PATH = os.environ.get("DICOW_HIP_LIB") or os.path.join(_HERE, "libdicow_hip.so")   # override: diagnostic builds
 _lib = None
 
 c_vp, c_i, c_i64, c_f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -69,6 +69,7 @@ class CtcArgs(C.Structure):
 
 
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_SCALE_N, EPI_GELU_BWD, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
+EPI_GELU_DAUX, EPI_MUL_AUX = 128, 256
 
 # name -> argtypes ; every function returns int
 _SIGS = {

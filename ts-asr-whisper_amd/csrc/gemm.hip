@@ -30,9 +30,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
 
 // grouped + XCD-aware tile order: consecutive tile ids share A/B panels; block b lands on XCD b % 8, so give
 // each XCD a contiguous chunk of the grouped order (bijective for any grid size).
-__device__ __forceinline__ void tile_coords(int ntm, int ntn, int& tm, int& tn) {
+__device__ __forceinline__ void tile_coords_id(int ntm, int ntn, int bid, int& tm, int& tn) {
     const int nwg = ntm * ntn;
-    const int bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     const int GM = 8;
@@ -43,6 +42,7 @@ __device__ __forceinline__ void tile_coords(int ntm, int ntn, int& tm, int& tn) 
     tm = first_m + rem % gsize;
     tn = rem / gsize;
 }
+__device__ __forceinline__ void tile_coords(int ntm, int ntn, int& tm, int& tn) { tile_coords_id(ntm, ntn, blockIdx.x, tm, tn); }
 
 // ------------------------------------------------------------------------------------------------ NT
 // LDS image of a [128 rows][64 k] bf16 tile: row stride 128 B; 16-B chunk c of row r stored at chunk
@@ -79,6 +79,81 @@ __device__ __forceinline__ void nt_stage_part(const unsigned short* __restrict__
 
 __device__ __forceinline__ bf16x8_t lds_frag_nt(const char* s, int row, int c) {
     return *reinterpret_cast<const bf16x8_t*>(s + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+}
+
+// FLAGS >= 0: the epilogue flag set is a compile-time constant (branch-free, small code); FLAGS < 0: runtime `rflags`.
+// pre_bias / pre_aux / pre_res: operand values the caller already holds (loaded ahead of the stores -- vmcnt retires in
+// order, so a load issued after a burst of stores waits for all of them); NULL = load here.
+template <int FLAGS = -1>
+__device__ __forceinline__ void nt_epilogue_math(const dicow_gemm_args& a, int rflags, float (&v)[4], float (&dg)[4], int m, int n,
+                                                 const unsigned short* aux, const float4* pre_bias, const uint2* pre_aux,
+                                                 const float4* pre_res) {
+    const int flags = FLAGS >= 0 ? FLAGS : rflags;
+    if (flags & DICOW_EPI_BIAS) {
+        const float4 bv = pre_bias ? *pre_bias : *reinterpret_cast<const float4*>(a.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+    if (flags & DICOW_EPI_SCALE_N) {
+        if (n < a.scale_ncols) { v[0] *= a.scale; v[1] *= a.scale; v[2] *= a.scale; v[3] *= a.scale; }
+    }
+    if (flags & DICOW_EPI_GELU) {
+        if (flags & DICOW_EPI_GELU_DAUX) {
+            // the activation and its derivative are both taken at the bf16-rounded pre-activation (AMP: fc1 output is bf16)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gelu_erf_both(bf2f(f2bf(v[e])), v[e], dg[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dg[e] = v[e];         // aux receives the pre-activation
+            if (aux) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+    }
+    if (flags & (DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) {
+        const uint2 u = pre_aux ? *pre_aux : *reinterpret_cast<const uint2*>(aux + (int64_t)m * a.ldaux + n);
+        float f[4] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                      __uint_as_float(u.y & 0xffff0000u)};
+        if (flags & DICOW_EPI_GELU_BWD) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f[e] = gelu_erf_grad(f[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= f[e];
+    }
+    if (flags & DICOW_EPI_RESIDUAL) {
+        const float4 rv = pre_res ? *pre_res : *reinterpret_cast<const float4*>(a.residual + (int64_t)m * a.ldr + n);
+        // AMP: the Linear output is rounded to bf16 before the fp32 residual add
+        v[0] = bf2f(f2bf(v[0])) + rv.x; v[1] = bf2f(f2bf(v[1])) + rv.y;
+        v[2] = bf2f(f2bf(v[2])) + rv.z; v[3] = bf2f(f2bf(v[3])) + rv.w;
+    }
+}
+
+template <int FLAGS = -1>
+__device__ __forceinline__ void nt_epilogue_quad(const dicow_gemm_args& a, int rflags, float (&v)[4], int m, int n,
+                                                 unsigned short* Cb, float* Cf, unsigned short* aux,
+                                                 const float4* pre_bias = nullptr, const uint2* pre_aux = nullptr,
+                                                 const float4* pre_res = nullptr) {
+    const int flags = FLAGS >= 0 ? FLAGS : rflags;
+    float dg[4];
+    nt_epilogue_math<FLAGS>(a, rflags, v, dg, m, n, aux, pre_bias, pre_aux, pre_res);
+    if ((flags & DICOW_EPI_GELU) && aux)
+        *reinterpret_cast<uint2*>(aux + (int64_t)m * a.ldaux + n) = make_uint2(pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3]));
+#ifdef NTW_NOSTORE
+    if (v[0] != 12345.678f) return;                   // diagnostic build: everything but the global stores
+#endif
+    if (flags & DICOW_EPI_OUT_F32) {
+        float* cp = Cf + (int64_t)m * a.ldc + n;
+        if (flags & DICOW_EPI_ACCUM) {
+            const float4 old = *reinterpret_cast<const float4*>(cp);
+            v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+        }
+        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        *reinterpret_cast<uint2*>(Cb + (int64_t)m * a.ldc + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
 }
 
 template <int STAGES, bool PRIO>
@@ -159,48 +234,7 @@ __global__ void __launch_bounds__(256, STAGES == 2 ? 2 : 4) gemm_nt_kernel(const
                 const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * hh;
                 if (n >= a.N) continue;
                 float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (flags & DICOW_EPI_BIAS) {
-                    const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-                    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-                }
-                if (flags & DICOW_EPI_SCALE_N) {
-                    if (n < a.scale_ncols) { v[0] *= a.scale; v[1] *= a.scale; v[2] *= a.scale; v[3] *= a.scale; }
-                }
-                if (flags & DICOW_EPI_GELU) {
-                    if (aux) {
-                        *reinterpret_cast<uint2*>(aux + (int64_t)m * a.ldaux + n) =
-                            make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                        // the activation is applied to the bf16-rounded pre-activation (AMP: fc1 output is bf16)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e]));
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-                }
-                if (flags & DICOW_EPI_GELU_BWD) {
-                    const uint2 u = *reinterpret_cast<const uint2*>(aux + (int64_t)m * a.ldaux + n);
-                    v[0] *= gelu_erf_grad(__uint_as_float(u.x << 16));
-                    v[1] *= gelu_erf_grad(__uint_as_float(u.x & 0xffff0000u));
-                    v[2] *= gelu_erf_grad(__uint_as_float(u.y << 16));
-                    v[3] *= gelu_erf_grad(__uint_as_float(u.y & 0xffff0000u));
-                }
-                if (flags & DICOW_EPI_RESIDUAL) {
-                    const float4 rv = *reinterpret_cast<const float4*>(a.residual + (int64_t)m * a.ldr + n);
-                    // AMP: the Linear output is rounded to bf16 before the fp32 residual add
-                    v[0] = bf2f(f2bf(v[0])) + rv.x; v[1] = bf2f(f2bf(v[1])) + rv.y;
-                    v[2] = bf2f(f2bf(v[2])) + rv.z; v[3] = bf2f(f2bf(v[3])) + rv.w;
-                }
-                if (flags & DICOW_EPI_OUT_F32) {
-                    float* cp = Cf + (int64_t)m * a.ldc + n;
-                    if (flags & DICOW_EPI_ACCUM) {
-                        const float4 old = *reinterpret_cast<const float4*>(cp);
-                        v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
-                    }
-                    *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    *reinterpret_cast<uint2*>(Cb + (int64_t)m * a.ldc + n) =
-                        make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-                }
+                nt_epilogue_quad(a, flags, v, m, n, Cb, Cf, aux);
             }
         }
     }
@@ -213,50 +247,6 @@ __global__ void __launch_bounds__(256, STAGES == 2 ? 2 : 4) gemm_nt_kernel(const
 // per CU with two waves per SIMD.
 #define NT256_STAGE (2 * 256 * BK * 2)       // A + B = 64 KiB
 #define NT256_LDS (2 * NT256_STAGE)
-
-template <typename T> struct epi_store;
-
-__device__ __forceinline__ void nt_epilogue_quad(const dicow_gemm_args& a, int flags, float (&v)[4], int m, int n,
-                                                 unsigned short* Cb, float* Cf, unsigned short* aux) {
-    if (flags & DICOW_EPI_BIAS) {
-        const float4 bv = *reinterpret_cast<const float4*>(a.bias + n);
-        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-    }
-    if (flags & DICOW_EPI_SCALE_N) {
-        if (n < a.scale_ncols) { v[0] *= a.scale; v[1] *= a.scale; v[2] *= a.scale; v[3] *= a.scale; }
-    }
-    if (flags & DICOW_EPI_GELU) {
-        if (aux) {
-            *reinterpret_cast<uint2*>(aux + (int64_t)m * a.ldaux + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e]));
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-    }
-    if (flags & DICOW_EPI_GELU_BWD) {
-        const uint2 u = *reinterpret_cast<const uint2*>(aux + (int64_t)m * a.ldaux + n);
-        v[0] *= gelu_erf_grad(__uint_as_float(u.x << 16));
-        v[1] *= gelu_erf_grad(__uint_as_float(u.x & 0xffff0000u));
-        v[2] *= gelu_erf_grad(__uint_as_float(u.y << 16));
-        v[3] *= gelu_erf_grad(__uint_as_float(u.y & 0xffff0000u));
-    }
-    if (flags & DICOW_EPI_RESIDUAL) {
-        const float4 rv = *reinterpret_cast<const float4*>(a.residual + (int64_t)m * a.ldr + n);
-        v[0] = bf2f(f2bf(v[0])) + rv.x; v[1] = bf2f(f2bf(v[1])) + rv.y;
-        v[2] = bf2f(f2bf(v[2])) + rv.z; v[3] = bf2f(f2bf(v[3])) + rv.w;
-    }
-    if (flags & DICOW_EPI_OUT_F32) {
-        float* cp = Cf + (int64_t)m * a.ldc + n;
-        if (flags & DICOW_EPI_ACCUM) {
-            const float4 old = *reinterpret_cast<const float4*>(cp);
-            v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
-        }
-        *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-        *reinterpret_cast<uint2*>(Cb + (int64_t)m * a.ldc + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-    }
-}
 
 template <int ABL>   // ablation: 0 = real kernel, 1 = no DMA after the first tile, 2 = no MFMA, 3 = no LDS fragment reads
 __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_args a) {
@@ -361,6 +351,275 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_arg
                 nt_epilogue_quad(a, flags, v, m, n, Cb, Cf, aux);
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ NT, 256x256, 4 waves
+// Same 256x256x64 stage image as gemm_nt256_kernel, but ONE wave per SIMD (256 threads), each owning a 128x128
+// output quadrant: 16 accumulator blocks = 256 registers (the unified 512-entry file lets them live in AGPRs).
+// Why: the 8-wave kernel is LDS-bandwidth co-critical -- per 16-deep slice a wave reads 6 fragments for 8 MFMAs, i.e.
+// per k-step the CU moves 192 KiB of fragments + 64 KiB of DMA = 2048 LDS clocks against 2048 MFMA clocks.  A 128x128
+// wave tile reads 8 fragments for 16 MFMAs (128 + 64 KiB = 1536 clocks), leaving the matrix pipe as the only
+// saturated resource.  With a single wave per SIMD nothing hides latency for us, so the instruction stream is laid
+// out by hand: every MFMA is followed by one LDS read (next slice) or one DMA instruction (next k-tile).
+//
+// The kernel is PERSISTENT: one workgroup per CU walks the tile list (virtual block id v = blockIdx.x + round *
+// gridDim.x through the same XCD-aware id -> tile map, so the tiles in flight are the same L2-friendly set).  A
+// per-workgroup timeline (tools/profile_ksteps.py) of the one-tile-per-workgroup form showed, for a K=1280 tile,
+// 30 us of k-loop against 10 us of epilogue + 1 us prologue + 2 us workgroup relaunch gap.  Here
+//   * the first-stage DMA of the NEXT tile is issued before the epilogue of the current one;
+//   * the epilogue sends the accumulators through LDS (the stage that was read last) so every store instruction covers
+//     2 rows x 256/512 contiguous bytes instead of 32 rows x 16 B (residual / aux reads likewise).
+__device__ __forceinline__ void ntw_stage_part(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
+                                               int64_t lda, int64_t ldb, int M, int N, int m0, int n0, int k0, char* sA,
+                                               char* sB, int lane, int q) {
+    const int rr = lane >> 3, p = lane & 7;
+    const int row = q * 8 + rr;
+    const int c = p ^ ((row >> 1) & 7);
+    int gm = m0 + row; gm = gm < M ? gm : M - 1;
+    int gn = n0 + row; gn = gn < N ? gn : N - 1;
+    glds16(A + (int64_t)gm * lda + k0 + c * 8, sA + q * 1024);
+    glds16(B + (int64_t)gn * ldb + k0 + c * 8, sB + q * 1024);
+}
+
+#define NTW_LDS (NT256_LDS + 1024)         // two stages + the tile's bias row
+
+template <int FLAGS, int EPI = 1>   // EPI 1: accumulators -> LDS -> row-contiguous stores; 0: stores straight from the MFMA layout
+__global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256;
+    const int nwg = ntm * ntn, total = nwg * (a.batch > 0 ? a.batch : 1);
+    const int wm = wave >> 1, wn = wave & 1;          // wave tile: rows m [wm*128, +128), cols n [wn*128, +128)
+    const int nk = a.K / BK;
+    const int flags = a.flags;
+    constexpr bool LDS_BIAS = FLAGS >= 0 && (FLAGS & DICOW_EPI_BIAS) != 0;
+    float* sbias = reinterpret_cast<float*>(smem + NT256_LDS);       // the tile's 256 bias values (compile-time-flag kernels)
+
+    int v = blockIdx.x;
+    int bz = v / nwg, tm, tn;
+    tile_coords_id(ntm, ntn, v - bz * nwg, tm, tn);
+    int m0 = tm * 256, n0 = tn * 256;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
+    const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
+    int par = 0;                                      // stage holding k-tile 0 of the current output tile
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        ntw_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, 0, smem, smem + 256 * 128, lane, wave * 8 + i);
+
+    while (true) {
+        f32x16_t acc[4][4];                           // [n block i][m block j]
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        bf16x8_t wf0[4], xf0[4], wf1[4], xf1[4];
+#define LDFRAG(WF, XF, KK)                                                                                   \
+    {                                                                                                        \
+        const int c_ = (KK) * 2 + (lane >> 5);                                                               \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) WF[i] = lds_frag_nt(sB, wn * 128 + i * 32 + (lane & 31), c_); \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) XF[j] = lds_frag_nt(sA, wm * 128 + j * 32 + (lane & 31), c_); \
+    }
+#define DOMFMA(WF, XF)                                                                                       \
+    { _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < 4; ++i)            \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0); }
+#define DMA4(I0) if (MORE) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                \
+        ntw_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, (t + 1) * BK, nA, nA + 256 * 128, lane, wave * 8 + (I0) + i_); }
+    // one slice: 16 MFMA with NR LDS reads and ND DMA instructions threaded between them (one per MFMA)
+#define SCHED(NR, ND)                                                                                        \
+    _Pragma("unroll") for (int s_ = 0; s_ < (NR); ++s_) {                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
+    _Pragma("unroll") for (int s_ = 0; s_ < (ND); ++s_) {                                                    \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } \
+    __builtin_amdgcn_sched_group_barrier(0x008, 16 - (NR) - (ND), 0);
+#define KSTEP(MORE_, FIRST_)                                                                                 \
+    {                                                                                                        \
+        constexpr bool MORE = MORE_;                                                                         \
+        char* sA = smem + ((t + par) & 1) * NT256_STAGE;                                                     \
+        char* sB = sA + 256 * 128;                                                                           \
+        char* nA = smem + ((t + par + 1) & 1) * NT256_STAGE;                                                 \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
+        __builtin_amdgcn_s_barrier();                                                                        \
+        asm volatile("" ::: "memory");                                                                       \
+        LDFRAG(wf0, xf0, 0) DMA4(0)                                                                          \
+        if (!(FIRST_)) { DOMFMA(wf1, xf1) SCHED(8, MORE ? 8 : 0) }                                           \
+        LDFRAG(wf1, xf1, 1) DMA4(4) DOMFMA(wf0, xf0) SCHED(8, MORE ? 8 : 0)                                  \
+        LDFRAG(wf0, xf0, 2) DOMFMA(wf1, xf1) SCHED(8, 0)                                                     \
+        LDFRAG(wf1, xf1, 3) DOMFMA(wf0, xf0) SCHED(8, 0)                                                     \
+    }
+#ifdef NTW_PROFILE
+        const long long pc0 = clock64(), pw0 = wall_clock64();
+#endif
+        // bias of this tile's 256 columns -> LDS (read back as quads by the epilogue; a global load there would queue
+        // behind the next tile's DMA).  Written after the first k-step's barrier: every wave has left the previous epilogue.
+        float bias_t = 0.f;
+        if (LDS_BIAS) { const int nb = n0 + tid; bias_t = a.bias[nb < a.N ? nb : a.N - 1]; }
+        int t = 0;
+        if (nk == 1) {
+            KSTEP(false, true)
+            if (LDS_BIAS) sbias[tid] = bias_t;
+        } else {
+            KSTEP(true, true)
+            if (LDS_BIAS) sbias[tid] = bias_t;
+            for (t = 1; t + 1 < nk; ++t) KSTEP(true, false)
+            KSTEP(false, false)
+        }
+        DOMFMA(wf1, xf1)
+#undef KSTEP
+#undef SCHED
+#undef LDFRAG
+#undef DOMFMA
+#undef DMA4
+#ifdef NTW_PROFILE
+        const long long pc1 = clock64(), pw1 = wall_clock64();
+        const int pv = v;
+#endif
+        // ---- this tile's output coordinates; then move the staging state on to the next tile and start its DMA
+        const int em0 = m0 + wm * 128, en0 = n0 + wn * 128, ebz = bz;
+        char* scr = smem + ((nk - 1 + par) & 1) * NT256_STAGE + wave * 16384;    // stage read last
+        par = (par + nk) & 1;
+        v += gridDim.x;
+        const bool more_tiles = v < total;
+        if (more_tiles) {
+            bz = v / nwg;
+            tile_coords_id(ntm, ntn, v - bz * nwg, tm, tn);
+            m0 = tm * 256; n0 = tn * 256;
+            A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
+            B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
+            char* fA = smem + par * NT256_STAGE;      // last read in k-step nk-2: released by the k-step nk-1 barrier
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                ntw_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, 0, fA, fA + 256 * 128, lane, wave * 8 + i);
+        }
+        unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)ebz * a.strideC;
+        float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)ebz * a.strideC;
+        unsigned short* aux = a.aux ? reinterpret_cast<unsigned short*>(a.aux) + (int64_t)ebz * a.strideAux : nullptr;
+#ifdef NTW_PROFILE
+        aux = nullptr;
+#endif
+        // the epilogue's lane-derived LDS offsets / guards are tile-invariant; hidden behind an opaque copy of the lane id
+        // so that they are not hoisted out of the tile loop into the k-loop's register budget (that spilled 60-90 VGPRs)
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int ml = le & 31, hh = le >> 5;
+#ifdef NTW_PROFILE
+        long long pj[5]; const long long pdma = wall_clock64();
+        for (int j = 0; j < 5; ++j) pj[j] = pdma;
+#endif
+        if (EPI == 0) {
+            // ablation: stores straight from the MFMA layout (32 rows x 16 B per instruction) -- measured 10 % slower
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = em0 + j * 32 + ml;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = en0 + i * 32 + 8 * q + 4 * hh;
+                        if (m < a.M && n < a.N) {
+                            float vv[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                            nt_epilogue_quad<FLAGS>(a, flags, vv, m, n, Cb, Cf, aux);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // every wave has finished its fragment reads of the last stage
+            asm volatile("" ::: "memory");
+#ifdef NTW_PROFILE
+            pj[0] = wall_clock64();
+#endif
+            {
+                // [32 rows][128 n] fp32 per wave and pass, row stride 512 B, 16-B chunk c of row r at c ^ (r & 31);
+                // each read-back instruction covers 2 rows x 512 B.  With compile-time flags the [m][n]-indexed inputs
+                // (saved gelu' / residual) of pass j+1 are requested BEFORE the stores of pass j are issued.
+                // (Tried and dropped: doing the math in the MFMA layout and sending packed bf16 rows through LDS -- half
+                // the LDS bytes, but every accumulator then needs a v_accvgpr_read + VALU pack instead of going
+                // AGPR -> LDS directly, and it measured 4-10 % slower on the plain/bias/GELU GEMMs.)
+                constexpr bool PRE_AUX = FLAGS >= 0 && (FLAGS & (DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) != 0;
+                constexpr bool PRE_RES = FLAGS >= 0 && (FLAGS & DICOW_EPI_RESIDUAL) != 0;
+                uint2 xa[2][PRE_AUX ? 16 : 1];
+                float4 xr[2][PRE_RES ? 16 : 1];
+                const int nq = en0 + 4 * ml, nqc = nq < a.N ? nq : a.N - 4;
+                float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (FLAGS >= 0 && (FLAGS & DICOW_EPI_BIAS)) bq = *reinterpret_cast<const float4*>(sbias + wn * 128 + 4 * ml);
+#define NTW_PREFETCH(J, BUF)                                                                                 \
+    if (PRE_AUX || PRE_RES) {                                                                                \
+        _Pragma("unroll") for (int it = 0; it < 16; ++it) {                                                  \
+            int m_ = em0 + (J) * 32 + it * 2 + hh; m_ = m_ < a.M ? m_ : a.M - 1;                             \
+            if (PRE_AUX) xa[BUF][it] = *reinterpret_cast<const uint2*>(aux + (int64_t)m_ * a.ldaux + nqc);   \
+            if (PRE_RES) xr[BUF][it] = *reinterpret_cast<const float4*>(a.residual + (int64_t)m_ * a.ldr + nqc); \
+        }                                                                                                    \
+    }
+                NTW_PREFETCH(0, 0)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int c = i * 8 + 2 * q + hh;
+                            *reinterpret_cast<float4*>(scr + ml * 512 + ((c ^ ml) << 4)) =
+                                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j < 3) { NTW_PREFETCH(j + 1, (j + 1) & 1) }
+                    if (FLAGS >= 0) {
+#pragma unroll
+                        for (int it = 0; it < 16; ++it) {
+                            const int row = it * 2 + hh;
+                            const float4 f = *reinterpret_cast<const float4*>(scr + row * 512 + ((ml ^ row) << 4));
+                            const int m = em0 + j * 32 + row;
+                            if (m < a.M && nq < a.N) {
+                                float vv[4] = {f.x, f.y, f.z, f.w};
+                                nt_epilogue_quad<FLAGS>(a, flags, vv, m, nq, Cb, Cf, aux, &bq, PRE_AUX ? &xa[j & 1][it] : nullptr,
+                                                        PRE_RES ? &xr[j & 1][it] : nullptr);
+                            }
+                        }
+                    } else {
+                        // runtime flags: a real loop keeps the code small (fully unrolled it was ~200 KB of instructions
+                        // and ran at instruction-cache-miss speed)
+#pragma unroll 1
+                        for (int pg = 0; pg < 4; ++pg) {
+#pragma unroll
+                            for (int pp = 0; pp < 4; ++pp) {
+                                const int row = (pg * 4 + pp) * 2 + hh;
+                                const float4 f = *reinterpret_cast<const float4*>(scr + row * 512 + ((ml ^ row) << 4));
+                                const int m = em0 + j * 32 + row;
+                                if (m < a.M && nq < a.N) {
+                                    float vv[4] = {f.x, f.y, f.z, f.w};
+                                    nt_epilogue_quad<FLAGS>(a, flags, vv, m, nq, Cb, Cf, aux);
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#ifdef NTW_PROFILE
+                    pj[j + 1] = wall_clock64();
+#endif
+                }
+#undef NTW_PREFETCH
+            }
+        }
+#ifdef NTW_PROFILE
+        if (a.aux && tid == 0) {
+            long long* pr = reinterpret_cast<long long*>(a.aux) + 6 * total + 8 * pv;
+            pr[0] = pdma - pw1; pr[1] = pj[0] - pdma; for (int j = 0; j < 4; ++j) pr[2 + j] = pj[j + 1] - pj[j];
+        }
+#endif
+#ifdef NTW_PROFILE
+        if (a.aux && tid == 0) {   // diagnostic build only: per-tile k-loop cycles and wall-clock (100 MHz) timestamps
+            long long* pr = reinterpret_cast<long long*>(a.aux) + 6 * pv;
+            pr[0] = pc1 - pc0; pr[1] = pw1 - pw0; pr[2] = pw0; pr[3] = pw0; pr[4] = pw1; pr[5] = wall_clock64();
+        }
+#endif
+        if (!more_tiles) break;
     }
 }
 
@@ -487,6 +746,8 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     DICOW_REQUIRE(!(a->flags & DICOW_EPI_RESIDUAL) || (a->residual && a->ldr % 4 == 0), "gemm_nt: RESIDUAL needs residual, ldr%%4==0");
     DICOW_REQUIRE(!(a->flags & DICOW_EPI_GELU_BWD) || (a->aux && a->ldaux % 4 == 0), "gemm_nt: GELU_BWD needs aux");
     DICOW_REQUIRE(!(a->flags & DICOW_EPI_ACCUM) || (a->flags & DICOW_EPI_OUT_F32), "gemm_nt: ACCUM needs OUT_F32");
+    DICOW_REQUIRE(!(a->flags & DICOW_EPI_MUL_AUX) || a->aux, "gemm_nt: MUL_AUX needs aux");
+    DICOW_REQUIRE(!(a->flags & DICOW_EPI_GELU_DAUX) || ((a->flags & DICOW_EPI_GELU) && a->aux), "gemm_nt: GELU_DAUX needs GELU and aux");
     DICOW_REQUIRE(!(a->aux) || a->ldaux % 4 == 0, "gemm_nt: ldaux must be a multiple of 4");
     const int batch = a->batch > 0 ? a->batch : 1;
     const int ntm = dicow_cdiv(a->M, BM), ntn = dicow_cdiv(a->N, BN);
@@ -500,6 +761,12 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     static bool attr256 = false;
     if (!attr256) {
         (void)hipFuncSetAttribute((const void*)gemm_nt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NTS_LDS);
+#define NTW_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_nt256w_kernel<F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS)
+        (void)hipFuncSetAttribute((const void*)gemm_nt256w_kernel<-1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS);
+        NTW_ATTR(-1); NTW_ATTR(0); NTW_ATTR(DICOW_EPI_BIAS); NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N);
+        NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU); NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32);
+        NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTW_ATTR(DICOW_EPI_MUL_AUX);
+#undef NTW_ATTR
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
@@ -511,7 +778,26 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     const bool big = (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
         const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
-        if (variant == 9) hipLaunchKernelGGL(gemm_nt256s_kernel, g256, dim3(512), NTS_LDS, (hipStream_t)stream, *a);
+        if (variant == 0 || variant == 10 || variant == 11) {
+            static int ncu = 0;
+            if (!ncu) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); ncu = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
+            const int total = (int)g256.x * batch;
+            const dim3 gp(total < ncu ? total : ncu);
+#define NTW_LAUNCH(F) hipLaunchKernelGGL((gemm_nt256w_kernel<F, 1>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a)
+            if (variant == 10) hipLaunchKernelGGL((gemm_nt256w_kernel<-1, 0>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a);   // ablation: direct stores
+            else switch (variant == 11 ? -1 : a->flags) {   // compile-time epilogues for the flag sets the training step uses
+                case 0: NTW_LAUNCH(0); break;
+                case DICOW_EPI_BIAS: NTW_LAUNCH(DICOW_EPI_BIAS); break;
+                case DICOW_EPI_BIAS | DICOW_EPI_SCALE_N: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N); break;
+                case DICOW_EPI_BIAS | DICOW_EPI_GELU: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_GELU); break;
+                case DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32); break;
+                case DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); break;
+                case DICOW_EPI_MUL_AUX: NTW_LAUNCH(DICOW_EPI_MUL_AUX); break;
+                default: NTW_LAUNCH(-1); break;
+            }
+#undef NTW_LAUNCH
+        }
+        else if (variant == 9) hipLaunchKernelGGL(gemm_nt256s_kernel, g256, dim3(512), NTS_LDS, (hipStream_t)stream, *a);
         else if (variant == 5) hipLaunchKernelGGL(gemm_nt256_kernel<1>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
         else if (variant == 6) hipLaunchKernelGGL(gemm_nt256_kernel<2>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
         else if (variant == 7) hipLaunchKernelGGL(gemm_nt256_kernel<3>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);

@@ -133,16 +133,16 @@ def linear_fwd(x, lw, M, out_dtype=BF16, residual=None, gelu_aux=None, flags=0, 
     if out is None:
         out = _e((M, lw.N), out_dtype, dev)
     ops.gemm_nt(x, lw.w, out, M, lw.N, lw.K, bias=lw.b, residual=residual, aux=gelu_aux,
-                flags=flags | (L.EPI_GELU if gelu_aux is not None else 0), scale=scale, scale_ncols=scale_ncols)
+                flags=flags | ((L.EPI_GELU | L.EPI_GELU_DAUX) if gelu_aux is not None else 0), scale=scale, scale_ncols=scale_ncols)
     return out
 
 
 def linear_dgrad(dy, lw, M, aux=None, out=None, out_dtype=BF16, accumulate=False, dy_cols=None):
-    """dx[M,K] = dy[M,N] @ W[N,K]  (NT GEMM against the transposed copy); optional GELU' epilogue."""
+    """dx[M,K] = dy[M,N] @ W[N,K]  (NT GEMM against the transposed copy); `aux` = gelu' saved by linear_fwd(gelu_aux=...)."""
     N = lw.N if dy_cols is None else dy_cols
     if out is None:
         out = _e((M, lw.K), out_dtype, dy.device)
-    flags = (L.EPI_GELU_BWD if aux is not None else 0) | (L.EPI_ACCUM if accumulate else 0)
+    flags = (L.EPI_MUL_AUX if aux is not None else 0) | (L.EPI_ACCUM if accumulate else 0)
     ops.gemm_nt(dy, lw.wt, out, M, lw.K, N, lda=dy.stride(0), ldb=lw.wt.stride(0), aux=aux, flags=flags)
     return out
 
