@@ -1,0 +1,43 @@
+"""Attention micro-benchmark at the encoder self-attention shape (B=16, H=20, L=1500, head_dim 64), in-situ-like:
+   a memory-bound copy between launches; fwd and bwd (delta + dq + dkv) timed separately.
+   python tools/bench_attn.py [B H Lq Lk causal]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import amd_pkg; amd_pkg.load()
+from ts_asr_whisper_amd import ops
+B, H, Lq, Lk, causal = (int(x) for x in (sys.argv[1:6] if len(sys.argv) > 5 else (16, 20, 1500, 1500, 0)))
+D = H * 64
+bf = torch.bfloat16
+g = torch.Generator(device="cuda").manual_seed(0)
+qkv = (torch.randn(B, Lq, 3 * D, device="cuda", generator=g)).to(bf)
+qkv[:, :, :D] *= 0.125
+kv = qkv if Lk == Lq else torch.randn(B, Lk, 3 * D, device="cuda", generator=g).to(bf)
+q, k, v = qkv[:, :, :D].view(B, Lq, H, 64), kv[:, :, D:2 * D].view(B, Lk, H, 64), kv[:, :, 2 * D:].view(B, Lk, H, 64)
+o = torch.empty(B, Lq, H, 64, dtype=bf, device="cuda"); lse = torch.empty(B, H, Lq, device="cuda")
+d_o = (torch.randn(B, Lq, H, 64, device="cuda", generator=g) * 0.01).to(bf)
+dqkv = torch.empty(B, Lq, 3 * D, dtype=bf, device="cuda"); dkv = dqkv if Lk == Lq else torch.empty(B, Lk, 3 * D, dtype=bf, device="cuda")
+dq, dk, dv = dqkv[:, :, :D].view(B, Lq, H, 64), dkv[:, :, D:2 * D].view(B, Lk, H, 64), dkv[:, :, 2 * D:].view(B, Lk, H, 64)
+delta = torch.empty(B, H, Lq, device="cuda")
+x1, x2 = torch.empty(1 << 28, dtype=torch.uint8, device="cuda"), torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+def timeit(fn, iters=10):
+    fn(); torch.cuda.synchronize(); evs = []
+    for _ in range(iters):
+        x1.copy_(x2)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record(); evs.append((s, e))
+    torch.cuda.synchronize()
+    return sum(s.elapsed_time(e) for s, e in evs) / iters
+fl = 4.0 * B * H * Lq * Lk * 64 * (0.5 if causal else 1.0)
+t = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, causal=bool(causal)))
+print(f"attn_fwd B{B} H{H} Lq{Lq} Lk{Lk} causal{causal}: {t*1e3:.1f} us  {fl/t/1e9:.0f} TF")
+t = timeit(lambda: ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=bool(causal), dq_scale=0.125))
+print(f"attn_bwd (delta+dq+dkv): {t*1e3:.1f} us  {3.5*fl/t/1e9:.0f} TF (7 matmul passes)")
+if os.environ.get("ATTN_PROFILE"):
+    ops.attn_fwd(q, k, v, o, lse, causal=bool(causal)); torch.cuda.synchronize()
+    nblk = B * H * ((Lq + 127) // 128)
+    pr = lse.view(-1).view(torch.int64)[:nblk * 8].view(-1, 8).double().cpu()
+    nt = pr[:, 6].mean()
+    names = ["stage+wait+barrier", "QK mfma + V tr issue", "softmax", "PV", "lgkm+end barrier"]
+    print(f"per k-tile cycles (wave 0, mean over {nblk} workgroups, {nt:.1f} tiles): " +
+          ", ".join(f"{n} {pr[:, i].mean() / nt:.0f}" for i, n in enumerate(names)) + f"; loop total {pr[:,5].mean()/nt:.0f}/tile; epilogue {pr[:,7].mean():.0f}")

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_ref = -INFINITY, l_run = 0.f;     // reference maximum (raw score units) and running sum of 2^((s - m_ref) log2 e)
 
     int kv_end = a.Lk;
     if (a.causal) { const int lim = q0 + 128 < a.Lk ? q0 + 128 : a.Lk; kv_end = lim; }   // keys <= last q row of the block
@@ -167,7 +167,15 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
 
     stage_tile64<false>(K, a.k_rs, 0, a.Lk, smem, wave, lane);
     stage_tile64<true>(V, a.v_rs, 0, a.Lk, smem + TILE_BYTES, wave, lane);
+#ifdef ATTN_PROFILE
+    long long pacc[6] = {0, 0, 0, 0, 0, 0}, pt[7];
+    const long long pstart = clock64();
+#define PT(i) pt[i] = clock64();
+#else
+#define PT(i)
+#endif
     for (int t = 0; t < nt; ++t) {
+        PT(0)
         char* sK = smem + (t & 1) * 2 * TILE_BYTES;
         char* sV = sK + TILE_BYTES;
         if (t + 1 < nt) {
@@ -180,6 +188,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        PT(1)
 
         // ---- S^T = K . Q^T  (two 32-key blocks)
         f32x16_t s[2];
@@ -198,42 +207,52 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
         tr8_t tv0, tv1;
         tr_issue_v<0>(tv0, va0, va1);
         tr_issue_v<4096>(tv1, va0, va1);
-        // ---- mask (tile-uniform test first), online softmax in log2 units
+        PT(2)
+        // ---- mask (tile-uniform test first), online softmax.  The loop is VALU-bound at head_dim 64 (32 scores per lane
+        // and k-tile against 16 MFMAs), so the per-score work is pared down to max3 / fma / exp2 / add / pack:
+        //   * the running maximum is kept in raw score units and log2(e) is folded into one fma per score;
+        //   * the accumulator rescale is LAZY: the reference maximum m_ref only moves when some row's maximum grew by more
+        //     than 2^8 (wave-uniform test), otherwise p = 2^((s - m_ref) log2 e) simply runs up to 256 -- exact in fp32 / bf16
+        //     range, and the final 1/l normalisation is unchanged.  After the first tiles the 32 multiplies on O vanish.
         const int k0 = t * KV_TILE;
         const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
-        float mx = -INFINITY;
+        if (need_mask) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = s[kb][r] * LOG2E;
-                if (need_mask) {
+                for (int r = 0; r < 16; ++r) {
                     const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= a.Lk || (a.causal && key > qrow)) v = -INFINITY;
+                    if (key >= a.Lk || (a.causal && key > qrow)) s[kb][r] = -INFINITY;
                 }
-                s[kb][r] = v;
-                mx = fmaxf(mx, v);
-            }
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);        // -> v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;      // fully masked so far: keep everything at 0
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        if (__builtin_amdgcn_ballot_w64(mx > m_ref + 8.0f * LN2) != 0) {       // also taken on the first tile (m_ref = -inf)
+            const float m_new = fmaxf(m_ref, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at 0
+            const float alpha = __builtin_amdgcn_exp2f((m_ref - m_use) * LOG2E);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            m_ref = m_new;
+        }
+        const float mL = (m_ref == -INFINITY) ? 0.f : m_ref * LOG2E;
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[kb][r] - m_use);
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mL));
                 s[kb][r] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+        l_run += psum;
 
+        PT(3)
         // ---- O^T += V^T . P^T
         {
             bf16x8_t vf[2][2];
@@ -254,10 +273,18 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
                 for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
             }
         }
+        PT(4)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        PT(5)
+#ifdef ATTN_PROFILE
+        for (int i = 0; i < 5; ++i) pacc[i] += pt[i + 1] - pt[i];
+#endif
     }
+#ifdef ATTN_PROFILE
+    const long long pend = clock64();
+#endif
 
     // ---- epilogue
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -273,9 +300,18 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
                     make_uint2(pack_bf16x2(o[d][4 * q4] * inv_l, o[d][4 * q4 + 1] * inv_l),
                                pack_bf16x2(o[d][4 * q4 + 2] * inv_l, o[d][4 * q4 + 3] * inv_l));
             }
+#ifndef ATTN_PROFILE
         if (a.lse && hh == 0)
-            a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = (m_run + __builtin_amdgcn_logf(l_tot)) * LN2;
+            a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = m_ref + __builtin_amdgcn_logf(l_tot) * LN2;
+#endif
     }
+#ifdef ATTN_PROFILE
+    if (a.lse && tid == 0) {       // diagnostic build: per-workgroup phase cycles of wave 0 overwrite the lse buffer
+        long long* pr = reinterpret_cast<long long*>(a.lse) + 8 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        for (int i = 0; i < 5; ++i) pr[i] = pacc[i];
+        pr[5] = pend - pstart; pr[6] = nt; pr[7] = clock64() - pend;
+    }
+#endif
 }
 
 static int check_strides(int64_t rs, const char* n) {

@@ -107,8 +107,9 @@ __device__ __forceinline__ void block_welford(float (&n)[R], float (&mu)[R], flo
     }
 }
 
-template <int R, int MAXT>
+template <int R, int MAXT, int MODE_T = -1>     // MODE_T: compile-time mode (see fddt_ln_bwd_kernel), -1 = runtime
 __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_fwd_args a) {
+    const int mode = MODE_T >= 0 ? MODE_T : a.mode;
     __shared__ float red[2][MAX_WAVES * R * 3];
     const int tid = threadIdx.x, col = tid * 4, D = a.D;
     const bool act = col < D;
@@ -118,8 +119,8 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
     int use = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        w[c] = (a.mode == 1 && a.w[c] && act) ? ld4(a.w[c] + col) : one;
-        b[c] = (a.mode != 0 && a.b[c] && act) ? ld4(a.b[c] + col) : zero;
+        w[c] = (mode == 1 && a.w[c] && act) ? ld4(a.w[c] + col) : one;
+        b[c] = (mode != 0 && a.b[c] && act) ? ld4(a.b[c] + col) : zero;
         if (a.b[c]) use |= 1 << c;
     }
     const bool do_ln = a.ln_w != nullptr;
@@ -136,11 +137,12 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
             const int64_t off = (int64_t)row * D + col;
             x[r] = zero;
             if (ok) x[r] = a.in_bf16 ? ld4_bf16(a.h_in, off) : ld4(reinterpret_cast<const float*>(a.h_in) + off);
-            if (a.mode != 0 && row < a.rows) {
+            if (mode != 0 && row < a.rows) {
                 const int bi = row / a.T, t = row - bi * a.T;
                 const float* mp = a.stno + (int64_t)bi * a.stno_bstride + t;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) m[r][c] = mp[(int64_t)c * a.T];
+                for (int c = 0; c < 4; ++c)      // row-indexed, identical in every lane: keep it in a scalar register
+                    m[r][c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp[(int64_t)c * a.T])));
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) m[r][c] = 0.f;
@@ -149,11 +151,11 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = row0 + r;
-            if (a.mode == 1) {
+            if (mode == 1) {
 #define FD(e) fddt_diag_elem(x[r].e, w[0].e, b[0].e, w[1].e, b[1].e, w[2].e, b[2].e, w[3].e, b[3].e, m[r][0], m[r][1], m[r][2], m[r][3])
                 F4_APPLY(x[r], FD);
 #undef FD
-            } else if (a.mode == 2) {
+            } else if (mode == 2) {
 #define FB(e) fddt_bias_elem(x[r].e, b[0].e, b[1].e, b[2].e, b[3].e, m[r][0], m[r][1], m[r][2], m[r][3], use)
                 F4_APPLY(x[r], FB);
 #undef FB
@@ -229,14 +231,21 @@ extern "C" int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream) 
     const int R = 4;
     const int block = pick_block(a->D);
     int grid = dicow_cdiv(a->rows, R);
-    static int occ[17] = {0};
-    const int cap = block <= 512 ? resident_grid(fddt_ln_fwd_kernel<R, 512>, block, &occ[block / 64])
-                                 : resident_grid(fddt_ln_fwd_kernel<R, 1024>, block, &occ[block / 64]);
+    static int occ[4][17] = {{0}};
+    const int variant = block > 512 ? 2 : (a->mode == 0 ? 1 : a->mode == 1 ? 3 : 0);
+    const int cap = variant == 2 ? resident_grid(fddt_ln_fwd_kernel<R, 1024>, block, &occ[2][block / 64])
+                  : variant == 1 ? resident_grid(fddt_ln_fwd_kernel<R, 512, 0>, block, &occ[1][block / 64])
+                  : variant == 3 ? resident_grid(fddt_ln_fwd_kernel<R, 512, 1>, block, &occ[3][block / 64])
+                                 : resident_grid(fddt_ln_fwd_kernel<R, 512>, block, &occ[0][block / 64]);
     if (grid > cap) grid = cap;
-    if (block <= 512)
-        hipLaunchKernelGGL((fddt_ln_fwd_kernel<R, 512>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
-    else
+    if (variant == 2)
         hipLaunchKernelGGL((fddt_ln_fwd_kernel<R, 1024>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+    else if (variant == 1)
+        hipLaunchKernelGGL((fddt_ln_fwd_kernel<R, 512, 0>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+    else if (variant == 3)
+        hipLaunchKernelGGL((fddt_ln_fwd_kernel<R, 512, 1>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+    else
+        hipLaunchKernelGGL((fddt_ln_fwd_kernel<R, 512>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("fddt_ln_fwd");
     return DICOW_OK;
 }
@@ -245,8 +254,14 @@ extern "C" int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream) 
 #define F4_FMA(acc, a_, b_) do { acc.x += (a_).x * (b_).x; acc.y += (a_).y * (b_).y; acc.z += (a_).z * (b_).z; acc.w += (a_).w * (b_).w; } while (0)
 #define F4_ADD(acc, a_) do { acc.x += (a_).x; acc.y += (a_).y; acc.z += (a_).z; acc.w += (a_).w; } while (0)
 
-template <int R, int MAXT>
+// MODE_T / LN_T: compile-time copies of mode / (a.ln_w != NULL) for the two shapes the encoder layers use (-1 = take
+// them from the arguments).  The LayerNorm-only body drops the FDDT vectors and their 32 gradient accumulators (76 instead
+// of 156 VGPRs): 4 instead of 2 resident workgroups per CU, and this kernel is latency-bound -- bytes in flight / memory
+// latency -- so that doubled its rate (2.3 -> 4.7 TB/s).  The FDDT(diag)+LN shape stays on the generic body: moving its
+// vectors or accumulators to LDS to gain a third workgroup measured slower (LDS read-modify-write traffic, spills).
+template <int R, int MAXT, int MODE_T = -1, int LN_T = -1>
 __global__ void __launch_bounds__(MAXT) fddt_ln_bwd_kernel(const dicow_fddt_ln_bwd_args a) {
+    const int mode = MODE_T >= 0 ? MODE_T : a.mode;
     __shared__ float red[2][MAX_WAVES * 2 * R];
     const int tid = threadIdx.x, col = tid * 4, D = a.D;
     const bool act = col < D;
@@ -256,11 +271,11 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
     int use = 0;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        w[c] = (a.mode == 1 && a.w[c] && act) ? ld4(a.w[c] + col) : one;
-        b[c] = (a.mode != 0 && a.b[c] && act) ? ld4(a.b[c] + col) : zero;
+        w[c] = (mode == 1 && a.w[c] && act) ? ld4(a.w[c] + col) : one;
+        b[c] = (mode != 0 && a.b[c] && act) ? ld4(a.b[c] + col) : zero;
         if (a.b[c]) use |= 1 << c;
     }
-    const bool do_ln = a.ln_w != nullptr;
+    const bool do_ln = LN_T >= 0 ? (LN_T != 0) : (a.ln_w != nullptr);
     if (do_ln && act) lnw = ld4(a.ln_w + col);
     const float inv_d = 1.0f / (float)D;
     float4 acc_lnw = zero, acc_lnb = zero, acc_cs = zero, acc_dw[4], acc_db[4];
@@ -269,7 +284,7 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
 
     int it = 0;
     for (int row0 = blockIdx.x * R; row0 < a.rows; row0 += gridDim.x * R, ++it) {
-        float4 hin[R], xh[R], dy[R], gr[R];
+        float4 hin[R], xh[R], dy[R], gr[R], scw[R];
         float m[R][4], rs[R];
         float sums[2 * R];
 #pragma unroll
@@ -283,23 +298,34 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
             if (ok && do_ln) dy[r] = a.dy_f32 ? ld4(reinterpret_cast<const float*>(a.d_y) + off) : ld4_bf16(a.d_y, off);
             gr[r] = (ok && a.g_res) ? ld4(a.g_res + off) : zero;      // issued with the other loads, ahead of the reduction
             if (do_ln && row < a.rows) { mu = a.mean[row]; rs[r] = a.rstd[row]; }
-            if (a.mode != 0 && row < a.rows) {
+            if (mode != 0 && row < a.rows) {
                 const int bi = row / a.T, t = row - bi * a.T;
                 const float* mp = a.stno + (int64_t)bi * a.stno_bstride + t;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) m[r][c] = mp[(int64_t)c * a.T];
+                for (int c = 0; c < 4; ++c)      // row-indexed, identical in every lane: keep it in a scalar register
+                    m[r][c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(mp[(int64_t)c * a.T])));
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) m[r][c] = 0.f;
             }
-            // recompute x = FDDT(h_in) + pos exactly as the forward did
+            // recompute x = FDDT(h_in) + pos.  Diagonal mode uses the collapsed form h * (sum_c m_c w_c) + sum_c m_c b_c
+            // (20 flops per element instead of the forward's 60; it differs from the forward's evaluation order by an ulp
+            // or two, which only perturbs x-hat inside the gradient formulas), and keeps sum_c m_c w_c for g0 below.
             float4 x = hin[r];
-            if (a.mode == 1) {
-#define FD(e) fddt_diag_elem(x.e, w[0].e, b[0].e, w[1].e, b[1].e, w[2].e, b[2].e, w[3].e, b[3].e, m[r][0], m[r][1], m[r][2], m[r][3])
-                F4_APPLY(x, FD);
-#undef FD
-            } else if (a.mode == 2) {
-#define FB(e) fddt_bias_elem(x.e, b[0].e, b[1].e, b[2].e, b[3].e, m[r][0], m[r][1], m[r][2], m[r][3], use)
+            if (mode == 1) {
+                float4 sw = zero, sb = zero;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float mc = m[r][c];
+                    const float4 wc = w[c], bc = b[c];
+                    sw.x += mc * wc.x; sw.y += mc * wc.y; sw.z += mc * wc.z; sw.w += mc * wc.w;
+                    sb.x += mc * bc.x; sb.y += mc * bc.y; sb.z += mc * bc.z; sb.w += mc * bc.w;
+                }
+                x = make_float4(x.x * sw.x + sb.x, x.y * sw.y + sb.y, x.z * sw.z + sb.z, x.w * sw.w + sb.w);
+                scw[r] = sw;
+            } else if (mode == 2) {
+                const float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+#define FB(e) fddt_bias_elem(x.e, b0.e, b1.e, b2.e, b3.e, m[r][0], m[r][1], m[r][2], m[r][3], use)
                 F4_APPLY(x, FB);
 #undef FB
             }
@@ -332,18 +358,16 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
                 F4_ADD(acc_lnb, dy[r]);
             }
             float4 g0 = g;
-            if (a.mode == 1) {
-                float4 sc = zero;
+            if (mode == 1) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float mc = m[r][c];
-                    sc.x += mc * w[c].x; sc.y += mc * w[c].y; sc.z += mc * w[c].z; sc.w += mc * w[c].w;
                     const float4 mg = make_float4(mc * g.x, mc * g.y, mc * g.z, mc * g.w);
                     F4_FMA(acc_dw[c], mg, hin[r]);
                     F4_ADD(acc_db[c], mg);
                 }
-                g0 = make_float4(g.x * sc.x, g.y * sc.y, g.z * sc.z, g.w * sc.w);
-            } else if (a.mode == 2) {
+                g0 = make_float4(g.x * scw[r].x, g.y * scw[r].y, g.z * scw[r].z, g.w * scw[r].w);
+            } else if (mode == 2) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float mc = m[r][c];
@@ -364,19 +388,21 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
     if (a.colsum_out) st4(part + 2 * D, acc_cs);
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        if (a.mode == 1 && a.dw[c]) st4(part + (3 + c) * D, acc_dw[c]);
-        if (a.mode != 0 && a.db[c]) st4(part + (7 + c) * D, acc_db[c]);
+        if (mode == 1 && a.dw[c]) st4(part + (3 + c) * D, acc_dw[c]);
+        if (mode != 0 && a.db[c]) st4(part + (7 + c) * D, acc_db[c]);
     }
 }
 
-static int bwd_grid(int rows, int D) {
+#define BWD_R0 2          // rows per trip and resident workgroups per CU of the LayerNorm-only (mode 0) body
+#define BWD_CU0 4
+static int bwd_grid(int rows, int D, int per_cu) {
     const int block = ((D / 4) + 63) / 64 * 64;
     int grid = (rows + 3) / 4;
-    const int cap = 256 * (block <= 256 ? 4 : 2);
+    const int cap = 256 * (block <= 256 ? 4 : per_cu);
     return grid > cap ? cap : grid;
 }
 
-extern "C" int64_t dicow_fddt_ln_bwd_ws_bytes(int rows, int D) { return (int64_t)bwd_grid(rows, D) * 11 * D * 4; }
+extern "C" int64_t dicow_fddt_ln_bwd_ws_bytes(int rows, int D) { return (int64_t)bwd_grid(rows, D, BWD_CU0) * 11 * D * 4; }
 
 extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) {
     DICOW_REQUIRE(a && a->h_in && a->rows > 0 && a->D > 0, "fddt_ln_bwd: null/empty input");
@@ -385,9 +411,10 @@ extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) 
     DICOW_REQUIRE(a->mode == 0 || (a->stno && a->T > 0), "fddt_ln_bwd: mode %d needs stno and T", a->mode);
     DICOW_REQUIRE(a->ln_w == nullptr || (a->mean && a->rstd && a->d_y), "fddt_ln_bwd: LayerNorm needs mean/rstd/d_y");
     DICOW_REQUIRE(a->ln_w || a->g_res, "fddt_ln_bwd: no incoming gradient");
-    const int R = 4;
     const int block = pick_block(a->D);
-    const int grid = bwd_grid(a->rows, a->D);
+    static const int r_env = getenv("DICOW_ROW_R") ? atoi(getenv("DICOW_ROW_R")) : 0;       // tuning knob: 0 = auto, 9 = generic body
+    const bool ln0 = block <= 512 && r_env != 9 && a->mode == 0 && a->ln_w;
+    const int grid = bwd_grid(a->rows, a->D, ln0 ? BWD_CU0 : 2);
     const int D = a->D;
     float* outs[11] = {a->ln_w ? a->dln_w : nullptr, a->ln_w ? a->dln_b : nullptr, a->colsum_out,
                        a->mode == 1 ? a->dw[0] : nullptr, a->mode == 1 ? a->dw[1] : nullptr, a->mode == 1 ? a->dw[2] : nullptr,
@@ -397,13 +424,15 @@ extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) 
     for (int k = 0; k < 11; ++k) any = any || outs[k];
     DICOW_REQUIRE(!any || (a->ws && a->ws_bytes >= (int64_t)grid * 11 * D * 4),
                   "fddt_ln_bwd: workspace too small (need %ld bytes)", (long)grid * 11 * D * 4);
-    static const int r_env = getenv("DICOW_ROW_R") ? atoi(getenv("DICOW_ROW_R")) : 2;
-    if (block <= 512 && r_env == 4)
-        hipLaunchKernelGGL((fddt_ln_bwd_kernel<4, 512>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
-    else if (block <= 512)
-        hipLaunchKernelGGL((fddt_ln_bwd_kernel<2, 512>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+    hipStream_t st = (hipStream_t)stream;
+    if (block > 512)
+        hipLaunchKernelGGL((fddt_ln_bwd_kernel<2, 1024>), dim3(grid), dim3(block), 0, st, *a);
+    else if (r_env == 9)                                                                    // generic body (ablation)
+        hipLaunchKernelGGL((fddt_ln_bwd_kernel<2, 512>), dim3(grid), dim3(block), 0, st, *a);
+    else if (ln0)
+        hipLaunchKernelGGL((fddt_ln_bwd_kernel<BWD_R0, 512, 0, 1>), dim3(grid), dim3(block), 0, st, *a);
     else
-        hipLaunchKernelGGL((fddt_ln_bwd_kernel<2, 1024>), dim3(grid), dim3(block), 0, (hipStream_t)stream, *a);
+        hipLaunchKernelGGL((fddt_ln_bwd_kernel<2, 512>), dim3(grid), dim3(block), 0, st, *a);
     DICOW_CHECK_LAUNCH("fddt_ln_bwd");
     if (any) return dicow_launch_reduce_multi(reinterpret_cast<const float*>(a->ws), grid, (int64_t)11 * D, D, outs, 11, D,
                                               (hipStream_t)stream);
