@@ -136,7 +136,7 @@ __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& s, int r0) {
 }
 
 __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_args a) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];      // K0 V0 K1 V1
+    __shared__ __attribute__((aligned(16))) char smem[6 * TILE_BYTES];      // three (K, V) slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
@@ -165,8 +165,14 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
     if (a.causal) { const int lim = q0 + 128 < a.Lk ? q0 + 128 : a.Lk; kv_end = lim; }   // keys <= last q row of the block
     const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
 
+    // Three-slot ring, ONE barrier per k-tile: the barrier that publishes tile t also proves every wave has left tile
+    // t-1, whose slot is then refilled with tile t+2 (two tiles of DMA lead instead of one).
     stage_tile64<false>(K, a.k_rs, 0, a.Lk, smem, wave, lane);
     stage_tile64<true>(V, a.v_rs, 0, a.Lk, smem + TILE_BYTES, wave, lane);
+    if (nt > 1) {
+        stage_tile64<false>(K, a.k_rs, KV_TILE, a.Lk, smem + 2 * TILE_BYTES, wave, lane);
+        stage_tile64<true>(V, a.v_rs, KV_TILE, a.Lk, smem + 3 * TILE_BYTES, wave, lane);
+    }
 #ifdef ATTN_PROFILE
     long long pacc[6] = {0, 0, 0, 0, 0, 0}, pt[7];
     const long long pstart = clock64();
@@ -174,20 +180,34 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
 #else
 #define PT(i)
 #endif
+    // K fragments are read one tile AHEAD (during the previous tile's softmax), so the QK^T MFMAs start right behind the
+    // barrier instead of behind an LDS round trip; for that, tile t+1 must already be visible during tile t: the wait
+    // at the top covers everything issued so far (tile t+1 was requested a full iteration earlier).
+    bf16x8_t kfr[2][4];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+            kfr[kb][kk] = *reinterpret_cast<const bf16x8_t*>(smem + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
+    int slot = 0;
     for (int t = 0; t < nt; ++t) {
         PT(0)
-        char* sK = smem + (t & 1) * 2 * TILE_BYTES;
+        char* sK = smem + slot * 2 * TILE_BYTES;
         char* sV = sK + TILE_BYTES;
-        if (t + 1 < nt) {
-            char* nK = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile64<false>(K, a.k_rs, (t + 1) * KV_TILE, a.Lk, nK, wave, lane);
-            stage_tile64<true>(V, a.v_rs, (t + 1) * KV_TILE, a.Lk, nK + TILE_BYTES, wave, lane);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int slot_n = slot == 2 ? 0 : slot + 1;
+        if (t > 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // tile t+1 landed (this wave's share)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        if (t + 2 < nt) {
+            char* nK = smem + (slot == 0 ? 2 : slot - 1) * 2 * TILE_BYTES;    // slot of tile t-1 == slot of tile t+2
+            stage_tile64<false>(K, a.k_rs, (t + 2) * KV_TILE, a.Lk, nK, wave, lane);
+            stage_tile64<true>(V, a.v_rs, (t + 2) * KV_TILE, a.Lk, nK + TILE_BYTES, wave, lane);
+        }
         PT(1)
 
         // ---- S^T = K . Q^T  (two 32-key blocks)
@@ -197,10 +217,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s[kb], 0, 0, 0);
-            }
+            for (int kk = 0; kk < 4; ++kk)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
         }
         // V^T fragments for both 32-key blocks: issued now, consumed after the softmax
         const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
@@ -264,7 +282,18 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
 #pragma unroll
                 for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
             }
-            tr_wait<0>(tv1);
+            {   // next tile's K fragments (unconditional: the counted LDS waits below rely on exactly 8 reads here; past the
+                // last tile this reads a stale slot and the values are never used)
+                const char* nKf = smem + slot_n * 2 * TILE_BYTES;
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        kfr[kb][kk] = *reinterpret_cast<const bf16x8_t*>(nKf + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
+                asm volatile("" ::: "memory");
+            }
+            tr_wait<8>(tv1);      // LDS returns in order: the 8 younger K-fragment reads may stay in flight
             tr_pack(vf, tv1);
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
@@ -274,9 +303,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
             }
         }
         PT(4)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        slot = slot_n;
         PT(5)
 #ifdef ATTN_PROFILE
         for (int i = 0; i < 5; ++i) pacc[i] += pt[i + 1] - pt[i];

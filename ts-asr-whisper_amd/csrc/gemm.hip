@@ -363,6 +363,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_arg
 // saturated resource.  With a single wave per SIMD nothing hides latency for us, so the instruction stream is laid
 // out by hand: every MFMA is followed by one LDS read (next slice) or one DMA instruction (next k-tile).
 //
+// (Tried and dropped: a 4-byte-per-lane "L2 warm-up" DMA for the k-slab two steps ahead, with the step barrier waiting
+// on vmcnt(2) instead of 0 -- 1-4 % slower; the two extra VMEM issues per step cost more than the HBM misses they hide.)
+//
 // The kernel is PERSISTENT: one workgroup per CU walks the tile list (virtual block id v = blockIdx.x + round *
 // gridDim.x through the same XCD-aware id -> tile map, so the tiles in flight are the same L2-friendly set).  A
 // per-workgroup timeline (tools/profile_ksteps.py) of the one-tile-per-workgroup form showed, for a K=1280 tile,
