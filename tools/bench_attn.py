@@ -41,3 +41,10 @@ if os.environ.get("ATTN_PROFILE"):
     names = ["stage+wait+barrier", "QK mfma + V tr issue", "softmax", "PV", "lgkm+end barrier"]
     print(f"per k-tile cycles (wave 0, mean over {nblk} workgroups, {nt:.1f} tiles): " +
           ", ".join(f"{n} {pr[:, i].mean() / nt:.0f}" for i, n in enumerate(names)) + f"; loop total {pr[:,5].mean()/nt:.0f}/tile; epilogue {pr[:,7].mean():.0f}")
+if os.environ.get("ATTN_PROFILE"):
+    ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=bool(causal), dq_scale=0.125); torch.cuda.synchronize()
+    nblk = B * H * ((Lk + 127) // 128)
+    pr = delta.view(-1).view(torch.int64)[:nblk * 8].view(-1, 8).double().cpu()
+    nt = pr[:, 6].mean()
+    names = ["stage+wait+barrier", "q-block 0 (16 MFMA + softmax + 16 MFMA)", "q-block 1", "lgkm + end barrier"]
+    print(f"dkv per q-tile cycles (wave 0, {nt:.1f} tiles): " + ", ".join(f"{n} {pr[:, i].mean() / nt:.0f}" for i, n in enumerate(names)) + f"; total {pr[:,5].mean()/nt:.0f}/tile")

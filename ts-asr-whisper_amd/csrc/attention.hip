@@ -135,13 +135,32 @@ __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& s, int r0) {
     return o;
 }
 
+// XCD-aware workgroup -> (row block, head, batch) map.  Workgroups are dealt round-robin to the 8 XCDs (dispatch id L
+// lands on XCD L % 8), each with a private 4 MiB L2; the natural (x = row block fastest) order therefore scatters the
+// row blocks that share one head's K/V (or Q/dO) over all 8 L2s and every one of them fetches the panels again
+// (measured: ~3.5x the algorithmic bytes on the fabric side of L2).  Here all row blocks of one (batch, head) get dispatch
+// ids in one residue class mod 8: a (batch, head) pair is served by a single XCD and its panels are fetched once.
+__device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& blk, int& h, int& b) {
+    const int L = blockIdx.x, nbh = H * B;
+    const int xcd = L & 7, idx = L >> 3;
+    const int full = (nbh >> 3) * nblk;               // dispatch slots per XCD covered by whole groups of 8 pairs
+    int bh;
+    if (idx < full) { bh = (idx / nblk) * 8 + xcd; blk = idx % nblk; }
+    else {                                            // the last (nbh % 8) pairs: plain row-block-fastest order
+        const int rem = (idx - full) * 8 + xcd;
+        bh = (nbh & ~7) + rem / nblk; blk = rem % nblk;
+    }
+    h = bh % H; b = bh / H;
+}
+
 __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_args a) {
     __shared__ __attribute__((aligned(16))) char smem[6 * TILE_BYTES];      // three (K, V) slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128;
+    int qblk, h, b;
+    attn_block_coords((a.Lq + 127) / 128, a.H, a.B, qblk, h, b);
+    const int q0 = qblk * 128;
     const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
     const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
     const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
@@ -334,7 +353,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
     }
 #ifdef ATTN_PROFILE
     if (a.lse && tid == 0) {       // diagnostic build: per-workgroup phase cycles of wave 0 overwrite the lse buffer
-        long long* pr = reinterpret_cast<long long*>(a.lse) + 8 * ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x);
+        long long* pr = reinterpret_cast<long long*>(a.lse) + 8 * blockIdx.x;
         for (int i = 0; i < 5; ++i) pr[i] = pacc[i];
         pr[5] = pend - pstart; pr[6] = nt; pr[7] = clock64() - pend;
     }
@@ -353,7 +372,7 @@ extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
     if (!check_strides(a->q_rs, "q") || !check_strides(a->k_rs, "k") || !check_strides(a->v_rs, "v") ||
         !check_strides(a->o_rs, "o")) return DICOW_ERR_INVALID;
     DICOW_REQUIRE(a->q_bs % 8 == 0 && a->k_bs % 8 == 0 && a->v_bs % 8 == 0 && a->o_bs % 4 == 0, "attn_fwd: batch strides must keep 16-byte alignment");
-    dim3 grid(dicow_cdiv(a->Lq, 128), a->H, a->B);
+    dim3 grid(dicow_cdiv(a->Lq, 128) * a->H * a->B);
     hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("attn_fwd");
     return DICOW_OK;
@@ -444,8 +463,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q0 = blockIdx.x * 128;
+    int qblk, h, b;
+    attn_block_coords((a.Lq + 127) / 128, a.H, a.B, qblk, h, b);
+    const int q0 = qblk * 128;
     const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
     const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
     const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
@@ -460,8 +480,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
         dof[kk] = *reinterpret_cast<const bf16x8_t*>(dO + (int64_t)qrow_c * a.do_rs + kk * 16 + hh * 8);
     }
     const int64_t stat = ((int64_t)b * a.H + h) * a.Lq + qrow_c;
-    const float lse2 = a.lse[stat] * LOG2E;
-    const float dlt = a.delta[stat];
+    // -lse and -delta seed the S and dP accumulators, so the MFMA chain itself delivers (s - lse) and (dP - delta): plain
+    // VALU work and MFMAs share one issue port per SIMD (tools/probe_overlap.hip: they do not overlap, transcendentals do),
+    // which makes every VALU instruction shaved off the softmax recompute a direct saving.
+    const float nlse = -a.lse[stat];
+    const float ndlt = -a.delta[stat];
 
     f32x16_t dq[2];
 #pragma unroll
@@ -502,7 +525,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
         for (int kb = 0; kb < 2; ++kb) {
             f32x16_t s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s[r] = nlse; dp[r] = ndlt; }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + uswz(kb * 32 + (lane & 31), kk * 2 + hh));
@@ -511,14 +534,16 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dp, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[r] * LOG2E - lse2);
-                if (need_mask) {
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E);
+            if (need_mask) {                          // one branch per block: a test inside the score loop becomes 16
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
                     const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= a.Lk || (a.causal && key > qrow)) p = 0.f;
+                    if (key >= a.Lk || (a.causal && key > qrow)) s[r] = 0.f;
                 }
-                ds[kb][r] = p * (dp[r] - dlt);
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[kb][r] = s[r] * dp[r];
         }
         // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
         {
@@ -573,8 +598,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int kblk0 = blockIdx.x * 128;
+    int kblk, h, b;
+    attn_block_coords((a.Lk + 127) / 128, a.H, a.B, kblk, h, b);
+    const int kblk0 = kblk * 128;
     const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
     const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
     const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
@@ -604,6 +630,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
         stage_tile64_u(dO, a.do_rs, t0 * KV_TILE, a.Lq, smem + TILE_BYTES, wave, lane);
         stage_stats64(lse, delta, t0 * KV_TILE, a.Lq, smem + 4 * TILE_BYTES, wave, lane);
     }
+    // lane-derived row-fragment offsets (swizzle XORs) computed once: plain VALU instructions share the SIMD's issue port
+    // with the MFMAs, so per-tile address arithmetic is pure loss
+    int fo[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fo[qb][kk] = uswz(qb * 32 + (lane & 31), kk * 2 + hh);
     for (int t = t0; t < nt; ++t) {
         char* sQ = smem + ((t - t0) & 1) * 2 * TILE_BYTES;
         char* sdO = sQ + TILE_BYTES;
@@ -631,32 +664,28 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
             tr8_t tdo, tq;                                                                                              \
             tr_issue_u<(QB) * 4096>(tdo, o00, o01, o10, o11);                                                           \
             tr_issue_u<(QB) * 4096>(tq, q00, q01, q10, q11);                                                            \
-            f32x16_t s, dp;                                                                                             \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }                                 \
+            f32x16_t s, dp;                       /* accumulators seeded with -lse[q], -delta[q] (see attn_bwd_dq_kernel) */ \
+            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                          \
+                const float4 lv = *reinterpret_cast<const float4*>(sStat + (QB) * 32 + 8 * q4 + 4 * hh);                 \
+                const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 64 + (QB) * 32 + 8 * q4 + 4 * hh);          \
+                s[4 * q4] = -lv.x; s[4 * q4 + 1] = -lv.y; s[4 * q4 + 2] = -lv.z; s[4 * q4 + 3] = -lv.w;                 \
+                dp[4 * q4] = -dv4.x; dp[4 * q4 + 1] = -dv4.y; dp[4 * q4 + 2] = -dv4.z; dp[4 * q4 + 3] = -dv4.w;         \
+            }                                                                                                           \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
-                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(sQ + uswz((QB) * 32 + (lane & 31), kk * 2 + hh)); \
-                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(sdO + uswz((QB) * 32 + (lane & 31), kk * 2 + hh)); \
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(sQ + fo[QB][kk]);                                 \
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(sdO + fo[QB][kk]);                                \
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);                                    \
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
             }                                                                                                           \
             f32x16_t pv, dsv;                                                                                           \
-            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                          \
-                const int qb = qt0 + (QB) * 32 + 8 * q4 + 4 * hh;                                                       \
-                const float4 lv = *reinterpret_cast<const float4*>(sStat + (QB) * 32 + 8 * q4 + 4 * hh);                 \
-                const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 64 + (QB) * 32 + 8 * q4 + 4 * hh);          \
-                const float l4[4] = {lv.x, lv.y, lv.z, lv.w};                                                           \
-                const float d4[4] = {dv4.x, dv4.y, dv4.z, dv4.w};                                                       \
-                _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                         \
-                    const int r = 4 * q4 + e;                                                                           \
-                    float p = __builtin_amdgcn_exp2f((s[r] - l4[e]) * LOG2E);                                           \
-                    if (need_mask) {                                                                                    \
-                        const int qq = qb + e;                                                                          \
-                        if (qq >= a.Lq || key >= a.Lk || (a.causal && key > qq)) p = 0.f;                               \
-                    }                                                                                                   \
-                    pv[r] = p;                                                                                          \
-                    dsv[r] = p * (dp[r] - d4[e]);                                                                       \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E);                \
+            if (need_mask) {                      /* ONE branch per block: a test inside the score loop becomes 16 */   \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
+                    const int qq = qt0 + (QB) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);                                   \
+                    if (qq >= a.Lq || key >= a.Lk || (a.causal && key > qq)) pv[r] = 0.f;                               \
                 }                                                                                                       \
             }                                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) dsv[r] = pv[r] * dp[r];                                      \
             bf16x8_t qtf[2][2], dotf[2][2];                                                                             \
             tr_wait<0>(tdo);                                                                                            \
             tr_wait<0>(tq);                                                                                             \
@@ -708,9 +737,9 @@ extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
                        (const unsigned short*)a->o, (const unsigned short*)a->d_o, a->delta, a->o_bs, a->o_rs, a->do_bs,
                        a->do_rs, a->B, a->H, a->Lq);
     DICOW_CHECK_LAUNCH("attn_delta");
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(dicow_cdiv(a->Lq, 128), a->H, a->B), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(dicow_cdiv(a->Lq, 128) * a->H * a->B), dim3(256), 0, st, *a);
     DICOW_CHECK_LAUNCH("attn_bwd_dq");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(dicow_cdiv(a->Lk, 128), a->H, a->B), dim3(256), 0, st, *a);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(dicow_cdiv(a->Lk, 128) * a->H * a->B), dim3(256), 0, st, *a);
     DICOW_CHECK_LAUNCH("attn_bwd_dkv");
     return DICOW_OK;
 }
