@@ -407,9 +407,29 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
     const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
     const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
     int par = 0;                                      // stage holding k-tile 0 of the current output tile
+    // DMA source = buffer descriptor (operand base) + scalar k offset + per-lane 32-bit byte offset (row * ld + swizzled chunk),
+    // the offsets being computed once per output tile: plain VALU instructions share the SIMD's issue port with the MFMAs
+    // (tools/probe_overlap.hip), and the 16 64-bit address adds per k-step of the pointer form cost ~6 % of the loop.
+    unsigned offA[8], offB[8];
+#define NTW_OFFSETS()                                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
+        const int q_ = wave * 8 + i, row_ = q_ * 8 + (lane >> 3), c_ = (lane & 7) ^ ((row_ >> 1) & 7);      \
+        int gm_ = m0 + row_; gm_ = gm_ < a.M ? gm_ : a.M - 1;                                                \
+        int gn_ = n0 + row_; gn_ = gn_ < a.N ? gn_ : a.N - 1;                                                \
+        offA[i] = (unsigned)(((int64_t)gm_ * a.lda + c_ * 8) * 2);                                           \
+        offB[i] = (unsigned)(((int64_t)gn_ * a.ldb + c_ * 8) * 2);                                           \
+    }
+#define NTW_RSRC()                                                                                           \
+    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, 0xffffffffu, 0x00020000);      \
+    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(B), 0, 0xffffffffu, 0x00020000);
+#define NTW_DMA(I, K0, SA)                                                                                   \
+    { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)((SA) + (wave * 8 + (I)) * 1024), 16, offA[I], (K0) * 2, 0, 0);             \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)((SA) + 256 * 128 + (wave * 8 + (I)) * 1024), 16, offB[I], (K0) * 2, 0, 0); }
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    NTW_RSRC()
+    NTW_OFFSETS()
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
-        ntw_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, 0, smem, smem + 256 * 128, lane, wave * 8 + i);
+    for (int i = 0; i < 8; ++i) NTW_DMA(i, 0, smem)
 
     while (true) {
         f32x16_t acc[4][4];                           // [n block i][m block j]
@@ -430,8 +450,7 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
 #define DOMFMA(WF, XF)                                                                                       \
     { _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < 4; ++i)            \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0); }
-#define DMA4(I0) if (MORE) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                \
-        ntw_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, (t + 1) * BK, nA, nA + 256 * 128, lane, wave * 8 + (I0) + i_); }
+#define DMA4(I0) if (MORE) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) NTW_DMA((I0) + i_, (t + 1) * BK, nA) }
     // one slice: 16 MFMA with NR LDS reads and ND DMA instructions threaded between them (one per MFMA)
 #define SCHED(NR, ND)                                                                                        \
     _Pragma("unroll") for (int s_ = 0; s_ < (NR); ++s_) {                                                    \
@@ -494,9 +513,10 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
             A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
             B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
             char* fA = smem + par * NT256_STAGE;      // last read in k-step nk-2: released by the k-step nk-1 barrier
+            NTW_OFFSETS()
+            NTW_RSRC()
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                ntw_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, 0, fA, fA + 256 * 128, lane, wave * 8 + i);
+            for (int i = 0; i < 8; ++i) NTW_DMA(i, 0, fA)
         }
         unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)ebz * a.strideC;
         float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)ebz * a.strideC;
@@ -625,6 +645,9 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
         if (!more_tiles) break;
     }
 }
+#undef NTW_OFFSETS
+#undef NTW_RSRC
+#undef NTW_DMA
 
 // ------------------------------------------------------------------------------------------------ NT, 256x256, staggered
 // Same tile / wave grid as gemm_nt256_kernel, but the contraction advances in 32-deep PHASES through a 4-stage LDS ring
@@ -778,7 +801,9 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
         attr256 = true;
     }
     // the 256x256 kernel wins once it can put ~one workgroup on every CU; smaller problems keep the 128x128 tiles
-    const bool big = (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
+    // the persistent kernel addresses its operands with 32-bit byte offsets from a per-batch base
+    const bool off32 = (int64_t)a->M * a->lda * 2 < (1ll << 32) && (int64_t)a->N * a->ldb * 2 < (1ll << 32);
+    const bool big = off32 && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
         const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
         if (variant == 0 || variant == 10 || variant == 11) {
