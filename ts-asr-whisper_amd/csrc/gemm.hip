@@ -1038,18 +1038,6 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const dicow_gemm_tn_arg
 #define TN256_STAGE (2 * TN256_OP)
 #define TN256_LDS (2 * TN256_STAGE)
 
-__device__ __forceinline__ void tn256_stage_part(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
-                                                 int64_t lda, int64_t ldb, int N1, int N2, int n1_0, int n2_0, int row_base,
-                                                 int rows_valid, char* sA, char* sB, int wave, int lane, int i) {
-    const int q = wave * 4 + i;                       // DMA instruction index: rows 2q, 2q+1 (1 KiB)
-    const int row = 2 * q + (lane >> 5), p = lane & 31;
-    const int c = p ^ ((row & 3) << 2);
-    const int grow = row_base + (row < rows_valid ? row : rows_valid - 1);
-    int ca = n1_0 + c * 8; ca = ca + 8 <= N1 ? ca : N1 - 8;
-    int cb = n2_0 + c * 8; cb = cb + 8 <= N2 ? cb : N2 - 8;
-    glds16(A + (int64_t)grow * lda + ca, sA + q * 1024);
-    glds16(B + (int64_t)grow * ldb + cb, sB + q * 1024);
-}
 __device__ __forceinline__ unsigned tn256_tr_addr(const char* s, int m, int n) {
     return (unsigned)(uintptr_t)(s + m * 512 + ((((n >> 3) ^ ((m & 3) << 2))) << 4) + ((n & 7) << 1));
 }
@@ -1116,14 +1104,36 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_
     const int G = lane >> 4, u = lane & 15;
     const int tr_row = 8 * (G >> 1) + (u >> 2);
     const int tr_col = 16 * (G & 1) + 4 * (u & 3);
+    // DMA through buffer descriptors: per-lane 32-bit byte offsets (row-in-tile * ld + swizzled, clamped column chunk) are
+    // computed ONCE; a contraction tile only changes the scalar offset (and, across batches, the descriptor base).  The
+    // pointer form cost ~75 VALU instructions per k-step (64-bit multiply-adds, clamps) on the issue port the 32 MFMAs
+    // share.  num_records = Mk rows: the rows a partial last tile reaches past the end read as ZERO, which is exactly the
+    // contribution they must make (no clamped duplicates to scrub out of LDS afterwards).
+    unsigned voA[4], voB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = wave * 4 + i;                   // DMA instruction index: rows 2q, 2q+1 (1 KiB)
+        const int row = 2 * q + (lane >> 5), p = lane & 31;
+        const int c = p ^ ((row & 3) << 2);
+        int ca = n1_0 + c * 8; ca = ca + 8 <= a.N1 ? ca : a.N1 - 8;
+        int cb = n2_0 + c * 8; cb = cb + 8 <= a.N2 ? cb : a.N2 - 8;
+        voA[i] = (unsigned)(((int64_t)row * a.lda + ca) * 2);
+        voB[i] = (unsigned)(((int64_t)row * a.ldb + cb) * 2);
+    }
     auto dma2 = [&](int kt, int i0) {                 // two DMA instruction pairs of contraction tile kt
         const int b = kt / tiles_per_batch, lt = kt - b * tiles_per_batch;
-        const int rv = (a.Mk - lt * TK) < TK ? (a.Mk - lt * TK) : TK;
         char* sA = smem + ((kt - kt0) & 1) * TN256_STAGE;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(A + (int64_t)b * a.strideA), 0, (unsigned)((int64_t)a.Mk * a.lda * 2), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(B + (int64_t)b * a.strideB), 0, (unsigned)((int64_t)a.Mk * a.ldb * 2), 0x00020000);
+        const int soA = (int)((int64_t)lt * TK * a.lda * 2), soB = (int)((int64_t)lt * TK * a.ldb * 2);
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
-            tn256_stage_part(A + (int64_t)b * a.strideA, B + (int64_t)b * a.strideB, a.lda, a.ldb, a.N1, a.N2, n1_0, n2_0,
-                             lt * TK, rv, sA, sA + TN256_OP, wave, lane, i0 + e);
+        for (int e = 0; e < 2; ++e) {
+            const int q = wave * 4 + i0 + e;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(sA + q * 1024), 16, voA[i0 + e], soA, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sA + TN256_OP + q * 1024), 16, voB[i0 + e], soB, 0, 0);
+        }
     };
     dma2(kt0, 0);
     dma2(kt0, 2);
@@ -1135,18 +1145,6 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        {   // zero the rows of a partial contraction tile (the DMA fetched clamped duplicates there)
-            const int lt = kt % tiles_per_batch;
-            const int rv = (a.Mk - lt * TK) < TK ? (a.Mk - lt * TK) : TK;
-            if (rv < TK) {
-                for (int i = tid; i < (TK - rv) * 32; i += 512) {
-                    const int off = (rv + (i >> 5)) * 512 + (i & 31) * 16;
-                    *reinterpret_cast<uint4*>(sA + off) = make_uint4(0, 0, 0, 0);
-                    *reinterpret_cast<uint4*>(sB + off) = make_uint4(0, 0, 0, 0);
-                }
-                __syncthreads();
-            }
-        }
         unsigned ad[6];
 #pragma unroll
         for (int i = 0; i < 2; ++i) ad[i] = tn256_tr_addr(sB, tr_row, w2 * 64 + i * 32 + tr_col);
@@ -1233,6 +1231,8 @@ static void tn_plan(const dicow_gemm_tn_args* a, int& tpb, int& total, int& nt, 
     tile = 128; splits = 1; nt = 1;
     for (int tl = 128; tl <= 256; tl += 128) {
         if (tl == 256 && (a->N1 < 256 || a->N2 < 256)) continue;
+        // the 256 kernel addresses each batch's operands through 32-bit buffer offsets
+        if (tl == 256 && ((int64_t)a->Mk * a->lda * 2 >= (1ll << 32) || (int64_t)a->Mk * a->ldb * 2 >= (1ll << 32))) continue;
         const int n = dicow_cdiv(a->N1, tl) * dicow_cdiv(a->N2, tl);
         const int slots = tl == 256 ? 256 : 512;               // resident workgroups on the chip
         const double rate = tl == 256 ? 0.85e15 : 0.69e15;
