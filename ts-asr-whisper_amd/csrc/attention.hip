@@ -33,18 +33,34 @@ __device__ __forceinline__ int kswz(int row, int c) { return row * 128 + ((c ^ (
 // V-style image: chunk c of row r at c ^ (((r>>1)&1)<<2)                              (ds_read_b64_tr_b16 fragments)
 __device__ __forceinline__ int vswz(int row, int c) { return row * 128 + ((c ^ (((row >> 1) & 1) << 2)) << 4); }
 
-// one wave-instruction moves 8 rows x 128 B; a 64-row tile needs 8 of them -> 2 per wave
-template <bool VSTYLE>
-__device__ __forceinline__ void stage_tile64(const unsigned short* __restrict__ base, int64_t rs, int row0, int nrows,
-                                             char* lds, int wave, int lane) {
+// ---- K/V/Q/dO tile staging through a buffer descriptor.  A tile source holds the descriptor of one (batch, head) slice
+// (num_records ends with the last valid row, so rows past the end read as ZERO -- they are masked anyway) and this wave's
+// two per-lane byte offsets (row-in-tile * row stride + swizzled 16-B chunk), computed once.  A tile then costs two DMA
+// instructions with a SCALAR row offset and no VALU address arithmetic -- plain VALU instructions share the SIMD's issue
+// port with the MFMAs (tools/probe_overlap.hip), so per-tile pointer math was ~20 % of the loop's VALU work.
+enum { SWZ_K = 0, SWZ_V = 1, SWZ_U = 2 };
+struct tile_src_t { __amdgpu_buffer_rsrc_t rs; unsigned vo[2]; int row_bytes; };
+__device__ __forceinline__ int rev3(int x);
+template <int SWZ>
+__device__ __forceinline__ tile_src_t make_tile_src(const unsigned short* base, int64_t rs, int nrows, int wave, int lane) {
+    tile_src_t t;
+    t.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base), 0,
+                                             (unsigned)(((int64_t)(nrows - 1) * rs + HD) * 2), 0x00020000);
+    t.row_bytes = (int)(rs * 2);
     const int rr = lane >> 3, p = lane & 7;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = (wave * 2 + i) * 8 + rr;
-        const int c = VSTYLE ? (p ^ (((row >> 1) & 1) << 2)) : (p ^ ((row >> 1) & 7));
-        int g = row0 + row; g = g < nrows ? g : nrows - 1;
-        glds16(base + (int64_t)g * rs + c * 8, lds + (wave * 2 + i) * 1024);
+        const int c = SWZ == SWZ_V ? (p ^ (((row >> 1) & 1) << 2)) : SWZ == SWZ_K ? (p ^ ((row >> 1) & 7)) : (p ^ rev3((row >> 1) & 7));
+        t.vo[i] = (unsigned)(row * (int)(rs * 2) + c * 16);
     }
+    return t;
+}
+__device__ __forceinline__ void stage_tile(const tile_src_t& t, int row0, char* lds, int wave) {
+    const int so = row0 * t.row_bytes;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(t.rs, (lds_void_t*)(lds + (wave * 2 + i) * 1024), 16, t.vo[i], so, 0, 0);
 }
 
 // 8 transposing reads (one 32-key block x 64 d) + wait, as ONE asm statement (see gemm.hip for the rationale).
@@ -184,13 +200,14 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
     if (a.causal) { const int lim = q0 + 128 < a.Lk ? q0 + 128 : a.Lk; kv_end = lim; }   // keys <= last q row of the block
     const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
 
+    const tile_src_t srcK = make_tile_src<SWZ_K>(K, a.k_rs, a.Lk, wave, lane), srcV = make_tile_src<SWZ_V>(V, a.v_rs, a.Lk, wave, lane);
     // Three-slot ring, ONE barrier per k-tile: the barrier that publishes tile t also proves every wave has left tile
     // t-1, whose slot is then refilled with tile t+2 (two tiles of DMA lead instead of one).
-    stage_tile64<false>(K, a.k_rs, 0, a.Lk, smem, wave, lane);
-    stage_tile64<true>(V, a.v_rs, 0, a.Lk, smem + TILE_BYTES, wave, lane);
+    stage_tile(srcK, 0, smem, wave);
+    stage_tile(srcV, 0, smem + TILE_BYTES, wave);
     if (nt > 1) {
-        stage_tile64<false>(K, a.k_rs, KV_TILE, a.Lk, smem + 2 * TILE_BYTES, wave, lane);
-        stage_tile64<true>(V, a.v_rs, KV_TILE, a.Lk, smem + 3 * TILE_BYTES, wave, lane);
+        stage_tile(srcK, KV_TILE, smem + 2 * TILE_BYTES, wave);
+        stage_tile(srcV, KV_TILE, smem + 3 * TILE_BYTES, wave);
     }
 #ifdef ATTN_PROFILE
     long long pacc[6] = {0, 0, 0, 0, 0, 0}, pt[7];
@@ -224,8 +241,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
         }
         if (t + 2 < nt) {
             char* nK = smem + (slot == 0 ? 2 : slot - 1) * 2 * TILE_BYTES;    // slot of tile t-1 == slot of tile t+2
-            stage_tile64<false>(K, a.k_rs, (t + 2) * KV_TILE, a.Lk, nK, wave, lane);
-            stage_tile64<true>(V, a.v_rs, (t + 2) * KV_TILE, a.Lk, nK + TILE_BYTES, wave, lane);
+            stage_tile(srcK, (t + 2) * KV_TILE, nK, wave);
+            stage_tile(srcV, (t + 2) * KV_TILE, nK + TILE_BYTES, wave);
         }
         PT(1)
 
@@ -388,18 +405,6 @@ extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
 __device__ __forceinline__ int rev3(int x) { return ((x & 1) << 2) | (x & 2) | ((x >> 2) & 1); }
 __device__ __forceinline__ int uswz(int row, int c) { return row * 128 + ((c ^ rev3((row >> 1) & 7)) << 4); }
 
-__device__ __forceinline__ void stage_tile64_u(const unsigned short* __restrict__ base, int64_t rs, int row0, int nrows,
-                                               char* lds, int wave, int lane) {
-    const int rr = lane >> 3, p = lane & 7;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 8 + rr;
-        const int c = p ^ rev3((row >> 1) & 7);
-        int g = row0 + row; g = g < nrows ? g : nrows - 1;
-        glds16(base + (int64_t)g * rs + c * 8, lds + (wave * 2 + i) * 1024);
-    }
-}
-
 // lane base address of a transposing read on a U image: rows 4*half + (u>>2) (+8*sec), 16 columns of d-block dblk
 __device__ __forceinline__ unsigned tr_base_u(const char* s, int lane, int dblk, int sec) {
     const int G = lane >> 4, u = lane & 15, hh = G >> 1;
@@ -496,15 +501,16 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
     if (a.causal) kv_end = q0 + 128 < a.Lk ? q0 + 128 : a.Lk;
     const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
 
-    stage_tile64_u(K, a.k_rs, 0, a.Lk, smem, wave, lane);
-    stage_tile64_u(V, a.v_rs, 0, a.Lk, smem + TILE_BYTES, wave, lane);
+    const tile_src_t srcK = make_tile_src<SWZ_U>(K, a.k_rs, a.Lk, wave, lane), srcV = make_tile_src<SWZ_U>(V, a.v_rs, a.Lk, wave, lane);
+    stage_tile(srcK, 0, smem, wave);
+    stage_tile(srcV, 0, smem + TILE_BYTES, wave);
     for (int t = 0; t < nt; ++t) {
         char* sK = smem + (t & 1) * 2 * TILE_BYTES;
         char* sV = sK + TILE_BYTES;
         if (t + 1 < nt) {
             char* nK = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile64_u(K, a.k_rs, (t + 1) * KV_TILE, a.Lk, nK, wave, lane);
-            stage_tile64_u(V, a.v_rs, (t + 1) * KV_TILE, a.Lk, nK + TILE_BYTES, wave, lane);
+            stage_tile(srcK, (t + 1) * KV_TILE, nK, wave);
+            stage_tile(srcV, (t + 1) * KV_TILE, nK + TILE_BYTES, wave);
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -625,9 +631,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
 
     const int t0 = a.causal ? (kblk0 / KV_TILE) : 0;                 // query tiles entirely before the key block see none of it
     const int nt = (a.Lq + KV_TILE - 1) / KV_TILE;
+    const tile_src_t srcQ = make_tile_src<SWZ_U>(Q, a.q_rs, a.Lq, wave, lane), srcdO = make_tile_src<SWZ_U>(dO, a.do_rs, a.Lq, wave, lane);
     if (t0 < nt) {
-        stage_tile64_u(Q, a.q_rs, t0 * KV_TILE, a.Lq, smem, wave, lane);
-        stage_tile64_u(dO, a.do_rs, t0 * KV_TILE, a.Lq, smem + TILE_BYTES, wave, lane);
+        stage_tile(srcQ, t0 * KV_TILE, smem, wave);
+        stage_tile(srcdO, t0 * KV_TILE, smem + TILE_BYTES, wave);
         stage_stats64(lse, delta, t0 * KV_TILE, a.Lq, smem + 4 * TILE_BYTES, wave, lane);
     }
     // lane-derived row-fragment offsets (swizzle XORs) computed once: plain VALU instructions share the SIMD's issue port
@@ -642,8 +649,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
         char* sdO = sQ + TILE_BYTES;
         if (t + 1 < nt) {
             char* nQ = smem + ((t - t0 + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile64_u(Q, a.q_rs, (t + 1) * KV_TILE, a.Lq, nQ, wave, lane);
-            stage_tile64_u(dO, a.do_rs, (t + 1) * KV_TILE, a.Lq, nQ + TILE_BYTES, wave, lane);
+            stage_tile(srcQ, (t + 1) * KV_TILE, nQ, wave);
+            stage_tile(srcdO, (t + 1) * KV_TILE, nQ + TILE_BYTES, wave);
             stage_stats64(lse, delta, (t + 1) * KV_TILE, a.Lq, smem + 4 * TILE_BYTES + ((t - t0 + 1) & 1) * 512, wave, lane);
             asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         } else {
