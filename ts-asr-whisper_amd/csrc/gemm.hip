@@ -572,12 +572,39 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
                 const int nq = en0 + 4 * ml, nqc = nq < a.N ? nq : a.N - 4;
                 float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (FLAGS >= 0 && (FLAGS & DICOW_EPI_BIAS)) bq = *reinterpret_cast<const float4*>(sbias + wn * 128 + 4 * ml);
+                // Global traffic of the compile-time-flag epilogues goes through buffer descriptors: per-lane byte offsets
+                // ((hh * ld + 4 ml) * element size) are tile-invariant, the row of each instruction is a SCALAR offset, rows past
+                // M fall outside num_records (stores dropped, loads return 0) and lanes past N get an out-of-range offset.
+                // The pointer form spent ~12 VALU instructions (64-bit multiply-adds, compares) plus an exec branch on every
+                // store -- ~3 us per tile on the issue port that is otherwise free to run the next tile's MFMAs.
+                constexpr int ESZ = (FLAGS >= 0 && (FLAGS & DICOW_EPI_OUT_F32)) ? 4 : 2;
+                constexpr bool AUX_IO = FLAGS >= 0 && (FLAGS & (DICOW_EPI_GELU | DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) != 0;
+                const unsigned OOB = 0x80000000u;
+                const bool nok = nq < a.N;
+                __amdgpu_buffer_rsrc_t rsC, rsX, rsR;
+                unsigned voC = OOB, voX = OOB, voR = OOB;
+                if (FLAGS >= 0) {
+                    rsC = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.C) + (int64_t)ebz * a.strideC * ESZ, 0,
+                                                            (unsigned)(((int64_t)(a.M - 1) * a.ldc + a.N) * ESZ), 0x00020000);
+                    if (nok) voC = (unsigned)((hh * (int)a.ldc + 4 * ml) * ESZ);
+                    if (AUX_IO) {
+                        rsX = __builtin_amdgcn_make_buffer_rsrc(aux, 0, (unsigned)(((int64_t)(a.M - 1) * a.ldaux + a.N) * 2), 0x00020000);
+                        if (nok) voX = (unsigned)((hh * (int)a.ldaux + 4 * ml) * 2);
+                    }
+                    if (PRE_RES) {
+                        rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual), 0,
+                                                                (unsigned)(((int64_t)(a.M - 1) * a.ldr + a.N) * 4), 0x00020000);
+                        if (nok) voR = (unsigned)((hh * (int)a.ldr + 4 * ml) * 4);
+                    }
+                }
+#define NTW_SOFF(J, IT, LD, SZ) ((int)((((int64_t)(em0 + (J) * 32 + (IT) * 2)) * (LD) + en0) * (SZ)))
 #define NTW_PREFETCH(J, BUF)                                                                                 \
     if (PRE_AUX || PRE_RES) {                                                                                \
         _Pragma("unroll") for (int it = 0; it < 16; ++it) {                                                  \
-            int m_ = em0 + (J) * 32 + it * 2 + hh; m_ = m_ < a.M ? m_ : a.M - 1;                             \
-            if (PRE_AUX) xa[BUF][it] = *reinterpret_cast<const uint2*>(aux + (int64_t)m_ * a.ldaux + nqc);   \
-            if (PRE_RES) xr[BUF][it] = *reinterpret_cast<const float4*>(a.residual + (int64_t)m_ * a.ldr + nqc); \
+            if (PRE_AUX) { const auto u_ = __builtin_amdgcn_raw_buffer_load_b64(rsX, voX, NTW_SOFF(J, it, a.ldaux, 2), 0); \
+                           xa[BUF][it] = make_uint2(u_[0], u_[1]); }                                         \
+            if (PRE_RES) { const auto r_ = __builtin_amdgcn_raw_buffer_load_b128(rsR, voR, NTW_SOFF(J, it, a.ldr, 4), 0);  \
+                           xr[BUF][it] = make_float4(__uint_as_float(r_[0]), __uint_as_float(r_[1]), __uint_as_float(r_[2]), __uint_as_float(r_[3])); } \
         }                                                                                                    \
     }
                 NTW_PREFETCH(0, 0)
@@ -598,11 +625,21 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
                         for (int it = 0; it < 16; ++it) {
                             const int row = it * 2 + hh;
                             const float4 f = *reinterpret_cast<const float4*>(scr + row * 512 + ((ml ^ row) << 4));
-                            const int m = em0 + j * 32 + row;
-                            if (m < a.M && nq < a.N) {
-                                float vv[4] = {f.x, f.y, f.z, f.w};
-                                nt_epilogue_quad<FLAGS>(a, flags, vv, m, nq, Cb, Cf, aux, &bq, PRE_AUX ? &xa[j & 1][it] : nullptr,
-                                                        PRE_RES ? &xr[j & 1][it] : nullptr);
+                            float vv[4] = {f.x, f.y, f.z, f.w}, dg[4];
+                            nt_epilogue_math<FLAGS>(a, flags, vv, dg, 0, nq, aux, &bq, PRE_AUX ? &xa[j & 1][it] : nullptr,
+                                                    PRE_RES ? &xr[j & 1][it] : nullptr);
+                            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+                            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+                            if ((FLAGS & DICOW_EPI_GELU) != 0) {
+                                const u32x2_t xv = {pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3])};
+                                if (aux) __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, voX, NTW_SOFF(j, it, a.ldaux, 2), 0);
+                            }
+                            if (ESZ == 4) {
+                                const u32x4_t ov = {__float_as_uint(vv[0]), __float_as_uint(vv[1]), __float_as_uint(vv[2]), __float_as_uint(vv[3])};
+                                __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, voC, NTW_SOFF(j, it, a.ldc, 4), 0);
+                            } else {
+                                const u32x2_t ov = {pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};
+                                __builtin_amdgcn_raw_buffer_store_b64(ov, rsC, voC, NTW_SOFF(j, it, a.ldc, 2), 0);
                             }
                         }
                     } else {
@@ -628,6 +665,7 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
 #endif
                 }
 #undef NTW_PREFETCH
+#undef NTW_SOFF
             }
         }
 #ifdef NTW_PROFILE
@@ -802,7 +840,9 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     }
     // the 256x256 kernel wins once it can put ~one workgroup on every CU; smaller problems keep the 128x128 tiles
     // the persistent kernel addresses its operands with 32-bit byte offsets from a per-batch base
-    const bool off32 = (int64_t)a->M * a->lda * 2 < (1ll << 32) && (int64_t)a->N * a->ldb * 2 < (1ll << 32);
+    const bool off32 = (int64_t)a->M * a->lda * 2 < (1ll << 31) && (int64_t)a->N * a->ldb * 2 < (1ll << 31) &&
+                       (int64_t)a->M * a->ldc * 4 < (1ll << 31) && (int64_t)a->M * a->ldaux * 2 < (1ll << 31) &&
+                       (int64_t)a->M * a->ldr * 4 < (1ll << 31);
     const bool big = off32 && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
         const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
