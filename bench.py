@@ -129,6 +129,21 @@ def cpu_baseline(cfg_name, labels):
                       f"best {best:.2f} s, host has {cores} logical cores"}
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC summary (counters cannot be read live)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01e_pmc_hbm_traffic.json")) as f:
+            d = json.load(f)
+        tot = n = 0
+        for k, v in d.items():
+            if k.startswith("gemm_nt256w") and v.get("hbm_read_bytes_per_launch_corrected") is not None:
+                tot += (v["hbm_read_bytes_per_launch_corrected"] + (v.get("hbm_write_bytes_per_launch") or 0)) * v["launches"]
+                n += v["launches"]
+        return round(tot / n) if n else None
+    except Exception:
+        return None
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,10 +217,12 @@ def main():
                                f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}{', CTC 0.3' if a.ctc else ''}",
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "trainable_params": ts.store.n_trainable},
         "loss": float(loss),
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt256_kernel / gemm_nt_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt256w_kernel / gemm_nt_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
                      "achieved": round(nt["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(nt["tflops"] / peak, 4),
-                     "traffic": None, "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // a.steps,
-                     "share_of_step": round(nt["total_ms"] / (dt * 1e3), 3)},
+                     "traffic": pmc_traffic(), "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // a.steps,
+                     "share_of_step": round(nt["total_ms"] / (dt * 1e3), 3),
+                     "traffic_source": "profiles/r01e_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                       "command; fabric-side bytes per gemm_nt256w launch, FETCH_SIZE x2 per the gfx950 correction)"},
         "kernels": {"gemm_tn_kernel": {"tflops": round(tn["tflops"], 1), "frac": round(tn["tflops"] / peak, 4),
                                        "share_of_step": round(tn["total_ms"] / (dt * 1e3), 3)}},
         "step_tflops": round((6.99 if not a.se else 10.7) * utts, 1),

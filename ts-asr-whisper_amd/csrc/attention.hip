@@ -502,6 +502,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
     const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
 
     const tile_src_t srcK = make_tile_src<SWZ_U>(K, a.k_rs, a.Lk, wave, lane), srcV = make_tile_src<SWZ_U>(V, a.v_rs, a.Lk, wave, lane);
+    // lane bases of the transposing reads, once (the stage only adds a scalar)
+    const unsigned kb00 = tr_base_u(smem, lane, 0, 0), kb01 = tr_base_u(smem, lane, 0, 1);
+    const unsigned kb10 = tr_base_u(smem, lane, 1, 0), kb11 = tr_base_u(smem, lane, 1, 1);
     stage_tile(srcK, 0, smem, wave);
     stage_tile(srcV, 0, smem + TILE_BYTES, wave);
     for (int t = 0; t < nt; ++t) {
@@ -521,8 +524,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
         const int k0 = t * KV_TILE;
         const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
         // K^T fragments for the dQ product: issued now, consumed after S / dP / dS
-        const unsigned k00 = tr_base_u(sK, lane, 0, 0), k01 = tr_base_u(sK, lane, 0, 1);
-        const unsigned k10 = tr_base_u(sK, lane, 1, 0), k11 = tr_base_u(sK, lane, 1, 1);
+        const unsigned stg = (unsigned)((t & 1) * 2 * TILE_BYTES);
+        const unsigned k00 = kb00 + stg, k01 = kb01 + stg, k10 = kb10 + stg, k11 = kb11 + stg;
         tr8_t tk0, tk1;
         tr_issue_u<0>(tk0, k00, k01, k10, k11);
         tr_issue_u<4096>(tk1, k00, k01, k10, k11);
@@ -644,6 +647,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
     for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) fo[qb][kk] = uswz(qb * 32 + (lane & 31), kk * 2 + hh);
+    const unsigned qb00 = tr_base_u(smem, lane, 0, 0), qb01 = tr_base_u(smem, lane, 0, 1);
+    const unsigned qb10 = tr_base_u(smem, lane, 1, 0), qb11 = tr_base_u(smem, lane, 1, 1);
     for (int t = t0; t < nt; ++t) {
         char* sQ = smem + ((t - t0) & 1) * 2 * TILE_BYTES;
         char* sdO = sQ + TILE_BYTES;
@@ -662,10 +667,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
         const int qt0 = t * KV_TILE;
         const float* sStat = reinterpret_cast<const float*>(smem + 4 * TILE_BYTES + ((t - t0) & 1) * 512);
         const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + 128 > a.Lk) || (a.causal && (kblk0 + wave * 32 + 31 > qt0));
-        const unsigned q00 = tr_base_u(sQ, lane, 0, 0), q01 = tr_base_u(sQ, lane, 0, 1);
-        const unsigned q10 = tr_base_u(sQ, lane, 1, 0), q11 = tr_base_u(sQ, lane, 1, 1);
-        const unsigned o00 = tr_base_u(sdO, lane, 0, 0), o01 = tr_base_u(sdO, lane, 0, 1);
-        const unsigned o10 = tr_base_u(sdO, lane, 1, 0), o11 = tr_base_u(sdO, lane, 1, 1);
+        const unsigned stg = (unsigned)(((t - t0) & 1) * 2 * TILE_BYTES);
+        const unsigned q00 = qb00 + stg, q01 = qb01 + stg, q10 = qb10 + stg, q11 = qb11 + stg;
+        const unsigned o00 = q00 + TILE_BYTES, o01 = q01 + TILE_BYTES, o10 = q10 + TILE_BYTES, o11 = q11 + TILE_BYTES;
 #define DKV_QBLOCK(QB)                                                                                                  \
         {                                                                                                               \
             tr8_t tdo, tq;                                                                                              \
