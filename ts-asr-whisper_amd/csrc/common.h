@@ -32,8 +32,14 @@ __device__ __forceinline__ unsigned short f2bfbits(float x) {
     bf16_t b = (bf16_t)x;
     return *reinterpret_cast<unsigned short*>(&b);
 }
+// ONE v_cvt_pk_bf16_f32 (two scalar casts + shift + or compile to four instructions, and plain VALU instructions are paid
+// in matrix-pipe time: they share the SIMD's issue port with the MFMAs)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    return (unsigned)f2bfbits(lo) | ((unsigned)f2bfbits(hi) << 16);
+    const f32x2_t v = {lo, hi};
+    const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+    return __builtin_bit_cast(unsigned, b);
 }
 
 // exact (erf) GELU and its derivative (Whisper activation_function="gelu"), evaluated with the Abramowitz-Stegun

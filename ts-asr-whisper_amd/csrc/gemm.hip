@@ -363,6 +363,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_arg
 // saturated resource.  With a single wave per SIMD nothing hides latency for us, so the instruction stream is laid
 // out by hand: every MFMA is followed by one LDS read (next slice) or one DMA instruction (next k-tile).
 //
+// (Tried and dropped: running only the whole rounds here and cutting the partial last round into 128x128 quarter tiles
+// for gemm_nt_kernel -- the quarter tiles quantise again (two resident per CU, each at half speed): 0.34 -> 0.40 ms.)
 // (Tried and dropped: a 4-byte-per-lane "L2 warm-up" DMA for the k-slab two steps ahead, with the step barrier waiting
 // on vmcnt(2) instead of 0 -- 1-4 % slower; the two extra VMEM issues per step cost more than the HBM misses they hide.)
 //
