@@ -184,7 +184,7 @@ int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream);
 
 typedef struct {
     const void* q; const void* k; const void* v; const void* o; const void* d_o;
-    const float* lse; float* delta;                 /* delta [B,H,Lq] workspace = rowsum(dO*O) */
+    const float* lse; float* delta;                 /* delta: workspace [2,B,H,Lq] fp32 (-rowsum(dO*O), -lse) */
     void* dq; void* dk; void* dv;                   /* bf16, same addressing as q/k/v */
     int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs, do_bs, do_rs;
     int64_t dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;

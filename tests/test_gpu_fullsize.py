@@ -47,7 +47,7 @@ def test_attention_backward_zero_upstream_and_dv_colsum(ops):
     o = torch.empty(4, T, H, 64, dtype=bf, device="cuda"); lse = torch.empty(4, H, T, device="cuda")
     ops.attn_fwd(q, k, v, o, lse)
     d_o = torch.ones(4, T, H, 64, dtype=bf, device="cuda")
-    dqkv = torch.empty_like(qkv); delta = torch.empty(4, H, T, device="cuda")
+    dqkv = torch.empty_like(qkv); delta = torch.empty(2, 4, H, T, device="cuda")
     dq, dk, dv = (dqkv[:, :, i * D:(i + 1) * D].view(4, T, H, 64) for i in range(3))
     ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv)
     # dO = ones: dV[key] = sum_q P[q,key] (column sums of the attention matrix) => sum over keys = number of queries

@@ -302,7 +302,7 @@ def test_attn_bwd(ops, B, H, Lq, Lk, causal):
     ops.attn_fwd(qd, kd, vd, o, lse, causal=causal)
     gq = torch.zeros(B, Lq, 3 * D, dtype=torch.bfloat16, device="cuda")
     gk = torch.zeros(B, Lk, 3 * D, dtype=torch.bfloat16, device="cuda")
-    delta = torch.empty(B, H, Lq, device="cuda")
+    delta = torch.empty(2, B, H, Lq, device="cuda")
     ops.attn_bwd(qd, kd, vd, o, dev(d_o, torch.bfloat16), lse, delta,
                  gq[:, :, :D].view(B, Lq, H, 64), gk[:, :, D:2 * D].view(B, Lk, H, 64), gk[:, :, 2 * D:].view(B, Lk, H, 64),
                  causal=causal, dq_scale=0.5)

@@ -18,7 +18,7 @@ o = torch.empty(B, Lq, H, 64, dtype=bf, device="cuda"); lse = torch.empty(B, H, 
 d_o = (torch.randn(B, Lq, H, 64, device="cuda", generator=g) * 0.01).to(bf)
 dqkv = torch.empty(B, Lq, 3 * D, dtype=bf, device="cuda"); dkv = dqkv if Lk == Lq else torch.empty(B, Lk, 3 * D, dtype=bf, device="cuda")
 dq, dk, dv = dqkv[:, :, :D].view(B, Lq, H, 64), dkv[:, :, D:2 * D].view(B, Lk, H, 64), dkv[:, :, 2 * D:].view(B, Lk, H, 64)
-delta = torch.empty(B, H, Lq, device="cuda")
+delta = torch.empty(2, B, H, Lq, device="cuda")
 x1, x2 = torch.empty(1 << 28, dtype=torch.uint8, device="cuda"), torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
 def timeit(fn, iters=10):
     fn(); torch.cuda.synchronize(); evs = []

@@ -438,7 +438,7 @@ __device__ __forceinline__ void tr_read_block_u(bf16x8_t (&f)[2][2], unsigned a0
 }
 
 __global__ void attn_delta_kernel(const unsigned short* __restrict__ o, const unsigned short* __restrict__ d_o,
-                                  float* __restrict__ delta, int64_t o_bs, int64_t o_rs, int64_t do_bs, int64_t do_rs,
+                                  const float* __restrict__ lse, float* __restrict__ delta, int64_t o_bs, int64_t o_rs, int64_t do_bs, int64_t do_rs,
                                   int B, int H, int Lq) {
     // one 16-lane group per (b, q, h): 4 bf16 per lane
     const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
@@ -459,7 +459,13 @@ __global__ void attn_delta_kernel(const unsigned short* __restrict__ o, const un
     }
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (gid < total && sub == 0) delta[((int64_t)b * H + h) * Lq + q] = s;
+    // workspace planes: [0] = -delta, [1] = -lse -- the values the dq / dkv kernels seed their accumulators with (negating
+    // them there cost 64 VALU instructions per query tile in the dkv loop)
+    if (gid < total && sub == 0) {
+        const int64_t i = ((int64_t)b * H + h) * Lq + q;
+        delta[i] = -s;
+        delta[(int64_t)B * H * Lq + i] = -lse[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
@@ -488,8 +494,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
     // -lse and -delta seed the S and dP accumulators, so the MFMA chain itself delivers (s - lse) and (dP - delta): plain
     // VALU work and MFMAs share one issue port per SIMD (tools/probe_overlap.hip: they do not overlap, transcendentals do),
     // which makes every VALU instruction shaved off the softmax recompute a direct saving.
-    const float nlse = -a.lse[stat];
-    const float ndlt = -a.delta[stat];
+    const float nlse = a.delta[(int64_t)a.B * a.H * a.Lq + stat];       // workspace planes written by attn_delta_kernel
+    const float ndlt = a.delta[stat];
 
     f32x16_t dq[2];
 #pragma unroll
@@ -614,8 +620,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
     const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
     const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
     const unsigned short* dO = reinterpret_cast<const unsigned short*>(a.d_o) + (int64_t)b * a.do_bs + h * HD;
-    const float* lse = a.lse + ((int64_t)b * a.H + h) * a.Lq;
-    const float* delta = a.delta + ((int64_t)b * a.H + h) * a.Lq;
+    const float* lse = a.delta + (int64_t)a.B * a.H * a.Lq + ((int64_t)b * a.H + h) * a.Lq;     // -lse plane of the workspace
+    const float* delta = a.delta + ((int64_t)b * a.H + h) * a.Lq;                                // -delta plane
 
     // this wave's 32 keys as B operands (column = key, k-slots = d)
     const int key = kblk0 + wave * 32 + (lane & 31);
@@ -679,8 +685,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
             _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                          \
                 const float4 lv = *reinterpret_cast<const float4*>(sStat + (QB) * 32 + 8 * q4 + 4 * hh);                 \
                 const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 64 + (QB) * 32 + 8 * q4 + 4 * hh);          \
-                s[4 * q4] = -lv.x; s[4 * q4 + 1] = -lv.y; s[4 * q4 + 2] = -lv.z; s[4 * q4 + 3] = -lv.w;                 \
-                dp[4 * q4] = -dv4.x; dp[4 * q4 + 1] = -dv4.y; dp[4 * q4 + 2] = -dv4.z; dp[4 * q4 + 3] = -dv4.w;         \
+                s[4 * q4] = lv.x; s[4 * q4 + 1] = lv.y; s[4 * q4 + 2] = lv.z; s[4 * q4 + 3] = lv.w;                     \
+                dp[4 * q4] = dv4.x; dp[4 * q4 + 1] = dv4.y; dp[4 * q4 + 2] = dv4.z; dp[4 * q4 + 3] = dv4.w;             \
             }                                                                                                           \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
                 const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(sQ + fo[QB][kk]);                                 \
@@ -745,7 +751,7 @@ extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int64_t groups = (int64_t)a->B * a->Lq * a->H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, st,
-                       (const unsigned short*)a->o, (const unsigned short*)a->d_o, a->delta, a->o_bs, a->o_rs, a->do_bs,
+                       (const unsigned short*)a->o, (const unsigned short*)a->d_o, a->lse, a->delta, a->o_bs, a->o_rs, a->do_bs,
                        a->do_rs, a->B, a->H, a->Lq);
     DICOW_CHECK_LAUNCH("attn_delta");
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(dicow_cdiv(a->Lq, 128) * a->H * a->B), dim3(256), 0, st, *a);

@@ -373,7 +373,7 @@ class EncoderEngine:
         ops.gemm_nt(d_attn, w.att.o.wt, d_o, rp, D, D, lda=2 * D)
         dq = _e((rp, D), BF16, dev)
         dkv = _e((rp, 2 * D), BF16, dev)
-        delta = _e((Bp, H, T), F32, dev)
+        delta = _e((2, Bp, H, T), F32, dev)
         ops.attn_bwd(heads(s.q, Bp, T, H), heads(s.kv[:, :D], Bp, T, H), heads(s.kv[:, D:], Bp, T, H), heads(s.o, Bp, T, H),
                      heads(d_o, Bp, T, H), s.lse, delta, heads(dq, Bp, T, H), heads(dkv[:, :D], Bp, T, H),
                      heads(dkv[:, D:], Bp, T, H), dq_scale=0.125)
@@ -426,7 +426,7 @@ class EncoderEngine:
             linear_wgrad(g2b, Ls.o, G.get(att.out_proj.weight), rows)
             d_o = linear_dgrad(g2b, w.att.o, rows)
             d_qkv = _e((rows, 3 * D), BF16, dev)
-            delta = _e((Bc, H, T), F32, dev)
+            delta = _e((2, Bc, H, T), F32, dev)
             qkv = Ls.qkv
             ops.attn_bwd(heads(qkv[:, :D], Bc, T, H), heads(qkv[:, D:2 * D], Bc, T, H), heads(qkv[:, 2 * D:], Bc, T, H),
                          heads(Ls.o, Bc, T, H), heads(d_o, Bc, T, H), Ls.lse, delta, heads(d_qkv[:, :D], Bc, T, H),
@@ -639,7 +639,7 @@ class DecoderEngine:
             d_o2 = linear_dgrad(g3b, w.ca.o, rows)
             dq = _e((rows, D), BF16, dev)
             dkv = _e((B * T, 2 * D), BF16, dev)
-            delta = _e((B, H, Lq), F32, dev)
+            delta = _e((2, B, H, Lq), F32, dev)
             ops.attn_bwd(heads(Ls.q, B, Lq, H), heads(Ls.kv[:, :D], B, T, H), heads(Ls.kv[:, D:], B, T, H), heads(Ls.o2, B, Lq, H),
                          heads(d_o2, B, Lq, H), Ls.lse2, delta, heads(dq, B, Lq, H), heads(dkv[:, :D], B, T, H),
                          heads(dkv[:, D:], B, T, H), dq_scale=0.125)
@@ -809,7 +809,7 @@ class CtcEngine:
         linear_wgrad(d_h, S.o, G.get(att.out_proj.weight), rows)
         d_o = linear_dgrad(d_h, W.att.o, rows)
         d_qkv = _e((rows, 3 * D), BF16, dev)
-        delta = _e((B, H, T), F32, dev)
+        delta = _e((2, B, H, T), F32, dev)
         qkv = S.qkv
         ops.attn_bwd(heads(qkv[:, :D], B, T, H), heads(qkv[:, D:2 * D], B, T, H), heads(qkv[:, 2 * D:], B, T, H),
                      heads(S.o, B, T, H), heads(d_o, B, T, H), S.lse_a, delta, heads(d_qkv[:, :D], B, T, H),

@@ -214,7 +214,8 @@ def attn_fwd(q, k, v, o, lse=None, causal=False):
 
 
 def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0):
-    """Backward of attn_fwd.  All [B,L,H,64] bf16 views; lse/delta [B,H,Lq] fp32 (delta is workspace)."""
+    """Backward of attn_fwd.  All [B,L,H,64] bf16 views; lse [B,H,Lq] fp32; delta = workspace [2,B,H,Lq] fp32."""
+    assert delta.numel() >= 2 * lse.numel(), "attn_bwd: delta workspace must hold 2*B*H*Lq floats"
     a = L.AttnBwdArgs()
     a.q, a.k, a.v, a.o, a.d_o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr()
     a.lse, a.delta = lse.data_ptr(), delta.data_ptr()
