@@ -141,6 +141,8 @@ int dicow_fddt_full_combine_bwd(const float* g, const float* stno, int64_t stno_
 #define DICOW_EPI_GELU_DAUX 128  /* with GELU: aux receives gelu'(pre-activation) (bf16) instead of the pre-activation,  */
                                  /* so that the backward GEMM needs one multiply (MUL_AUX) and no transcendental    */
 #define DICOW_EPI_MUL_AUX  256   /* C = acc * aux[m,n]  (aux = saved gelu' from GELU_DAUX, bf16)                      */
+#define DICOW_EPI_COLSUM   512   /* colsum_out[n] += sum_m C[m,n] (bias gradient of the layer that produced the GEMM's */
+                                 /* input gradient); needs colsum_ws of dicow_gemm_nt_colsum_ws_bytes(M, N) bytes     */
 typedef struct {
     const void* A; const void* B; void* C;
     const float* bias; const float* residual; void* aux;
@@ -148,8 +150,10 @@ typedef struct {
     int64_t lda, ldb, ldc, ldr, ldaux;
     int batch; int64_t strideA, strideB, strideC, strideAux;   /* grid.z batches (conv stem: per-utterance strided views) */
     int flags; float scale; int scale_ncols;
+    float* colsum_out; void* colsum_ws; int64_t colsum_ws_bytes;   /* DICOW_EPI_COLSUM only (else NULL / 0) */
 } dicow_gemm_args;
 int dicow_gemm_nt(const dicow_gemm_args* a, void* stream);
+int64_t dicow_gemm_nt_colsum_ws_bytes(int M, int N);
 
 /* C[N1,N2] (+)= sum_m A[m,N1] * B[m,N2]  (fp32 C): every weight gradient dW = dY^T X.  When the output has too few
  * tiles to fill the chip the contraction is split over grid.z; the splits write fp32 partials to the caller's

@@ -196,6 +196,13 @@ def test_gemm_nt_epilogues(ops, M, N, K):
     C7 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     ops.gemm_nt(Ad, Bd, C7, M, N, K, aux=daux, flags=L.EPI_MUL_AUX)
     assert maxdiff(C7.float().cpu(), (A @ B.t()) * daux.float().cpu()) < 4e-2
+    # ... and the same with the fused column sum (bias gradient of the producing layer): out += colsum(C)
+    C8 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    cs = torch.full((N,), 0.5, device="cuda")
+    ops.gemm_nt(Ad, Bd, C8, M, N, K, aux=daux, flags=L.EPI_MUL_AUX, colsum_out=cs)
+    assert maxdiff(C8.float().cpu(), C7.float().cpu()) == 0.0
+    ref_cs = 0.5 + ((A @ B.t()) * daux.float().cpu()).double().sum(0)
+    assert maxdiff(cs.cpu(), ref_cs) < 2e-3 * max(1.0, float(ref_cs.abs().max())) + 0.15 * (M ** 0.5) * 2 ** -8
     # accumulate
     C5 = dev(res.clone())
     ops.gemm_nt(Ad, Bd, C5, M, N, K, flags=L.EPI_ACCUM)

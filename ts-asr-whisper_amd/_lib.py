@@ -29,7 +29,8 @@ class GemmArgs(C.Structure):
                 ("M", c_i), ("N", c_i), ("K", c_i),
                 ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("ldr", c_i64), ("ldaux", c_i64),
                 ("batch", c_i), ("strideA", c_i64), ("strideB", c_i64), ("strideC", c_i64), ("strideAux", c_i64),
-                ("flags", c_i), ("scale", c_f), ("scale_ncols", c_i)]
+                ("flags", c_i), ("scale", c_f), ("scale_ncols", c_i),
+                ("colsum_out", c_vp), ("colsum_ws", c_vp), ("colsum_ws_bytes", c_i64)]
 
 
 class GemmTnArgs(C.Structure):
@@ -69,7 +70,7 @@ class CtcArgs(C.Structure):
 
 
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_SCALE_N, EPI_GELU_BWD, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
-EPI_GELU_DAUX, EPI_MUL_AUX = 128, 256
+EPI_GELU_DAUX, EPI_MUL_AUX, EPI_COLSUM = 128, 256, 512
 
 # name -> argtypes ; every function returns int
 _SIGS = {
@@ -130,6 +131,7 @@ def lib():
 
 _SIGS64 = {   # functions returning int64_t (workspace sizes)
     "dicow_colsum_ws_bytes": [c_i, c_i],
+    "dicow_gemm_nt_colsum_ws_bytes": [c_i, c_i],
     "dicow_fddt_ln_bwd_ws_bytes": [c_i, c_i],
     "dicow_gemm_tn_ws_bytes": [C.POINTER(GemmTnArgs)],
     "dicow_logmel_ws_bytes": [c_i, c_i],

@@ -583,6 +583,9 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
                 // The pointer form spent ~12 VALU instructions (64-bit multiply-adds, compares) plus an exec branch on every
                 // store -- ~3 us per tile on the issue port that is otherwise free to run the next tile's MFMAs.
                 constexpr int ESZ = (FLAGS >= 0 && (FLAGS & DICOW_EPI_OUT_F32)) ? 4 : 2;
+                constexpr bool COLSUM = FLAGS >= 0 && (FLAGS & DICOW_EPI_COLSUM) != 0;
+                const bool edge_m = em0 + 128 > a.M;
+                float cs[4] = {0.f, 0.f, 0.f, 0.f};
                 constexpr bool AUX_IO = FLAGS >= 0 && (FLAGS & (DICOW_EPI_GELU | DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) != 0;
                 const unsigned OOB = 0x80000000u;
                 const bool nok = nq < a.N;
@@ -633,6 +636,11 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
                             float vv[4] = {f.x, f.y, f.z, f.w}, dg[4];
                             nt_epilogue_math<FLAGS>(a, flags, vv, dg, 0, nq, aux, &bq, PRE_AUX ? &xa[j & 1][it] : nullptr,
                                                     PRE_RES ? &xr[j & 1][it] : nullptr);
+                            if (COLSUM) {             // bias gradient: column sums of the result (rows past M excluded)
+                                const float ok = (!edge_m || em0 + j * 32 + row < a.M) ? 1.f : 0.f;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) cs[e] = fmaf(vv[e], ok, cs[e]);
+                            }
                             typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
                             typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
                             if ((FLAGS & DICOW_EPI_GELU) != 0) {
@@ -668,6 +676,16 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
 #ifdef NTW_PROFILE
                     pj[j + 1] = wall_clock64();
 #endif
+                }
+                if (COLSUM) {
+                    // partial sums of this wave's 128 rows -> colsum_ws[(tile row * 2 + wm)][N]; every (row, column) of the
+                    // workspace is written exactly once per launch, the host adds the 2 * ceil(M/256) rows up afterwards
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cs[e] += __shfl_xor(cs[e], 32, 64);
+                    if (hh == 0 && nok) {
+                        float* wsr = reinterpret_cast<float*>(a.colsum_ws) + (int64_t)((em0 >> 7) + 0) * a.N + nq;
+                        *reinterpret_cast<float4*>(wsr) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                    }
                 }
 #undef NTW_PREFETCH
 #undef NTW_SOFF
@@ -805,7 +823,34 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256s_kernel(const dicow_gemm_ar
     }
 }
 
+// ws for DICOW_EPI_COLSUM: the fused path needs 2 * ceil(M/256) partial rows; the fallback runs dicow_colsum_bf16 on C
+extern "C" int64_t dicow_gemm_nt_colsum_ws_bytes(int M, int N) {
+    const int64_t fused = (int64_t)2 * dicow_cdiv(M, 256) * N * 4, fb = dicow_colsum_ws_bytes(M, N);
+    return fused > fb ? fused : fb;
+}
+
+static int gemm_nt_impl(const dicow_gemm_args* a, void* stream, bool* fused_colsum);
+
 extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
+    DICOW_REQUIRE(a && a->A && a->B && a->C, "gemm_nt: null operand");
+    if (!(a->flags & DICOW_EPI_COLSUM)) return gemm_nt_impl(a, stream, nullptr);
+    DICOW_REQUIRE(a->colsum_out && a->colsum_ws && a->colsum_ws_bytes >= dicow_gemm_nt_colsum_ws_bytes(a->M, a->N),
+                  "gemm_nt: COLSUM needs colsum_out and colsum_ws of dicow_gemm_nt_colsum_ws_bytes() bytes");
+    DICOW_REQUIRE(!(a->flags & DICOW_EPI_OUT_F32) && a->batch <= 1, "gemm_nt: COLSUM supports a single bf16 result");
+    bool fused = false;
+    int rc = gemm_nt_impl(a, stream, &fused);
+    if (rc != DICOW_OK) return rc;
+    if (fused)          // add the per-wave partial rows up: colsum_out[n] += sum_p ws[p][n]
+        return dicow_launch_reduce_parts(reinterpret_cast<const float*>(a->colsum_ws), 2 * dicow_cdiv(a->M, 256), a->N,
+                                         a->colsum_out, a->N, (hipStream_t)stream);
+    return dicow_colsum_bf16(a->C, a->ldc, a->colsum_out, a->M, a->N, a->colsum_ws, a->colsum_ws_bytes, stream);
+}
+
+static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_colsum) {
+    dicow_gemm_args a_copy = *a_in;
+    dicow_gemm_args* a = &a_copy;
+    const bool want_colsum = (a->flags & DICOW_EPI_COLSUM) != 0;
+    a->flags &= ~DICOW_EPI_COLSUM;                    // put back below where the fused epilogue exists
     DICOW_REQUIRE(a && a->A && a->B && a->C, "gemm_nt: null operand");
     DICOW_REQUIRE(a->M > 0 && a->N > 0 && a->K > 0, "gemm_nt: empty problem M=%d N=%d K=%d", a->M, a->N, a->K);
     DICOW_REQUIRE(a->K % BK == 0, "gemm_nt: K=%d must be a multiple of %d (pad the operands)", a->K, BK);
@@ -835,6 +880,7 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
         NTW_ATTR(-1); NTW_ATTR(0); NTW_ATTR(DICOW_EPI_BIAS); NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N);
         NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU); NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32);
         NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTW_ATTR(DICOW_EPI_MUL_AUX);
+        NTW_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
 #undef NTW_ATTR
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
@@ -857,6 +903,7 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
             const int total = (int)g256.x * batch;
             const dim3 gp(total < ncu ? total : ncu);
 #define NTW_LAUNCH(F) hipLaunchKernelGGL((gemm_nt256w_kernel<F, 1>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a)
+            if (want_colsum && variant == 0 && a->flags == DICOW_EPI_MUL_AUX) { a->flags |= DICOW_EPI_COLSUM; *fused_colsum = true; }
             if (variant == 10) hipLaunchKernelGGL((gemm_nt256w_kernel<-1, 0>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a);   // ablation: direct stores
             else switch (variant == 11 ? -1 : a->flags) {   // compile-time epilogues for the flag sets the training step uses
                 case 0: NTW_LAUNCH(0); break;
@@ -866,6 +913,7 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
                 case DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32); break;
                 case DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); break;
                 case DICOW_EPI_MUL_AUX: NTW_LAUNCH(DICOW_EPI_MUL_AUX); break;
+                case DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM: NTW_LAUNCH(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM); break;
                 default: NTW_LAUNCH(-1); break;
             }
 #undef NTW_LAUNCH

@@ -137,13 +137,13 @@ def linear_fwd(x, lw, M, out_dtype=BF16, residual=None, gelu_aux=None, flags=0, 
     return out
 
 
-def linear_dgrad(dy, lw, M, aux=None, out=None, out_dtype=BF16, accumulate=False, dy_cols=None):
+def linear_dgrad(dy, lw, M, aux=None, out=None, out_dtype=BF16, accumulate=False, dy_cols=None, colsum_out=None):
     """dx[M,K] = dy[M,N] @ W[N,K]  (NT GEMM against the transposed copy); `aux` = gelu' saved by linear_fwd(gelu_aux=...)."""
     N = lw.N if dy_cols is None else dy_cols
     if out is None:
         out = _e((M, lw.K), out_dtype, dy.device)
     flags = (L.EPI_MUL_AUX if aux is not None else 0) | (L.EPI_ACCUM if accumulate else 0)
-    ops.gemm_nt(dy, lw.wt, out, M, lw.K, N, lda=dy.stride(0), ldb=lw.wt.stride(0), aux=aux, flags=flags)
+    ops.gemm_nt(dy, lw.wt, out, M, lw.K, N, lda=dy.stride(0), ldb=lw.wt.stride(0), aux=aux, flags=flags, colsum_out=colsum_out)
     return out
 
 
@@ -411,8 +411,7 @@ class EncoderEngine:
             rows, Bc = Ls.rows, Ls.B_after
             # ---- FFN backward
             linear_wgrad(gb, Ls.a, G.get(lyr.fc2.weight), rows)
-            d_u = linear_dgrad(gb, w.fc2, rows, aux=Ls.u)
-            bias_grad(d_u, G.get(lyr.fc1.bias))
+            d_u = linear_dgrad(gb, w.fc2, rows, aux=Ls.u, colsum_out=G.get(lyr.fc1.bias))     # fc1 bias grad = colsum(d_u), fused
             linear_wgrad(d_u, Ls.xln2, G.get(lyr.fc1.weight), rows)
             d_xln2 = linear_dgrad(d_u, w.fc1, rows)
             g2 = _e((rows, D), F32, dev)

@@ -148,8 +148,9 @@ def fddt_ln_bwd(h_in, rows, D, *, mode=MODE_NONE, stno=None, stno_bstride=None, 
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residual=None, ldr=None, aux=None,
-            ldaux=None, flags=0, scale=1.0, scale_ncols=0, batch=1, strideA=0, strideB=0, strideC=0, strideAux=0):
-    """C[M,N] = epilogue(A[M,K] @ B[N,K]^T).  Pointers + leading dimensions; see include/dicow_hip.h."""
+            ldaux=None, flags=0, scale=1.0, scale_ncols=0, batch=1, strideA=0, strideB=0, strideC=0, strideAux=0, colsum_out=None):
+    """C[M,N] = epilogue(A[M,K] @ B[N,K]^T).  Pointers + leading dimensions; see include/dicow_hip.h.
+    colsum_out [N] fp32: += column sums of the result (a bias gradient), fused into the epilogue."""
     a = L.GemmArgs()
     a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
     a.bias, a.residual, a.aux = _p(bias), _p(residual), _p(aux)
@@ -166,6 +167,10 @@ def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, re
         flags |= L.EPI_BIAS
     if residual is not None:
         flags |= L.EPI_RESIDUAL
+    if colsum_out is not None:
+        flags |= L.EPI_COLSUM
+        ws = workspace(L.lib().dicow_gemm_nt_colsum_ws_bytes(M, N), C_out.device)
+        a.colsum_out, a.colsum_ws, a.colsum_ws_bytes = colsum_out.data_ptr(), ws.data_ptr(), ws.numel()
     a.flags, a.scale, a.scale_ncols = flags, scale, scale_ncols
     L.call_struct("dicow_gemm_nt", a)
 
