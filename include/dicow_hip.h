@@ -194,8 +194,12 @@ typedef struct {
     int64_t dq_bs, dq_rs, dk_bs, dk_rs, dv_bs, dv_rs;
     int B, H, Lq, Lk; int causal;
     float dq_scale;                                 /* head_dim^-0.5 folded into dq (gradient of the pre-scale) */
+    /* optional fused bias gradients: dq_colsum[h*64+d] += sum_{b,q} dq (as stored), dv_colsum likewise; NULL = off.
+       cs_ws: dicow_attn_bwd_colsum_ws_bytes(B, H, Lq, Lk) bytes of scratch (per-wave partial rows, reduced afterwards) */
+    float* dq_colsum; float* dv_colsum; void* cs_ws; int64_t cs_ws_bytes;
 } dicow_attn_bwd_args;
 int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream);
+int64_t dicow_attn_bwd_colsum_ws_bytes(int B, int H, int Lq, int Lk);
 
 
 /* ------------------------------------------------------------------------------------------------ loss

@@ -310,10 +310,14 @@ def test_attn_bwd(ops, B, H, Lq, Lk, causal):
     gq = torch.zeros(B, Lq, 3 * D, dtype=torch.bfloat16, device="cuda")
     gk = torch.zeros(B, Lk, 3 * D, dtype=torch.bfloat16, device="cuda")
     delta = torch.empty(2, B, H, Lq, device="cuda")
+    csq, csv = torch.full((D,), 0.25, device="cuda"), torch.full((D,), -0.5, device="cuda")
     ops.attn_bwd(qd, kd, vd, o, dev(d_o, torch.bfloat16), lse, delta,
                  gq[:, :, :D].view(B, Lq, H, 64), gk[:, :, D:2 * D].view(B, Lk, H, 64), gk[:, :, 2 * D:].view(B, Lk, H, 64),
-                 causal=causal, dq_scale=0.5)
+                 causal=causal, dq_scale=0.5, dq_colsum=csq, dv_colsum=csv)
     tol = lambda ref: 2e-2 * max(1.0, float(ref.abs().max()))
+    # fused bias gradients: column sums of exactly the values that were stored (accumulated onto the initial contents)
+    assert maxdiff(csq.cpu(), 0.25 + gq[:, :, :D].float().cpu().double().sum((0, 1))) < 1e-3 * (1 + B * Lq) ** 0.5
+    assert maxdiff(csv.cpu(), -0.5 + gk[:, :, 2 * D:].float().cpu().double().sum((0, 1))) < 1e-3 * (1 + B * Lk) ** 0.5
     assert maxdiff(gq[:, :, :D].float().cpu().view(B, Lq, H, 64), 0.5 * q.grad) < tol(q.grad)
     assert maxdiff(gk[:, :, D:2 * D].float().cpu().view(B, Lk, H, 64), k.grad) < tol(k.grad)
     assert maxdiff(gk[:, :, 2 * D:].float().cpu().view(B, Lk, H, 64), v.grad) < tol(v.grad)

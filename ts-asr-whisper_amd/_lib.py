@@ -53,7 +53,8 @@ class AttnBwdArgs(C.Structure):
                 ("q_bs", c_i64), ("q_rs", c_i64), ("k_bs", c_i64), ("k_rs", c_i64), ("v_bs", c_i64), ("v_rs", c_i64),
                 ("o_bs", c_i64), ("o_rs", c_i64), ("do_bs", c_i64), ("do_rs", c_i64),
                 ("dq_bs", c_i64), ("dq_rs", c_i64), ("dk_bs", c_i64), ("dk_rs", c_i64), ("dv_bs", c_i64), ("dv_rs", c_i64),
-                ("B", c_i), ("H", c_i), ("Lq", c_i), ("Lk", c_i), ("causal", c_i), ("dq_scale", c_f)]
+                ("B", c_i), ("H", c_i), ("Lq", c_i), ("Lk", c_i), ("causal", c_i), ("dq_scale", c_f),
+                ("dq_colsum", c_vp), ("dv_colsum", c_vp), ("cs_ws", c_vp), ("cs_ws_bytes", c_i64)]
 
 
 class CeArgs(C.Structure):
@@ -132,6 +133,7 @@ def lib():
 _SIGS64 = {   # functions returning int64_t (workspace sizes)
     "dicow_colsum_ws_bytes": [c_i, c_i],
     "dicow_gemm_nt_colsum_ws_bytes": [c_i, c_i],
+    "dicow_attn_bwd_colsum_ws_bytes": [c_i, c_i, c_i, c_i],
     "dicow_fddt_ln_bwd_ws_bytes": [c_i, c_i],
     "dicow_gemm_tn_ws_bytes": [C.POINTER(GemmTnArgs)],
     "dicow_logmel_ws_bytes": [c_i, c_i],

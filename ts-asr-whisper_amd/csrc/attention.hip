@@ -96,6 +96,35 @@ __device__ __forceinline__ unsigned tr_base(const char* s, int lane, int dblk) {
     return (unsigned)(uintptr_t)(s + row * 128 + (c << 4) + ((u & 1) << 3));
 }
 
+// Sum over the 32 lanes of each half-wave with DPP (no LDS): quad swaps, half-row / row mirrors, then row_bcast15 into
+// the odd rows; lane 31 ends up with the total of lanes 0-31 and lane 63 with that of lanes 32-63.
+__device__ __forceinline__ float half_wave_sum_dpp(float v) {
+    int x;
+#define DPP_ADD(ctrl, rmask) \
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xf, false); v += __int_as_float(x);
+    DPP_ADD(0xB1, 0xf)    // quad_perm [1,0,3,2]
+    DPP_ADD(0x4E, 0xf)    // quad_perm [2,3,0,1]
+    DPP_ADD(0x141, 0xf)   // row_half_mirror
+    DPP_ADD(0x140, 0xf)   // row_mirror        -> every lane holds its 16-lane row sum
+    DPP_ADD(0x142, 0xa)   // row_bcast15 into rows 1,3
+#undef DPP_ADD
+    return v;
+}
+// Fused bias gradient: column sums of a wave's [32 rows][64 d] output tile (values as stored, rows past the end excluded)
+// -> one partial row of the workspace: ws[row_id][h*64 + d].  vals[d][r]: the MFMA accumulator layout of the epilogues.
+__device__ __forceinline__ void tile_colsum_partial(const f32x16_t (&acc)[2], float scale, bool row_ok, float* ws_row, int lane) {
+    const int hh = lane >> 5;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            // sum the bf16-rounded values that are actually stored (what a separate column-sum pass would read)
+            const float v = row_ok ? bf2f(f2bf(acc[d][r] * scale)) : 0.f;
+            const float t = half_wave_sum_dpp(v);
+            if ((lane & 31) == 31) ws_row[d * 32 + 8 * (r >> 2) + 4 * hh + (r & 3)] = t;
+        }
+}
+
 // ---- split issue / wait forms of the transposing reads: the 8 reads of a 32-row block are issued EARLY (before the
 // MFMAs / softmax that do not depend on them) and waited for right before their first consumer; the wait names the
 // destination registers ("+v") so that no consumer is scheduled above it (cdna_hip_programming.md section 5.7 form (ii)).
@@ -584,6 +613,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    if (a.dq_colsum) {        // q_proj bias gradient, fused: partial row (b, q block, wave) of the first workspace plane
+        const int nqb = (a.Lq + 127) / 128;
+        float* wsr = reinterpret_cast<float*>(a.cs_ws) + ((int64_t)((b * nqb + qblk) * 4 + wave) * a.H + h) * HD;
+        tile_colsum_partial(dq, a.dq_scale, qrow < a.Lq, wsr, lane);
+    }
     if (qrow < a.Lq) {
         unsigned short* DQ = reinterpret_cast<unsigned short*>(a.dq) + (int64_t)b * a.dq_bs + (int64_t)qrow * a.dq_rs + h * HD;
         const float sc = a.dq_scale;
@@ -724,6 +758,12 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    if (a.dv_colsum) {        // v_proj bias gradient, fused: second workspace plane, partial row (b, key block, wave)
+        const int nqb = (a.Lq + 127) / 128, nkb = (a.Lk + 127) / 128;
+        float* wsr = reinterpret_cast<float*>(a.cs_ws) + (int64_t)a.B * nqb * 4 * a.H * HD +
+                     ((int64_t)((b * nkb + kblk) * 4 + wave) * a.H + h) * HD;
+        tile_colsum_partial(dv, 1.0f, key < a.Lk, wsr, lane);
+    }
     if (key < a.Lk) {
         unsigned short* DK = reinterpret_cast<unsigned short*>(a.dk) + (int64_t)b * a.dk_bs + (int64_t)key * a.dk_rs + h * HD;
         unsigned short* DV = reinterpret_cast<unsigned short*>(a.dv) + (int64_t)b * a.dv_bs + (int64_t)key * a.dv_rs + h * HD;
@@ -740,7 +780,14 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
     }
 }
 
+extern "C" int64_t dicow_attn_bwd_colsum_ws_bytes(int B, int H, int Lq, int Lk) {
+    return (int64_t)B * (dicow_cdiv(Lq, 128) + dicow_cdiv(Lk, 128)) * 4 * H * HD * 4;
+}
+
 extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
+    DICOW_REQUIRE(!(a && (a->dq_colsum || a->dv_colsum)) ||
+                  (a->cs_ws && a->cs_ws_bytes >= dicow_attn_bwd_colsum_ws_bytes(a->B, a->H, a->Lq, a->Lk)),
+                  "attn_bwd: fused column sums need cs_ws of dicow_attn_bwd_colsum_ws_bytes() bytes");
     DICOW_REQUIRE(a && a->q && a->k && a->v && a->o && a->d_o && a->lse && a->delta && a->dq && a->dk && a->dv,
                   "attn_bwd: null operand");
     DICOW_REQUIRE(a->B > 0 && a->H > 0 && a->Lq > 0 && a->Lk > 0, "attn_bwd: empty problem");
@@ -758,5 +805,14 @@ extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
     DICOW_CHECK_LAUNCH("attn_bwd_dq");
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(dicow_cdiv(a->Lk, 128) * a->H * a->B), dim3(256), 0, st, *a);
     DICOW_CHECK_LAUNCH("attn_bwd_dkv");
+    if (a->dq_colsum || a->dv_colsum) {               // add the per-wave partial rows up (no atomics)
+        const int64_t D = (int64_t)a->H * HD;
+        const int rq = a->B * dicow_cdiv(a->Lq, 128) * 4, rk = a->B * dicow_cdiv(a->Lk, 128) * 4;
+        const float* ws = reinterpret_cast<const float*>(a->cs_ws);
+        int rc = DICOW_OK;
+        if (a->dq_colsum) rc = dicow_launch_reduce_parts(ws, rq, D, a->dq_colsum, D, st);
+        if (rc == DICOW_OK && a->dv_colsum) rc = dicow_launch_reduce_parts(ws + (int64_t)rq * D, rk, D, a->dv_colsum, D, st);
+        return rc;
+    }
     return DICOW_OK;
 }

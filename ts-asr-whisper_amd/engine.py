@@ -429,9 +429,8 @@ class EncoderEngine:
             qkv = Ls.qkv
             ops.attn_bwd(heads(qkv[:, :D], Bc, T, H), heads(qkv[:, D:2 * D], Bc, T, H), heads(qkv[:, 2 * D:], Bc, T, H),
                          heads(Ls.o, Bc, T, H), heads(d_o, Bc, T, H), Ls.lse, delta, heads(d_qkv[:, :D], Bc, T, H),
-                         heads(d_qkv[:, D:2 * D], Bc, T, H), heads(d_qkv[:, 2 * D:], Bc, T, H), dq_scale=0.125)
-            bias_grad(d_qkv[:, :D], G.get(att.q_proj.bias))
-            bias_grad(d_qkv[:, 2 * D:], G.get(att.v_proj.bias))
+                         heads(d_qkv[:, D:2 * D], Bc, T, H), heads(d_qkv[:, 2 * D:], Bc, T, H), dq_scale=0.125,
+                         dq_colsum=G.get(att.q_proj.bias), dv_colsum=G.get(att.v_proj.bias))   # q / v bias grads, fused
             qkv_wgrad(d_qkv, Ls.xln, G.get(att.q_proj.weight), G.get(att.k_proj.weight), G.get(att.v_proj.weight), rows, D)
             d_xln = linear_dgrad(d_qkv, w.att.qkv, rows)
             # ---- LayerNorm1 (+ SCB) + FDDT backward; the column sum of the result is the previous fc2's bias grad

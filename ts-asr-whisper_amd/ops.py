@@ -218,7 +218,7 @@ def attn_fwd(q, k, v, o, lse=None, causal=False):
     L.call_struct("dicow_attn_fwd", a)
 
 
-def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0):
+def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0, dq_colsum=None, dv_colsum=None):
     """Backward of attn_fwd.  All [B,L,H,64] bf16 views; lse [B,H,Lq] fp32; delta = workspace [2,B,H,Lq] fp32."""
     assert delta.numel() >= 2 * lse.numel(), "attn_bwd: delta workspace must hold 2*B*H*Lq floats"
     a = L.AttnBwdArgs()
@@ -235,6 +235,9 @@ def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0
     a.dv_bs, a.dv_rs = _bs_rs(dv, "dv")
     a.B, a.Lq, a.H = q.shape[0], q.shape[1], q.shape[2]
     a.Lk, a.causal, a.dq_scale = k.shape[1], int(causal), dq_scale
+    if dq_colsum is not None or dv_colsum is not None:       # fused q / v bias gradients ([H*64] fp32, accumulated)
+        ws = workspace(L.lib().dicow_attn_bwd_colsum_ws_bytes(a.B, a.H, a.Lq, a.Lk), q.device)
+        a.dq_colsum, a.dv_colsum, a.cs_ws, a.cs_ws_bytes = _p(dq_colsum), _p(dv_colsum), ws.data_ptr(), ws.numel()
     L.call_struct("dicow_attn_bwd", a)
 
 
