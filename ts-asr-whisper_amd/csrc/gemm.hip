@@ -367,7 +367,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_arg
 // for gemm_nt_kernel -- the quarter tiles quantise again (two resident per CU, each at half speed): 0.34 -> 0.40 ms.)
 // (Tried and dropped: running only the whole rounds here and cutting the partial last round into 128x128 quarter tiles
 // for gemm_nt_kernel -- the quarter tiles quantise again (two resident per CU, each at half speed): 0.34 -> 0.40 ms.
-// Unrolling the k-loop by two to make the LDS stage an immediate (12 -> 4 VALU adds per step): 2-4 % slower.)
+// Unrolling the k-loop by two to make the LDS stage an immediate (12 -> 4 VALU adds per step): 2-4 % slower.
+// A dynamic per-XCD tile queue (one returning atomic per tile, fetched three k-steps ahead) against the 5-20 % CU-to-CU
+// spread: 12-25 % slower -- the device-scope atomic's round trip sits in the k-loop's vmcnt(0) wait.)
 // (Tried and dropped: a 4-byte-per-lane "L2 warm-up" DMA for the k-slab two steps ahead, with the step barrier waiting
 // on vmcnt(2) instead of 0 -- 1-4 % slower; the two extra VMEM issues per step cost more than the HBM misses they hide.)
 //
