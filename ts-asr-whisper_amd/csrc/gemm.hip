@@ -1172,6 +1172,9 @@ __device__ __forceinline__ void tn256_mfma(f32x16_t (&acc)[2][4], const tn256_fr
         for (int i = 0; i < 2; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f2[i], f1[j], acc[i][j], 0, 0, 0);
 }
 
+// (Tried and dropped: the 4-wave / 128x128-wave-tile / AGPR form that pays off for the NT kernel.  Here every MFMA operand
+// comes from ds_read_b64_tr_b16 -- 16 LDS instructions per 16 MFMAs instead of 8 -- and a single wave per SIMD cannot hide
+// their issue: 0.78 PF with batched reads, 0.73 PF with reads threaded between groups of 4 MFMAs, against 0.82 PF here.)
 __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_args a, int tiles_per_batch, int total_tiles,
                                                             int tiles_per_split) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
