@@ -393,8 +393,159 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, LDS-staged rows
+// The FDDT(diag)+LayerNorm backward of every encoder layer (fp32 h_in, bf16 d_y, fp32 g_res; mode 1, no pos).  Same column-
+// owner arithmetic as fddt_ln_bwd_kernel, but the rows of trip t+1 are fetched by LDS-DMA (buffer_load ... lds) while trip
+// t is computed: the bytes in flight no longer live in VGPRs, which is what capped the generic body at two workgroups of
+// 2 rows per CU (2.0 TB/s, latency-bound).  Every lane reads back exactly the LDS bytes its own wave's DMA wrote (h_in /
+// g_res: its own 16 B; d_y: the wave's 512 B segment, fetched by lanes 0-31), so the wave's counted vmcnt wait is the
+// only synchronisation the staging needs -- no extra barrier.  Stores go through a buffer descriptor too (rows past the
+// end are dropped by num_records), so the number of VMEM operations per trip is fixed and the wait can be counted.
+typedef __attribute__((address_space(3))) void lds_void_t;
+template <int R, bool OUT_BF16>
+__global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fddt_ln_bwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) char stg[];       // [2 stages][R rows][10*D bytes]: h_in | g_res | d_y
+    __shared__ float red[2][MAX_WAVES * 2 * R];
+    const int tid = threadIdx.x, lane = tid & 63, col = tid * 4, D = a.D;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const float4 zero = make_float4(0, 0, 0, 0);
+    float4 w[4], b[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { w[c] = ld4(a.w[c] + col); b[c] = ld4(a.b[c] + col); }
+    const float4 lnw = ld4(a.ln_w + col);
+    const float inv_d = 1.0f / (float)D;
+    float4 acc_lnw = zero, acc_lnb = zero, acc_cs = zero, acc_dw[4], acc_db[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { acc_dw[c] = zero; acc_db[c] = zero; }
+
+    const unsigned nb32 = (unsigned)((int64_t)a.rows * D * 4), nb16 = (unsigned)((int64_t)a.rows * D * 2);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.h_in), 0, nb32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsG = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.g_res), 0, nb32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.d_y), 0, nb16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.g_out, 0, nb32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(OUT_BF16 ? a.g_out_bf16 : (void*)a.g_out, 0, OUT_BF16 ? nb16 : nb32, 0x00020000);
+    const unsigned vo32 = (unsigned)(col * 4);                       // this lane's 16 B of an fp32 row
+    const unsigned voY = (unsigned)(wave * 512 + (lane & 31) * 16);  // lanes 0-31: the wave's 512 B of a bf16 row
+    const int row_lds = 10 * D;
+    auto stage_rows = [&](int row0, int s) {                         // 3 DMA instructions per row and wave
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            char* base = stg + (s * R + r) * row_lds;
+            const int so32 = (row0 + r) * D * 4, so16 = (row0 + r) * D * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (lds_void_t*)(base + wave * 1024), 16, vo32, so32, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_void_t*)(base + 4 * D + wave * 1024), 16, vo32, so32, 0, 0);
+            if (lane < 32 && (int)voY < 2 * D)       // (a last, partly filled wave: only the lanes inside the row)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void_t*)(base + 8 * D + wave * 512), 16, voY, so16, 0, 0);
+        }
+    };
+    // per-row scalars (mean, rstd, 4 STNO masks) of a trip are ordinary loads: they are requested one trip ahead, BEFORE
+    // that trip's DMA, so that waiting for them never drags a younger DMA along (vmcnt retires in order)
+    float sc_n[R][6];
+    auto load_scalars = [&](int row0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int row = row0 + r; row = row < a.rows ? row : a.rows - 1;
+            const int bi = row / a.T, t = row - bi * a.T;
+            const float* mp = a.stno + (int64_t)bi * a.stno_bstride + t;
+            sc_n[r][0] = a.mean[row]; sc_n[r][1] = a.rstd[row];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sc_n[r][2 + c] = mp[(int64_t)c * a.T];
+        }
+    };
+    const int stride = gridDim.x * R;
+    int row0 = blockIdx.x * R, it = 0;
+    if (row0 < a.rows) { load_scalars(row0); stage_rows(row0, 0); }
+    for (; row0 < a.rows; row0 += stride, ++it) {
+        const int s = it & 1;
+        float sc[R][6];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) sc[r][c] = sc_n[r][c];
+        load_scalars(row0 + stride);
+        stage_rows(row0 + stride, s ^ 1);                            // (past the end: out-of-range rows read as zero)
+        // younger than this trip's DMA: the previous trip's stores, the scalars and the DMA just issued -- fixed counts
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(9 * R) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((OUT_BF16 ? 11 : 10) * R) : "memory");
+        float4 hin[R], xh[R], dy[R], scw[R];
+        float m[R][4], rs[R], sums[2 * R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            const bool rok = row < a.rows;
+            const char* base = stg + (s * R + r) * row_lds;
+            hin[r] = *reinterpret_cast<const float4*>(base + tid * 16);
+            const uint2 uy = *reinterpret_cast<const uint2*>(base + 8 * D + tid * 8);
+            dy[r] = make_float4(__uint_as_float(uy.x << 16), __uint_as_float(uy.x & 0xffff0000u),
+                                __uint_as_float(uy.y << 16), __uint_as_float(uy.y & 0xffff0000u));
+            const float mu = rok ? sc[r][0] : 0.f;
+            rs[r] = rok ? sc[r][1] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)      // row-indexed, identical in every lane: scalar registers
+                m[r][c] = rok ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sc[r][2 + c]))) : 0.f;
+            float4 sw = zero, sb = zero;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float mc = m[r][c];
+                sw.x += mc * w[c].x; sw.y += mc * w[c].y; sw.z += mc * w[c].z; sw.w += mc * w[c].w;
+                sb.x += mc * b[c].x; sb.y += mc * b[c].y; sb.z += mc * b[c].z; sb.w += mc * b[c].w;
+            }
+            scw[r] = sw;
+            const float4 x = make_float4(hin[r].x * sw.x + sb.x, hin[r].y * sw.y + sb.y, hin[r].z * sw.z + sb.z, hin[r].w * sw.w + sb.w);
+            xh[r] = make_float4((x.x - mu) * rs[r], (x.y - mu) * rs[r], (x.z - mu) * rs[r], (x.w - mu) * rs[r]);
+            const float4 dxh = make_float4(dy[r].x * lnw.x, dy[r].y * lnw.y, dy[r].z * lnw.z, dy[r].w * lnw.w);
+            sums[2 * r] = (dxh.x + dxh.y) + (dxh.z + dxh.w);
+            sums[2 * r + 1] = (dxh.x * xh[r].x + dxh.y * xh[r].y) + (dxh.z * xh[r].z + dxh.w * xh[r].w);
+        }
+        block_sum<2 * R>(sums, red[it & 1], nwaves);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const char* base = stg + (s * R + r) * row_lds;
+            float4 g = *reinterpret_cast<const float4*>(base + 4 * D + tid * 16);
+            const float c1 = sums[2 * r] * inv_d, c2 = sums[2 * r + 1] * inv_d;
+            g.x += rs[r] * (dy[r].x * lnw.x - c1 - xh[r].x * c2);
+            g.y += rs[r] * (dy[r].y * lnw.y - c1 - xh[r].y * c2);
+            g.z += rs[r] * (dy[r].z * lnw.z - c1 - xh[r].z * c2);
+            g.w += rs[r] * (dy[r].w * lnw.w - c1 - xh[r].w * c2);
+            F4_FMA(acc_lnw, dy[r], xh[r]);
+            F4_ADD(acc_lnb, dy[r]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float mc = m[r][c];
+                const float4 mg = make_float4(mc * g.x, mc * g.y, mc * g.z, mc * g.w);
+                F4_FMA(acc_dw[c], mg, hin[r]);
+                F4_ADD(acc_db[c], mg);
+            }
+            const float4 g0 = make_float4(g.x * scw[r].x, g.y * scw[r].y, g.z * scw[r].z, g.w * scw[r].w);
+            F4_ADD(acc_cs, g0);
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+            const int so32 = (row0 + r) * D * 4;
+            const u32x4_t ov = {__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g0.z), __float_as_uint(g0.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rsO, vo32, so32, 0);
+            if (OUT_BF16) {
+                const u32x2_t bv = {pack_bf16x2(g0.x, g0.y), pack_bf16x2(g0.z, g0.w)};
+                __builtin_amdgcn_raw_buffer_store_b64(bv, rsB, (unsigned)(col * 2), (row0 + r) * D * 2, 0);
+            }
+        }
+    }
+    // per-workgroup partial column sums -> workspace [block][11][D]
+    float* part = reinterpret_cast<float*>(a.ws) + (int64_t)blockIdx.x * 11 * D + col;
+    if (a.dln_w) st4(part + 0 * D, acc_lnw);
+    if (a.dln_b) st4(part + 1 * D, acc_lnb);
+    if (a.colsum_out) st4(part + 2 * D, acc_cs);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (a.dw[c]) st4(part + (3 + c) * D, acc_dw[c]);
+        if (a.db[c]) st4(part + (7 + c) * D, acc_db[c]);
+    }
+}
+
 #define BWD_R0 2          // rows per trip and resident workgroups per CU of the LayerNorm-only (mode 0) body
 #define BWD_CU0 4
+#define BWD_RS 2          // rows per trip / resident workgroups per CU of the LDS-staged FDDT(diag)+LN body
+#define BWD_CUS 2
 static int bwd_grid(int rows, int D, int per_cu) {
     const int block = ((D / 4) + 63) / 64 * 64;
     int grid = (rows + 3) / 4;
@@ -414,7 +565,11 @@ extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) 
     const int block = pick_block(a->D);
     static const int r_env = getenv("DICOW_ROW_R") ? atoi(getenv("DICOW_ROW_R")) : 0;       // tuning knob: 0 = auto, 9 = generic body
     const bool ln0 = block <= 512 && r_env != 9 && a->mode == 0 && a->ln_w;
-    const int grid = bwd_grid(a->rows, a->D, ln0 ? BWD_CU0 : 2);
+    // LDS-staged body: the encoder-layer shape (every FDDT vector present, fp32 in, bf16 d_y, residual gradient, no pos)
+    const bool staged = block <= 512 && block * 4 == a->D && a->D % 8 == 0 && r_env != 9 && r_env != 8 && a->mode == 1 && a->ln_w && !a->in_bf16 &&
+                        !a->dy_f32 && a->g_res && a->g_out && !a->pos && a->w[0] && a->w[1] && a->w[2] && a->w[3] &&
+                        a->b[0] && a->b[1] && a->b[2] && a->b[3] && (int64_t)a->rows * a->D * 4 < (1ll << 31);
+    const int grid = bwd_grid(a->rows, a->D, ln0 ? BWD_CU0 : staged ? BWD_CUS : 2);
     const int D = a->D;
     float* outs[11] = {a->ln_w ? a->dln_w : nullptr, a->ln_w ? a->dln_b : nullptr, a->colsum_out,
                        a->mode == 1 ? a->dw[0] : nullptr, a->mode == 1 ? a->dw[1] : nullptr, a->mode == 1 ? a->dw[2] : nullptr,
@@ -429,6 +584,10 @@ extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) 
         hipLaunchKernelGGL((fddt_ln_bwd_kernel<2, 1024>), dim3(grid), dim3(block), 0, st, *a);
     else if (r_env == 9)                                                                    // generic body (ablation)
         hipLaunchKernelGGL((fddt_ln_bwd_kernel<2, 512>), dim3(grid), dim3(block), 0, st, *a);
+    else if (staged && a->g_out_bf16)
+        hipLaunchKernelGGL((fddt_ln_bwd_staged_kernel<BWD_RS, true>), dim3(grid), dim3(block), 2 * BWD_RS * 10 * a->D, st, *a);
+    else if (staged)
+        hipLaunchKernelGGL((fddt_ln_bwd_staged_kernel<BWD_RS, false>), dim3(grid), dim3(block), 2 * BWD_RS * 10 * a->D, st, *a);
     else if (ln0)
         hipLaunchKernelGGL((fddt_ln_bwd_kernel<BWD_R0, 512, 0, 1>), dim3(grid), dim3(block), 0, st, *a);
     else
