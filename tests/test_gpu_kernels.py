@@ -147,6 +147,19 @@ def test_gemm_nt_plain(ops, M, N, K):
     assert maxdiff(Cb.float().cpu(), ref) < 1e-2 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("R,C,ld,ld_t", [(1280, 1280, None, None), (3840, 1280, None, None), (200, 136, 144, 208), (77, 130, None, None)])
+def test_cast_transpose(ops, R, C, ld, ld_t):
+    """AMP weight copies: bf16 [R,C] and bf16 [C,R] of an fp32 matrix (vectorised kernel and the scalar fallback)."""
+    g = torch.Generator().manual_seed(R + C)
+    w = torch.randn(R, C, generator=g)
+    out = torch.zeros(R, ld or C, dtype=torch.bfloat16, device="cuda")
+    out_t = torch.zeros(C, ld_t or R, dtype=torch.bfloat16, device="cuda")
+    ops.cast_transpose_bf16(dev(w), out, out_t, ld=ld, ld_t=ld_t)
+    ref = w.to(torch.bfloat16)
+    assert torch.equal(out[:, :C].cpu(), ref) and torch.equal(out_t[:, :R].cpu(), ref.t())
+    if ld: assert float(out[:, C:].float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("M,N,K", [(300, 256, 192), (6100, 2244, 128)])     # 128x128 tiles / persistent 256x256 kernel
 def test_gemm_nt_epilogues(ops, M, N, K):
     from ts_asr_whisper_amd import _lib as L
