@@ -136,7 +136,7 @@ def pmc_traffic():
             d = json.load(f)
         tot = n = 0
         for k, v in d.items():
-            if k.startswith("gemm_nt256w") and v.get("hbm_read_bytes_per_launch_corrected") is not None:
+            if k.startswith(("gemm_nt256w", "gemm_ntw")) and v.get("hbm_read_bytes_per_launch_corrected") is not None:
                 tot += (v["hbm_read_bytes_per_launch_corrected"] + (v.get("hbm_write_bytes_per_launch") or 0)) * v["launches"]
                 n += v["launches"]
         return round(tot / n) if n else None
@@ -217,7 +217,7 @@ def main():
                                f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}{', CTC 0.3' if a.ctc else ''}",
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "trainable_params": ts.store.n_trainable},
         "loss": float(loss),
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt256w_kernel / gemm_nt_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_ntw_kernel (persistent 256x256 / 192x320) / gemm_nt_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
                      "achieved": round(nt["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(nt["tflops"] / peak, 4),
                      "traffic": pmc_traffic(), "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // a.steps,
                      "share_of_step": round(nt["total_ms"] / (dt * 1e3), 3),

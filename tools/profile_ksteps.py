@@ -1,5 +1,5 @@
 """Diagnostic: per-workgroup timeline of the 4-wave NT kernel (DICOW_HIP_LIB=<libdicow_hip.so built with -DNTW_PROFILE>).
-   DICOW_NT_VARIANT=11 python tools/profile_ksteps.py M N K"""
+   python tools/profile_ksteps.py M N K"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -354,24 +354,28 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_arg
     }
 }
 
-// ------------------------------------------------------------------------------------------------ NT, 256x256, 4 waves
-// Same 256x256x64 stage image as gemm_nt256_kernel, but ONE wave per SIMD (256 threads), each owning a 128x128
-// output quadrant: 16 accumulator blocks = 256 registers (the unified 512-entry file lets them live in AGPRs).
-// Why: the 8-wave kernel is LDS-bandwidth co-critical -- per 16-deep slice a wave reads 6 fragments for 8 MFMAs, i.e.
-// per k-step the CU moves 192 KiB of fragments + 64 KiB of DMA = 2048 LDS clocks against 2048 MFMA clocks.  A 128x128
-// wave tile reads 8 fragments for 16 MFMAs (128 + 64 KiB = 1536 clocks), leaving the matrix pipe as the only
+// ------------------------------------------------------------------------------------------------ NT, persistent, 4 waves
+// Same 64 KiB stage budget as gemm_nt256_kernel ((BM + BN) = 512 rows x 128 B), but ONE wave per SIMD (256 threads), each
+// owning a (NJ*32) x (NI*32) quadrant of the BM x BN = (2*NJ*32) x (2*NI*32) output tile; the accumulator blocks
+// (16 for 128x128, 15 for 96x160) live in AGPRs (unified 512-entry file).
+// Why one wave per SIMD: the 8-wave kernel is LDS-bandwidth co-critical -- per 16-deep slice a wave reads 6 fragments for
+// 8 MFMAs, i.e. per k-step the CU moves 192 KiB of fragments + 64 KiB of DMA = 2048 LDS clocks against 2048 MFMA clocks.
+// A 128x128 wave tile reads 8 fragments for 16 MFMAs (128 + 64 KiB = 1536 clocks), leaving the matrix pipe as the only
 // saturated resource.  With a single wave per SIMD nothing hides latency for us, so the instruction stream is laid
 // out by hand: every MFMA is followed by one LDS read (next slice) or one DMA instruction (next k-tile).
+// Why two tile shapes: tail quantisation.  M = 24000 rows are 93.75 tiles of 256 -- 470 / 1410 / 1880 tiles for
+// N = 1280 / 3840 / 5120, i.e. 1.84 / 5.5 / 7.3 rounds of 256 workgroups: 8 % of every big GEMM is a partial last round.
+// 192 x 320 tiles (NJ, NI = 3, 5) cut the same problems into 500 / 1500 / 2000 tiles = 1.95 / 5.86 / 7.81 rounds (2.3 %
+// idle); dicow_gemm_nt picks the shape with the smaller padded work.
 //
-// (Tried and dropped: running only the whole rounds here and cutting the partial last round into 128x128 quarter tiles
-// for gemm_nt_kernel -- the quarter tiles quantise again (two resident per CU, each at half speed): 0.34 -> 0.40 ms.)
 // (Tried and dropped: running only the whole rounds here and cutting the partial last round into 128x128 quarter tiles
 // for gemm_nt_kernel -- the quarter tiles quantise again (two resident per CU, each at half speed): 0.34 -> 0.40 ms.
 // Unrolling the k-loop by two to make the LDS stage an immediate (12 -> 4 VALU adds per step): 2-4 % slower.
 // A dynamic per-XCD tile queue (one returning atomic per tile, fetched three k-steps ahead) against the 5-20 % CU-to-CU
-// spread: 12-25 % slower -- the device-scope atomic's round trip sits in the k-loop's vmcnt(0) wait.)
-// (Tried and dropped: a 4-byte-per-lane "L2 warm-up" DMA for the k-slab two steps ahead, with the step barrier waiting
-// on vmcnt(2) instead of 0 -- 1-4 % slower; the two extra VMEM issues per step cost more than the HBM misses they hide.)
+// spread: 12-25 % slower -- the device-scope atomic's round trip sits in the k-loop's vmcnt(0) wait.
+// A 4-byte-per-lane "L2 warm-up" DMA for the k-slab two steps ahead, with the step barrier waiting on vmcnt(2) instead
+// of 0: 1-4 % slower; the two extra VMEM issues per step cost more than the HBM misses they hide.
+// Stores straight from the MFMA layout (32 rows x 16 B per instruction) instead of the LDS transpose: 10 % slower.)
 //
 // The kernel is PERSISTENT: one workgroup per CU walks the tile list (virtual block id v = blockIdx.x + round *
 // gridDim.x through the same XCD-aware id -> tile map, so the tiles in flight are the same L2-friendly set).  A
@@ -380,135 +384,133 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_arg
 //   * the first-stage DMA of the NEXT tile is issued before the epilogue of the current one;
 //   * the epilogue sends the accumulators through LDS (the stage that was read last) so every store instruction covers
 //     2 rows x 256/512 contiguous bytes instead of 32 rows x 16 B (residual / aux reads likewise).
-__device__ __forceinline__ void ntw_stage_part(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
-                                               int64_t lda, int64_t ldb, int M, int N, int m0, int n0, int k0, char* sA,
-                                               char* sB, int lane, int q) {
-    const int rr = lane >> 3, p = lane & 7;
-    const int row = q * 8 + rr;
-    const int c = p ^ ((row >> 1) & 7);
-    int gm = m0 + row; gm = gm < M ? gm : M - 1;
-    int gn = n0 + row; gn = gn < N ? gn : N - 1;
-    glds16(A + (int64_t)gm * lda + k0 + c * 8, sA + q * 1024);
-    glds16(B + (int64_t)gn * ldb + k0 + c * 8, sB + q * 1024);
-}
+#define NTW_LDS (NT256_LDS + 2048)         // two stages + the tile's bias row (up to 320 floats)
 
-#define NTW_LDS (NT256_LDS + 1024)         // two stages + the tile's bias row
-
-template <int FLAGS, int EPI = 1>   // EPI 1: accumulators -> LDS -> row-contiguous stores; 0: stores straight from the MFMA layout
-__global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args a) {
+template <int FLAGS, int NJ, int NI>
+__global__ void __launch_bounds__(256) gemm_ntw_kernel(const dicow_gemm_args a) {
+    static_assert(NJ + NI == 8 && NI >= 4 && NI <= 5, "stage image is (BM + BN) = 512 rows; the epilogue handles 4 or 5 column blocks");
+    constexpr int BMT = 2 * NJ * 32, BNT = 2 * NI * 32;              // output tile
+    constexpr int WMR = NJ * 32, WNC = NI * 32;                      // wave quadrant
+    constexpr int NDA = 2 * NJ, NDB = 2 * NI;                        // DMA instructions (8 rows x 128 B) per wave and k-step
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256;
+    const int ntm = (a.M + BMT - 1) / BMT, ntn = (a.N + BNT - 1) / BNT;
     const int nwg = ntm * ntn, total = nwg * (a.batch > 0 ? a.batch : 1);
-    const int wm = wave >> 1, wn = wave & 1;          // wave tile: rows m [wm*128, +128), cols n [wn*128, +128)
+    const int wm = wave >> 1, wn = wave & 1;          // wave quadrant: rows m [wm*WMR, +WMR), cols n [wn*WNC, +WNC)
     const int nk = a.K / BK;
     const int flags = a.flags;
     constexpr bool LDS_BIAS = FLAGS >= 0 && (FLAGS & DICOW_EPI_BIAS) != 0;
-    float* sbias = reinterpret_cast<float*>(smem + NT256_LDS);       // the tile's 256 bias values (compile-time-flag kernels)
+    float* sbias = reinterpret_cast<float*>(smem + NT256_LDS);       // the tile's BNT bias values (compile-time-flag kernels)
 
     int v = blockIdx.x;
     int bz = v / nwg, tm, tn;
     tile_coords_id(ntm, ntn, v - bz * nwg, tm, tn);
-    int m0 = tm * 256, n0 = tn * 256;
+    int m0 = tm * BMT, n0 = tn * BNT;
     const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
     const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
     int par = 0;                                      // stage holding k-tile 0 of the current output tile
     // DMA source = buffer descriptor (operand base) + scalar k offset + per-lane 32-bit byte offset (row * ld + swizzled chunk),
     // the offsets being computed once per output tile: plain VALU instructions share the SIMD's issue port with the MFMAs
     // (tools/probe_overlap.hip), and the 16 64-bit address adds per k-step of the pointer form cost ~6 % of the loop.
-    unsigned offA[8], offB[8];
+    // Instruction d < NDA of a wave moves row group wave*NDA + d of the A image, d >= NDA row group wave*NDB + d - NDA of B.
+    unsigned off[16];
 #define NTW_OFFSETS()                                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                          \
-        const int q_ = wave * 8 + i, row_ = q_ * 8 + (lane >> 3), c_ = (lane & 7) ^ ((row_ >> 1) & 7);      \
-        int gm_ = m0 + row_; gm_ = gm_ < a.M ? gm_ : a.M - 1;                                                \
-        int gn_ = n0 + row_; gn_ = gn_ < a.N ? gn_ : a.N - 1;                                                \
-        offA[i] = (unsigned)(((int64_t)gm_ * a.lda + c_ * 8) * 2);                                           \
-        offB[i] = (unsigned)(((int64_t)gn_ * a.ldb + c_ * 8) * 2);                                           \
+    _Pragma("unroll") for (int d = 0; d < 16; ++d) {                                                         \
+        const int q_ = d < NDA ? wave * NDA + d : wave * NDB + d - NDA;                                      \
+        const int row_ = q_ * 8 + (lane >> 3), c_ = (lane & 7) ^ ((row_ >> 1) & 7);                          \
+        if (d < NDA) { int g_ = m0 + row_; g_ = g_ < a.M ? g_ : a.M - 1; off[d] = (unsigned)(((int64_t)g_ * a.lda + c_ * 8) * 2); } \
+        else { int g_ = n0 + row_; g_ = g_ < a.N ? g_ : a.N - 1; off[d] = (unsigned)(((int64_t)g_ * a.ldb + c_ * 8) * 2); } \
     }
 #define NTW_RSRC()                                                                                           \
     rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, 0xffffffffu, 0x00020000);      \
     rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(B), 0, 0xffffffffu, 0x00020000);
-#define NTW_DMA(I, K0, SA)                                                                                   \
-    { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)((SA) + (wave * 8 + (I)) * 1024), 16, offA[I], (K0) * 2, 0, 0);             \
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)((SA) + 256 * 128 + (wave * 8 + (I)) * 1024), 16, offB[I], (K0) * 2, 0, 0); }
+#define NTW_DMA(D, K0, SA)                                                                                   \
+    { if ((D) < NDA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)((SA) + (wave * NDA + (D)) * 1024), 16, off[D], (K0) * 2, 0, 0); \
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)((SA) + BMT * 128 + (wave * NDB + (D) - NDA) * 1024), 16, off[D], (K0) * 2, 0, 0); }
     __amdgpu_buffer_rsrc_t rsA, rsB;
     NTW_RSRC()
     NTW_OFFSETS()
 #pragma unroll
-    for (int i = 0; i < 8; ++i) NTW_DMA(i, 0, smem)
+    for (int d = 0; d < 16; ++d) NTW_DMA(d, 0, smem)
 
     while (true) {
-        f32x16_t acc[4][4];                           // [n block i][m block j]
+        f32x16_t acc[NI][NJ];                         // [n block i][m block j]
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NJ; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-        bf16x8_t wf0[4], xf0[4], wf1[4], xf1[4];
+        bf16x8_t wf0[NI], xf0[NJ], wf1[NI], xf1[NJ];
 #define LDFRAG(WF, XF, KK)                                                                                   \
     {                                                                                                        \
         const int c_ = (KK) * 2 + (lane >> 5);                                                               \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) WF[i] = lds_frag_nt(sB, wn * 128 + i * 32 + (lane & 31), c_); \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) XF[j] = lds_frag_nt(sA, wm * 128 + j * 32 + (lane & 31), c_); \
+        _Pragma("unroll") for (int i = 0; i < NI; ++i) WF[i] = lds_frag_nt(sB, wn * WNC + i * 32 + (lane & 31), c_); \
+        _Pragma("unroll") for (int j = 0; j < NJ; ++j) XF[j] = lds_frag_nt(sA, wm * WMR + j * 32 + (lane & 31), c_); \
     }
 #define DOMFMA(WF, XF)                                                                                       \
-    { _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < 4; ++i)            \
+    { _Pragma("unroll") for (int j = 0; j < NJ; ++j) _Pragma("unroll") for (int i = 0; i < NI; ++i)          \
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0); }
-#define DMA4(I0) if (MORE) { _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) NTW_DMA((I0) + i_, (t + 1) * BK, nA) }
-    // one slice: 16 MFMA with NR LDS reads and ND DMA instructions threaded between them (one per MFMA)
+#define DMA8(D0) if (MORE) { _Pragma("unroll") for (int d_ = 0; d_ < 8; ++d_) NTW_DMA((D0) + d_, (t + 1) * BK, nA) }
+    // one slice: NJ*NI MFMAs with NR LDS reads and ND DMA instructions threaded between them (one per MFMA while they last)
 #define SCHED(NR, ND)                                                                                        \
     _Pragma("unroll") for (int s_ = 0; s_ < (NR); ++s_) {                                                    \
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
     _Pragma("unroll") for (int s_ = 0; s_ < (ND); ++s_) {                                                    \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); } \
-    __builtin_amdgcn_sched_group_barrier(0x008, 16 - (NR) - (ND), 0);
+        if ((NR) + s_ < NJ * NI) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }                                                 \
+    if (NJ * NI - (NR) - (ND) > 0) __builtin_amdgcn_sched_group_barrier(0x008, NJ * NI - (NR) - (ND), 0);
 #define KSTEP(MORE_, FIRST_)                                                                                 \
     {                                                                                                        \
         constexpr bool MORE = MORE_;                                                                         \
         char* sA = smem + ((t + par) & 1) * NT256_STAGE;                                                     \
-        char* sB = sA + 256 * 128;                                                                           \
+        char* sB = sA + BMT * 128;                                                                           \
         char* nA = smem + ((t + par + 1) & 1) * NT256_STAGE;                                                 \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
         __builtin_amdgcn_s_barrier();                                                                        \
         asm volatile("" ::: "memory");                                                                       \
-        LDFRAG(wf0, xf0, 0) DMA4(0)                                                                          \
+        LDFRAG(wf0, xf0, 0) DMA8(0)                                                                          \
         if (!(FIRST_)) { DOMFMA(wf1, xf1) SCHED(8, MORE ? 8 : 0) }                                           \
-        LDFRAG(wf1, xf1, 1) DMA4(4) DOMFMA(wf0, xf0) SCHED(8, MORE ? 8 : 0)                                  \
+        LDFRAG(wf1, xf1, 1) DMA8(8) DOMFMA(wf0, xf0) SCHED(8, MORE ? 8 : 0)                                  \
         LDFRAG(wf0, xf0, 2) DOMFMA(wf1, xf1) SCHED(8, 0)                                                     \
         LDFRAG(wf1, xf1, 3) DOMFMA(wf0, xf0) SCHED(8, 0)                                                     \
     }
 #ifdef NTW_PROFILE
         const long long pc0 = clock64(), pw0 = wall_clock64();
 #endif
-        // bias of this tile's 256 columns -> LDS (read back as quads by the epilogue; a global load there would queue
+        // bias of this tile's BNT columns -> LDS (read back as quads by the epilogue; a global load there would queue
         // behind the next tile's DMA).  Written after the first k-step's barrier: every wave has left the previous epilogue.
-        float bias_t = 0.f;
-        if (LDS_BIAS) { const int nb = n0 + tid; bias_t = a.bias[nb < a.N ? nb : a.N - 1]; }
+        float bias_t = 0.f, bias_u = 0.f;
+        if (LDS_BIAS) {
+            const int nb = n0 + tid; bias_t = a.bias[nb < a.N ? nb : a.N - 1];
+            if (BNT > 256 && tid < BNT - 256) { const int nc = n0 + 256 + tid; bias_u = a.bias[nc < a.N ? nc : a.N - 1]; }
+        }
+#define NTW_PUT_BIAS() if (LDS_BIAS) { sbias[tid] = bias_t; if (BNT > 256 && tid < BNT - 256) sbias[256 + tid] = bias_u; }
         int t = 0;
         if (nk == 1) {
             KSTEP(false, true)
-            if (LDS_BIAS) sbias[tid] = bias_t;
+            NTW_PUT_BIAS()
         } else {
             KSTEP(true, true)
-            if (LDS_BIAS) sbias[tid] = bias_t;
+            NTW_PUT_BIAS()
             for (t = 1; t + 1 < nk; ++t) KSTEP(true, false)
             KSTEP(false, false)
         }
         DOMFMA(wf1, xf1)
+#undef NTW_PUT_BIAS
 #undef KSTEP
 #undef SCHED
 #undef LDFRAG
 #undef DOMFMA
-#undef DMA4
+#undef DMA8
 #ifdef NTW_PROFILE
         const long long pc1 = clock64(), pw1 = wall_clock64();
         const int pv = v;
 #endif
         // ---- this tile's output coordinates; then move the staging state on to the next tile and start its DMA
-        const int em0 = m0 + wm * 128, en0 = n0 + wn * 128, ebz = bz;
+        const int em0 = m0 + wm * WMR, en0 = n0 + wn * WNC, ebz = bz, etm = tm;
         char* scr = smem + ((nk - 1 + par) & 1) * NT256_STAGE + wave * 16384;    // stage read last
         par = (par + nk) & 1;
         v += gridDim.x;
@@ -516,14 +518,14 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
         if (more_tiles) {
             bz = v / nwg;
             tile_coords_id(ntm, ntn, v - bz * nwg, tm, tn);
-            m0 = tm * 256; n0 = tn * 256;
+            m0 = tm * BMT; n0 = tn * BNT;
             A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
             B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
             char* fA = smem + par * NT256_STAGE;      // last read in k-step nk-2: released by the k-step nk-1 barrier
             NTW_OFFSETS()
             NTW_RSRC()
 #pragma unroll
-            for (int i = 0; i < 8; ++i) NTW_DMA(i, 0, fA)
+            for (int d = 0; d < 16; ++d) NTW_DMA(d, 0, fA)
         }
         unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)ebz * a.strideC;
         float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)ebz * a.strideC;
@@ -536,173 +538,188 @@ __global__ void __launch_bounds__(256) gemm_nt256w_kernel(const dicow_gemm_args 
         int le = lane;
         asm volatile("" : "+v"(le));
         const int ml = le & 31, hh = le >> 5;
+        const int tr8 = le >> 3, tq = le & 7;         // tail pass (5th column block): 8 rows x 8 column quads per instruction
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                 // every wave has finished its fragment reads of the last stage
+        asm volatile("" ::: "memory");
 #ifdef NTW_PROFILE
-        long long pj[5]; const long long pdma = wall_clock64();
-        for (int j = 0; j < 5; ++j) pj[j] = pdma;
+        const long long pj0 = wall_clock64();
 #endif
-        if (EPI == 0) {
-            // ablation: stores straight from the MFMA layout (32 rows x 16 B per instruction) -- measured 10 % slower
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int m = em0 + j * 32 + ml;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = en0 + i * 32 + 8 * q + 4 * hh;
-                        if (m < a.M && n < a.N) {
-                            float vv[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                            nt_epilogue_quad<FLAGS>(a, flags, vv, m, n, Cb, Cf, aux);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+        {
+            // Pass (j): [32 rows][128 n] fp32 per wave, row stride 512 B, 16-B chunk c of row r at c ^ (r & 31); each
+            // read-back instruction covers 2 rows x 512 B.  NI == 5 adds a tail pass per j for the 5th column block:
+            // [32 rows][32 n], row stride 128 B, chunk c of row r at c ^ (r & 7), 8 rows x 128 B per instruction.  With
+            // compile-time flags the [m][n]-indexed inputs (saved gelu' / residual) of pass j+1 are requested BEFORE the
+            // stores of pass j are issued (vmcnt retires in order).
+            // (Tried and dropped: doing the math in the MFMA layout and sending packed bf16 rows through LDS -- half
+            // the LDS bytes, but every accumulator then needs a v_accvgpr_read + VALU pack instead of going
+            // AGPR -> LDS directly, and it measured 4-10 % slower on the plain/bias/GELU GEMMs.)
+            constexpr bool TAIL = NI == 5;
+            constexpr int NIT = 16 + (TAIL ? 4 : 0);  // read-back instructions per j: 16 main + 4 tail
+            constexpr bool PRE_AUX = FLAGS >= 0 && (FLAGS & (DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) != 0;
+            constexpr bool PRE_RES = FLAGS >= 0 && (FLAGS & DICOW_EPI_RESIDUAL) != 0;
+            uint2 xa[2][PRE_AUX ? NIT : 1];
+            float4 xr[2][PRE_RES ? NIT : 1];
+            const int nq = en0 + 4 * ml, nqt = en0 + 128 + 4 * tq;
+            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), bqt = bq;
+            if (FLAGS >= 0 && (FLAGS & DICOW_EPI_BIAS)) {
+                bq = *reinterpret_cast<const float4*>(sbias + wn * WNC + 4 * ml);
+                if (TAIL) bqt = *reinterpret_cast<const float4*>(sbias + wn * WNC + 128 + 4 * tq);
+            }
+            // Global traffic of the compile-time-flag epilogues goes through buffer descriptors: per-lane byte offsets
+            // are tile-invariant, the row of each instruction is a SCALAR offset, rows past M fall outside num_records
+            // (stores dropped, loads return 0) and lanes past N get an out-of-range offset.  The pointer form spent ~12
+            // VALU instructions (64-bit multiply-adds, compares) plus an exec branch on every store -- ~3 us per tile on
+            // the issue port that is otherwise free to run the next tile's MFMAs.
+            constexpr int ESZ = (FLAGS >= 0 && (FLAGS & DICOW_EPI_OUT_F32)) ? 4 : 2;
+            constexpr bool COLSUM = FLAGS >= 0 && (FLAGS & DICOW_EPI_COLSUM) != 0;
+            const bool edge_m = em0 + WMR > a.M;
+            float cs[4] = {0.f, 0.f, 0.f, 0.f}, cst[4] = {0.f, 0.f, 0.f, 0.f};
+            constexpr bool AUX_IO = FLAGS >= 0 && (FLAGS & (DICOW_EPI_GELU | DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) != 0;
+            const unsigned OOB = 0x80000000u;
+            const bool nok = nq < a.N, nokt = nqt < a.N;
+            __amdgpu_buffer_rsrc_t rsC, rsX, rsR;
+            unsigned voC = OOB, voX = OOB, voR = OOB, voCt = OOB, voXt = OOB, voRt = OOB;
+            if (FLAGS >= 0) {
+                rsC = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.C) + (int64_t)ebz * a.strideC * ESZ, 0,
+                                                        (unsigned)(((int64_t)(a.M - 1) * a.ldc + a.N) * ESZ), 0x00020000);
+                if (nok) voC = (unsigned)((hh * (int)a.ldc + 4 * ml) * ESZ);
+                if (TAIL && nokt) voCt = (unsigned)((tr8 * (int)a.ldc + 128 + 4 * tq) * ESZ);
+                if (AUX_IO) {
+                    rsX = __builtin_amdgcn_make_buffer_rsrc(aux, 0, (unsigned)(((int64_t)(a.M - 1) * a.ldaux + a.N) * 2), 0x00020000);
+                    if (nok) voX = (unsigned)((hh * (int)a.ldaux + 4 * ml) * 2);
+                    if (TAIL && nokt) voXt = (unsigned)((tr8 * (int)a.ldaux + 128 + 4 * tq) * 2);
+                }
+                if (PRE_RES) {
+                    rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual), 0,
+                                                            (unsigned)(((int64_t)(a.M - 1) * a.ldr + a.N) * 4), 0x00020000);
+                    if (nok) voR = (unsigned)((hh * (int)a.ldr + 4 * ml) * 4);
+                    if (TAIL && nokt) voRt = (unsigned)((tr8 * (int)a.ldr + 128 + 4 * tq) * 4);
                 }
             }
-        } else {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();             // every wave has finished its fragment reads of the last stage
-            asm volatile("" ::: "memory");
-#ifdef NTW_PROFILE
-            pj[0] = wall_clock64();
-#endif
-            {
-                // [32 rows][128 n] fp32 per wave and pass, row stride 512 B, 16-B chunk c of row r at c ^ (r & 31);
-                // each read-back instruction covers 2 rows x 512 B.  With compile-time flags the [m][n]-indexed inputs
-                // (saved gelu' / residual) of pass j+1 are requested BEFORE the stores of pass j are issued.
-                // (Tried and dropped: doing the math in the MFMA layout and sending packed bf16 rows through LDS -- half
-                // the LDS bytes, but every accumulator then needs a v_accvgpr_read + VALU pack instead of going
-                // AGPR -> LDS directly, and it measured 4-10 % slower on the plain/bias/GELU GEMMs.)
-                constexpr bool PRE_AUX = FLAGS >= 0 && (FLAGS & (DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) != 0;
-                constexpr bool PRE_RES = FLAGS >= 0 && (FLAGS & DICOW_EPI_RESIDUAL) != 0;
-                uint2 xa[2][PRE_AUX ? 16 : 1];
-                float4 xr[2][PRE_RES ? 16 : 1];
-                const int nq = en0 + 4 * ml, nqc = nq < a.N ? nq : a.N - 4;
-                float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (FLAGS >= 0 && (FLAGS & DICOW_EPI_BIAS)) bq = *reinterpret_cast<const float4*>(sbias + wn * 128 + 4 * ml);
-                // Global traffic of the compile-time-flag epilogues goes through buffer descriptors: per-lane byte offsets
-                // ((hh * ld + 4 ml) * element size) are tile-invariant, the row of each instruction is a SCALAR offset, rows past
-                // M fall outside num_records (stores dropped, loads return 0) and lanes past N get an out-of-range offset.
-                // The pointer form spent ~12 VALU instructions (64-bit multiply-adds, compares) plus an exec branch on every
-                // store -- ~3 us per tile on the issue port that is otherwise free to run the next tile's MFMAs.
-                constexpr int ESZ = (FLAGS >= 0 && (FLAGS & DICOW_EPI_OUT_F32)) ? 4 : 2;
-                constexpr bool COLSUM = FLAGS >= 0 && (FLAGS & DICOW_EPI_COLSUM) != 0;
-                const bool edge_m = em0 + 128 > a.M;
-                float cs[4] = {0.f, 0.f, 0.f, 0.f};
-                constexpr bool AUX_IO = FLAGS >= 0 && (FLAGS & (DICOW_EPI_GELU | DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) != 0;
-                const unsigned OOB = 0x80000000u;
-                const bool nok = nq < a.N;
-                __amdgpu_buffer_rsrc_t rsC, rsX, rsR;
-                unsigned voC = OOB, voX = OOB, voR = OOB;
-                if (FLAGS >= 0) {
-                    rsC = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.C) + (int64_t)ebz * a.strideC * ESZ, 0,
-                                                            (unsigned)(((int64_t)(a.M - 1) * a.ldc + a.N) * ESZ), 0x00020000);
-                    if (nok) voC = (unsigned)((hh * (int)a.ldc + 4 * ml) * ESZ);
-                    if (AUX_IO) {
-                        rsX = __builtin_amdgcn_make_buffer_rsrc(aux, 0, (unsigned)(((int64_t)(a.M - 1) * a.ldaux + a.N) * 2), 0x00020000);
-                        if (nok) voX = (unsigned)((hh * (int)a.ldaux + 4 * ml) * 2);
-                    }
-                    if (PRE_RES) {
-                        rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual), 0,
-                                                                (unsigned)(((int64_t)(a.M - 1) * a.ldr + a.N) * 4), 0x00020000);
-                        if (nok) voR = (unsigned)((hh * (int)a.ldr + 4 * ml) * 4);
-                    }
-                }
-#define NTW_SOFF(J, IT, LD, SZ) ((int)((((int64_t)(em0 + (J) * 32 + (IT) * 2)) * (LD) + en0) * (SZ)))
+            // scalar byte offset of read-back instruction IT of pass J: main instructions step 2 rows, tail ones 8 rows
+#define NTW_SOFF(J, IT, LD, SZ) ((int)((((int64_t)(em0 + (J) * 32 + ((IT) < 16 ? (IT) * 2 : ((IT) - 16) * 8))) * (LD) + en0) * (SZ)))
 #define NTW_PREFETCH(J, BUF)                                                                                 \
     if (PRE_AUX || PRE_RES) {                                                                                \
-        _Pragma("unroll") for (int it = 0; it < 16; ++it) {                                                  \
-            if (PRE_AUX) { const auto u_ = __builtin_amdgcn_raw_buffer_load_b64(rsX, voX, NTW_SOFF(J, it, a.ldaux, 2), 0); \
+        _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                 \
+            if (PRE_AUX) { const auto u_ = __builtin_amdgcn_raw_buffer_load_b64(rsX, it < 16 ? voX : voXt, NTW_SOFF(J, it, a.ldaux, 2), 0); \
                            xa[BUF][it] = make_uint2(u_[0], u_[1]); }                                         \
-            if (PRE_RES) { const auto r_ = __builtin_amdgcn_raw_buffer_load_b128(rsR, voR, NTW_SOFF(J, it, a.ldr, 4), 0);  \
+            if (PRE_RES) { const auto r_ = __builtin_amdgcn_raw_buffer_load_b128(rsR, it < 16 ? voR : voRt, NTW_SOFF(J, it, a.ldr, 4), 0);  \
                            xr[BUF][it] = make_float4(__uint_as_float(r_[0]), __uint_as_float(r_[1]), __uint_as_float(r_[2]), __uint_as_float(r_[3])); } \
         }                                                                                                    \
     }
-                NTW_PREFETCH(0, 0)
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            // math + stores of one read-back quad (compile-time flags): IT = instruction index, TL = tail pass
+#define NTW_EMIT(J, IT, F4, TL)                                                                              \
+    {                                                                                                        \
+        float vv[4] = {(F4).x, (F4).y, (F4).z, (F4).w}, dg[4];                                               \
+        nt_epilogue_math<FLAGS>(a, flags, vv, dg, 0, (TL) ? nqt : nq, aux, (TL) ? &bqt : &bq,                \
+                                PRE_AUX ? &xa[(J) & 1][IT] : nullptr, PRE_RES ? &xr[(J) & 1][IT] : nullptr); \
+        if (COLSUM) {                                 /* bias gradient: column sums of the result, rows past M excluded */ \
+            const int rw_ = (TL) ? ((IT) - 16) * 8 + tr8 : (IT) * 2 + hh;                                    \
+            const float ok_ = (!edge_m || em0 + (J) * 32 + rw_ < a.M) ? 1.f : 0.f;                           \
+            _Pragma("unroll") for (int e = 0; e < 4; ++e) { if (TL) cst[e] = fmaf(vv[e], ok_, cst[e]); else cs[e] = fmaf(vv[e], ok_, cs[e]); } \
+        }                                                                                                    \
+        if ((FLAGS & DICOW_EPI_GELU) != 0) {                                                                 \
+            const u32x2_t xv = {pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3])};                       \
+            if (aux) __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (TL) ? voXt : voX, NTW_SOFF(J, IT, a.ldaux, 2), 0); \
+        }                                                                                                    \
+        if (ESZ == 4) {                                                                                      \
+            const u32x4_t ov = {__float_as_uint(vv[0]), __float_as_uint(vv[1]), __float_as_uint(vv[2]), __float_as_uint(vv[3])}; \
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, (TL) ? voCt : voC, NTW_SOFF(J, IT, a.ldc, 4), 0); \
+        } else {                                                                                             \
+            const u32x2_t ov = {pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};                       \
+            __builtin_amdgcn_raw_buffer_store_b64(ov, rsC, (TL) ? voCt : voC, NTW_SOFF(J, IT, a.ldc, 2), 0); \
+        }                                                                                                    \
+    }
+            NTW_PREFETCH(0, 0)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NJ; ++j) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int c = i * 8 + 2 * q + hh;
-                            *reinterpret_cast<float4*>(scr + ml * 512 + ((c ^ ml) << 4)) =
-                                make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                        }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (j < 3) { NTW_PREFETCH(j + 1, (j + 1) & 1) }
-                    if (FLAGS >= 0) {
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = i * 8 + 2 * q + hh;
+                        *reinterpret_cast<float4*>(scr + ml * 512 + ((c ^ ml) << 4)) =
+                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < NJ) { NTW_PREFETCH(j + 1, (j + 1) & 1) }
+                if (FLAGS >= 0) {
 #pragma unroll
-                        for (int it = 0; it < 16; ++it) {
-                            const int row = it * 2 + hh;
-                            const float4 f = *reinterpret_cast<const float4*>(scr + row * 512 + ((ml ^ row) << 4));
-                            float vv[4] = {f.x, f.y, f.z, f.w}, dg[4];
-                            nt_epilogue_math<FLAGS>(a, flags, vv, dg, 0, nq, aux, &bq, PRE_AUX ? &xa[j & 1][it] : nullptr,
-                                                    PRE_RES ? &xr[j & 1][it] : nullptr);
-                            if (COLSUM) {             // bias gradient: column sums of the result (rows past M excluded)
-                                const float ok = (!edge_m || em0 + j * 32 + row < a.M) ? 1.f : 0.f;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) cs[e] = fmaf(vv[e], ok, cs[e]);
-                            }
-                            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-                            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-                            if ((FLAGS & DICOW_EPI_GELU) != 0) {
-                                const u32x2_t xv = {pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3])};
-                                if (aux) __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, voX, NTW_SOFF(j, it, a.ldaux, 2), 0);
-                            }
-                            if (ESZ == 4) {
-                                const u32x4_t ov = {__float_as_uint(vv[0]), __float_as_uint(vv[1]), __float_as_uint(vv[2]), __float_as_uint(vv[3])};
-                                __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, voC, NTW_SOFF(j, it, a.ldc, 4), 0);
-                            } else {
-                                const u32x2_t ov = {pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};
-                                __builtin_amdgcn_raw_buffer_store_b64(ov, rsC, voC, NTW_SOFF(j, it, a.ldc, 2), 0);
-                            }
-                        }
-                    } else {
-                        // runtime flags: a real loop keeps the code small (fully unrolled it was ~200 KB of instructions
-                        // and ran at instruction-cache-miss speed)
+                    for (int it = 0; it < 16; ++it) {
+                        const int row = it * 2 + hh;
+                        const float4 f = *reinterpret_cast<const float4*>(scr + row * 512 + ((ml ^ row) << 4));
+                        NTW_EMIT(j, it, f, false)
+                    }
+                } else {
+                    // runtime flags: a real loop keeps the code small (fully unrolled it was ~200 KB of instructions
+                    // and ran at instruction-cache-miss speed)
 #pragma unroll 1
-                        for (int pg = 0; pg < 4; ++pg) {
+                    for (int pg = 0; pg < 4; ++pg) {
 #pragma unroll
-                            for (int pp = 0; pp < 4; ++pp) {
-                                const int row = (pg * 4 + pp) * 2 + hh;
-                                const float4 f = *reinterpret_cast<const float4*>(scr + row * 512 + ((ml ^ row) << 4));
-                                const int m = em0 + j * 32 + row;
-                                if (m < a.M && nq < a.N) {
-                                    float vv[4] = {f.x, f.y, f.z, f.w};
-                                    nt_epilogue_quad<FLAGS>(a, flags, vv, m, nq, Cb, Cf, aux);
-                                }
+                        for (int pp = 0; pp < 4; ++pp) {
+                            const int row = (pg * 4 + pp) * 2 + hh;
+                            const float4 f = *reinterpret_cast<const float4*>(scr + row * 512 + ((ml ^ row) << 4));
+                            const int m = em0 + j * 32 + row;
+                            if (m < a.M && nq < a.N) {
+                                float vv[4] = {f.x, f.y, f.z, f.w};
+                                nt_epilogue_quad<FLAGS>(a, flags, vv, m, nq, Cb, Cf, aux);
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (TAIL) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = 2 * q + hh;
+                        *reinterpret_cast<float4*>(scr + ml * 128 + ((c ^ (ml & 7)) << 4)) =
+                            make_float4(acc[NI - 1][j][4 * q], acc[NI - 1][j][4 * q + 1], acc[NI - 1][j][4 * q + 2], acc[NI - 1][j][4 * q + 3]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int it = 16; it < 20; ++it) {
+                        const int row = (it - 16) * 8 + tr8;
+                        const float4 f = *reinterpret_cast<const float4*>(scr + row * 128 + ((tq ^ (row & 7)) << 4));
+                        if (FLAGS >= 0) {
+                            NTW_EMIT(j, it, f, true)
+                        } else {
+                            const int m = em0 + j * 32 + row;
+                            if (m < a.M && nqt < a.N) {
+                                float vv[4] = {f.x, f.y, f.z, f.w};
+                                nt_epilogue_quad<FLAGS>(a, flags, vv, m, nqt, Cb, Cf, aux);
                             }
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
-#ifdef NTW_PROFILE
-                    pj[j + 1] = wall_clock64();
-#endif
                 }
-                if (COLSUM) {
-                    // partial sums of this wave's 128 rows -> colsum_ws[(tile row * 2 + wm)][N]; every (row, column) of the
-                    // workspace is written exactly once per launch, the host adds the 2 * ceil(M/256) rows up afterwards
+            }
+            if (COLSUM) {
+                // partial sums of this wave's WMR rows -> colsum_ws[(tile row * 2 + wm)][N]; every (row, column) of the
+                // workspace is written exactly once per launch, the host adds the 2 * ceil(M/BMT) rows up afterwards
+                float* wsr = reinterpret_cast<float*>(a.colsum_ws) + (int64_t)(etm * 2 + wm) * a.N;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) cs[e] += __shfl_xor(cs[e], 32, 64);
-                    if (hh == 0 && nok) {
-                        float* wsr = reinterpret_cast<float*>(a.colsum_ws) + (int64_t)((em0 >> 7) + 0) * a.N + nq;
-                        *reinterpret_cast<float4*>(wsr) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                for (int e = 0; e < 4; ++e) cs[e] += __shfl_xor(cs[e], 32, 64);
+                if (hh == 0 && nok) *reinterpret_cast<float4*>(wsr + nq) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+                if (TAIL) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        cst[e] += __shfl_xor(cst[e], 8, 64); cst[e] += __shfl_xor(cst[e], 16, 64); cst[e] += __shfl_xor(cst[e], 32, 64);
                     }
+                    if (tr8 == 0 && nokt) *reinterpret_cast<float4*>(wsr + nqt) = make_float4(cst[0], cst[1], cst[2], cst[3]);
                 }
+            }
+#undef NTW_EMIT
 #undef NTW_PREFETCH
 #undef NTW_SOFF
-            }
         }
-#ifdef NTW_PROFILE
-        if (a.aux && tid == 0) {
-            long long* pr = reinterpret_cast<long long*>(a.aux) + 6 * total + 8 * pv;
-            pr[0] = pdma - pw1; pr[1] = pj[0] - pdma; for (int j = 0; j < 4; ++j) pr[2 + j] = pj[j + 1] - pj[j];
-        }
-#endif
 #ifdef NTW_PROFILE
         if (a.aux && tid == 0) {   // diagnostic build only: per-tile k-loop cycles and wall-clock (100 MHz) timestamps
             long long* pr = reinterpret_cast<long long*>(a.aux) + 6 * pv;
             pr[0] = pc1 - pc0; pr[1] = pw1 - pw0; pr[2] = pw0; pr[3] = pw0; pr[4] = pw1; pr[5] = wall_clock64();
+            (void)pj0;
         }
 #endif
         if (!more_tiles) break;
@@ -827,28 +844,29 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256s_kernel(const dicow_gemm_ar
 
 // ws for DICOW_EPI_COLSUM: the fused path needs 2 * ceil(M/256) partial rows; the fallback runs dicow_colsum_bf16 on C
 extern "C" int64_t dicow_gemm_nt_colsum_ws_bytes(int M, int N) {
-    const int64_t fused = (int64_t)2 * dicow_cdiv(M, 256) * N * 4, fb = dicow_colsum_ws_bytes(M, N);
+    const int64_t fused = (int64_t)2 * dicow_cdiv(M, 192) * N * 4, fb = dicow_colsum_ws_bytes(M, N);
     return fused > fb ? fused : fb;
 }
 
-static int gemm_nt_impl(const dicow_gemm_args* a, void* stream, bool* fused_colsum);
+static int gemm_nt_impl(const dicow_gemm_args* a, void* stream, bool* fused_colsum, int* colsum_rows);
 
 extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     DICOW_REQUIRE(a && a->A && a->B && a->C, "gemm_nt: null operand");
-    if (!(a->flags & DICOW_EPI_COLSUM)) return gemm_nt_impl(a, stream, nullptr);
+    if (!(a->flags & DICOW_EPI_COLSUM)) return gemm_nt_impl(a, stream, nullptr, nullptr);
     DICOW_REQUIRE(a->colsum_out && a->colsum_ws && a->colsum_ws_bytes >= dicow_gemm_nt_colsum_ws_bytes(a->M, a->N),
                   "gemm_nt: COLSUM needs colsum_out and colsum_ws of dicow_gemm_nt_colsum_ws_bytes() bytes");
     DICOW_REQUIRE(!(a->flags & DICOW_EPI_OUT_F32) && a->batch <= 1, "gemm_nt: COLSUM supports a single bf16 result");
     bool fused = false;
-    int rc = gemm_nt_impl(a, stream, &fused);
+    int rows = 0;
+    int rc = gemm_nt_impl(a, stream, &fused, &rows);
     if (rc != DICOW_OK) return rc;
     if (fused)          // add the per-wave partial rows up: colsum_out[n] += sum_p ws[p][n]
-        return dicow_launch_reduce_parts(reinterpret_cast<const float*>(a->colsum_ws), 2 * dicow_cdiv(a->M, 256), a->N,
+        return dicow_launch_reduce_parts(reinterpret_cast<const float*>(a->colsum_ws), rows, a->N,
                                          a->colsum_out, a->N, (hipStream_t)stream);
     return dicow_colsum_bf16(a->C, a->ldc, a->colsum_out, a->M, a->N, a->colsum_ws, a->colsum_ws_bytes, stream);
 }
 
-static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_colsum) {
+static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_colsum, int* colsum_rows) {
     dicow_gemm_args a_copy = *a_in;
     dicow_gemm_args* a = &a_copy;
     const bool want_colsum = (a->flags & DICOW_EPI_COLSUM) != 0;
@@ -877,8 +895,8 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     static bool attr256 = false;
     if (!attr256) {
         (void)hipFuncSetAttribute((const void*)gemm_nt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NTS_LDS);
-#define NTW_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_nt256w_kernel<F, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS)
-        (void)hipFuncSetAttribute((const void*)gemm_nt256w_kernel<-1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS);
+#define NTW_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntw_kernel<F, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS); \
+                    (void)hipFuncSetAttribute((const void*)gemm_ntw_kernel<F, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS)
         NTW_ATTR(-1); NTW_ATTR(0); NTW_ATTR(DICOW_EPI_BIAS); NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N);
         NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU); NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32);
         NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTW_ATTR(DICOW_EPI_MUL_AUX);
@@ -899,15 +917,24 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     const bool big = off32 && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
         const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
-        if (variant == 0 || variant == 10 || variant == 11) {
+        if (variant == 0 || variant == 11 || variant == 12 || variant == 13) {
             static int ncu = 0;
             if (!ncu) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); ncu = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
-            const int total = (int)g256.x * batch;
+            // tile shape: 192x320 where its whole rounds of `ncu` workgroups pad the problem less than 256x256 does AND the
+            // output is narrow (measured at M = 24000: N = 1280 shapes gain 2-4.5 %; N = 3840 is neutral and N = 5120 with
+            // the GELU epilogue loses 5 % -- more, smaller tiles mean more epilogues); DICOW_NT_VARIANT 12 / 13 force
+            // 256x256 / 192x320
+            const int64_t t44 = (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch;
+            const int64_t t35 = (int64_t)dicow_cdiv(a->M, 192) * dicow_cdiv(a->N, 320) * batch;
+            const int64_t w44 = dicow_cdiv(t44, ncu) * 256 * 256, w35 = dicow_cdiv(t35, ncu) * 192 * 320;
+            const bool use35 = variant == 13 || (variant != 12 && a->N >= 320 && a->N <= 2048 && w35 < w44);
+            const int total = (int)(use35 ? t35 : t44);
             const dim3 gp(total < ncu ? total : ncu);
-#define NTW_LAUNCH(F) hipLaunchKernelGGL((gemm_nt256w_kernel<F, 1>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a)
-            if (want_colsum && variant == 0 && a->flags == DICOW_EPI_MUL_AUX) { a->flags |= DICOW_EPI_COLSUM; *fused_colsum = true; }
-            if (variant == 10) hipLaunchKernelGGL((gemm_nt256w_kernel<-1, 0>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a);   // ablation: direct stores
-            else switch (variant == 11 ? -1 : a->flags) {   // compile-time epilogues for the flag sets the training step uses
+            if (colsum_rows) *colsum_rows = 2 * dicow_cdiv(a->M, use35 ? 192 : 256);
+#define NTW_LAUNCH(F) { if (use35) hipLaunchKernelGGL((gemm_ntw_kernel<F, 3, 5>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); \
+                        else hipLaunchKernelGGL((gemm_ntw_kernel<F, 4, 4>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); }
+            if (want_colsum && variant != 11 && a->flags == DICOW_EPI_MUL_AUX) { a->flags |= DICOW_EPI_COLSUM; *fused_colsum = true; }
+            switch (variant == 11 ? -1 : a->flags) {   // compile-time epilogues for the flag sets the training step uses
                 case 0: NTW_LAUNCH(0); break;
                 case DICOW_EPI_BIAS: NTW_LAUNCH(DICOW_EPI_BIAS); break;
                 case DICOW_EPI_BIAS | DICOW_EPI_SCALE_N: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N); break;
