@@ -203,6 +203,103 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, LDS-staged rows
+// The FDDT(diag) + LayerNorm forward of every encoder layer (fp32 in, fp32 h_out, bf16 y, mean / rstd), with the rows of the
+// next trip fetched by LDS-DMA while the current trip is computed -- see fddt_ln_bwd_staged_kernel for the scheme.  The FDDT
+// arithmetic is the reference's evaluation order (fddt_diag_elem), bit-exact like the generic body.
+typedef __attribute__((address_space(3))) void lds_void_f_t;
+template <int R>
+__global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fddt_ln_fwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) char stg[];       // [2 stages][R rows][4*D bytes]
+    __shared__ float red[2][MAX_WAVES * R * 3];
+    const int tid = threadIdx.x, col = tid * 4, D = a.D;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nwaves = blockDim.x >> 6;
+    float4 w[4], b[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { w[c] = ld4(a.w[c] + col); b[c] = ld4(a.b[c] + col); }
+    const float4 lnw = ld4(a.ln_w + col), lnb = ld4(a.ln_b + col);
+    const float inv_d = 1.0f / (float)D;
+    const unsigned nb32 = (unsigned)((int64_t)a.rows * D * 4), nb16 = (unsigned)((int64_t)a.rows * D * 2);
+    const __amdgpu_buffer_rsrc_t rsH = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.h_in), 0, nb32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(a.h_out, 0, nb32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(a.y_bf16, 0, nb16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc(a.mean, 0, (unsigned)(a.rows * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(a.rstd, 0, (unsigned)(a.rows * 4), 0x00020000);
+    const unsigned vo32 = (unsigned)(col * 4), vo16 = (unsigned)(col * 2);
+    const unsigned voStat = tid == 0 ? 0u : 0x80000000u;             // every wave issues the store; only thread 0's lands
+    const int row_lds = 4 * D;
+    auto stage_rows = [&](int row0, int s) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (lds_void_f_t*)(stg + (s * R + r) * row_lds + wave * 1024), 16, vo32,
+                                                     (row0 + r) * D * 4, 0, 0);
+    };
+    float m_n[R][4];
+    auto load_masks = [&](int row0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int row = row0 + r; row = row < a.rows ? row : a.rows - 1;
+            const int bi = row / a.T, t = row - bi * a.T;
+            const float* mp = a.stno + (int64_t)bi * a.stno_bstride + t;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m_n[r][c] = mp[(int64_t)c * a.T];
+        }
+    };
+    const int stride = gridDim.x * R;
+    int row0 = blockIdx.x * R, it = 0;
+    if (row0 < a.rows) { load_masks(row0); stage_rows(row0, 0); }
+    for (; row0 < a.rows; row0 += stride, ++it) {
+        const int s = it & 1;
+        float m[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m[r][c] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m_n[r][c])));
+        load_masks(row0 + stride);
+        stage_rows(row0 + stride, s ^ 1);
+        // younger than this trip's DMA: the previous trip's 4R stores, the next trip's 4R mask loads and R DMA instructions
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(5 * R) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(9 * R) : "memory");
+        float4 x[R];
+        float sm[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            x[r] = *reinterpret_cast<const float4*>(stg + (s * R + r) * row_lds + tid * 16);
+#define FD(e) fddt_diag_elem(x[r].e, w[0].e, b[0].e, w[1].e, b[1].e, w[2].e, b[2].e, w[3].e, b[3].e, m[r][0], m[r][1], m[r][2], m[r][3])
+            F4_APPLY(x[r], FD);
+#undef FD
+            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+            const u32x4_t ov = {__float_as_uint(x[r].x), __float_as_uint(x[r].y), __float_as_uint(x[r].z), __float_as_uint(x[r].w)};
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rsO, vo32, (row0 + r) * D * 4, 0);
+            sm[r] = (x[r].x + x[r].y) + (x[r].z + x[r].w);
+        }
+        block_sum<R>(sm, red[0], nwaves);
+        float mu[R], q[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            mu[r] = sm[r] * inv_d;
+            const float dx = x[r].x - mu[r], dy = x[r].y - mu[r], dz = x[r].z - mu[r], dw = x[r].w - mu[r];
+            q[r] = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        block_sum<R>(q, red[1], nwaves);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float rs = rsqrtf(q[r] * inv_d + a.eps);
+            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu[r]), rsM, voStat, (row0 + r) * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rs), rsS, voStat, (row0 + r) * 4, 0);
+            float4 y;
+            y.x = (x[r].x - mu[r]) * rs * lnw.x + lnb.x;
+            y.y = (x[r].y - mu[r]) * rs * lnw.y + lnb.y;
+            y.z = (x[r].z - mu[r]) * rs * lnw.z + lnb.z;
+            y.w = (x[r].w - mu[r]) * rs * lnw.w + lnb.w;
+            const u32x2_t yv = {pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)};
+            __builtin_amdgcn_raw_buffer_store_b64(yv, rsY, vo16, (row0 + r) * D * 2, 0);
+        }
+    }
+}
+
 // resident workgroups per CU for a row kernel (occupancy API, cached): the grid is sized to exactly fill the chip
 // once and every workgroup strides over rows, so no partial tail wave runs at low occupancy.
 template <typename K>
@@ -231,6 +328,19 @@ extern "C" int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream) 
     const int R = 4;
     const int block = pick_block(a->D);
     int grid = dicow_cdiv(a->rows, R);
+    static const int fwd_env = getenv("DICOW_ROW_FWD") ? atoi(getenv("DICOW_ROW_FWD")) : 0;      // 9: generic body (ablation)
+    const bool staged = fwd_env != 9 && block <= 512 && block * 4 == a->D && a->mode == 1 && a->ln_w && !a->in_bf16 && a->h_out &&
+                        a->y_bf16 && !a->y_f32 && a->mean && a->rstd && !a->pos && a->w[0] && a->w[1] && a->w[2] && a->w[3] &&
+                        a->b[0] && a->b[1] && a->b[2] && a->b[3] && (int64_t)a->rows * a->D * 4 < (1ll << 31);
+    if (staged) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)fddt_ln_fwd_staged_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 4 * 2048); attr = true; }
+        const int cap = 256 * 3;                      // three resident workgroups per CU (40 KiB of staging each at D = 1280)
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL((fddt_ln_fwd_staged_kernel<4>), dim3(grid), dim3(block), 2 * R * 4 * a->D, (hipStream_t)stream, *a);
+        DICOW_CHECK_LAUNCH("fddt_ln_fwd_staged");
+        return DICOW_OK;
+    }
     static int occ[4][17] = {{0}};
     const int variant = block > 512 ? 2 : (a->mode == 0 ? 1 : a->mode == 1 ? 3 : 0);
     const int cap = variant == 2 ? resident_grid(fddt_ln_fwd_kernel<R, 1024>, block, &occ[2][block / 64])
