@@ -152,6 +152,9 @@ def main():
     torch.cuda.set_device(local)
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the gradient all-reduce overlaps the backward pass and needs few channels; every RCCL channel is a workgroup that
+        # keeps a CU from the persistent GEMM (trainer.GradReducer reserves DICOW_RCCL_CUS = 16 CUs for them)
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     import amd_pkg
     pkg = amd_pkg.load()

@@ -35,6 +35,11 @@ extern "C" {
 #define DICOW_ABI_VERSION 1
 
 int dicow_abi_version(void);
+/* Number of CUs the persistent NT GEMM may occupy (0 = all, the default).  Its workgroups own a whole CU each for the
+ * length of the launch; when a communication kernel (RCCL: one workgroup per channel) runs beside the step, leave it
+ * that many CUs -- otherwise the GEMM workgroups that find their CU taken start only when another one has finished its
+ * whole tile list.  Returns the previous value. */
+int dicow_set_gemm_cus(int n);
 const char* dicow_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------ casts

@@ -222,6 +222,24 @@ def test_gemm_nt_epilogues(ops, M, N, K):
     assert maxdiff(C5.cpu(), res + A @ B.t()) < 2e-4
 
 
+def test_gemm_nt_cu_limit(ops):
+    """dicow_set_gemm_cus: the persistent kernel on fewer workgroups than CUs (CUs left to RCCL) gives the same result."""
+    M, N, K = 6100, 2244, 128
+    g = torch.Generator().manual_seed(11)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * K ** -0.5)
+    Ad, Bd = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
+    C0 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    C1 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(Ad, Bd, C0, M, N, K)
+    prev = ops.set_gemm_cus(100)
+    try:
+        ops.gemm_nt(Ad, Bd, C1, M, N, K)
+    finally:
+        ops.set_gemm_cus(prev)
+    assert torch.equal(C0.cpu(), C1.cpu())
+    assert maxdiff(C0.float().cpu(), A @ B.t()) < 3e-2
+
+
 def test_gelu_device_accuracy(ops):
     """The A&S-7.1.26 GELU used by the epilogues against float64 erf: |err| < 1e-6 before the bf16 rounding."""
     from ts_asr_whisper_amd import _lib as L

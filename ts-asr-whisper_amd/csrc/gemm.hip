@@ -842,6 +842,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256s_kernel(const dicow_gemm_ar
     }
 }
 
+static int g_gemm_cus = 0;                 // dicow_set_gemm_cus(): CUs the persistent kernel may occupy (0 = all)
+extern "C" int dicow_set_gemm_cus(int n) { const int old = g_gemm_cus; g_gemm_cus = n > 0 ? n : 0; return old; }
+
 // ws for DICOW_EPI_COLSUM: the fused path needs 2 * ceil(M/256) partial rows; the fallback runs dicow_colsum_bf16 on C
 extern "C" int64_t dicow_gemm_nt_colsum_ws_bytes(int M, int N) {
     const int64_t fused = (int64_t)2 * dicow_cdiv(M, 192) * N * 4, fb = dicow_colsum_ws_bytes(M, N);
@@ -918,8 +921,9 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
         const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
         if (variant == 0 || variant == 11 || variant == 12 || variant == 13) {
-            static int ncu = 0;
-            if (!ncu) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); ncu = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
+            static int ncu_all = 0;
+            if (!ncu_all) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); ncu_all = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
+            const int ncu = (g_gemm_cus > 0 && g_gemm_cus < ncu_all) ? g_gemm_cus : ncu_all;   // CUs left to us (dicow_set_gemm_cus)
             // tile shape: 192x320 where its whole rounds of `ncu` workgroups pad the problem less than 256x256 does AND the
             // output is narrow (measured at M = 24000: N = 1280 shapes gain 2-4.5 %; N = 3840 is neutral and N = 5120 with
             // the GELU epilogue loses 5 % -- more, smaller tiles mean more epilogues); DICOW_NT_VARIANT 12 / 13 force
@@ -929,7 +933,11 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             const int64_t w44 = dicow_cdiv(t44, ncu) * 256 * 256, w35 = dicow_cdiv(t35, ncu) * 192 * 320;
             const bool use35 = variant == 13 || (variant != 12 && a->N >= 320 && a->N <= 2048 && w35 < w44);
             const int total = (int)(use35 ? t35 : t44);
-            const dim3 gp(total < ncu ? total : ncu);
+            // balanced grid: with r = ceil(total / ncu) rounds needed anyway, ceil(total / r) workgroups each take r (or
+            // r - 1) tiles -- e.g. 470 tiles run on 235 workgroups x 2 instead of 214 x 2 + 42 x 1: same makespan, fewer
+            // CUs competing for L2 / HBM / power while the last round is partial (measured 0.304 -> 0.287 ms)
+            const int rounds = dicow_cdiv(total, ncu);
+            const dim3 gp(dicow_cdiv(total, rounds));
             if (colsum_rows) *colsum_rows = 2 * dicow_cdiv(a->M, use35 ? 192 : 256);
 #define NTW_LAUNCH(F) { if (use35) hipLaunchKernelGGL((gemm_ntw_kernel<F, 3, 5>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); \
                         else hipLaunchKernelGGL((gemm_ntw_kernel<F, 4, 4>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); }

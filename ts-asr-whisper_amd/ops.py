@@ -40,6 +40,11 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return t
 
 
+def set_gemm_cus(n: int) -> int:
+    """CUs the persistent NT GEMM may occupy (0 = all); returns the previous setting (dicow_set_gemm_cus)."""
+    return L.lib().dicow_set_gemm_cus(int(n))
+
+
 def _arr4(ts):
     a = (C.c_void_p * 4)()
     for i, t in enumerate(ts):

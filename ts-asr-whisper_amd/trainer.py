@@ -148,6 +148,14 @@ class GradReducer:
         # the RCCL code path on a 1-GPU box)
         self.force = os.environ.get("DICOW_FORCE_REDUCE") == "1" and dist.is_initialized()
         self.stream = torch.cuda.Stream() if ((self.world > 1 or self.force) and torch.cuda.is_available()) else None
+        if self.stream is not None and self.world > 1:
+            # RCCL runs one workgroup per channel beside the backward pass; the persistent GEMM's workgroups own a whole CU
+            # each, so leave the channels their CUs (the all-reduce of 2.5 GB has the whole backward pass to hide in and
+            # needs few channels: DICOW_RCCL_CUS, default 16; launchers should cap NCCL_MAX_NCHANNELS accordingly).
+            from . import ops
+            reserve = int(os.environ.get("DICOW_RCCL_CUS", "16"))
+            ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+            ops.set_gemm_cus(max(ncu - reserve, ncu // 2))
         self.seg = {name: (a, b) for name, a, b in store.segments}
         self.pending = []
 
