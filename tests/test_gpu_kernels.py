@@ -160,7 +160,7 @@ def test_cast_transpose(ops, R, C, ld, ld_t):
     if ld: assert float(out[:, C:].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (6100, 2244, 128)])     # 128x128 tiles / persistent 256x256 kernel
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (6100, 2244, 128), (12200, 1284, 64)])   # 128x128 / persistent 256x256 / 192x320
 def test_gemm_nt_epilogues(ops, M, N, K):
     from ts_asr_whisper_amd import _lib as L
     g = torch.Generator().manual_seed(5)
@@ -292,7 +292,8 @@ def _attn_ref(q, k, v, causal):
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", [(1, 2, 128, 64, False), (2, 3, 100, 100, False), (1, 2, 1500, 1500, False),
-                                             (2, 2, 77, 77, True), (1, 2, 300, 300, True), (2, 2, 50, 1500, False)])
+                                             (2, 2, 77, 77, True), (1, 2, 300, 300, True), (2, 2, 50, 1500, False),
+                                             (3, 4, 140, 140, True)])      # 12 (batch, head) pairs: one XCD group of 8 + a remainder
 def test_attn_fwd(ops, B, H, Lq, Lk, causal):
     g = torch.Generator().manual_seed(B * 1000 + Lq + Lk)
     D = H * 64
@@ -316,7 +317,7 @@ def test_attn_fwd(ops, B, H, Lq, Lk, causal):
 
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", [(1, 2, 128, 64, False), (2, 3, 100, 100, False), (1, 2, 1500, 1500, False),
                                              (2, 2, 77, 77, True), (1, 2, 300, 300, True), (2, 2, 50, 1500, False),
-                                             (1, 1, 200, 130, False)])
+                                             (1, 1, 200, 130, False), (3, 4, 140, 140, False)])
 def test_attn_bwd(ops, B, H, Lq, Lk, causal):
     g = torch.Generator().manual_seed(B * 999 + Lq + 3 * Lk)
     D = H * 64
