@@ -32,7 +32,7 @@ fl = 4.0 * B * H * Lq * Lk * 64 * (0.5 if causal else 1.0)
 t = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, causal=bool(causal)))
 print(f"attn_fwd B{B} H{H} Lq{Lq} Lk{Lk} causal{causal}: {t*1e3:.1f} us  {fl/t/1e9:.0f} TF")
 t = timeit(lambda: ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=bool(causal), dq_scale=0.125))
-print(f"attn_bwd (delta+dq+dkv): {t*1e3:.1f} us  {3.5*fl/t/1e9:.0f} TF (7 matmul passes)")
+print(f"attn_bwd (dq+dkv): {t*1e3:.1f} us  {3.5*fl/t/1e9:.0f} TF (7 matmul passes)")
 if os.environ.get("ATTN_PROFILE"):
     ops.attn_fwd(q, k, v, o, lse, causal=bool(causal)); torch.cuda.synchronize()
     nblk = B * H * ((Lq + 127) // 128)

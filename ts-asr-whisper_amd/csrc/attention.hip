@@ -426,7 +426,7 @@ extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
 
 // ================================================================================================ backward
 // Three kernels (deterministic, no atomics):
-//   attn_delta_kernel : delta[b,h,q] = sum_d dO[q,d] * O[q,d]
+//   (delta[b,h,q] = sum_d dO[q,d] * O[q,d] is computed in the dq kernel prologue and published with -lse for the dkv kernel)
 //   attn_bwd_dq_kernel: per 128-query block, loop over key tiles   (S^T, dP^T, dQ^T += K^T . dS^T)
 //   attn_bwd_dkv_kernel: per 128-key block, loop over query tiles  (S, dP, dV^T += dO^T . P, dK^T += Q^T . dS)
 // All LDS tiles use the "universal" image U: 16-B chunk c of row r stored at c ^ rev3((r>>1)&7), which is
@@ -466,37 +466,6 @@ __device__ __forceinline__ void tr_read_block_u(bf16x8_t (&f)[2][2], unsigned a0
     f[1][1] = __builtin_shufflevector(r6, r7, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 
-__global__ void attn_delta_kernel(const unsigned short* __restrict__ o, const unsigned short* __restrict__ d_o,
-                                  const float* __restrict__ lse, float* __restrict__ delta, int64_t o_bs, int64_t o_rs, int64_t do_bs, int64_t do_rs,
-                                  int B, int H, int Lq) {
-    // one 16-lane group per (b, q, h): 4 bf16 per lane
-    const int64_t gid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int sub = threadIdx.x & 15;
-    const int64_t total = (int64_t)B * Lq * H;
-    float s = 0.f;
-    int b = 0, q = 0, h = 0;
-    if (gid < total) {
-        h = (int)(gid % H);
-        const int64_t bq = gid / H;
-        q = (int)(bq % Lq); b = (int)(bq / Lq);
-        const uint2 uo = *reinterpret_cast<const uint2*>(o + (int64_t)b * o_bs + (int64_t)q * o_rs + h * HD + sub * 4);
-        const uint2 ud = *reinterpret_cast<const uint2*>(d_o + (int64_t)b * do_bs + (int64_t)q * do_rs + h * HD + sub * 4);
-        s = __uint_as_float(uo.x << 16) * __uint_as_float(ud.x << 16) +
-            __uint_as_float(uo.x & 0xffff0000u) * __uint_as_float(ud.x & 0xffff0000u) +
-            __uint_as_float(uo.y << 16) * __uint_as_float(ud.y << 16) +
-            __uint_as_float(uo.y & 0xffff0000u) * __uint_as_float(ud.y & 0xffff0000u);
-    }
-#pragma unroll
-    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    // workspace planes: [0] = -delta, [1] = -lse -- the values the dq / dkv kernels seed their accumulators with (negating
-    // them there cost 64 VALU instructions per query tile in the dkv loop)
-    if (gid < total && sub == 0) {
-        const int64_t i = ((int64_t)b * H + h) * Lq + q;
-        delta[i] = -s;
-        delta[(int64_t)B * H * Lq + i] = -lse[i];
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ dQ
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bwd_args a) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];      // K0 V0 K1 V1 (U images)
@@ -523,8 +492,24 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
     // -lse and -delta seed the S and dP accumulators, so the MFMA chain itself delivers (s - lse) and (dP - delta): plain
     // VALU work and MFMAs share one issue port per SIMD (tools/probe_overlap.hip: they do not overlap, transcendentals do),
     // which makes every VALU instruction shaved off the softmax recompute a direct saving.
-    const float nlse = a.delta[(int64_t)a.B * a.H * a.Lq + stat];       // workspace planes written by attn_delta_kernel
-    const float ndlt = a.delta[stat];
+    // delta[q] = rowsum(dO * O) is computed right here from the row this lane pair already holds (it used to be a kernel of
+    // its own); the negated (delta, lse) planes are published for attn_bwd_dkv_kernel, which is launched after this one.
+    const unsigned short* Op = reinterpret_cast<const unsigned short*>(a.o) + (int64_t)b * a.o_bs + h * HD;
+    float dsum = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(Op + (int64_t)qrow_c * a.o_rs + kk * 16 + hh * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            dsum = fmaf(bfbits2f((unsigned short)of[e]), bfbits2f((unsigned short)dof[kk][e]), dsum);
+    }
+    dsum += __shfl_xor(dsum, 32, 64);
+    const float nlse = -a.lse[stat];
+    const float ndlt = -dsum;
+    if (hh == 0 && qrow < a.Lq) {
+        a.delta[stat] = ndlt;
+        a.delta[(int64_t)a.B * a.H * a.Lq + stat] = nlse;
+    }
 
     f32x16_t dq[2];
 #pragma unroll
@@ -796,11 +781,6 @@ extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
     for (int i = 0; i < 16; ++i) DICOW_REQUIRE(rs[i] % 4 == 0, "attn_bwd: strides must keep 8-byte alignment");
     DICOW_REQUIRE(a->q_rs % 8 == 0 && a->k_rs % 8 == 0 && a->v_rs % 8 == 0 && a->do_rs % 8 == 0, "attn_bwd: q/k/v/dO row strides %% 8");
     hipStream_t st = (hipStream_t)stream;
-    const int64_t groups = (int64_t)a->B * a->Lq * a->H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 16 + 255) / 256)), dim3(256), 0, st,
-                       (const unsigned short*)a->o, (const unsigned short*)a->d_o, a->lse, a->delta, a->o_bs, a->o_rs, a->do_bs,
-                       a->do_rs, a->B, a->H, a->Lq);
-    DICOW_CHECK_LAUNCH("attn_delta");
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(dicow_cdiv(a->Lq, 128) * a->H * a->B), dim3(256), 0, st, *a);
     DICOW_CHECK_LAUNCH("attn_bwd_dq");
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(dicow_cdiv(a->Lk, 128) * a->H * a->B), dim3(256), 0, st, *a);
