@@ -511,11 +511,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
         a.delta[(int64_t)a.B * a.H * a.Lq + stat] = nlse;
     }
 
-    f32x16_t dq[2];
+    f32x16_t dq[2], seed_s, seed_p;
 #pragma unroll
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[d][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { seed_s[r] = nlse; seed_p[r] = ndlt; }
 
     int kv_end = a.Lk;
     if (a.causal) kv_end = q0 + 128 < a.Lk ? q0 + 128 : a.Lk;
@@ -552,9 +554,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
         f32x16_t ds[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            f32x16_t s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = nlse; dp[r] = ndlt; }
+            // the first MFMA of each chain takes the loop-invariant seed registers as C and writes a fresh D: no per-tile
+            // v_mov of 2 x 16 seed values (they were a quarter of this loop's VALU instructions)
+            f32x16_t s = seed_s, dp = seed_p;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + uswz(kb * 32 + (lane & 31), kk * 2 + hh));
