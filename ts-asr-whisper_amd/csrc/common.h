@@ -49,14 +49,16 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 // ~40 instructions of erff/expf: the GEMM epilogues that apply it run one wave per SIMD, so every VALU cycle in them
 // is a cycle the matrix pipe idles.  The same exponential gives the Gaussian density, so the derivative is ~free.
 __device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    const float e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);          // exp(-x^2/2)
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float h = 0.5f * p * t * e;                                                // Phi(-|x|)
+    // z = |x| sqrt(log2(e)/2): exp(-x^2/2) = 2^(-z^2) needs no further scaling, t = 1/(1 + p |x|/sqrt2) = 1/(1 + p' z), and the
+    // 0.5 of 0.5*erfc is folded into the polynomial coefficients (two multiplies fewer per element than the textbook form)
+    const float z = fabsf(x) * 0.84932180028801907f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.27273748087922245f, z, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-(z * z));                                // exp(-x^2/2)
+    float p = fmaf(0.5307027145f, t, -0.7265760135f);
+    p = fmaf(p, t, 0.7107068705f);
+    p = fmaf(p, t, -0.142248368f);
+    p = fmaf(p, t, 0.127414796f);
+    const float h = p * t * e;                                                       // Phi(-|x|)
     cdf = x >= 0.f ? 1.0f - h : h;
     pdf = e * 0.3989422804014327f;
 }
