@@ -274,6 +274,33 @@ int64_t dicow_logmel_ws_bytes(int B, int n_samples);
 int dicow_logmel(const float* wave, int B, int n_samples, const float* tw_cos, const float* tw_sin, const float* fb, int M,
                  float* out, void* ws, int64_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ batch augmentation
+ * The collator's training-time augmentations (reference src/data/collators.py:189-214), applied to the batch where it
+ * already lives (HBM).  The random decisions are drawn on the host from the torch CPU generator in the reference's
+ * own order (ts-asr-whisper_amd/augment.py) and arrive here as small plans, so a seed reproduces the reference.
+ *
+ * dicow_stno_noise_rescale (collators.py:50-77): for i < n_rows, r = rows[i]:
+ *     x = stno[r] + noise[i] * sd;  x -= min(min_c x, 0);  stno[r] = x / sum_c x         (in place; rows distinct)
+ *   stno fp32 [B, C=4, T], rows int32 [n_rows], noise fp32 [n_rows, C, T] (N(0,1) draws), sd = sqrt(variance).
+ * dicow_stno_segment_augment (collators.py:79-138): for each changed segment s (segments are disjoint):
+ *     dominant = argmax_c mean_t stno[b, c, start:end];  target = the pick-th class != dominant
+ *     x = keep * stno[b, :, t] + soft * onehot(target);  stno[b, :, t] = x / sum_c x      (in place)
+ *   segs int32 [n_seg, 4] = (b, start, end, pick), coef fp32 [n_seg, 2] = (keep = 1 - softness, soft = softness).
+ * dicow_specaug_joint (collators.py:209-214; src/data/augmentations.py:85-120 time warp, :23-79 masks, :363-379
+ *   masks limited to features [:128]): x = [mel ; stno repeated `sub` times along time]  (M + 4 feature rows, T frames)
+ *     time warp: frames [0, center) are resampled to [0, warped) and [center, T) to [warped, T) with torch's bicubic
+ *       kernel (align_corners = false, A = -0.75, border clamp per piece);  warped < 0 disables the warp
+ *     frequency masks fmask int32 [B, n_fmask, 2] = (pos, len) and time masks tmask int32 [B, n_tmask, 2] zero
+ *       x[b, pos:pos+len] on feature rows < n_maskable (= min(128, M + 4) in the reference)
+ *     mel_out fp32 [B, M, T] = rows < M;  stno_out fp32 [B, 4, T/sub] = mean over each `sub` frames of rows >= M.
+ *   Out of place (mel_out != mel, stno_out != stno). */
+int dicow_stno_noise_rescale(float* stno, const int* rows, const float* noise, int n_rows, int C, int T, float sd,
+                             void* stream);
+int dicow_stno_segment_augment(float* stno, const int* segs, const float* coef, int n_seg, int C, int T, void* stream);
+int dicow_specaug_joint(const float* mel, const float* stno, float* mel_out, float* stno_out, int B, int M, int T, int sub,
+                        int center, int warped, const int* fmask, int n_fmask, const int* tmask, int n_tmask,
+                        int n_maskable, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ optimizer
  * Fused AdamW + global-norm clipping on flat fp32 regions (src/models/containers.py:100-114 two param groups;
  * HF Trainer max_grad_norm 1.0).  dicow_sumsq_f32 accumulates sum(x^2) into out[0]; dicow_adamw_f32 applies

@@ -415,9 +415,95 @@ def f10_ctc():
     save("f10_ctc", **arrs)
 
 
+# ----------------------------------------------------------------------------- F11: collator augmentations
+def _install_placeholders():
+    import importlib.abc
+    import importlib.machinery
+    absent = ("lhotse", "torchaudio", "omegaconf", "wandb", "hydra", "peft", "meeteval", "jiwer")
+
+    class _Any(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return type(k, (), {})
+
+    class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, name, path=None, target=None):
+            if name.split(".")[0] in absent:
+                return importlib.machinery.ModuleSpec(name, self, is_package=True)
+            return None
+
+        def create_module(self, spec):
+            return _Any(spec.name)
+
+        def exec_module(self, module):
+            pass
+
+    if not any(type(f).__name__ == "_Finder" for f in sys.meta_path):
+        sys.meta_path.append(_Finder())
+
+
+def hashed_mel(B, M, T):
+    """Deterministic pseudo-random mel in [-1, 1] from integer arithmetic only (exact in fp32 on every platform)."""
+    b = np.arange(B, dtype=np.int64)[:, None, None]
+    m = np.arange(M, dtype=np.int64)[None, :, None]
+    t = np.arange(T, dtype=np.int64)[None, None, :]
+    h = (m * 7919 + t * 104729 + b * 1299709 + (m * t) % 613 * 31) % 2001 - 1000
+    return torch.from_numpy((h.astype(np.float64) / 1000.0).astype(np.float32))
+
+
+def f11_augment():
+    """STNO Gaussian noise + renormalisation, STNO soft segment augmentation and the joint SpecAug over mel (+) STNO of
+    the reference collator (src/data/collators.py:50-138, 209-214; src/data/augmentations.py), driven by the global torch
+    CPU generator: every case stores the seed, the inputs and the reference outputs."""
+    _install_placeholders()
+    from data.collators import DataCollator
+    from data.augmentations import SpecAug
+    arrs = {}
+    g = torch.Generator().manual_seed(123)
+    B, T = 6, 1500
+    stno = torch.softmax(torch.randn(B, 4, T, generator=g) * 2.0, dim=1)
+    stno[1, :, 700:] = torch.tensor([1.0, 0, 0, 0])[:, None]          # padding-as-silence tail
+    stno[3] = torch.nn.functional.one_hot(torch.randint(0, 4, (T,), generator=g), 4).T.float()   # hard labels
+    arrs["stno"] = stno
+    # (a) Gaussian noise + rescale: recipe values var 0.2 on 75 % of the rows, and an edge case (fraction -> 0 rows)
+    for i, (var, frac, seed) in enumerate(((0.2, 0.75, 11), (0.05, 0.5, 12), (0.2, 0.1, 13))):
+        torch.manual_seed(seed)
+        out = DataCollator.add_gaussian_noise_and_rescale(stno.clone(), var, frac)
+        arrs[f"noise_{i}_cfg"] = np.array([var, frac, seed], dtype=np.float64)
+        arrs[f"noise_{i}_out"] = out
+    arrs["n_noise"] = np.array(3)
+    # (b) soft segment augmentation: recipe values change_prob 0.1, lengths 5..50, plus a dense case
+    for i, (cp, lo, hi, seed) in enumerate(((0.1, 5, 50, 21), (0.6, 3, 12, 22))):
+        torch.manual_seed(seed)
+        out = DataCollator.soft_segment_augmentation(stno.clone(), change_prob=cp, min_seg_len=lo, max_seg_len=hi)
+        arrs[f"seg_{i}_cfg"] = np.array([cp, lo, hi, seed], dtype=np.float64)
+        arrs[f"seg_{i}_out"] = out
+    arrs["n_seg"] = np.array(2)
+    # (c) joint SpecAug exactly as the collator wires it (collators.py:209-214), M = 128 and M = 80 mel bins
+    spec_params = dict(apply_time_warp=True, time_warp_window=5, time_warp_mode="bicubic", apply_freq_mask=True,
+                       freq_mask_width_range=[0, 27], num_freq_mask=2, apply_time_mask=True,
+                       time_mask_width_ratio_range=[0, 0.05], num_time_mask=5)
+    aug = SpecAug(**spec_params)
+    for i, (M, Bs, Tm, seed) in enumerate(((128, 1, 3000, 31), (80, 2, 600, 32), (128, 2, 400, 33))):
+        mel = hashed_mel(Bs, M, Tm)                       # regenerated by the tests from the same integer formula
+        st = stno[:Bs, :, :Tm // 2].clone()
+        torch.manual_seed(seed)
+        x = torch.concatenate([mel, st.repeat_interleave(2, dim=2)], dim=1).permute(0, 2, 1)
+        y = aug(x)[0].permute(0, 2, 1)
+        st_out = torch.stack(y[:, M:, :].split(2, dim=-1)).mean(dim=-1).permute(1, 2, 0)
+        arrs[f"spec_{i}_cfg"] = np.array([M, Bs, Tm, seed])
+        arrs[f"spec_{i}_mel_out"] = y[:, :M, :]
+        arrs[f"spec_{i}_stno_out"] = st_out
+    arrs["n_spec"] = np.array(3)
+    save("f11_augment", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11"]
     fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
-           "f8": f8_se, "f10": f10_ctc}
+           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment}
     for w in which:
         fns[w]()

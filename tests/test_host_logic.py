@@ -88,3 +88,64 @@ def test_product_mel_filterbank_matches_oracle():
     from oracle import logmel as ol
     for m in (80, 128):
         assert np.allclose(features.mel_filter_bank(m), ol.mel_filter_bank(m), atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------ augmentation planner
+def _next_draw():
+    return float(torch.rand(1))
+
+
+def test_augment_planner_consumes_the_generator_like_the_reference_restatement():
+    """The planner must make the same draws in the same order as the collator (pinned by the oracle against golden F11):
+    after either one runs from the same seed the generator has to be in the same state."""
+    from oracle import augment as oaug
+    from ts_asr_whisper_amd import augment as paug
+    stno = load_golden("f11_augment")["stno"]
+    B, C, Tn = stno.shape
+    torch.manual_seed(3)
+    oaug.soft_segment_augmentation(stno.copy(), 0.3, 4, 30)
+    a = _next_draw()
+    torch.manual_seed(3)
+    segs, coef = paug.plan_soft_segments(B, C, Tn, 0.3, 4, 30)
+    assert _next_draw() == a
+    assert segs.dtype == torch.int32 and segs.shape[1] == 4 and coef.shape == (segs.shape[0], 2)
+    assert (segs[:, 2] > segs[:, 1]).all() and (segs[:, 2] - segs[:, 1] <= 30).all() and (segs[:, 3] < C - 1).all()
+    assert torch.allclose(coef.sum(1), torch.ones(len(coef)))
+
+    torch.manual_seed(4)
+    oaug.add_gaussian_noise_and_rescale(stno.copy(), 0.2, 0.75)
+    a = _next_draw()
+    torch.manual_seed(4)
+    rows, noise, sd = paug.plan_gaussian_noise(B, C, Tn, 0.2, 0.75)
+    assert _next_draw() == a
+    assert rows.numel() == int(B * 0.75) == noise.shape[0] and len(set(rows.tolist())) == rows.numel()
+    assert sd == float(np.float32(0.2 ** 0.5))
+    assert paug.plan_gaussian_noise(B, C, Tn, 0.2, 0.1) is None              # int(6 * 0.1) == 0 rows: no draw at all
+
+    x = np.zeros((3, 400, 132), np.float32)
+    torch.manual_seed(5)
+    oaug.spec_aug(x)
+    a = _next_draw()
+    torch.manual_seed(5)
+    plan = paug.plan_spec_aug(3, 400, 132)
+    assert _next_draw() == a
+    assert plan.fmask.shape == (3, 2, 2) and plan.tmask.shape == (3, 5, 2)
+    assert 0 < plan.warped < 400 and abs(plan.warped - plan.center) <= 5
+    assert int(plan.fmask[..., 1].max()) < 27 and int(plan.tmask[..., 1].max()) < 20
+    assert int((plan.fmask[..., 0] + plan.fmask[..., 1]).max()) <= 128
+
+
+def test_augment_planner_short_inputs_skip_the_warp():
+    from ts_asr_whisper_amd import augment as paug
+    torch.manual_seed(0)
+    plan = paug.plan_spec_aug(2, 10, 132)               # T - window <= window: no warp draw (augmentations.py:101)
+    assert plan.warped < 0
+    assert plan.tmask.numel() == 0                      # floor(10 * 0.05) == 0: the ratio mask is skipped as well
+
+
+def test_augment_refuses_cpu_tensors():
+    from ts_asr_whisper_amd import augment as paug
+    with pytest.raises(Exception, match="GPU"):
+        paug.add_gaussian_noise_and_rescale(torch.rand(2, 4, 8), 0.2, 1.0)
+    with pytest.raises(Exception, match="GPU"):
+        paug.spec_aug_joint(torch.rand(1, 80, 20), torch.rand(1, 4, 10))

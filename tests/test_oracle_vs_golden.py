@@ -6,7 +6,8 @@ import torch
 from oracle import stno as ostno
 from oracle import logmel as ologmel
 from oracle import dicow_oracle as O
-from tests.util import load_golden, golden_cfg, golden_params, T, maxdiff
+from oracle import augment as oaug
+from tests.util import load_golden, golden_cfg, golden_params, T, maxdiff, hashed_mel
 
 
 def test_f1_stno_bit_exact():
@@ -192,3 +193,53 @@ def test_f10_ctc_branch():
             assert maxdiff(p[k[2:]].grad, ref) < 1e-5 + 2e-3 * float(ref.abs().max()), k
             n += 1
     assert n > 30
+
+
+# ------------------------------------------------------------------------------------------------ F11: batch augmentation
+def test_f11_gaussian_noise_bit_exact():
+    z = load_golden("f11_augment")
+    stno = z["stno"]
+    for i in range(int(z["n_noise"])):
+        var, frac, seed = z[f"noise_{i}_cfg"]
+        torch.manual_seed(int(seed))
+        got = oaug.add_gaussian_noise_and_rescale(stno.copy(), float(var), float(frac))
+        want = z[f"noise_{i}_out"]
+        assert np.array_equal(got, want), f"case {i}"
+        touched = (got != stno).any(axis=(1, 2))
+        assert touched.sum() == int(stno.shape[0] * frac)
+        assert np.allclose(got.sum(1), 1.0, atol=1e-5) and got.min() >= 0
+
+
+def test_f11_soft_segments_bit_exact():
+    z = load_golden("f11_augment")
+    stno = z["stno"]
+    for i in range(int(z["n_seg"])):
+        cp, lo, hi, seed = z[f"seg_{i}_cfg"]
+        torch.manual_seed(int(seed))
+        got = oaug.soft_segment_augmentation(stno.copy(), float(cp), int(lo), int(hi))
+        assert np.array_equal(got, z[f"seg_{i}_out"]), f"case {i}"
+        assert np.allclose(got.sum(1), 1.0, atol=1e-5)
+
+
+def test_f11_spec_aug_joint():
+    """fp32 bicubic: the restatement is within 1e-6 of the reference (ATen's accumulation order is not reproduced
+    bit-for-bit); masks and the random decisions must agree exactly."""
+    z = load_golden("f11_augment")
+    for i in range(int(z["n_spec"])):
+        M, B, Tm, seed = (int(v) for v in z[f"spec_{i}_cfg"])
+        mel, stno = hashed_mel(B, M, Tm), z["stno"][:B, :, :Tm // 2]
+        torch.manual_seed(seed)
+        mel_out, stno_out = oaug.spec_aug_joint(mel, stno)
+        want_mel, want_stno = z[f"spec_{i}_mel_out"], z[f"spec_{i}_stno_out"]
+        assert np.abs(mel_out - want_mel).max() < 1e-6, f"case {i}"
+        assert np.abs(stno_out - want_stno).max() < 1e-6, f"case {i}"
+        assert np.array_equal(mel_out == 0, want_mel == 0), f"case {i}: mask pattern"
+        assert (want_mel == 0).mean() > 0.05
+
+
+def test_spec_aug_without_warp_only_masks():
+    torch.manual_seed(5)
+    mel, stno = hashed_mel(2, 128, 200), np.full((2, 4, 100), 0.25, np.float32)
+    mo, so = oaug.spec_aug_joint(mel, stno, apply_time_warp=False)
+    keep = mo != 0
+    assert np.array_equal(mo[keep], mel[keep]) and np.array_equal(so, stno)      # 128 mel bins: STNO rows are never masked

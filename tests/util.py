@@ -45,3 +45,13 @@ def T(z, k, dtype=None):
 
 def maxdiff(a, b):
     return float((a.double() - b.double()).abs().max())
+
+
+def hashed_mel(B, M, T):
+    """Deterministic pseudo-random mel in [-1, 1] from integer arithmetic only; the inputs of golden F11's SpecAug cases
+    (same formula as tests/golden/make_golden.py:hashed_mel)."""
+    b = np.arange(B, dtype=np.int64)[:, None, None]
+    m = np.arange(M, dtype=np.int64)[None, :, None]
+    t = np.arange(T, dtype=np.int64)[None, None, :]
+    h = (m * 7919 + t * 104729 + b * 1299709 + (m * t) % 613 * 31) % 2001 - 1000
+    return (h.astype(np.float64) / 1000.0).astype(np.float32)

@@ -187,8 +187,9 @@ class TrainStep:
 
     def __init__(self, model, lr=2e-6, fddt_lr_multiplier=100.0, weight_decay=0.0, max_grad_norm=1.0, warmup_steps=0,
                  max_steps=0, frozen_keywords=("decoder",), preheat_prefixes=("model.encoder.fddts", "model.encoder.initial_fddt"),
-                 process_group=None):
+                 process_group=None, augmenter=None):
         self.model = model
+        self.augmenter = augmenter          # augment.BatchAugmenter: the collator's training-time block, on the GPU
         freeze_by_keyword(model, frozen_keywords)
         self.store = FlatStore(model, preheat_prefixes)
         self.opt = FusedAdamW(self.store, lr, fddt_lr_multiplier, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
@@ -199,6 +200,8 @@ class TrainStep:
 
     def step(self, batch):
         self.store.zero_grad()
+        if self.augmenter is not None:      # enrollments are collated "nested" and stay clean (collators.py:189,216-220)
+            batch = self.augmenter(dict(batch))
         out = self.model(**batch)
         out.loss.backward()
         self.reducer.finish()
