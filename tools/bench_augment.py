@@ -42,6 +42,7 @@ for name, fn in (("plan_soft_segments (host only)", lambda: A.plan_soft_segments
     print(f"{name:36s} host {h:8.3f} ms   wall/gpu {g:8.3f} ms")
 # kernels alone, plans prepared ahead
 plan = A.plan_spec_aug(B, 2 * Tn, M + 4)
+plan.fmask, plan.tmask = plan.fmask.cuda(), plan.tmask.cuda()
 h, g = timed(lambda: A.spec_aug_joint(mel, stno, plan=plan), 50)
 byt = 2 * mel.numel() * 4 + 2 * stno.numel() * 4
 print(f"spec_aug_joint kernel (fixed plan)    host {h:8.3f} ms   gpu {g:8.3f} ms   {byt / g / 1e6:.0f} GB/s algorithmic")

@@ -34,18 +34,60 @@ def _need_gpu(t: torch.Tensor, name: str):
         raise L.DicowError(f"{name}: expected a contiguous fp32 tensor, got {t.dtype} contiguous={t.is_contiguous()}")
 
 
+class _Staging:
+    """Pinned host buffers for the plan uploads, reused across steps (allocating pinned memory per call costs more than
+    the whole augmentation).  A slot is recycled only after the copy that last read it has completed."""
+    SLOTS = 4
+
+    def __init__(self):
+        self.buf = [None] * self.SLOTS
+        self.done = [None] * self.SLOTS
+        self.i = 0
+
+    def host(self, shape, dtype) -> torch.Tensor:
+        """A pinned host tensor of the given shape from the next slot (valid until SLOTS further requests)."""
+        k, self.i = self.i, (self.i + 1) % self.SLOTS
+        nbytes = math.prod(shape) * torch.empty(0, dtype=dtype).element_size()
+        if self.done[k] is not None:
+            self.done[k].synchronize()
+        if self.buf[k] is None or self.buf[k].numel() < nbytes:
+            self.buf[k] = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8).pin_memory()
+        h = self.buf[k][:nbytes].view(dtype).view(shape)
+        h._dicow_slot = k
+        return h
+
+    def send(self, h: torch.Tensor, device) -> torch.Tensor:
+        out = h.to(device, non_blocking=True)
+        self.done[h._dicow_slot] = torch.cuda.Event()
+        self.done[h._dicow_slot].record()
+        return out
+
+    def upload(self, t: torch.Tensor, device) -> torch.Tensor:
+        if t.is_cuda:
+            return t
+        if t.numel() == 0:
+            return t.to(device)
+        h = self.host(tuple(t.shape), t.dtype)
+        h.copy_(t)
+        return self.send(h, device)
+
+
+_staging = _Staging()
+
+
 def _up(t: torch.Tensor, device) -> torch.Tensor:
-    return t.pin_memory().to(device, non_blocking=True) if t.numel() else t.to(device)
+    return _staging.upload(t.contiguous(), device)
 
 
 # ------------------------------------------------------------------------------------------------- Gaussian noise
-def plan_gaussian_noise(B: int, C: int, T: int, variance: float, fraction: float):
-    """Draws of collators.py:54-65: which rows, and their N(0,1) noise.  Returns None when no row is selected."""
+def plan_gaussian_noise(B: int, C: int, T: int, variance: float, fraction: float, pinned: bool = False):
+    """Draws of collators.py:54-65: which rows, and their N(0,1) noise.  Returns None when no row is selected.
+    pinned: draw the noise straight into a pinned staging slot (the upload then needs no extra host copy)."""
     n = int(B * fraction)
     if n == 0:
         return None
     rows = torch.randperm(B)[:n].to(torch.int32)
-    noise = torch.randn((n, C, T))
+    noise = torch.randn((n, C, T), out=_staging.host((n, C, T), torch.float32)) if pinned else torch.randn((n, C, T))
     return rows, noise, float(torch.tensor(variance ** 0.5, dtype=torch.float32))
 
 
@@ -53,11 +95,11 @@ def add_gaussian_noise_and_rescale(stno: torch.Tensor, variance: float = 0.05, f
     """stno fp32 [B, 4, T] on the GPU; modified in place and returned."""
     _need_gpu(stno, "add_gaussian_noise_and_rescale")
     B, C, T = stno.shape
-    plan = plan_gaussian_noise(B, C, T, variance, fraction)
+    plan = plan_gaussian_noise(B, C, T, variance, fraction, pinned=True)
     if plan is None:
         return stno
     rows, noise, sd = plan
-    rows_d, noise_d = _up(rows, stno.device), _up(noise, stno.device)
+    rows_d, noise_d = _up(rows, stno.device), _staging.send(noise, stno.device)
     L.call("dicow_stno_noise_rescale", stno.data_ptr(), rows_d.data_ptr(), noise_d.data_ptr(), rows.numel(), C, T, sd,
            L.stream())
     return stno
