@@ -86,6 +86,46 @@ __global__ void __launch_bounds__(256) kh(const char* base, long long ld_bytes, 
     if (tid == 0) cyc[b] = clock64() - t0;
 }
 
+// Same k-slabs through the VGPR path: 16 buffer_load_dwordx4 per wave and step into registers (no LDS at all).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+template <int DEPTH>
+__global__ void __launch_bounds__(256) kv(const char* base, long long ld_bytes, int nsteps, int mode, long long* cyc, unsigned* sink) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    long long rowA, rowB;
+    if (mode == 0) { rowA = 0; rowB = 256; }
+    else if (mode == 1) { rowA = (long long)(b % 64) * 256; rowB = 64 * 256 + (long long)(b / 64) * 256; }
+    else { rowA = (long long)b * 512; rowB = rowA + 256; }
+    unsigned off[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) {
+        const int q = wave * 8 + (d & 7), row = q * 8 + (lane >> 3), c = (lane & 7) ^ ((row >> 1) & 7);
+        const long long g = (d < 8 ? rowA : rowB) + row;
+        off[d] = (unsigned)(g * ld_bytes + c * 16);
+    }
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(base), 0, 0xffffffffu, 0x00020000);
+    u32x4_t r[DEPTH][16];
+    unsigned acc = 0;
+    const long long t0 = clock64();
+#pragma unroll 1
+    for (int t = 0; t < nsteps; t += DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u)
+#pragma unroll
+            for (int d = 0; d < 16; ++d) r[u][d] = __builtin_amdgcn_raw_buffer_load_b128(rs, off[d], (t + u) * 128, 0);
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            if (u == 0 && DEPTH == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int d = 0; d < 16; ++d) { asm volatile("" : "+v"(r[u][d])); acc ^= r[u][d][0]; }
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    if (tid == 0) cyc[b] = clock64() - t0;
+    if (acc == 0x12345678u) sink[tid] = acc;
+}
+
 int main() {
     const long long ld = 10240;                          // K = 5120 bf16
     const long long rows = 256LL * 512 + 1024;
@@ -132,6 +172,23 @@ int main() {
             double mean = 0; for (auto v : h) mean += v; mean /= 256;
             const double us = ms * 100.0;
             printf("half-row mode %d depth %d: %.1f us per launch, %.0f shader clocks per 64 KiB = %.1f B/clk/CU, %.2f TB/s chip\n",
+                   mode, depth, us, mean / nsteps, 65536.0 / (mean / nsteps), 256 * 65536.0 * nsteps / us / 1e6);
+        }
+    }
+    unsigned* sink; hipMalloc(&sink, 4096);
+    for (int mode = 0; mode < 2; ++mode) {
+        for (int depth = 1; depth <= 2; ++depth) {
+            hipEventRecord(e0);
+            for (int i = 0; i < 10; ++i) {
+                if (depth == 1) hipLaunchKernelGGL(kv<1>, dim3(256), dim3(256), 0, 0, buf, ld, nsteps, mode, cyc, sink);
+                else hipLaunchKernelGGL(kv<2>, dim3(256), dim3(256), 0, 0, buf, ld, nsteps, mode, cyc, sink);
+            }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            std::vector<long long> h(256); hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);
+            double mean = 0; for (auto v : h) mean += v; mean /= 256;
+            const double us = ms * 100.0;
+            printf("to-VGPR mode %d depth %d: %.1f us per launch, %.0f shader clocks per 64 KiB = %.1f B/clk/CU, %.2f TB/s chip\n",
                    mode, depth, us, mean / nsteps, 65536.0 / (mean / nsteps), 256 * 65536.0 * nsteps / us / 1e6);
         }
     }
