@@ -149,3 +149,23 @@ def test_augment_refuses_cpu_tensors():
         paug.add_gaussian_noise_and_rescale(torch.rand(2, 4, 8), 0.2, 1.0)
     with pytest.raises(Exception, match="GPU"):
         paug.spec_aug_joint(torch.rand(1, 80, 20), torch.rand(1, 4, 10))
+
+
+# ------------------------------------------------------------------------------------------------ optimizer schedule
+def test_lr_schedule_matches_hf_cosine_with_warmup():
+    """k-th optimizer step of FusedAdamW uses the lr HF's Trainer would (LambdaLR steps after the optimizer)."""
+    import types
+    import transformers
+    from oracle.optim import cosine_with_warmup_lambda
+    from ts_asr_whisper_amd.trainer import FusedAdamW
+    store = types.SimpleNamespace(params=torch.zeros(1), runs=[])
+    opt = FusedAdamW(store, lr=2e-6, warmup_steps=7, max_steps=50)
+    ref_opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=2e-6)
+    sched = transformers.get_cosine_schedule_with_warmup(ref_opt, 7, 50)
+    for k in range(1, 56):
+        want = ref_opt.param_groups[0]["lr"]
+        assert abs(opt.lr_at(k) - want) < 1e-18, k
+        assert abs(2e-6 * cosine_with_warmup_lambda(k - 1, 7, 50) - want) < 1e-18
+        ref_opt.step()
+        sched.step()
+    assert FusedAdamW(store, lr=1e-3).lr_at(1) == 1e-3            # no schedule configured: constant

@@ -109,32 +109,49 @@ class FlatStore:
 
 
 class FusedAdamW:
-    """Two-group AdamW + global-norm clipping in fused HIP kernels over the FlatStore (no host synchronisation)."""
+    """Two-group AdamW + global-norm clipping in fused HIP kernels over the FlatStore (no host synchronisation).
+
+    Mirrors what the reference's harness does with ``torch.optim.AdamW`` (containers.py:100-114) under the HF Trainer:
+      * the k-th optimizer step uses the scheduler's lambda(k - 1) (LambdaLR: the scheduler steps AFTER the optimizer), with
+        ``get_cosine_schedule_with_warmup`` as the lambda (dicow_v3.yaml:66-67);
+      * bias correction counts the updates each parameter has RECEIVED (torch keeps ``state['step']`` per parameter and
+        skips parameters without a gradient), which matters for the staged unfreezing of trainers.py:122-137: a run
+        that was frozen during the preheat phase starts at step 1 when it is unfrozen;
+      * the preheat group has weight decay 0 whatever the base group uses (containers.py:109-111);
+      * clipping: g *= min(1, max_norm / (||g||_2 + 1e-6)) over every gradient of the step."""
 
     def __init__(self, store, lr=2e-6, fddt_lr_multiplier=100.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
                  max_grad_norm=1.0, warmup_steps=0, max_steps=0, schedule="cosine"):
         self.s, self.lr, self.mult, self.betas, self.eps, self.wd = store, lr, fddt_lr_multiplier, betas, eps, weight_decay
         self.max_norm, self.warmup, self.max_steps, self.schedule = max_grad_norm, warmup_steps, max_steps, schedule
-        self.t = 0
+        self.t = 0                                        # optimizer steps taken (= HF state.global_step)
+        self.run_t = [0] * len(store.runs)                # updates received per run
         self.gnorm_sq = torch.zeros(1, dtype=F32, device=store.params.device)
 
-    def lr_at(self, t):
-        if self.warmup and t <= self.warmup:
-            return self.lr * t / max(1, self.warmup)
-        if self.schedule == "cosine" and self.max_steps > self.warmup:
-            prog = min(1.0, (t - self.warmup) / (self.max_steps - self.warmup))
-            return self.lr * 0.5 * (1.0 + math.cos(math.pi * prog))
+    def lr_at(self, k):
+        """Learning rate of the k-th optimizer step (k = 1, 2, ...)."""
+        sched_step = k - 1
+        if sched_step < self.warmup:
+            return self.lr * sched_step / max(1, self.warmup)
+        if self.schedule == "cosine" and self.max_steps > 0:
+            prog = (sched_step - self.warmup) / max(1, self.max_steps - self.warmup)
+            return self.lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
         return self.lr
 
-    def step(self, trainable_runs=None):
+    def step(self, preheat_only=False):
+        """preheat_only: update only the runs of the preheat group (the others are frozen: no gradient, no update)."""
         s = self.s
         self.t += 1
         lr = self.lr_at(self.t)
         self.gnorm_sq.zero_()
-        ops.sumsq(s.grads, self.gnorm_sq)
-        for a, b, pre in (trainable_runs or s.runs):
+        ops.sumsq(s.grads, self.gnorm_sq)                 # frozen runs hold zeros
+        for i, (a, b, pre) in enumerate(s.runs):
+            if preheat_only and not pre:
+                continue
+            self.run_t[i] += 1
             ops.adamw(s.params[a:b], s.grads[a:b], s.exp_avg[a:b], s.exp_avg_sq[a:b], lr * (self.mult if pre else 1.0),
-                      self.betas[0], self.betas[1], self.eps, self.wd, self.t, gnorm_sq=self.gnorm_sq, max_norm=self.max_norm)
+                      self.betas[0], self.betas[1], self.eps, 0.0 if pre else self.wd, self.run_t[i], gnorm_sq=self.gnorm_sq,
+                      max_norm=self.max_norm)
 
 
 class GradReducer:
@@ -158,10 +175,11 @@ class GradReducer:
             ops.set_gemm_cus(max(ncu - reserve, ncu // 2))
         self.seg = {name: (a, b) for name, a, b in store.segments}
         self.pending = []
+        self.preheat_only = False     # staged freezing, phase 1: only the preheat runs carry gradients
 
     def segment_ready(self, name):
         """Called right after the segment's backward kernels have been enqueued on the current stream."""
-        if (self.world == 1 and not self.force) or name not in self.seg:
+        if (self.world == 1 and not self.force) or name not in self.seg or self.preheat_only:
             return
         a, b = self.seg[name]
         if self.stream is None:                       # CPU / gloo tests: synchronous
@@ -177,7 +195,23 @@ class GradReducer:
             dist.all_reduce(buf, group=self.pg)
             buf.div_(self.world)
 
+    def _reduce_preheat_runs(self):
+        """Phase 1 of the staged freezing: the frozen runs hold zeros, so only the (small) preheat runs are exchanged,
+        after the backward pass, as one coalesced buffer."""
+        runs = [(a, b) for a, b, pre in self.s.runs if pre]
+        if not runs:
+            return
+        flat = torch.cat([self.s.grads[a:b] for a, b in runs])
+        dist.all_reduce(flat, group=self.pg)
+        flat.div_(self.world)
+        off = 0
+        for a, b in runs:
+            self.s.grads[a:b].copy_(flat[off:off + b - a])
+            off += b - a
+
     def finish(self):
+        if self.preheat_only and (self.world > 1 or self.force):
+            self._reduce_preheat_runs()
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
 
@@ -187,7 +221,7 @@ class TrainStep:
 
     def __init__(self, model, lr=2e-6, fddt_lr_multiplier=100.0, weight_decay=0.0, max_grad_norm=1.0, warmup_steps=0,
                  max_steps=0, frozen_keywords=("decoder",), preheat_prefixes=("model.encoder.fddts", "model.encoder.initial_fddt"),
-                 process_group=None, augmenter=None):
+                 process_group=None, augmenter=None, use_fddt_only_n_steps=0):
         self.model = model
         self.augmenter = augmenter          # augment.BatchAugmenter: the collator's training-time block, on the GPU
         freeze_by_keyword(model, frozen_keywords)
@@ -197,17 +231,48 @@ class TrainStep:
         self.reducer = GradReducer(self.store, process_group)
         model.model.encoder._segment_hook = self.reducer.segment_ready
         model._segment_hook = self.reducer.segment_ready
+        # Staged freezing (reference train.py:174-178 + trainers.py:122-137, dicow_v3.yaml:68 use_fddt_only_n_steps 2000):
+        # while fewer than n optimizer steps have been taken only the preheat-prefixed parameters train; the engine skips
+        # every weight-gradient GEMM of a parameter that does not require grad, dgrad still flows down to layer 0's FDDT.
+        self.use_fddt_only_n_steps = use_fddt_only_n_steps
+        self.warmup_phase = use_fddt_only_n_steps > 0
+        if self.warmup_phase:
+            self._set_phase(preheat_only=True)
+
+    def _set_phase(self, preheat_only):
+        for p, _, _, pre in self.store.entries:
+            p.requires_grad_(pre or not preheat_only)
+        self.reducer.preheat_only = preheat_only
+        self.model.model.encoder._sig = None
+        self.model._sig = None
+
+    @property
+    def global_step(self):
+        return self.opt.t
+
+    def begin_step(self):
+        """trainers.py:122-137: once n optimizer steps are done, unfreeze everything the keywords do not freeze."""
+        if self.warmup_phase and self.global_step >= self.use_fddt_only_n_steps:
+            self._set_phase(preheat_only=False)
+            self.warmup_phase = False
+        self.store.zero_grad()
+
+    def finish_step(self):
+        """Gradients are in the flat store: exchange (DP), clip, AdamW, invalidate the bf16 compute copies."""
+        self.reducer.finish()
+        self.opt.step(preheat_only=self.warmup_phase)
+        # the fused optimizer writes through raw pointers (no torch version bump): invalidate the bf16 weight copies
+        enc = self.model.model.encoder
+        enc._sig = None
+        enc._ctc_sig = None
+        if any(p.requires_grad for p in self.model.model.decoder.parameters()):
+            self.model._sig = None
 
     def step(self, batch):
-        self.store.zero_grad()
+        self.begin_step()
         if self.augmenter is not None:      # enrollments are collated "nested" and stay clean (collators.py:189,216-220)
             batch = self.augmenter(dict(batch))
         out = self.model(**batch)
         out.loss.backward()
-        self.reducer.finish()
-        self.opt.step()
-        # the fused optimizer writes through raw pointers (no torch version bump): invalidate the bf16 weight copies
-        self.model.model.encoder._sig = None
-        if any(p.requires_grad for p in self.model.model.decoder.parameters()):
-            self.model._sig = None
+        self.finish_step()
         return out.loss.detach()
