@@ -176,10 +176,11 @@ class GradReducer:
         self.seg = {name: (a, b) for name, a, b in store.segments}
         self.pending = []
         self.preheat_only = False     # staged freezing, phase 1: only the preheat runs carry gradients
+        self.hold = False             # gradient accumulation: not the last micro-batch yet, nothing to exchange
 
     def segment_ready(self, name):
         """Called right after the segment's backward kernels have been enqueued on the current stream."""
-        if (self.world == 1 and not self.force) or name not in self.seg or self.preheat_only:
+        if (self.world == 1 and not self.force) or name not in self.seg or self.preheat_only or self.hold:
             return
         a, b = self.seg[name]
         if self.stream is None:                       # CPU / gloo tests: synchronous
@@ -268,11 +269,40 @@ class TrainStep:
         if any(p.requires_grad for p in self.model.model.decoder.parameters()):
             self.model._sig = None
 
-    def step(self, batch):
-        self.begin_step()
+    def _micro(self, batch, scale):
         if self.augmenter is not None:      # enrollments are collated "nested" and stay clean (collators.py:189,216-220)
             batch = self.augmenter(dict(batch))
         out = self.model(**batch)
-        out.loss.backward()
-        self.finish_step()
+        (out.loss if scale == 1.0 else out.loss * scale).backward()
         return out.loss.detach()
+
+    def step(self, batch):
+        """One optimizer step on one batch, or -- given a list / tuple of batches -- on their accumulated gradients
+        (HF Trainer gradient_accumulation_steps: each micro-batch's mean loss is divided by the number of micro-batches,
+        gradients sum in place in the flat store, ranks exchange them once, after the last micro-batch's backward)."""
+        micro = list(batch) if isinstance(batch, (list, tuple)) else [batch]
+        self.begin_step()
+        loss = None
+        for i, b in enumerate(micro):
+            self.reducer.hold = i + 1 < len(micro)
+            l = self._micro(b, 1.0 / len(micro))
+            loss = l if loss is None else loss + l
+        self.finish_step()
+        return loss / len(micro)
+
+    # ---- checkpoint / resume of the optimizer side (the model side is model.state_dict(), reference key names)
+    def state_dict(self):
+        o = self.opt
+        return {"global_step": o.t, "run_t": list(o.run_t), "warmup_phase": self.warmup_phase,
+                "exp_avg": self.store.exp_avg.clone(), "exp_avg_sq": self.store.exp_avg_sq.clone(),
+                "layout": [(a, b, pre) for a, b, pre in self.store.runs]}
+
+    def load_state_dict(self, sd):
+        if [tuple(r) for r in sd["layout"]] != [tuple(r) for r in self.store.runs]:
+            raise ValueError("optimizer state was saved for a different set of trainable parameters")
+        self.opt.t, self.opt.run_t = int(sd["global_step"]), list(sd["run_t"])
+        self.store.exp_avg.copy_(sd["exp_avg"])
+        self.store.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if bool(sd["warmup_phase"]) != self.warmup_phase:
+            self._set_phase(preheat_only=bool(sd["warmup_phase"]))
+            self.warmup_phase = bool(sd["warmup_phase"])
