@@ -47,7 +47,21 @@ def _worker(rank, world, port, q):
         for name, a, b in store.segments:
             red.segment_ready(name)
         red.finish()
-        q.put((rank, local.numpy(), store.grads.clone().numpy(), [s[0] for s in store.segments]))
+        full = store.grads.clone()
+        # gradient accumulation: while `hold` is set (not the last micro-batch) nothing is exchanged
+        store.grads.copy_(local)
+        red.hold = True
+        for name, a, b in store.segments:
+            red.segment_ready(name)
+        assert torch.equal(store.grads, local)
+        red.hold = False
+        # staged freezing, phase 1: only the preheat runs are exchanged (one coalesced all-reduce in finish())
+        red.preheat_only = True
+        for name, a, b in store.segments:
+            red.segment_ready(name)
+        red.finish()
+        q.put((rank, local.numpy(), full.numpy(), [s[0] for s in store.segments], store.grads.clone().numpy(),
+               [(a, b, pre) for a, b, pre in store.runs]))
     finally:
         dist.destroy_process_group()
 
@@ -65,8 +79,14 @@ def test_dp_allreduce_matches_mean_of_ranks():
         assert p.exitcode == 0
     res.sort(key=lambda t: t[0])
     mean = torch.from_numpy(res[0][1] + res[1][1]) / 2
-    for _, _, reduced, segs in res:
+    for _, local, reduced, segs, pre_reduced, runs in res:
         assert torch.allclose(torch.from_numpy(reduced), mean, atol=1e-6)
+        want = torch.from_numpy(local).clone()
+        for a, b, pre in runs:
+            if pre:
+                want[a:b] = mean[a:b]
+        assert any(pre for _, _, pre in runs) and not all(pre for _, _, pre in runs)
+        assert torch.allclose(torch.from_numpy(pre_reduced), want, atol=1e-6)
     # segments are laid out in backward-completion order: final LN, then layers N-1 .. 0, then the stem
     assert res[0][3] == ["final_ln", "layer2", "layer1", "layer0", "stem"]
 
