@@ -501,9 +501,38 @@ def f11_augment():
     save("f11_augment", **arrs)
 
 
+# ----------------------------------------------------------------------------- F12: STNO seek windows of long-form decoding
+def f12_seek():
+    """DiCoWGenerationMixin.prepare_kwargs_for_generate (src/models/dicow/generation.py:73-118) called as a plain function
+    on a stand-in `self` that carries only what it reads (conv strides, max_source_positions, use_enrollments)."""
+    from models.dicow.generation import DiCoWGenerationMixin
+    ns = types.SimpleNamespace
+    arrs = {}
+    g = torch.Generator().manual_seed(5)
+    cases = [  # (max_source_positions, total stno frames, batch, seek (feature frames), max_frames, batch_idx_map)
+        (1500, 4500, 3, [0, 3000, 6000], [9000, 9000, 7200], [0, 1, 2]),
+        (1500, 4500, 2, [2000, 0, 7400], [9000, 9000, 8000], [2, 0]),
+        (100, 260, 4, [0, 100, 300, 440], [520, 520, 520, 470], [3, 1, 2, 0]),
+    ]
+    for i, (msp, tot, cur, seek, maxf, bmap) in enumerate(cases):
+        Bfull = len(seek)
+        stno = torch.softmax(torch.randn(Bfull, 4, tot, generator=g), dim=1)
+        me = ns(model=ns(encoder=ns(conv1=ns(stride=(1,)), conv2=ns(stride=(2,)))),
+                config=ns(max_source_positions=msp, use_enrollments=False), stno_mask_seek=None)
+        kwargs = {"stno_mask": stno.clone()}
+        att = torch.ones(Bfull, 2 * tot, dtype=torch.long)
+        out_kw, out_att = DiCoWGenerationMixin.prepare_kwargs_for_generate(
+            me, torch.tensor(maxf), cur, torch.tensor(bmap), torch.tensor(seek), kwargs, att)
+        arrs[f"c{i}.stno"], arrs[f"c{i}.out"] = stno, out_kw["stno_mask"]
+        arrs[f"c{i}.seek"], arrs[f"c{i}.max_frames"], arrs[f"c{i}.map"] = np.array(seek), np.array(maxf), np.array(bmap)
+        arrs[f"c{i}.msp"], arrs[f"c{i}.att_rows"] = np.array(msp), out_att.shape[0]
+    arrs["n_cases"] = np.array(len(cases))
+    save("f12_seek", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12"]
     fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
-           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment}
+           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek}
     for w in which:
         fns[w]()

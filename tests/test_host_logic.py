@@ -169,3 +169,12 @@ def test_lr_schedule_matches_hf_cosine_with_warmup():
         ref_opt.step()
         sched.step()
     assert FusedAdamW(store, lr=1e-3).lr_at(1) == 1e-3            # no schedule configured: constant
+
+
+def test_product_stno_seek_windows_match_reference_golden():
+    from ts_asr_whisper_amd.generation import stno_seek_windows
+    z = load_golden("f12_seek")
+    for i in range(int(z["n_cases"])):
+        got = stno_seek_windows(torch.from_numpy(z[f"c{i}.stno"]), z[f"c{i}.seek"], z[f"c{i}.max_frames"], z[f"c{i}.map"],
+                                num_frames=int(z[f"c{i}.msp"]))
+        assert np.array_equal(got.numpy(), z[f"c{i}.out"]), i

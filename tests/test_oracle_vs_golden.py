@@ -243,3 +243,14 @@ def test_spec_aug_without_warp_only_masks():
     mo, so = oaug.spec_aug_joint(mel, stno, apply_time_warp=False)
     keep = mo != 0
     assert np.array_equal(mo[keep], mel[keep]) and np.array_equal(so, stno)      # 128 mel bins: STNO rows are never masked
+
+
+# ------------------------------------------------------------------------------------------------ F12: STNO seek windows
+def test_f12_stno_seek_windows_bit_exact():
+    from oracle import generation as ogen
+    z = load_golden("f12_seek")
+    for i in range(int(z["n_cases"])):
+        got = ogen.stno_seek_windows(z[f"c{i}.stno"], z[f"c{i}.seek"], z[f"c{i}.max_frames"], z[f"c{i}.map"],
+                                     num_frames=int(z[f"c{i}.msp"]))
+        assert np.array_equal(got, z[f"c{i}.out"]), i
+        assert got.shape[0] == int(z[f"c{i}.att_rows"]) and np.allclose(got.sum(1), 1.0, atol=1e-6)

@@ -1,0 +1,36 @@
+"""Time the decoding path at whisper-large-v3-turbo dims: encoder once + KV-cached greedy steps.
+usage: python tools/bench_decode.py [B] [new_tokens]"""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import amd_pkg
+
+pkg = amd_pkg.load()
+from ts_asr_whisper_amd.data import synthetic_batch
+from ts_asr_whisper_amd.generation import GreedyDecoder
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 124
+cfg = pkg.DiCoWConfig.preset("whisper-large-v3-turbo", use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True,
+                             fddt_init="suppressive", non_target_fddt_value=0.5)
+torch.manual_seed(0)
+model = pkg.DiCoWForConditionalGeneration(cfg).cuda().eval()
+model.tie_weights()
+b = synthetic_batch(cfg, B, 8, seed=1)
+prompt = torch.full((B, 4), cfg.decoder_start_token_id, dtype=torch.long)
+dec = GreedyDecoder(model)
+dec.generate(b["input_features"], b["stno_mask"], prompt, 4, eos_token_id=-1)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+st = dec.encode(b["input_features"], b["stno_mask"])
+torch.cuda.synchronize()
+t1 = time.perf_counter()
+seq = dec.generate(b["input_features"], b["stno_mask"], prompt, N, eos_token_id=-1)
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+enc_ms, tot_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+print(f"B={B}: encoder + cross K/V {enc_ms:.1f} ms; generate({N} tokens) {tot_ms:.1f} ms -> {(tot_ms - enc_ms) / (N + 3):.3f} ms per decoder step, "
+      f"{B * N / tot_ms * 1e3:.0f} tokens/s, {B / tot_ms * 1e3:.1f} windows/s")

@@ -239,7 +239,8 @@ class EncoderEngine:
         pre2 = _e((B * T, D), BF16, dev)
         ops.gemm_nt(g1p, W.conv2, x2, T, D, 3 * D, lda=2 * D, bias=enc.conv2.bias.detach(), aux=pre2, flags=L.EPI_GELU,
                     batch=B, strideA=(Tin + 2) * D, strideC=T * D, strideAux=T * D)
-        S.xt, S.g1p, S.pre1, S.pre2, S.x2 = xt, g1p, pre1, pre2, x2
+        if need_grad:
+            S.xt, S.g1p, S.pre1, S.pre2, S.x2 = xt, g1p, pre1, pre2, x2
         # ---- initial FDDT + positions (encoder.py:173-180)
         rows = B * T
         pos = enc.embed_positions.weight
@@ -296,11 +297,15 @@ class EncoderEngine:
             mean2, rstd2 = _e((rows,), F32, dev), _e((rows,), F32, dev)
             ops.fddt_ln_fwd(h2, rows, D, mode=ops.MODE_NONE, ln_w=ln2.weight.detach(), ln_b=ln2.bias.detach(), y_bf16=xln2,
                             mean=mean2, rstd=rstd2)
-            u = _e((rows, F_), BF16, dev)
-            a = linear_fwd(xln2, w.fc1, rows, gelu_aux=u)
+            if need_grad:
+                u = _e((rows, F_), BF16, dev)                     # gelu'(pre-activation), consumed by the backward pass
+                a = linear_fwd(xln2, w.fc1, rows, gelu_aux=u)
+            else:
+                u, a = None, linear_fwd(xln2, w.fc1, rows, flags=L.EPI_GELU)
             h = linear_fwd(a, w.fc2, rows, out_dtype=F32, residual=h2)
-            Ls.qkv, Ls.o, Ls.lse, Ls.h2, Ls.xln2, Ls.mean2, Ls.rstd2, Ls.u, Ls.a = qkv, o, lse, h2, xln2, mean2, rstd2, u, a
-            S.layers.append(Ls)
+            if need_grad:                                         # inference: nothing is kept, buffers recycle per layer
+                Ls.qkv, Ls.o, Ls.lse, Ls.h2, Ls.xln2, Ls.mean2, Ls.rstd2, Ls.u, Ls.a = qkv, o, lse, h2, xln2, mean2, rstd2, u, a
+                S.layers.append(Ls)
         rows = Bc * T
         S.h_last, S.B_out, S.bstride_out = h, Bc, bstride
         enc_out = _e((rows, D), F32, dev)

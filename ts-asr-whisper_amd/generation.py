@@ -1,0 +1,133 @@
+"""Decoding side of the path: encoder once, KV-cached greedy decoder, STNO seek windows.
+
+Mirrors, for the in-training evaluation the reference runs every ``eval_steps``:
+  * ``stno_seek_windows``   reference DiCoWGenerationMixin.prepare_kwargs_for_generate (src/models/dicow/generation.py
+                            :73-106): the STNO mask of each active sample's current 30 s window, padded as silence;
+  * ``GreedyDecoder``       the compute HF greedy search drives through the DiCoW model: the STNO-conditioned encoder runs
+                            ONCE per window, the cross-attention K/V of every decoder layer are projected ONCE, and each new
+                            token costs one decoder step against a per-layer self-attention KV cache; logits go through the
+                            SuppressTokens / SuppressTokensAtBegin processors the reference wires (generation.py:286-306),
+                            finished rows are padded, decoding stops when every row has produced eos.
+
+Every matrix product, attention and LayerNorm is a C-ABI kernel call (the same ones the training step uses; single-row
+queries go through dicow_attn_fwd with Lq = 1).  Not here: beam search, temperature fallback, the timestamp logits
+processor, CTC-prefix rescoring (decoding.py) and the long-form seek loop of HF's generate -- control flow around
+this step function, out of the measured path.  No CPU fallback.
+"""
+from types import SimpleNamespace as NS
+
+import torch
+
+from . import _lib as L
+from . import ops
+from .engine import heads, linear_fwd
+
+F32, BF16 = torch.float32, torch.bfloat16
+
+
+def stno_seek_windows(stno_mask, seek, max_frames, batch_idx_map, num_frames=1500):
+    """stno_mask [B_all, 4, T_total] (any device); seek / max_frames: feature-frame positions per ORIGINAL sample;
+    batch_idx_map: original index of each still-active sample.  Returns [len(map), 4, num_frames] on stno_mask's device."""
+    out = stno_mask.new_zeros((len(batch_idx_map), stno_mask.shape[1], num_frames))
+    out[:, 0, :] = 1.0                                                # padding frames are silence
+    for i, prev in enumerate(int(b) for b in batch_idx_map):
+        s = int(seek[prev]) // 2
+        n = max(0, min(int(max_frames[prev]) // 2 - s, num_frames))
+        out[i, :, :n] = stno_mask[prev, :, s:s + n]
+    return out
+
+
+class GreedyDecoder:
+    """``GreedyDecoder(model).generate(...)`` for a ``DiCoWForConditionalGeneration`` on the GPU."""
+
+    def __init__(self, model):
+        self.model, self.cfg = model, model.config
+
+    # ---- one decoder step for position t over the caches
+    def _step(self, ids, t, st):
+        model, cfg, W = self.model, self.cfg, st.W
+        dec = model.model.decoder
+        B, D, H = st.B, cfg.d_model, cfg.decoder_attention_heads
+        dev = ids.device
+        h = torch.empty(B, D, dtype=F32, device=dev)
+        ops.embed_fwd(ids.view(B, 1).contiguous(), dec.embed_tokens.weight.detach(), dec.embed_positions.weight.detach()[t:], h)
+        x = torch.empty(B, D, dtype=BF16, device=dev)
+        o = torch.empty(B, D, dtype=BF16, device=dev)
+
+        def ln(src, mod):
+            ops.fddt_ln_fwd(src, B, D, ln_w=mod.weight.detach(), ln_b=mod.bias.detach(), y_bf16=x)
+            return x
+
+        for i, lyr in enumerate(dec.layers):
+            w, c = W.layers[i], st.layers[i]
+            qkv = linear_fwd(ln(h, lyr.self_attn_layer_norm), w.sa.qkv, B, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+            c.k[:, t].copy_(qkv[:, D:2 * D])
+            c.v[:, t].copy_(qkv[:, 2 * D:])
+            ops.attn_fwd(heads(qkv[:, :D], B, 1, H), c.k[:, :t + 1].view(B, t + 1, H, 64), c.v[:, :t + 1].view(B, t + 1, H, 64),
+                         heads(o, B, 1, H))
+            h = linear_fwd(o, w.sa.o, B, out_dtype=F32, residual=h)
+            q = linear_fwd(ln(h, lyr.encoder_attn_layer_norm), w.ca.q, B, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+            ops.attn_fwd(heads(q, B, 1, H), heads(c.ckv[:, :D], B, st.T, H), heads(c.ckv[:, D:], B, st.T, H), heads(o, B, 1, H))
+            h = linear_fwd(o, w.ca.o, B, out_dtype=F32, residual=h)
+            a = linear_fwd(ln(h, lyr.final_layer_norm), w.fc1, B, flags=L.EPI_GELU)
+            h = linear_fwd(a, w.fc2, B, out_dtype=F32, residual=h)
+        logits = torch.empty(B, W.vpad, dtype=F32, device=dev)
+        ops.gemm_nt(ln(h, dec.layer_norm), W.head.w, logits, B, W.vpad, D)
+        return logits[:, :cfg.vocab_size]
+
+    @torch.no_grad()
+    def encode(self, input_features, stno_mask, enrollments=None):
+        """Encoder once + the cross-attention K/V of every decoder layer once.  Returns the decoding state."""
+        model, cfg = self.model, self.cfg
+        if not input_features.is_cuda:
+            raise L.DicowError("GreedyDecoder: tensors must be on the GPU (no CPU fallback)")
+        enc_out = model.model.encoder(input_features, stno_mask=stno_mask, enrollments=enrollments).last_hidden_state
+        B, T, D = enc_out.shape
+        W = model._engine().W
+        enc_bf = ops.cast_bf16(enc_out.contiguous().to(F32)).view(B * T, D)
+        Lmax = cfg.max_target_positions
+        st = NS(B=B, T=T, W=W, enc_out=enc_out, layers=[])
+        for w in W.layers:
+            st.layers.append(NS(ckv=linear_fwd(enc_bf, w.ca.kv, B * T),
+                                k=torch.empty(B, Lmax, D, dtype=BF16, device=enc_out.device),
+                                v=torch.empty(B, Lmax, D, dtype=BF16, device=enc_out.device)))
+        return st
+
+    @torch.no_grad()
+    def generate(self, input_features, stno_mask, decoder_input_ids, max_new_tokens, eos_token_id=None, pad_token_id=None,
+                 suppress_tokens=None, begin_suppress_tokens=None, enrollments=None, return_scores=False):
+        """decoder_input_ids int64 [B, P]: the forced prefix (start token, language / task / timestamp tokens).
+        Returns sequences [B, P + n] (and the processed fp32 scores [n, B, V] of the generated positions)."""
+        cfg = self.cfg
+        eos = cfg.eos_token_id if eos_token_id is None else eos_token_id
+        pad = cfg.pad_token_id if pad_token_id is None else pad_token_id
+        st = self.encode(input_features, stno_mask, enrollments)
+        dev = st.enc_out.device
+        ids = decoder_input_ids.to(dev)
+        B, P = ids.shape
+        if P < 1 or P + max_new_tokens > cfg.max_target_positions:
+            raise ValueError(f"prompt {P} + max_new_tokens {max_new_tokens} exceeds max_target_positions {cfg.max_target_positions}")
+        sup = None if not suppress_tokens else torch.as_tensor(list(suppress_tokens), device=dev)
+        bsup = None if not begin_suppress_tokens else torch.as_tensor(list(begin_suppress_tokens), device=dev)
+        for t in range(P - 1):                                       # prefill the caches with the prefix
+            self._step(ids[:, t], t, st)
+        unfinished = torch.ones(B, dtype=torch.bool, device=dev)
+        seq, scores = [ids], []
+        cur = ids[:, P - 1]
+        for n in range(max_new_tokens):
+            logits = self._step(cur, P - 1 + n, st)
+            if sup is not None:
+                logits[:, sup] = -float("inf")
+            if bsup is not None and n == 0:
+                logits[:, bsup] = -float("inf")
+            if return_scores:
+                scores.append(logits.clone())
+            nxt = logits.argmax(-1)
+            nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+            seq.append(nxt[:, None])
+            unfinished = unfinished & (nxt != eos)
+            cur = nxt
+            if not bool(unfinished.any()):
+                break
+        out = torch.cat(seq, dim=1)
+        return (out, torch.stack(scores)) if return_scores else out

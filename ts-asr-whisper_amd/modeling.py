@@ -292,11 +292,11 @@ class _FDDTFullFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------ encoder
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc, input_features, stno, enrollments, *params):
+    def forward(ctx, enc, input_features, stno, enrollments, need_grad, *params):
         eng = enc._engine()
-        out, S = eng.forward(input_features, stno, enrollments)
-        ctx.enc, ctx.S, ctx.params = enc, S, params
-        enc._last_state = S
+        out, S = eng.forward(input_features, stno, enrollments, need_grad=need_grad)
+        ctx.enc, ctx.S, ctx.params = enc, (S if need_grad else None), params
+        enc._last_state = S if need_grad else None
         return out
 
     @staticmethod
@@ -305,7 +305,7 @@ class _EncoderFn(torch.autograd.Function):
         G = GradSink(ctx.params, d_enc.device)
         D = enc.config.d_model
         enc._engine(prepare=False).backward(S, d_enc.contiguous().view(-1, D).to(F32), G)
-        return (None, None, None, None) + tuple(G.result(p) for p in ctx.params)
+        return (None, None, None, None, None) + tuple(G.result(p) for p in ctx.params)
 
 
 class DiCoWEncoder(nn.Module):
@@ -388,7 +388,9 @@ class DiCoWEncoder(nn.Module):
             raise ValueError("stno_mask is required")
         ctc_ids = {id(p) for p in self.ctc_parameters()} if self.ctc_weight > 0.0 else set()
         params = [p for p in self.parameters() if id(p) not in ctc_ids]
-        out = _EncoderFn.apply(self, input_features, stno_mask, enrollments, *params)
+        # under torch.no_grad() (evaluation / decoding) no activation is kept for a backward pass
+        need_grad = torch.is_grad_enabled() and (input_features.requires_grad or any(p.requires_grad for p in params))
+        out = _EncoderFn.apply(self, input_features, stno_mask, enrollments, need_grad, *params)
         if return_dict is False:
             return (out,)
         return ModelOutput(last_hidden_state=out, hidden_states=None, attentions=None)
