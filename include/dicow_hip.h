@@ -301,6 +301,31 @@ int dicow_specaug_joint(const float* mel, const float* stno, float* mel_out, flo
                         int center, int warped, const int* fmask, int n_fmask, const int* tmask, int n_tmask,
                         int n_maskable, void* stream);
 
+/* ------------------------------------------------------------------------------------------------ CTC prefix scoring
+ * Joint CTC / attention decoding (reference src/models/dicow/decoding.py; CTCPrefixScore :8-163 is the hot part: a Python
+ * loop over the encoder frames per decoded token).  Log-probabilities are x[b, t, c] = logits[b, t, alias[c]] - lse[b, t]:
+ *   dicow_ctc_frame_lse     lse[row] = logsumexp_v logits[row, v < V1]   (the log_softmax of decoding.py:183)
+ *   alias int32 [V1] or NULL: column read for label c (the reference copies lower-cased columns over the upper-cased
+ *                           ones, decoding.py:181-186)
+ *   dicow_ctc_prefix_init   r0 fp32 [B, T, 2] = state of the empty prefix (CTCPrefixScore.initial_state, :36-43)
+ *   dicow_ctc_prefix_score  CTCPrefixScore.__call__ (:122-163) for n hypotheses x C candidate labels:
+ *       rows int32 [n]         batch row of each hypothesis (the reference's `samples_to_be_decoded` mask, as indices)
+ *       cs int32 [n, C]        candidate next labels;  decoded_len int32 [n] labels already in the prefix;
+ *       last int32 [n]         last label of the prefix;  r_prev fp32 [n, T, 2] its state (non-blank, blank)
+ *       psi fp32 [n, C]        log prefix probability of prefix + candidate (eos: probability of ending, blank: logzero)
+ *       r fp32 [n, T, 2, C]    the candidates' states (the caller keeps the chosen one as the next r_prev)
+ *   logits fp32 or bf16 (in_bf16) [B, T, ld >= V1], frame-major. */
+typedef struct {
+    const void* logits; int in_bf16; int64_t ld; const float* lse; const int* alias;
+    const int* rows; const int* cs; const int* decoded_len; const int* last; const float* r_prev;
+    float* psi; float* r;
+    int n, C, T, blank, eos;
+} dicow_ctc_prefix_args;
+int dicow_ctc_frame_lse(const void* logits, int in_bf16, int64_t rows, int V1, int64_t ld, float* lse, void* stream);
+int dicow_ctc_prefix_init(const void* logits, int in_bf16, int64_t ld, const float* lse, int B, int T, int blank_col, float* r0,
+                          void* stream);
+int dicow_ctc_prefix_score(const dicow_ctc_prefix_args* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ optimizer
  * Fused AdamW + global-norm clipping on flat fp32 regions (src/models/containers.py:100-114 two param groups;
  * HF Trainer max_grad_norm 1.0).  dicow_sumsq_f32 accumulates sum(x^2) into out[0]; dicow_adamw_f32 applies

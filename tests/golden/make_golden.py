@@ -530,9 +530,81 @@ def f12_seek():
     save("f12_seek", **arrs)
 
 
+# ----------------------------------------------------------------------------- F13: CTC prefix scoring / joint decoding
+def f13_ctc_prefix():
+    """CTCPrefixScore and CTCRescorerLogitsProcessor of src/models/dicow/decoding.py driven for a few greedy steps on random
+    encoder logits: every call's inputs, scores and states are stored."""
+    from models.dicow.decoding import CTCPrefixScore, CTCRescorerLogitsProcessor
+    arrs = {}
+    g = torch.Generator().manual_seed(13)
+    # (a) the scorer alone: 3 chained calls, ragged prefix lengths, a finished row dropped in the last call
+    B, Tn, V, C = 4, 37, 24, 7
+    blank, eos = V - 1, 20
+    x = torch.log_softmax(torch.randn(B, Tn, V, generator=g) * 2.0, dim=-1)
+    sc = CTCPrefixScore(x, blank, eos)
+    r, s0 = sc.initial_state()
+    arrs["a.x"], arrs["a.blank"], arrs["a.eos"], arrs["a.r0"] = x, np.array(blank), np.array(eos), r
+    y = torch.full((B, 1), blank, dtype=torch.long)
+    dl = torch.zeros(B, dtype=torch.long)
+    for step in range(3):
+        cs = torch.stack([torch.randperm(V - 1, generator=g)[:C] for _ in range(B)])
+        cs[:, -1] = eos
+        cs[0, 0] = int(y[0, -1]) if step else cs[0, 0]           # a candidate equal to the last label (repeat rule)
+        active = torch.ones(B, dtype=torch.bool)
+        if step == 2:
+            active[1] = False
+        psi, rr = sc(y[active], cs[active], dl[active], active, r[active])
+        arrs[f"a.{step}.y"], arrs[f"a.{step}.cs"], arrs[f"a.{step}.dl"] = y.clone(), cs, dl.clone()
+        arrs[f"a.{step}.active"], arrs[f"a.{step}.r_prev"] = active, r.clone()
+        arrs[f"a.{step}.psi"], arrs[f"a.{step}.r"] = psi.clone(), rr.clone()
+        # extend rows 0..2 by a non-eos candidate; row 3 keeps its prefix (a timestamp step in the real decoder)
+        pick = torch.tensor([1, 2, 0, 0])
+        nr = r.clone()
+        idx = torch.nonzero(active)[:, 0]
+        for j, b in enumerate(idx.tolist()):
+            if b != 3:
+                nr[b] = rr[j, :, :, pick[b]]
+        newtok = cs[torch.arange(B), pick]
+        y = torch.cat([y, torch.where(torch.arange(B) == 3, y[:, -1], newtok)[:, None]], dim=1)
+        dl = dl + (torch.arange(B) != 3).long()
+        r = nr
+    arrs["a.steps"] = np.array(3)
+
+    # (b) the logits processor with a stand-in tokenizer, greedy (num_beams 1), 4 steps
+    B, Tn, V = 3, 29, 41                                             # encoder logits have V + 1 entries (blank last)
+    ts0, eos_id, bos_id, pad_id = 30, 28, 29, 28
+    tok = types.SimpleNamespace(upper_cased_tokens={3: 13, 4: 14}, prefix_tokens=[bos_id, 27],
+                                get_vocab=lambda: {"<|0.00|>": ts0}, eos_token_id=eos_id, vocab={"#": 0})
+    enc_logits = torch.randn(B, Tn, V + 1, generator=g) * 2.0
+    proc = CTCRescorerLogitsProcessor(enc_logits.clone(), torch.full((B,), Tn), V, pad_id, eos_id, bos_id, tok, 0, 0.3, 1, False,
+                                      ctc_tokens_to_score=6)
+    arrs["b.enc_logits"] = enc_logits
+    arrs["b.cfg"] = np.array([V, ts0, eos_id, bos_id, pad_id, 6])
+    arrs["b.upper"], arrs["b.prefix"], arrs["b.weight"] = np.array([[3, 13], [4, 14]]), np.array([bos_id, 27]), np.array(0.3)
+    ids = torch.tensor([[bos_id, 27]] * B)
+    forced = [None, None, torch.tensor([31, -1, -1]), None]          # step 2: row 0 emits a timestamp token
+    for step in range(4):
+        scores = torch.log_softmax(torch.randn(B, V, generator=g) * 1.5, dim=-1)
+        out = proc(ids, scores.clone())
+        nxt = out.argmax(-1)
+        if forced[step] is not None:
+            nxt = torch.where(forced[step] >= 0, forced[step], nxt)
+        if step == 3:
+            nxt[1] = eos_id
+        proc.update_state(nxt, torch.arange(B))
+        arrs[f"b.{step}.ids"], arrs[f"b.{step}.scores"], arrs[f"b.{step}.out"], arrs[f"b.{step}.next"] = ids.clone(), scores, out, nxt
+        arrs[f"b.{step}.state"], arrs[f"b.{step}.score_prev"] = proc.ctc_state_prev.clone(), proc.ctc_score_prev.clone()
+        ids = torch.cat([ids, nxt[:, None]], dim=1)
+    # one more call after row 1 ended with eos (it is skipped by the scorer)
+    scores = torch.log_softmax(torch.randn(B, V, generator=g) * 1.5, dim=-1)
+    arrs["b.4.ids"], arrs["b.4.scores"], arrs["b.4.out"] = ids.clone(), scores, proc(ids, scores.clone())
+    arrs["b.steps"] = np.array(4)
+    save("f13_ctc_prefix", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12", "f13"]
     fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
-           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek}
+           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix}
     for w in which:
         fns[w]()

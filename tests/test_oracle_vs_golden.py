@@ -254,3 +254,37 @@ def test_f12_stno_seek_windows_bit_exact():
                                      num_frames=int(z[f"c{i}.msp"]))
         assert np.array_equal(got, z[f"c{i}.out"]), i
         assert got.shape[0] == int(z[f"c{i}.att_rows"]) and np.allclose(got.sum(1), 1.0, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ F13: CTC prefix scoring
+def _close_lz(got, want, tol):
+    real = want > -1e9
+    assert np.array_equal(real, got > -1e9) and np.array_equal(got[~real], want[~real])
+    return (not real.any()) or float(np.abs(got[real] - want[real]).max()) < tol
+
+
+def test_f13_ctc_prefix_scorer():
+    from oracle import ctc_prefix as ocp
+    z = load_golden("f13_ctc_prefix")
+    x, blank, eos = z["a.x"], int(z["a.blank"]), int(z["a.eos"])
+    assert _close_lz(ocp.initial_state(x, blank), z["a.r0"], 1e-4)
+    for s in range(int(z["a.steps"])):
+        act = z[f"a.{s}.active"]
+        psi, r = ocp.prefix_score(x, np.nonzero(act)[0], z[f"a.{s}.cs"][act], z[f"a.{s}.dl"][act], z[f"a.{s}.y"][act][:, -1],
+                                  z[f"a.{s}.r_prev"][act], blank, eos)
+        assert _close_lz(psi, z[f"a.{s}.psi"], 5e-6) and _close_lz(r, z[f"a.{s}.r"], 5e-5), s
+
+
+def test_f13_ctc_rescorer_processor():
+    from oracle import ctc_prefix as ocp
+    z = load_golden("f13_ctc_prefix")
+    V, ts0, eos, bos, pad, k = (int(v) for v in z["b.cfg"])
+    p = ocp.CtcRescorer(z["b.enc_logits"], V, eos, bos, ts0, z["b.upper"], len(z["b.prefix"]), float(z["b.weight"]), k)
+    for s in range(int(z["b.steps"])):
+        out = p(z[f"b.{s}.ids"], z[f"b.{s}.scores"])
+        assert float(np.abs(out - z[f"b.{s}.out"]).max()) < 5e-5 * max(1.0, float(np.abs(z[f"b.{s}.out"]).max()) / 1e9), s
+        p.update_state(z[f"b.{s}.next"], np.arange(3))
+        assert _close_lz(p.state_prev, z[f"b.{s}.state"], 5e-5) and float(np.abs(p.score_prev - z[f"b.{s}.score_prev"]).max()) < 1e-5
+    out = p(z["b.4.ids"], z["b.4.scores"])
+    real = z["b.4.out"] > -1e8
+    assert float(np.abs(out - z["b.4.out"])[real].max()) < 5e-5 and np.allclose(out[~real], z["b.4.out"][~real], rtol=1e-6)

@@ -70,6 +70,12 @@ class CtcArgs(C.Structure):
                 ("loss_sum", c_vp), ("d_logits", c_vp)]
 
 
+class CtcPrefixArgs(C.Structure):
+    _fields_ = [("logits", c_vp), ("in_bf16", c_i), ("ld", c_i64), ("lse", c_vp), ("alias", c_vp), ("rows", c_vp), ("cs", c_vp),
+                ("decoded_len", c_vp), ("last", c_vp), ("r_prev", c_vp), ("psi", c_vp), ("r", c_vp), ("n", c_i), ("C", c_i),
+                ("T", c_i), ("blank", c_i), ("eos", c_i)]
+
+
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_SCALE_N, EPI_GELU_BWD, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 EPI_GELU_DAUX, EPI_MUL_AUX, EPI_COLSUM = 128, 256, 512
 
@@ -103,6 +109,9 @@ _SIGS = {
     "dicow_stno_noise_rescale": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_f, c_vp],
     "dicow_stno_segment_augment": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_specaug_joint": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_i, c_vp, c_i, c_i, c_vp],
+    "dicow_ctc_frame_lse": [c_vp, c_i, c_i64, c_i, c_i64, c_vp, c_vp],
+    "dicow_ctc_prefix_init": [c_vp, c_i, c_i64, c_vp, c_i, c_i, c_i, c_vp, c_vp],
+    "dicow_ctc_prefix_score": [C.POINTER(CtcPrefixArgs), c_vp],
     "dicow_sumsq_f32": [c_vp, c_i64, c_vp, c_vp],
     "dicow_adamw_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_f, c_vp],
 }

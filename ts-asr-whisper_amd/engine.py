@@ -711,6 +711,26 @@ class CtcEngine:
         return W
 
     def forward(self, enc_bf, B, T, labels):
+        cfg, W = self.cfg, self.W
+        dev = enc_bf.device
+        S = self.encode_logits(enc_bf, B, T)
+        logits, Tn = S.logits, S.Tn
+        Cc = cfg.vocab_size + 1
+        lab = labels.contiguous()
+        Lc = lab.shape[1]
+        S.lse, S.nll, S.tlen = _e((B * Tn,), F32, dev), _e((B,), F32, dev), _e((B,), F32, dev)
+        Smax = 2 * Lc + 1
+        S.ab = _e((2, B, Tn, Smax), F32, dev)
+        S.acc = torch.zeros(1, dtype=F32, device=dev)
+        S.labels = lab
+        S.ctc = ops.ctc_args(logits, W.cpad, B, Tn, Cc, lab, S.lse, S.ab[0], S.ab[1], S.nll, S.tlen, S.acc)
+        ops.ctc_loss_fwd(S.ctc)
+        if cfg.ctc_loss_reduction != "mean":
+            raise L.DicowError("only ctc_loss_reduction='mean' (reference default) is implemented")
+        return S.acc[0] / B, S
+
+    def encode_logits(self, enc_bf, B, T):
+        """The CTC branch up to its logits (encoder.py:87-106, get_enc_logits): S.logits bf16 [B * Tn, cpad]."""
         enc, cfg, W = self.enc, self.cfg, self.W
         dev = enc_bf.device
         D, H = cfg.d_model, cfg.encoder_attention_heads
@@ -748,22 +768,10 @@ class CtcEngine:
             S.hpad, S.c1pad, S.T1 = hpad, c1pad, T1
             Tn = T2
         S.h, S.Tn = h, Tn
-        Cc = cfg.vocab_size + 1
         logits = _e((B * Tn, W.cpad), BF16, dev)
         ops.gemm_nt(h, W.head.w, logits, B * Tn, W.cpad, D)
         S.logits = logits
-        lab = labels.contiguous()
-        Lc = lab.shape[1]
-        S.lse, S.nll, S.tlen = _e((B * Tn,), F32, dev), _e((B,), F32, dev), _e((B,), F32, dev)
-        Smax = 2 * Lc + 1
-        S.ab = _e((2, B, Tn, Smax), F32, dev)
-        S.acc = torch.zeros(1, dtype=F32, device=dev)
-        S.labels = lab
-        S.ctc = ops.ctc_args(logits, W.cpad, B, Tn, Cc, lab, S.lse, S.ab[0], S.ab[1], S.nll, S.tlen, S.acc)
-        ops.ctc_loss_fwd(S.ctc)
-        if cfg.ctc_loss_reduction != "mean":
-            raise L.DicowError("only ctc_loss_reduction='mean' (reference default) is implemented")
-        return S.acc[0] / B, S
+        return S
 
     def backward(self, S, grad_loss, G):
         """Returns d_enc fp32 [B*T, D]."""

@@ -95,8 +95,10 @@ class GreedyDecoder:
 
     @torch.no_grad()
     def generate(self, input_features, stno_mask, decoder_input_ids, max_new_tokens, eos_token_id=None, pad_token_id=None,
-                 suppress_tokens=None, begin_suppress_tokens=None, enrollments=None, return_scores=False):
+                 suppress_tokens=None, begin_suppress_tokens=None, enrollments=None, return_scores=False, ctc=None):
         """decoder_input_ids int64 [B, P]: the forced prefix (start token, language / task / timestamp tokens).
+        ctc: dict(weight=..., first_timestamp=..., upper_cased=[(lo, up), ...], prefix_len=..., n_score=500) switches on the
+        joint CTC / attention scoring of generation.py:249-268 (log-softmax, then ctc_decoding.CtcRescorer on the model's CTC head).
         Returns sequences [B, P + n] (and the processed fp32 scores [n, B, V] of the generated positions)."""
         cfg = self.cfg
         eos = cfg.eos_token_id if eos_token_id is None else eos_token_id
@@ -109,6 +111,13 @@ class GreedyDecoder:
             raise ValueError(f"prompt {P} + max_new_tokens {max_new_tokens} exceeds max_target_positions {cfg.max_target_positions}")
         sup = None if not suppress_tokens else torch.as_tensor(list(suppress_tokens), device=dev)
         bsup = None if not begin_suppress_tokens else torch.as_tensor(list(begin_suppress_tokens), device=dev)
+        rescorer = None
+        if ctc is not None and ctc.get("weight", 0.0) > 0.0:
+            from .ctc_decoding import CtcRescorer
+            enc_logits = self.model.get_enc_logits(st.enc_out)
+            rescorer = CtcRescorer(enc_logits, cfg.vocab_size, eos, ids[0, 0].item(), ctc["first_timestamp"], ctc.get("upper_cased", ()),
+                                   ctc.get("prefix_len", P), ctc["weight"], ctc.get("n_score", 500))
+            rows = torch.arange(B, device=dev)
         for t in range(P - 1):                                       # prefill the caches with the prefix
             self._step(ids[:, t], t, st)
         unfinished = torch.ones(B, dtype=torch.bool, device=dev)
@@ -120,10 +129,14 @@ class GreedyDecoder:
                 logits[:, sup] = -float("inf")
             if bsup is not None and n == 0:
                 logits[:, bsup] = -float("inf")
+            if rescorer is not None:
+                logits = rescorer(torch.cat(seq, dim=1), torch.log_softmax(logits, dim=-1))
             if return_scores:
                 scores.append(logits.clone())
             nxt = logits.argmax(-1)
             nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
+            if rescorer is not None:
+                rescorer.update_state(nxt, rows)
             seq.append(nxt[:, None])
             unfinished = unfinished & (nxt != eos)
             cur = nxt

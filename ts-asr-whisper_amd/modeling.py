@@ -558,7 +558,17 @@ class DiCoWForConditionalGeneration(nn.Module):
         return self.model.encoder
 
     def get_enc_logits(self, hidden_states):
-        raise NotImplementedError("get_enc_logits is used by CTC-rescored decoding (out of the training path)")
+        """CTC head on the encoder output (reference modeling_dicow.py get_enc_logits -> encoder.py:87-106), used by the
+        CTC-rescored decoding: returns bf16 logits [B, Tn, vocab_size + 1] (a view into a 128-padded row, blank last)."""
+        enc = self.model.encoder
+        if enc.ctc_weight <= 0.0:
+            raise L.DicowError("get_enc_logits: the model was built without a CTC head (ctc_weight == 0)")
+        _require_cuda(hidden_states, "get_enc_logits")
+        B, T, D = hidden_states.shape
+        with torch.no_grad():
+            enc_bf = ops.cast_bf16(hidden_states.detach().contiguous().to(F32)).view(B * T, D)
+            S = enc._ctc_engine().encode_logits(enc_bf, B, T)
+        return S.logits.view(B, S.Tn, -1)[:, :, :self.config.vocab_size + 1]
 
     def get_decoder(self):
         return self.model.decoder
