@@ -326,6 +326,15 @@ int dicow_ctc_prefix_init(const void* logits, int in_bf16, int64_t ld, const flo
                           void* stream);
 int dicow_ctc_prefix_score(const dicow_ctc_prefix_args* a, void* stream);
 
+/* Whisper's timestamp rules on next-token scores, in place (reference src/models/dicow/utils.py:5-14 =
+ * transformers' WhisperTimeStampLogitsProcessor + eos allowed at the first generated position):
+ * scores fp32 [B, ld >= V]; input_ids int64 [B, L] (prompt + generated so far), begin_index = prompt length;
+ * timestamp_begin = no_timestamps + 1; max_initial_timestamp_index < 0: no cap; detect_from_logprob: if the total
+ * probability of the timestamp labels exceeds every text label's, text labels are removed. */
+int dicow_whisper_timestamp_rules(float* scores, int64_t ld, int B, int V, const int64_t* input_ids, int L, int begin_index,
+                                  int timestamp_begin, int eos, int no_timestamps, int max_initial_timestamp_index,
+                                  int detect_from_logprob, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ optimizer
  * Fused AdamW + global-norm clipping on flat fp32 regions (src/models/containers.py:100-114 two param groups;
  * HF Trainer max_grad_norm 1.0).  dicow_sumsq_f32 accumulates sum(x^2) into out[0]; dicow_adamw_f32 applies

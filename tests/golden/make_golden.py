@@ -602,9 +602,41 @@ def f13_ctc_prefix():
     save("f13_ctc_prefix", **arrs)
 
 
+# ----------------------------------------------------------------------------- F14: timestamp rules logits processor
+def f14_timestamp_rules():
+    """WhisperTimeStampLogitsProcessorCustom (src/models/dicow/utils.py:5-14 on top of HF's WhisperTimeStampLogitsProcessor)
+    on crafted prefixes: first step, after text, after one / two timestamps, timestamp-heavy scores, no initial cap."""
+    from models.dicow.utils import WhisperTimeStampLogitsProcessorCustom
+    arrs = {}
+    g = torch.Generator().manual_seed(14)
+    V, eos, no_ts, ts0, begin = 120, 50, 59, 60, 3
+    prompt = [51, 52, 53]
+    seqs = [[], [5], [5, 7], [61], [61, 63], [5, 61], [5, 7, 61, 61], [5, 61, 61, 9], [5, 61, 61, 9, 70], [5, 61, 61, 9, 70, 70]]
+    n = 0
+    for max_init in (25, None):
+        gc = types.SimpleNamespace(eos_token_id=eos, no_timestamps_token_id=no_ts, max_initial_timestamp_index=max_init,
+                                   forced_decoder_ids=None)
+        proc = WhisperTimeStampLogitsProcessorCustom(gc, begin_index=begin)
+        by_len = {}
+        for q in seqs:
+            by_len.setdefault(len(q), []).append(q)
+        for L, rows in by_len.items():
+            ids = torch.tensor([prompt + q for q in rows])
+            for boost in (0.0, 6.0):
+                sc = torch.randn(len(rows), V, generator=g) * 2.0
+                sc[:, ts0:] += boost                                    # boost: the timestamp mass beats every text token
+                out = proc(ids, sc.clone())
+                arrs[f"c{n}.ids"], arrs[f"c{n}.scores"], arrs[f"c{n}.out"] = ids, sc, out
+                arrs[f"c{n}.max_init"] = np.array(-1 if max_init is None else max_init)
+                n += 1
+    arrs["n_cases"] = np.array(n)
+    arrs["cfg"] = np.array([V, eos, no_ts, ts0, begin])
+    save("f14_timestamp_rules", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12", "f13"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12", "f13", "f14"]
     fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
-           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix}
+           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules}
     for w in which:
         fns[w]()

@@ -114,3 +114,46 @@ def test_generate_full_size_shapes(pkg):
     prompt = torch.full((4, 4), cfg.decoder_start_token_id, dtype=torch.long)
     seq, scores = GreedyDecoder(model).generate(b["input_features"], b["stno_mask"], prompt, 24, eos_token_id=-1, return_scores=True)
     assert seq.shape == (4, 28) and bool(torch.isfinite(scores).all())
+
+
+def test_timestamp_rules_vs_reference_and_oracle(pkg):
+    """dicow_whisper_timestamp_rules vs golden F14 (the reference processor) -- masks and surviving scores bit-exact -- and vs
+    the oracle at the real vocabulary size with long generated suffixes."""
+    from ts_asr_whisper_amd.generation import timestamp_rules
+    from oracle.timestamp_rules import timestamp_rules as oracle_rules
+    z = load_golden("f14_timestamp_rules")
+    V, eos, no_ts, ts0, begin = (int(v) for v in z["cfg"])
+    for i in range(int(z["n_cases"])):
+        mi = int(z[f"c{i}.max_init"])
+        got = timestamp_rules(torch.from_numpy(z[f"c{i}.ids"]).cuda(), torch.from_numpy(z[f"c{i}.scores"]).cuda(), begin, eos, no_ts,
+                              None if mi < 0 else mi).cpu().numpy()
+        assert np.array_equal(got, z[f"c{i}.out"]), i
+    g = torch.Generator().manual_seed(9)
+    V, eos, no_ts, begin, B = 51866, 50257, 50364, 4, 16
+    for L_new, boost in ((0, 0.0), (1, 0.0), (40, 0.0), (41, 8.0), (200, 0.0)):
+        ids = torch.randint(0, 50000, (B, begin + L_new), generator=g)
+        for b in range(B):                                   # sprinkle timestamp pairs, some rows end on one or two timestamps
+            for j in range(begin + 2, begin + L_new - 1, 9):
+                ids[b, j] = ids[b, j + 1] = no_ts + 1 + j
+            if L_new and b % 3 == 0:
+                ids[b, -1] = no_ts + 300
+            if L_new > 1 and b % 6 == 0:
+                ids[b, -2] = no_ts + 300
+        sc = torch.randn(B, 51968, generator=g)[:, :V] * 3          # a padded row, like the decoder's logits view
+        sc[:, no_ts + 1:] += boost
+        want = oracle_rules(ids.numpy(), sc.numpy(), begin, eos, no_ts, 50)
+        got = timestamp_rules(ids.cuda(), sc.cuda(), begin, eos, no_ts, 50).cpu().numpy()
+        assert np.array_equal(got, want), (L_new, boost)
+
+
+def test_greedy_decode_with_timestamp_rules(pkg):
+    """Sequences produced under the rules obey them: first token a timestamp (or eos), timestamps in pairs and non-decreasing."""
+    from ts_asr_whisper_amd.generation import GreedyDecoder
+    z, model, cfg, x, st, prompt = _setup(pkg)
+    no_ts, eos = 399, 5
+    seq = GreedyDecoder(model).generate(x.cuda(), st.cuda(), prompt, 12, eos_token_id=eos, pad_token_id=cfg.pad_token_id,
+                                        timestamps=dict(no_timestamps_token_id=no_ts, max_initial_timestamp_index=20)).cpu()
+    for row in seq[:, prompt.shape[1]:].tolist():
+        assert row[0] == eos or no_ts < row[0] <= no_ts + 1 + 20
+        stamps = [t for t in row if t > no_ts]
+        assert stamps == sorted(stamps) and no_ts not in row

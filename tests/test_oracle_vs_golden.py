@@ -288,3 +288,14 @@ def test_f13_ctc_rescorer_processor():
     out = p(z["b.4.ids"], z["b.4.scores"])
     real = z["b.4.out"] > -1e8
     assert float(np.abs(out - z["b.4.out"])[real].max()) < 5e-5 and np.allclose(out[~real], z["b.4.out"][~real], rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ F14: timestamp rules
+def test_f14_timestamp_rules_bit_exact():
+    from oracle.timestamp_rules import timestamp_rules
+    z = load_golden("f14_timestamp_rules")
+    V, eos, no_ts, ts0, begin = (int(v) for v in z["cfg"])
+    for i in range(int(z["n_cases"])):
+        mi = int(z[f"c{i}.max_init"])
+        got = timestamp_rules(z[f"c{i}.ids"], z[f"c{i}.scores"], begin, eos, no_ts, None if mi < 0 else mi)
+        assert np.array_equal(got, z[f"c{i}.out"]), i

@@ -112,6 +112,7 @@ _SIGS = {
     "dicow_ctc_frame_lse": [c_vp, c_i, c_i64, c_i, c_i64, c_vp, c_vp],
     "dicow_ctc_prefix_init": [c_vp, c_i, c_i64, c_vp, c_i, c_i, c_i, c_vp, c_vp],
     "dicow_ctc_prefix_score": [C.POINTER(CtcPrefixArgs), c_vp],
+    "dicow_whisper_timestamp_rules": [c_vp, c_i64, c_i, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "dicow_sumsq_f32": [c_vp, c_i64, c_vp, c_vp],
     "dicow_adamw_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_f, c_vp],
 }

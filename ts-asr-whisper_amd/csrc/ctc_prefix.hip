@@ -193,3 +193,76 @@ extern "C" int dicow_ctc_prefix_score(const dicow_ctc_prefix_args* a, void* stre
     DICOW_CHECK_LAUNCH("ctc_prefix_score_kernel");
     return DICOW_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ timestamp rules
+// Whisper's timestamp constraints on one row of next-token scores (reference src/models/dicow/utils.py:5-14 over
+// transformers' WhisperTimeStampLogitsProcessor): the reference loops over the batch on the host (`.tolist()` per row) around
+// ~10 masked assignments and a log_softmax; here one workgroup per row derives the three facts it needs from the generated
+// suffix (was the last / the one before a timestamp, the last timestamp emitted), evaluates the mask per label, reduces
+// max(text) and logsumexp(timestamps) in one pass, and writes the row once.
+__global__ void __launch_bounds__(256) timestamp_rules_kernel(float* __restrict__ scores, int64_t ld, int V, const int64_t* __restrict__ ids,
+                                                              int L, int begin, int ts0, int eos, int no_ts, int max_init, int detect) {
+    __shared__ float red_m[4], red_t[4], red_s[4];
+    __shared__ int facts[3];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    float* row = scores + (int64_t)k * ld;
+    const int64_t* seq = ids + (int64_t)k * L;
+    if (tid == 0) {
+        const int n = L - begin;
+        const int last_ts = n >= 1 && seq[L - 1] >= ts0;
+        const int pen_ts = n < 2 || seq[L - 2] >= ts0;
+        int upto = -1;                                    // labels in [ts0, upto) are forbidden (timestamps do not decrease)
+        for (int j = L - 1; j >= begin; --j)
+            if (seq[j] >= ts0) { upto = (int)seq[j] + ((last_ts && !pen_ts) ? 0 : 1); break; }
+        facts[0] = last_ts; facts[1] = pen_ts; facts[2] = upto;
+    }
+    __syncthreads();
+    const int last_ts = facts[0], pen_ts = facts[1], upto = facts[2];
+    const bool first = L == begin;
+    const float eos_score = (first && eos < V) ? row[eos] : 0.f;
+    auto banned = [&](int v) {
+        if (v == no_ts) return true;
+        if (last_ts && (pen_ts ? v >= ts0 : v < eos)) return true;
+        if (v >= ts0 && v < upto) return true;
+        if (first && (v < ts0 || (max_init >= 0 && v > ts0 + max_init))) return true;
+        return false;
+    };
+    // max over text labels, online logsumexp over timestamp labels (both after the rules above)
+    float mt = -INFINITY, tm = -INFINITY, tsum = 0.f;
+    for (int v = tid; v < V; v += 256) {
+        if (banned(v)) continue;
+        const float s = row[v];
+        if (v < ts0) mt = fmaxf(mt, s);
+        else if (s > tm) { tsum = tsum * expf(tm - s) + 1.f; tm = s; }
+        else tsum += expf(s - tm);
+    }
+    const float wm = wave_max(tm);
+    tsum = wave_sum(tm == -INFINITY ? 0.f : tsum * expf(tm - wm));
+    mt = wave_max(mt);
+    if ((tid & 63) == 0) { red_m[tid >> 6] = mt; red_t[tid >> 6] = wm; red_s[tid >> 6] = tsum; }
+    __syncthreads();
+    mt = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+    tm = fmaxf(fmaxf(red_t[0], red_t[1]), fmaxf(red_t[2], red_t[3]));
+    float tot = 0.f;
+    for (int w = 0; w < 4; ++w) tot += red_t[w] == -INFINITY ? 0.f : red_s[w] * expf(red_t[w] - tm);
+    const float ts_lse = tm == -INFINITY ? -INFINITY : tm + logf(tot);
+    const bool only_ts = detect && ts_lse > mt;           // the normaliser of log_softmax cancels in the comparison
+    for (int v = tid; v < V; v += 256)
+        if (banned(v) || (only_ts && v < ts0)) row[v] = -INFINITY;
+    if (first && eos < V) {                               // utils.py:10-12: a silent window may end immediately
+        __syncthreads();
+        if (tid == 0) row[eos] = eos_score;
+    }
+}
+
+extern "C" int dicow_whisper_timestamp_rules(float* scores, int64_t ld, int B, int V, const int64_t* input_ids, int L, int begin_index,
+                                             int timestamp_begin, int eos, int no_timestamps, int max_initial_timestamp_index,
+                                             int detect_from_logprob, void* stream) {
+    DICOW_REQUIRE(scores && input_ids && B > 0 && V > 0 && ld >= V && L >= begin_index && begin_index >= 0,
+                  "whisper_timestamp_rules: bad args B=%d V=%d L=%d begin=%d", B, V, L, begin_index);
+    DICOW_REQUIRE(timestamp_begin > 0 && timestamp_begin <= V && no_timestamps >= 0 && eos >= 0, "whisper_timestamp_rules: bad token ids");
+    timestamp_rules_kernel<<<B, 256, 0, (hipStream_t)stream>>>(scores, ld, V, input_ids, L, begin_index, timestamp_begin, eos, no_timestamps,
+                                                               max_initial_timestamp_index, detect_from_logprob);
+    DICOW_CHECK_LAUNCH("timestamp_rules_kernel");
+    return DICOW_OK;
+}

@@ -37,6 +37,20 @@ def stno_seek_windows(stno_mask, seek, max_frames, batch_idx_map, num_frames=150
     return out
 
 
+def timestamp_rules(input_ids, scores, begin_index, eos_token_id, no_timestamps_token_id, max_initial_timestamp_index=None,
+                    detect_from_logprob=True):
+    """WhisperTimeStampLogitsProcessorCustom.__call__ (reference src/models/dicow/utils.py:5-14): scores fp32 [B, V] on the
+    GPU are constrained IN PLACE (and returned); input_ids int64 [B, L] = prompt (begin_index tokens) + generated tokens."""
+    if not scores.is_cuda or scores.dtype != F32 or scores.stride(1) != 1:
+        raise L.DicowError("timestamp_rules: scores must be fp32 rows on the GPU (no CPU fallback)")
+    ids = input_ids.to(device=scores.device, dtype=torch.int64).contiguous()
+    B, V = scores.shape
+    L.call("dicow_whisper_timestamp_rules", scores.data_ptr(), scores.stride(0), B, V, ids.data_ptr(), ids.shape[1], begin_index,
+           no_timestamps_token_id + 1, eos_token_id, no_timestamps_token_id,
+           -1 if max_initial_timestamp_index is None else max_initial_timestamp_index, int(detect_from_logprob), L.stream())
+    return scores
+
+
 class GreedyDecoder:
     """``GreedyDecoder(model).generate(...)`` for a ``DiCoWForConditionalGeneration`` on the GPU."""
 
@@ -95,10 +109,13 @@ class GreedyDecoder:
 
     @torch.no_grad()
     def generate(self, input_features, stno_mask, decoder_input_ids, max_new_tokens, eos_token_id=None, pad_token_id=None,
-                 suppress_tokens=None, begin_suppress_tokens=None, enrollments=None, return_scores=False, ctc=None):
+                 suppress_tokens=None, begin_suppress_tokens=None, enrollments=None, return_scores=False, ctc=None,
+                 timestamps=None):
         """decoder_input_ids int64 [B, P]: the forced prefix (start token, language / task / timestamp tokens).
         ctc: dict(weight=..., first_timestamp=..., upper_cased=[(lo, up), ...], prefix_len=..., n_score=500) switches on the
         joint CTC / attention scoring of generation.py:249-268 (log-softmax, then ctc_decoding.CtcRescorer on the model's CTC head).
+        timestamps: dict(no_timestamps_token_id=..., max_initial_timestamp_index=...) applies Whisper's timestamp rules
+        (return_timestamps=True in the reference, generation.py:272-281), after the suppress lists and before the CTC term.
         Returns sequences [B, P + n] (and the processed fp32 scores [n, B, V] of the generated positions)."""
         cfg = self.cfg
         eos = cfg.eos_token_id if eos_token_id is None else eos_token_id
@@ -129,6 +146,9 @@ class GreedyDecoder:
                 logits[:, sup] = -float("inf")
             if bsup is not None and n == 0:
                 logits[:, bsup] = -float("inf")
+            if timestamps is not None:
+                logits = timestamp_rules(torch.cat(seq, dim=1), logits, P, eos, timestamps["no_timestamps_token_id"],
+                                         timestamps.get("max_initial_timestamp_index"))
             if rescorer is not None:
                 logits = rescorer(torch.cat(seq, dim=1), torch.log_softmax(logits, dim=-1))
             if return_scores:
