@@ -134,7 +134,8 @@ def _bf(x):
     return x.bfloat16().float()
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (1500, 1152, 384), (333, 516, 1280), (3000, 5120, 1280)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 384, 128), (1500, 1152, 384), (333, 516, 1280), (3000, 5120, 1280),
+                                   (16, 1280, 1280), (1, 51968, 1280), (7, 36, 5120)])          # last three: the skinny decode-step kernel
 def test_gemm_nt_plain(ops, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * K ** -0.5)
@@ -160,7 +161,8 @@ def test_cast_transpose(ops, R, C, ld, ld_t):
     if ld: assert float(out[:, C:].float().abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (6100, 2244, 128), (12200, 1284, 64)])   # 128x128 / persistent 256x256 / 192x320
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (6100, 2244, 128), (12200, 1284, 64),     # 128x128 / persistent 256x256 / 192x320
+                                   (16, 1284, 1280), (5, 260, 192)])                           # skinny (M <= 16)
 def test_gemm_nt_epilogues(ops, M, N, K):
     from ts_asr_whisper_amd import _lib as L
     g = torch.Generator().manual_seed(5)

@@ -200,9 +200,10 @@ extern "C" int dicow_ctc_prefix_score(const dicow_ctc_prefix_args* a, void* stre
 // ~10 masked assignments and a log_softmax; here one workgroup per row derives the three facts it needs from the generated
 // suffix (was the last / the one before a timestamp, the last timestamp emitted), evaluates the mask per label, reduces
 // max(text) and logsumexp(timestamps) in one pass, and writes the row once.
-__global__ void __launch_bounds__(256) timestamp_rules_kernel(float* __restrict__ scores, int64_t ld, int V, const int64_t* __restrict__ ids,
+#define TSR_BLOCK 1024
+__global__ void __launch_bounds__(TSR_BLOCK) timestamp_rules_kernel(float* __restrict__ scores, int64_t ld, int V, const int64_t* __restrict__ ids,
                                                               int L, int begin, int ts0, int eos, int no_ts, int max_init, int detect) {
-    __shared__ float red_m[4], red_t[4], red_s[4];
+    __shared__ float red_m[TSR_BLOCK / 64], red_t[TSR_BLOCK / 64], red_s[TSR_BLOCK / 64];
     __shared__ int facts[3];
     const int k = blockIdx.x, tid = threadIdx.x;
     float* row = scores + (int64_t)k * ld;
@@ -229,7 +230,7 @@ __global__ void __launch_bounds__(256) timestamp_rules_kernel(float* __restrict_
     };
     // max over text labels, online logsumexp over timestamp labels (both after the rules above)
     float mt = -INFINITY, tm = -INFINITY, tsum = 0.f;
-    for (int v = tid; v < V; v += 256) {
+    for (int v = tid; v < V; v += TSR_BLOCK) {
         if (banned(v)) continue;
         const float s = row[v];
         if (v < ts0) mt = fmaxf(mt, s);
@@ -241,13 +242,14 @@ __global__ void __launch_bounds__(256) timestamp_rules_kernel(float* __restrict_
     mt = wave_max(mt);
     if ((tid & 63) == 0) { red_m[tid >> 6] = mt; red_t[tid >> 6] = wm; red_s[tid >> 6] = tsum; }
     __syncthreads();
-    mt = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
-    tm = fmaxf(fmaxf(red_t[0], red_t[1]), fmaxf(red_t[2], red_t[3]));
+    mt = red_m[0];
+    tm = red_t[0];
+    for (int w = 1; w < TSR_BLOCK / 64; ++w) { mt = fmaxf(mt, red_m[w]); tm = fmaxf(tm, red_t[w]); }
     float tot = 0.f;
-    for (int w = 0; w < 4; ++w) tot += red_t[w] == -INFINITY ? 0.f : red_s[w] * expf(red_t[w] - tm);
+    for (int w = 0; w < TSR_BLOCK / 64; ++w) tot += red_t[w] == -INFINITY ? 0.f : red_s[w] * expf(red_t[w] - tm);
     const float ts_lse = tm == -INFINITY ? -INFINITY : tm + logf(tot);
     const bool only_ts = detect && ts_lse > mt;           // the normaliser of log_softmax cancels in the comparison
-    for (int v = tid; v < V; v += 256)
+    for (int v = tid; v < V; v += TSR_BLOCK)
         if (banned(v) || (only_ts && v < ts0)) row[v] = -INFINITY;
     if (first && eos < V) {                               // utils.py:10-12: a silent window may end immediately
         __syncthreads();
@@ -261,7 +263,7 @@ extern "C" int dicow_whisper_timestamp_rules(float* scores, int64_t ld, int B, i
     DICOW_REQUIRE(scores && input_ids && B > 0 && V > 0 && ld >= V && L >= begin_index && begin_index >= 0,
                   "whisper_timestamp_rules: bad args B=%d V=%d L=%d begin=%d", B, V, L, begin_index);
     DICOW_REQUIRE(timestamp_begin > 0 && timestamp_begin <= V && no_timestamps >= 0 && eos >= 0, "whisper_timestamp_rules: bad token ids");
-    timestamp_rules_kernel<<<B, 256, 0, (hipStream_t)stream>>>(scores, ld, V, input_ids, L, begin_index, timestamp_begin, eos, no_timestamps,
+    timestamp_rules_kernel<<<B, TSR_BLOCK, 0, (hipStream_t)stream>>>(scores, ld, V, input_ids, L, begin_index, timestamp_begin, eos, no_timestamps,
                                                                max_initial_timestamp_index, detect_from_logprob);
     DICOW_CHECK_LAUNCH("timestamp_rules_kernel");
     return DICOW_OK;

@@ -240,6 +240,53 @@ __global__ void __launch_bounds__(256, STAGES == 2 ? 2 : 4) gemm_nt_kernel(const
     }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, skinny (M <= 16)
+// One decoder step of a batch of <= 16 hypotheses: C[M, N] = x[M, K] W[N, K]^T streams the whole weight matrix once for a
+// handful of rows -- HBM-bound, and the 128-row tiles above spend 25 us per call on it with N / 128 workgroups.  Here a
+// workgroup owns 16 output columns: v_mfma_f32_16x16x32_bf16 with the WEIGHT rows as the A operand and x as B, so that a lane
+// ends up with 4 consecutive n of one row m (what nt_epilogue_quad stores); the four waves split the k-steps (interleaved),
+// every lane keeps 8 x 16-byte weight loads in flight, partial sums meet in LDS.  N / 16 workgroups: 80 for a D x D
+// projection, 3248 for the tied head.
+#define SKINNY_UNROLL 8
+__global__ void __launch_bounds__(256) gemm_nt_skinny_kernel(const dicow_gemm_args a) {
+    __shared__ float red[3][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * 16, nrow = n0 + (lane & 15), m = lane & 15, kc = (lane >> 4) * 8;
+    const bool mvalid = m < a.M;
+    const unsigned short* W = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)(nrow < a.N ? nrow : a.N - 1) * a.ldb + kc;
+    const unsigned short* X = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)(mvalid ? m : 0) * a.lda + kc;
+    f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+    const int nsteps = a.K / 32;
+    for (int s = wave; s < nsteps; s += 4 * SKINNY_UNROLL) {
+        bf16x8_t wv[SKINNY_UNROLL], xv[SKINNY_UNROLL];
+#pragma unroll
+        for (int u = 0; u < SKINNY_UNROLL; ++u) {
+            const int st = s + 4 * u;
+            const int so = (st < nsteps ? st : s) * 32;                      // past the end: a harmless re-read, weighted by zero
+            wv[u] = *reinterpret_cast<const bf16x8_t*>(W + so);
+            xv[u] = *reinterpret_cast<const bf16x8_t*>(X + so);
+            if (!mvalid || st >= nsteps) xv[u] = bf16x8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < SKINNY_UNROLL; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[u], xv[u], acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[wave - 1][lane][e] = acc[e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = acc[e] + red[0][lane][e] + red[1][lane][e] + red[2][lane][e];
+    const int n = n0 + (lane >> 4) * 4;
+    if (!mvalid || n >= a.N) return;
+    unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C);
+    float* Cf = reinterpret_cast<float*>(a.C);
+    unsigned short* aux = reinterpret_cast<unsigned short*>(a.aux);
+    nt_epilogue_quad(a, a.flags, v, m, n, Cb, Cf, aux);
+}
+
 // ------------------------------------------------------------------------------------------------ NT, 256x256 tile
 // 512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 (M) x 64 (N) = 4x2 MFMA tiles (128 fp32 accumulators/lane).
 // Twice the arithmetic intensity of the 128x128 kernel (128 flop per LDS-staged byte): at ~0.7 PFLOP/s the small
@@ -895,6 +942,12 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
         attr_set = true;
     }
     static const int variant = getenv("DICOW_NT_VARIANT") ? atoi(getenv("DICOW_NT_VARIANT")) : 0;     // tuning knob
+    if (a->M <= 16 && batch == 1 && variant == 0) {       // a decoding step: stream the weights once (gemm_nt_skinny_kernel)
+        hipLaunchKernelGGL(gemm_nt_skinny_kernel, dim3(dicow_cdiv(a->N, 16)), dim3(256), 0, (hipStream_t)stream, *a);
+        DICOW_CHECK_LAUNCH("gemm_nt_skinny_kernel");
+        if (fused_colsum) *fused_colsum = false;
+        return DICOW_OK;
+    }
     static bool attr256 = false;
     if (!attr256) {
         (void)hipFuncSetAttribute((const void*)gemm_nt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NTS_LDS);
