@@ -157,3 +157,16 @@ def test_greedy_decode_with_timestamp_rules(pkg):
         assert row[0] == eos or no_ts < row[0] <= no_ts + 1 + 20
         stamps = [t for t in row if t > no_ts]
         assert stamps == sorted(stamps) and no_ts not in row
+
+
+def test_graph_captured_steps_match_eager(pkg):
+    """use_graphs=True: the first window captures one graph per position, the second window replays them on new data."""
+    from ts_asr_whisper_amd.generation import GreedyDecoder
+    z, model, cfg, x, st, prompt = _setup(pkg)
+    eager, graphed = GreedyDecoder(model), GreedyDecoder(model, use_graphs=True)
+    x2, st2 = x.flip(0).contiguous(), st.flip(0).contiguous()
+    for xi, si in ((x, st), (x2, st2), (x, st)):
+        a, sa = eager.generate(xi.cuda(), si.cuda(), prompt, 9, eos_token_id=-1, return_scores=True)
+        b, sb = graphed.generate(xi.cuda(), si.cuda(), prompt, 9, eos_token_id=-1, return_scores=True)
+        assert torch.equal(a, b) and torch.equal(sa, sb)
+    assert len(graphed._persist[2].graphs) == prompt.shape[1] - 1 + 9
