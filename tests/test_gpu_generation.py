@@ -170,3 +170,23 @@ def test_graph_captured_steps_match_eager(pkg):
         b, sb = graphed.generate(xi.cuda(), si.cuda(), prompt, 9, eos_token_id=-1, return_scores=True)
         assert torch.equal(a, b) and torch.equal(sa, sb)
     assert len(graphed._persist[2].graphs) == prompt.shape[1] - 1 + 9
+
+
+def test_model_generate_wrapper(pkg):
+    """model.generate(...) with an HF-style generation_config equals the explicit GreedyDecoder call; unsupported modes say so."""
+    import types
+    from ts_asr_whisper_amd.generation import GreedyDecoder
+    z, model, cfg, x, st, prompt = _setup(pkg)
+    gc = types.SimpleNamespace(eos_token_id=5, pad_token_id=cfg.pad_token_id, suppress_tokens=[3, 4], begin_suppress_tokens=[20],
+                               return_timestamps=True, no_timestamps_token_id=399, max_initial_timestamp_index=20, max_length=14,
+                               decoder_start_token_id=cfg.decoder_start_token_id, ctc_weight=0.0, num_beams=1)
+    model.tokenizer = types.SimpleNamespace(prefix_tokens=[cfg.decoder_start_token_id, 7, 9])
+    a = model.generate(input_features=x.cuda(), stno_mask=st.cuda(), generation_config=gc)
+    want_prompt = torch.tensor([[cfg.decoder_start_token_id, 7, 9]] * 2)
+    b = GreedyDecoder(model).generate(x.cuda(), st.cuda(), want_prompt, 11, eos_token_id=5, pad_token_id=cfg.pad_token_id,
+                                      suppress_tokens=[3, 4], begin_suppress_tokens=[20],
+                                      timestamps=dict(no_timestamps_token_id=399, max_initial_timestamp_index=20))
+    assert torch.equal(a, b) and a.shape[1] <= 14
+    with pytest.raises(NotImplementedError):
+        model.generate(input_features=x.cuda(), stno_mask=st.cuda(), generation_config=gc, num_beams=5)
+    model.tokenizer = None

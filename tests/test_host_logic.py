@@ -178,3 +178,45 @@ def test_product_stno_seek_windows_match_reference_golden():
         got = stno_seek_windows(torch.from_numpy(z[f"c{i}.stno"]), z[f"c{i}.seek"], z[f"c{i}.max_frames"], z[f"c{i}.map"],
                                 num_frames=int(z[f"c{i}.msp"]))
         assert np.array_equal(got.numpy(), z[f"c{i}.out"]), i
+
+
+# ------------------------------------------------------------------------------------------------ checkpoints
+def _tiny_cfg():
+    return pkg.DiCoWConfig(vocab_size=256, d_model=64, encoder_layers=2, encoder_attention_heads=1, decoder_layers=1,
+                           decoder_attention_heads=1, encoder_ffn_dim=128, decoder_ffn_dim=128, max_source_positions=20,
+                           max_target_positions=16, pad_token_id=250, use_pre_pos_fddt=True)
+
+
+def test_save_and_from_pretrained_round_trip(tmp_path):
+    torch.manual_seed(0)
+    m = pkg.DiCoWForConditionalGeneration(_tiny_cfg())
+    m.save_pretrained(tmp_path / "ckpt")
+    assert sorted(os.listdir(tmp_path / "ckpt")) == ["config.json", "model.safetensors"]
+    m2 = pkg.DiCoWForConditionalGeneration.from_pretrained(str(tmp_path / "ckpt"))
+    assert m2._load_report == {"missing": [], "unexpected": []}
+    for (n, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), n
+    assert m2.proj_out.weight is m2.model.decoder.embed_tokens.weight          # tied after loading
+    assert m2.config.to_dict() == m.config.to_dict()
+
+
+def test_from_pretrained_plain_whisper_checkpoint_keeps_fddt_init(tmp_path):
+    """A checkpoint without the FDDT keys (plain Whisper): they are reported missing and keep the reference initialisation,
+    overrides reach the config (containers.py:47-50 passes the DiCoW switches as from_pretrained kwargs)."""
+    from safetensors.torch import save_file
+    import json
+    torch.manual_seed(0)
+    m = pkg.DiCoWForConditionalGeneration(_tiny_cfg())
+    sd = {k: v.clone() for k, v in m.state_dict().items() if "fddt" not in k and k != "proj_out.weight"}
+    os.makedirs(tmp_path / "w")
+    save_file(sd, str(tmp_path / "w" / "model.safetensors"))
+    plain = {k: v for k, v in m.config.to_dict().items() if "fddt" not in k}
+    json.dump(plain, open(tmp_path / "w" / "config.json", "w"))
+    m2 = pkg.DiCoWForConditionalGeneration.from_pretrained(str(tmp_path / "w"), use_fddt=True, use_pre_pos_fddt=True,
+                                                          fddt_init="suppressive", non_target_fddt_value=0.5)
+    assert m2._load_report["missing"] and all("fddt" in k for k in m2._load_report["missing"]) and not m2._load_report["unexpected"]
+    assert torch.equal(m2.model.encoder.layers[0].fc1.weight, m.model.encoder.layers[0].fc1.weight)
+    w = m2.model.encoder.initial_fddt.non_target_linear.weight
+    assert torch.allclose(w, torch.full_like(w, 0.5))                           # suppressive init with non_target_fddt_value
+    m3 = pkg.DiCoWForConditionalGeneration.from_pretrained("openai/whisper-tiny", use_fddt=True)
+    assert m3.config.d_model == 384 and m3._load_report["missing"] is None

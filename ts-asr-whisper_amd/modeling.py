@@ -551,6 +551,89 @@ class DiCoWForConditionalGeneration(nn.Module):
     def tie_weights(self):
         self.proj_out.weight = self.model.decoder.embed_tokens.weight
 
+    # -- checkpoints: the reference builds the model with ``from_pretrained(name, **overrides)`` (containers.py:47-50)
+    @classmethod
+    def from_pretrained(cls, name_or_path, **overrides):
+        """Local directory with ``config.json`` + ``model.safetensors`` / ``pytorch_model.bin`` (an HF Whisper or a DiCoW
+        checkpoint: identical key names), or a preset name such as ``openai/whisper-large-v3-turbo`` (no network in this
+        build: the preset gives the architecture, weights stay randomly initialised).  Keys the checkpoint lacks -- the
+        FDDT / SCB / CTC modules of a plain Whisper checkpoint -- keep their reference initialisation, like HF's
+        ``from_pretrained`` does for newly added modules."""
+        import json
+        import os
+        if os.path.isdir(str(name_or_path)):
+            with open(os.path.join(name_or_path, "config.json")) as f:
+                cfg = DiCoWConfig.from_hf(json.load(f), **overrides)
+            model = cls(cfg)
+            st_path, bin_path = os.path.join(name_or_path, "model.safetensors"), os.path.join(name_or_path, "pytorch_model.bin")
+            if os.path.exists(st_path):
+                from safetensors.torch import load_file
+                sd = load_file(st_path)
+            elif os.path.exists(bin_path):
+                sd = torch.load(bin_path, map_location="cpu", weights_only=True)
+            else:
+                raise FileNotFoundError(f"no model.safetensors / pytorch_model.bin under {name_or_path}")
+            if "proj_out.weight" not in sd and "model.decoder.embed_tokens.weight" in sd:
+                sd["proj_out.weight"] = sd["model.decoder.embed_tokens.weight"]          # safetensors drops the tied copy
+            missing, unexpected = model.load_state_dict(sd, strict=False)
+            model.tie_weights()
+            model._load_report = {"missing": list(missing), "unexpected": list(unexpected)}
+            return model
+        model = cls(DiCoWConfig.preset(str(name_or_path), **overrides))
+        model._load_report = {"missing": None, "unexpected": None, "note": "preset architecture, random initialisation (offline build)"}
+        return model
+
+    def save_pretrained(self, directory):
+        import json
+        import os
+        from safetensors.torch import save_file
+        os.makedirs(directory, exist_ok=True)
+        with open(os.path.join(directory, "config.json"), "w") as f:
+            json.dump(dict(self.config.to_dict(), model_type="DiCoW", architectures=["DiCoWForConditionalGeneration"]), f, indent=1)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items() if k != "proj_out.weight"}     # tied
+        save_file(sd, os.path.join(directory, "model.safetensors"))
+
+    def generate(self, input_features=None, stno_mask=None, attention_mask=None, decoder_input_ids=None, max_new_tokens=None,
+                 max_length=None, generation_config=None, enrollments=None, num_beams=1, return_timestamps=None, **kwargs):
+        """Short-form (one 30 s window) greedy decoding with the reference's logits-processor chain (generation.GreedyDecoder).
+        ``generation_config``: any object with the HF / reference attribute names (eos_token_id, pad_token_id, suppress_tokens,
+        begin_suppress_tokens, return_timestamps, no_timestamps_token_id, max_initial_timestamp_index, ctc_weight, ...).
+        The prompt is ``decoder_input_ids`` or [decoder_start_token_id] + the tokenizer's prefix tokens."""
+        from .generation import GreedyDecoder
+        gc = generation_config if generation_config is not None else self.generation_config
+        get = (lambda k, d=None: getattr(gc, k, d) if gc is not None else d)
+        if (num_beams or 1) > 1 or (get("num_beams", 1) or 1) > 1:
+            raise NotImplementedError("beam search is outside this build's decoding path (greedy only)")
+        if input_features.shape[-1] != 2 * self.config.max_source_positions:
+            raise NotImplementedError("long-form inputs: cut 30 s windows with generation.stno_seek_windows and decode each")
+        cfg = self.config
+        B = input_features.shape[0]
+        if decoder_input_ids is None:
+            prefix = list(getattr(self.tokenizer, "prefix_tokens", [])) if self.tokenizer is not None else []
+            start = get("decoder_start_token_id", cfg.decoder_start_token_id)
+            prompt = prefix if (prefix and prefix[0] == start) else [start] + prefix
+            decoder_input_ids = torch.tensor([prompt] * B, dtype=torch.long)
+        P = decoder_input_ids.shape[1]
+        if max_new_tokens is None:
+            limit = max_length if max_length is not None else get("max_length", cfg.max_target_positions)
+            max_new_tokens = min(limit, cfg.max_target_positions) - P
+        ts = return_timestamps if return_timestamps is not None else get("return_timestamps", False)
+        timestamps = None
+        if ts:
+            timestamps = dict(no_timestamps_token_id=get("no_timestamps_token_id"),
+                              max_initial_timestamp_index=get("max_initial_timestamp_index"))
+        ctc = None
+        if (get("ctc_weight", 0.0) or 0.0) > 0.0:
+            tok = self.tokenizer
+            ctc = dict(weight=get("ctc_weight"), first_timestamp=tok.get_vocab()["<|0.00|>"],
+                       upper_cased=list(getattr(tok, "upper_cased_tokens", {}).items()), prefix_len=len(tok.prefix_tokens))
+        if not hasattr(self, "_decoder"):
+            self._decoder = GreedyDecoder(self)
+        return self._decoder.generate(input_features, stno_mask, decoder_input_ids, max_new_tokens,
+                                      eos_token_id=get("eos_token_id", cfg.eos_token_id), pad_token_id=get("pad_token_id", cfg.pad_token_id),
+                                      suppress_tokens=get("suppress_tokens"), begin_suppress_tokens=get("begin_suppress_tokens"),
+                                      enrollments=enrollments, ctc=ctc, timestamps=timestamps)
+
     def post_init(self):
         self.tie_weights()
 
