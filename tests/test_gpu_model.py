@@ -207,3 +207,35 @@ def test_f10_ctc_branch(pkg):
     ref = {k[2:]: T(z, k) for k in z.files if k.startswith("g.")}
     worst = _check_grads(model, ref, tol_rel=8e-2, min_checked=30)
     print("worst CTC-model grad rel err:", worst)
+
+
+def test_ctc_pretraining_api_return_logits_and_get_loss(pkg):
+    """The encoder-only CTC pre-training path (src/utils/trainers.py:76-101): ``encoder(..., return_logits=True).logits`` ->
+    ``encoder.get_loss(logits, labels)`` -> backward, vs the oracle (pinned by golden F10) with the same bf16 rounding points."""
+    z = load_golden("f10_ctc")
+    model, cfg = build_model(pkg, z)
+    enc = model.model.encoder
+    x, st, lab = T(z, "x"), T(z, "stno"), T(z, "labels")
+    prefix = [int(v) for v in z["prefix"]]
+    labels = lab.clone()                                   # what CustomTrainerEncoder.compute_loss does to the labels
+    for tok in prefix:
+        if bool((labels[:, 0] == tok).all()):
+            labels = labels[:, 1:]
+    labels[labels == cfg.eos_token_id] = -100
+    out = enc(x.cuda(), stno_mask=st.cuda(), return_logits=True)
+    assert out.logits.shape == (x.shape[0], cfg.max_source_positions // 4, cfg.vocab_size + 1)
+    loss = enc.get_loss(out.logits, labels.cuda())
+    loss.backward()
+    ocfg, p = golden_cfg(z), golden_params(z, requires_grad=True)
+    oenc = O.encoder_forward(p, ocfg, x, st, emu=True)
+    ologits = O.ctc_logits(p, ocfg, oenc, emu=True)
+    oloss = O.ctc_loss(ologits, O.ctc_prepare_labels(lab, ocfg, prefix))
+    oloss.backward()
+    assert maxdiff(out.logits.float().cpu(), ologits.detach()) < 5e-2
+    assert abs(float(loss) - float(oloss)) < 2e-2 * max(1.0, abs(float(oloss)))
+    ref = {n: t.grad for n, t in p.items() if t.grad is not None and n.startswith("model.encoder.")}
+    worst = _check_grads(model, ref, tol_rel=8e-2, min_checked=30)
+    print("worst grad rel err (CTC pre-training path):", worst)
+    # logits handed over as an ordinary fp32 tensor (not the padded bf16 rows) give the same loss
+    loss2 = enc.get_loss(out.logits.detach().float().contiguous(), labels.cuda())
+    assert abs(float(loss2) - float(loss)) < 1e-3

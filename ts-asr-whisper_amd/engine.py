@@ -783,6 +783,16 @@ class CtcEngine:
         d_logits = _e((B * Tn, W.cpad), BF16, dev)
         S.ctc.d_logits = d_logits.data_ptr()
         ops.ctc_loss_bwd(S.ctc, grad_loss.to(F32).reshape(1))
+        return self.backward_from_logits(S, d_logits, G)
+
+    def backward_from_logits(self, S, d_logits, G):
+        """d_logits bf16 [B*Tn, cpad] (padding columns zero) -> d_enc fp32 [B*T, D]; the head, the subsampling convs and the
+        extra attention layer accumulate their gradients into G."""
+        enc, cfg, W = self.enc, self.cfg, self.W
+        dev = S.logits.device
+        D, H = cfg.d_model, cfg.encoder_attention_heads
+        B, T, Tn = S.B, S.T, S.Tn
+        rows = B * T
         glm = G.get(enc.lm_head.weight)
         if glm is not None:
             tmp = torch.zeros(W.cpad, D, dtype=F32, device=dev)          # vocab+1 is not a multiple of 8: padded rows

@@ -10,6 +10,7 @@ in ``engine.py`` -> ``libdicow_hip.so``.  Modules refuse CPU tensors: there is n
 import math
 import re
 from collections import OrderedDict
+from types import SimpleNamespace as NS_
 from typing import Optional
 
 import torch
@@ -352,6 +353,22 @@ class DiCoWEncoder(nn.Module):
 
     _CTC_PREFIXES = ("additional_self_attention_layer.", "subsample_conv", "lm_head.")
 
+    def get_loss(self, logits, labels):
+        """CTC loss of ``forward(..., return_logits=True).logits`` (reference encoder.py:108-135)."""
+        if int(labels.max()) >= self.config.vocab_size:
+            raise ValueError(f"Label values must be <= vocab_size: {self.config.vocab_size}")
+        lab = labels.to(logits.device)
+        if self.config.remove_timestamps_from_ctc:          # encoder.py:111-113: keep labels below the first task token
+            keep = lab < self.first_task_token
+            order = torch.argsort((~keep).to(torch.int8), dim=1, stable=True)
+            lab = torch.gather(lab, 1, order)
+            cnt = keep.sum(dim=1, keepdim=True)
+            lab = torch.where(torch.arange(lab.shape[1], device=lab.device)[None, :] < cnt, lab, torch.full_like(lab, -100))
+            lab = lab[:, :max(int(cnt.max()), 1)]
+        valid = lab >= 0                                    # valid targets first (CTC target_lengths = count of >= 0)
+        lab = torch.gather(lab, 1, torch.argsort((~valid).to(torch.int8), dim=1, stable=True)).contiguous()
+        return _CtcLossFn.apply(self, logits, lab)
+
     def ctc_parameters(self):
         return [p for n, p in self.named_parameters() if n.startswith(self._CTC_PREFIXES)]
 
@@ -382,8 +399,6 @@ class DiCoWEncoder(nn.Module):
     def forward(self, input_features, attention_mask=None, head_mask=None, output_attentions=None, output_hidden_states=None,
                 return_dict=None, stno_mask=None, return_logits=False, enrollments=None):
         _require_cuda(input_features, "DiCoWEncoder")
-        if return_logits:
-            raise NotImplementedError("return_logits (CTC head) is a 'next' row (SURVEY.md section 8 f2)")
         if stno_mask is None:
             raise ValueError("stno_mask is required")
         ctc_ids = {id(p) for p in self.ctc_parameters()} if self.ctc_weight > 0.0 else set()
@@ -391,6 +406,11 @@ class DiCoWEncoder(nn.Module):
         # under torch.no_grad() (evaluation / decoding) no activation is kept for a backward pass
         need_grad = torch.is_grad_enabled() and (input_features.requires_grad or any(p.requires_grad for p in params))
         out = _EncoderFn.apply(self, input_features, stno_mask, enrollments, need_grad, *params)
+        if return_logits:                                   # encoder.py:233-240 (CTC pre-training / get_enc_logits)
+            if self.ctc_weight <= 0.0:
+                raise L.DicowError("return_logits needs the CTC head (ctc_weight > 0)")
+            logits = _CtcLogitsFn.apply(self, out, *self.ctc_parameters())
+            return ModelOutput(loss=None, logits=logits, hidden_states=out)
         if return_dict is False:
             return (out,)
         return ModelOutput(last_hidden_state=out, hidden_states=None, attentions=None)
@@ -417,6 +437,73 @@ class _CtcFn(torch.autograd.Function):
         if hook is not None:
             hook("ctc")
         return (None, d_enc.view(S.B, S.T, -1), None) + tuple(G.result(p) for p in ctx.params)
+
+
+class _CtcLogitsFn(torch.autograd.Function):
+    """Encoder output -> CTC-head logits as an autograd node (the ``return_logits=True`` path of encoder.py:233-240, which
+    the CTC pre-training trainer calls: src/utils/trainers.py:76-101)."""
+
+    @staticmethod
+    def forward(ctx, enc, enc_out, *params):
+        eng = enc._ctc_engine()
+        B, T, D = enc_out.shape
+        enc_bf = ops.cast_bf16(enc_out.contiguous().to(F32)).view(B * T, D)
+        S = eng.encode_logits(enc_bf, B, T)
+        ctx.enc, ctx.S, ctx.params = enc, S, params
+        return S.logits.view(B, S.Tn, -1)[:, :, :enc.config.vocab_size + 1]
+
+    @staticmethod
+    def backward(ctx, g):
+        enc, S = ctx.enc, ctx.S
+        eng = enc._ctc_engine(prepare=False)
+        cpad, V1 = eng.W.cpad, enc.config.vocab_size + 1
+        pad = getattr(enc, "_ctc_dlogits", None)
+        if pad is not None and pad.shape == (S.B * S.Tn, cpad) and g.data_ptr() == pad.data_ptr() and g.stride() == (S.Tn * cpad, cpad, 1):
+            d = pad                                           # get_loss's own padded gradient buffer: no copy
+        else:
+            d = torch.zeros(S.B * S.Tn, cpad, dtype=BF16, device=g.device)
+            d.view(S.B, S.Tn, cpad)[:, :, :V1].copy_(g)
+        enc._ctc_dlogits = None
+        G = GradSink(ctx.params, g.device)
+        d_enc = eng.backward_from_logits(S, d, G)
+        hook = getattr(enc, "_segment_hook", None)
+        if hook is not None:
+            hook("ctc")
+        return (None, d_enc.view(S.B, S.T, -1)) + tuple(G.result(p) for p in ctx.params)
+
+
+class _CtcLossFn(torch.autograd.Function):
+    """CTC loss of given logits (encoder.py:108-135: fp32 log-softmax, blank = last class, reduction "mean", zero_infinity)."""
+
+    @staticmethod
+    def forward(ctx, enc, logits, labels):
+        B, Tn, V1 = logits.shape
+        dev = logits.device
+        if logits.dtype == BF16 and logits.stride(2) == 1 and logits.stride(0) == Tn * logits.stride(1):
+            buf, ld = logits, logits.stride(1)                # the padded rows produced by _CtcLogitsFn
+        else:
+            ld = (V1 + 127) // 128 * 128
+            buf = torch.zeros(B, Tn, ld, dtype=BF16, device=dev)
+            buf[:, :, :V1].copy_(logits)
+        lab = labels.contiguous()
+        S = NS_(B=B, Tn=Tn, ld=ld, buf=buf)
+        S.lse, S.nll, S.tlen = (torch.empty(n, dtype=F32, device=dev) for n in (B * Tn, B, B))
+        S.ab = torch.empty(2, B, Tn, 2 * lab.shape[1] + 1, dtype=F32, device=dev)
+        S.acc = torch.zeros(1, dtype=F32, device=dev)
+        S.labels = lab
+        S.ctc = ops.ctc_args(buf, ld, B, Tn, V1, lab, S.lse, S.ab[0], S.ab[1], S.nll, S.tlen, S.acc)
+        ops.ctc_loss_fwd(S.ctc)
+        ctx.enc, ctx.S, ctx.V1 = enc, S, V1
+        return S.acc[0] / B
+
+    @staticmethod
+    def backward(ctx, g):
+        enc, S = ctx.enc, ctx.S
+        d = torch.empty(S.B * S.Tn, S.ld, dtype=BF16, device=g.device)
+        S.ctc.d_logits = d.data_ptr()
+        ops.ctc_loss_bwd(S.ctc, g.to(F32).reshape(1))
+        enc._ctc_dlogits = d
+        return None, d.view(S.B, S.Tn, S.ld)[:, :, :ctx.V1], None
 
 
 def prepare_ctc_labels(labels, config, prefix_tokens, first_task_token):
