@@ -239,3 +239,50 @@ def test_ctc_pretraining_api_return_logits_and_get_loss(pkg):
     # logits handed over as an ordinary fp32 tensor (not the padded bf16 rows) give the same loss
     loss2 = enc.get_loss(out.logits.detach().float().contiguous(), labels.cuda())
     assert abs(float(loss2) - float(loss)) < 1e-3
+
+
+@pytest.mark.parametrize("se", [False, True])
+def test_dense_fddt_inside_the_encoder_vs_oracle(pkg, se):
+    """fddt_is_diagonal=False (FDDT.py:13-16: a D x D Linear per class) through the fused encoder path, plain and SE-DiCoW
+    (dense FDDT before the speaker-communication blocks), vs the oracle with the same bf16 rounding points: loss + gradients."""
+    from oracle.dicow_oracle import OracleConfig
+    kw = dict(vocab_size=512, d_model=128, encoder_layers=3, encoder_attention_heads=2, decoder_layers=2, decoder_attention_heads=2,
+              encoder_ffn_dim=256, decoder_ffn_dim=256, max_source_positions=100, max_target_positions=32, pad_token_id=500,
+              bos_token_id=500, eos_token_id=500, decoder_start_token_id=501, num_mel_bins=80, use_fddt=True, fddt_is_diagonal=False,
+              use_pre_pos_fddt=True, fddt_init="suppressive", non_target_fddt_value=0.5)
+    if se:
+        kw.update(use_enrollments=True, scb_layers=2)
+    cfg = pkg.DiCoWConfig(**kw)
+    torch.manual_seed(3)
+    model = pkg.DiCoWForConditionalGeneration(cfg)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():                                   # make every class matrix / gate matter
+        for n, p_ in model.named_parameters():
+            if "fddt" in n or "ca_enrolls" in n:
+                p_.add_(torch.randn(p_.shape, generator=g) * 0.05)
+    state = {n: t.detach().clone() for n, t in model.state_dict().items()}
+    model = model.cuda()
+    model.tie_weights()
+    B, L_ = 2, 10
+    x = torch.randn(B, 80, 200, generator=g).clamp_(-1.5, 1.5)
+    st = torch.softmax(torch.randn(B, 4, 100, generator=g) * 2, dim=1)
+    lab = torch.randint(0, 400, (B, L_), generator=g)
+    batch = dict(input_features=x.cuda(), stno_mask=st.cuda(), labels=lab.cuda(), upp_labels=lab.cuda())
+    enr = None
+    if se:
+        enr = {"input_features": torch.randn(B, 80, 200, generator=g).clamp_(-1.5, 1.5), "stno_mask": torch.softmax(torch.randn(B, 4, 100, generator=g), 1)}
+        batch["enrollments"] = {k: v.cuda() for k, v in enr.items()}
+    out = model(**batch)
+    out.loss.backward()
+    ocfg = OracleConfig(**{k: v for k, v in cfg.to_dict().items() if k in OracleConfig.__dataclass_fields__})
+    p = {n: t.clone().requires_grad_(t.is_floating_point()) for n, t in state.items()}
+    p["proj_out.weight"] = p["model.decoder.embed_tokens.weight"]
+    ref = O.model_forward(p, ocfg, x, st, lab, lab, enrollments=enr, emu=True)
+    ref["loss"].backward()
+    assert maxdiff(out.encoder_last_hidden_state.cpu(), ref["encoder_last_hidden_state"].detach()) < 4e-2
+    assert abs(float(out.loss) - float(ref["loss"])) < 1e-2
+    trainable = {n for n, q in model.named_parameters() if q.requires_grad}
+    grads = {n: t.grad for n, t in p.items() if t.grad is not None and n in trainable}
+    assert any("fddts.1.target_linear.weight" in n for n in grads) and grads["model.encoder.initial_fddt.silence_linear.weight"].shape == (128, 128)
+    worst = _check_grads(model, grads, tol_rel=6e-2, min_checked=60)
+    print("worst grad rel err (dense FDDT):", worst)

@@ -127,6 +127,58 @@ def fddt_ptrs(fddt, cfg):
     return (ops.MODE_BIAS if fddt.bias_only else ops.MODE_DIAG), tuple(w), tuple(b)
 
 
+# full (D x D) FDDT (FDDT.py:13-16, 53-62): one GEMM [rows, D] x [D, 4D] + masked combine; shared by the standalone FDDT
+# module and the fused encoder path
+def fddt_is_full(fddt):
+    return fddt is not None and not fddt.is_diagonal
+
+
+def prep_full_fddt(fddt, dev):
+    D = fddt.d_model
+    w = NS(use=0)
+    w.Wc = torch.zeros(4 * D, D, dtype=BF16, device=dev)
+    w.Wct = torch.zeros(D, 4 * D, dtype=BF16, device=dev)
+    w.bias = torch.zeros(4 * D, dtype=F32, device=dev)
+    for c, name in enumerate(CLS):
+        m = getattr(fddt, name, None)
+        if m is not None:
+            w.use |= 1 << c
+            ops.cast_transpose_bf16(m.weight.detach(), out=w.Wc[c * D:(c + 1) * D], out_t=w.Wct[:, c * D:(c + 1) * D], ld=D, ld_t=4 * D)
+            w.bias[c * D:(c + 1) * D] = m.bias.detach()
+    return w
+
+
+def full_fddt_fwd(w, h, stno, bstride, rows, T, D):
+    """h fp32 or bf16 [rows, D] -> (h' fp32 [rows, D], bf16 copy of h kept for the weight gradients)."""
+    hb = h if h.dtype == BF16 else ops.cast_bf16(h)
+    y4 = _e((rows, 4 * D), BF16, h.device)
+    ops.gemm_nt(hb, w.Wc, y4, rows, 4 * D, D, bias=w.bias)
+    out = _e((rows, D), F32, h.device)
+    L.call("dicow_fddt_full_combine_fwd", y4.data_ptr(), h.data_ptr(), int(h.dtype == BF16), stno.data_ptr(), bstride, w.use,
+           out.data_ptr(), rows, T, D, L.stream())
+    return out, hb
+
+
+def full_fddt_bwd(fddt, w, hb, g, stno, bstride, G, rows, T, D):
+    """g fp32 [rows, D] = dL/dh' -> dL/dh fp32 [rows, D]; weight / bias gradients accumulate into G."""
+    dev = g.device
+    d_y4 = torch.zeros(rows, 4 * D, dtype=BF16, device=dev)
+    gh = _e((rows, D), F32, dev)
+    L.call("dicow_fddt_full_combine_bwd", g.data_ptr(), stno.data_ptr(), bstride, w.use, d_y4.data_ptr(), gh.data_ptr(), rows, T, D,
+           L.stream())
+    ops.gemm_nt(d_y4, w.Wct, gh, rows, D, 4 * D, flags=L.EPI_ACCUM)
+    for c, name in enumerate(CLS):
+        m = getattr(fddt, name, None)
+        if m is None:
+            continue
+        sl = d_y4[:, c * D:(c + 1) * D]
+        if G.get(m.bias) is not None:
+            ops.colsum_bf16(sl, G.get(m.bias))
+        if G.get(m.weight) is not None:
+            ops.gemm_tn(sl, hb, G.get(m.weight), rows, D, D, lda=4 * D, ldb=D, ldc=D)
+    return gh
+
+
 # ------------------------------------------------------------------------------------------------ building blocks
 def linear_fwd(x, lw, M, out_dtype=BF16, residual=None, gelu_aux=None, flags=0, scale=1.0, scale_ncols=0, out=None):
     dev = x.device
@@ -205,14 +257,11 @@ class EncoderEngine:
                 s.f0 = prep_linear([blk.cae.ffn[0].weight], [blk.cae.ffn[0].bias], dev)
                 s.f3 = prep_linear([blk.cae.ffn[3].weight], [blk.cae.ffn[3].bias], dev)
                 W.scb.append(s)
+        W.full_init = prep_full_fddt(enc.initial_fddt, dev) if (cfg.use_fddt and cfg.use_pre_pos_fddt and fddt_is_full(enc.initial_fddt)) else None
+        W.full = [prep_full_fddt(f, dev) if fddt_is_full(f) else None for f in (enc.fddts if cfg.use_fddt else [])]
         self.W = W
         return W
 
-    def _fddt_full_fwd(self, fddt, h_in, stno, bstride, rows, T, D, h_out):
-        raise L.DicowError("full (D x D) FDDT inside the fused encoder path is not wired yet; use fddt_is_diagonal=True "
-                           "or the standalone FDDT module")
-
-    # -- forward
     def forward(self, input_features, stno_mask, enrollments=None, need_grad=True):
         enc, cfg, W = self.enc, self.cfg, self.W
         dev = input_features.device
@@ -247,7 +296,11 @@ class EncoderEngine:
         init_fddt = enc.initial_fddt if (cfg.use_fddt and cfg.use_pre_pos_fddt) else None
         mode, fw, fb = fddt_ptrs(init_fddt, cfg)
         h = _e((rows, D), F32, dev)
-        ops.fddt_ln_fwd(x2, rows, D, mode=mode, stno=stno, T=T, w=fw, b=fb, pos=pos.detach(), h_out=h)
+        if W.full_init is not None:                  # dense initial FDDT, then the positions
+            hf0, S.x2b = full_fddt_fwd(W.full_init, x2, stno, 4 * T, rows, T, D)
+            ops.fddt_ln_fwd(hf0, rows, D, mode=ops.MODE_NONE, T=T, pos=pos.detach(), h_out=h)
+        else:
+            ops.fddt_ln_fwd(x2, rows, D, mode=mode, stno=stno, T=T, w=fw, b=fb, pos=pos.detach(), h_out=h)
         bstride = 4 * T
         Bc = B
         for i, lyr in enumerate(enc.layers):
@@ -257,6 +310,11 @@ class EncoderEngine:
             fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None
             mode, fw, fb = fddt_ptrs(fd, cfg)
             use_scb = cfg.use_enrollments and cfg.scb_layers is not None and i < cfg.scb_layers
+            wfull = W.full[i] if (fd is not None and i < len(W.full)) else None
+            if wfull is not None:                    # dense FDDT: its own GEMM + combine, the rest of the layer sees "no FDDT"
+                h, Ls.full_hb = full_fddt_fwd(wfull, h, stno, bstride, rows, T, D)
+                Ls.h_in = h
+                mode, fw, fb = ops.MODE_NONE, (None,) * 4, (None,) * 4
             xln = _e((rows, D), BF16, dev)
             mean, rstd = _e((rows,), F32, dev), _e((rows,), F32, dev)
             ln = lyr.self_attn_layer_norm
@@ -448,7 +506,23 @@ class EncoderEngine:
             rows_in = Ls.B * T
             g0 = _e((rows_in, D), F32, dev)
             g0b = _e((rows_in, D), BF16, dev) if i > 0 else None
-            if not hasattr(Ls, "scb"):
+            wfull = W.full[i] if (fd is not None and i < len(W.full)) else None
+            if wfull is not None:                    # dense FDDT: LayerNorm (+ SCB) backward first, then its own backward
+                gf = _e((rows, D), F32, dev)
+                ops.fddt_ln_bwd(Ls.hp, rows, D, mode=ops.MODE_NONE, ln_w=ln.weight.detach(), mean=Ls.mean, rstd=Ls.rstd,
+                                d_y=d_xln, g_res=g2, g_out=gf, dln_w=G.get(ln.weight), dln_b=G.get(ln.bias))
+                if hasattr(Ls, "scb"):
+                    if getattr(Ls, "dropped", False):
+                        full = torch.zeros(rows_in, D, dtype=F32, device=dev)
+                        full.view(Ls.B // 2, 2, T, D)[:, 0].copy_(gf.view(Ls.B // 2, T, D))
+                        gf = full
+                    gf = self._scb_bwd(i, Ls.scb, gf, G, T)
+                g0 = full_fddt_bwd(fd, wfull, Ls.full_hb, gf, S.stno, Ls.bstride, G, rows_in, T, D)
+                if i > 0:
+                    g0b = ops.cast_bf16(g0)
+                    if prev_b2 is not None:
+                        ops.colsum_bf16(g0b, prev_b2)
+            elif not hasattr(Ls, "scb"):
                 ops.fddt_ln_bwd(Ls.h_in, rows, D, mode=mode, stno=S.stno, stno_bstride=Ls.bstride, T=T, w=fw, b=fb,
                                 ln_w=ln.weight.detach(), mean=Ls.mean, rstd=Ls.rstd, d_y=d_xln, g_res=g2, g_out=g0,
                                 g_out_bf16=g0b, dln_w=G.get(ln.weight), dln_b=G.get(ln.bias), dw=dw, db=db,
@@ -486,8 +560,11 @@ class EncoderEngine:
         db = tuple(G.get(x) for x in fb)
         if not conv_train and all(x is None for x in dw + db):
             return
-        d_x2 = _e((rows, D), BF16, dev)
-        ops.fddt_ln_bwd(S.x2, rows, D, mode=mode, stno=S.stno, T=T, w=fw, b=fb, g_res=g, g_out_bf16=d_x2, dw=dw, db=db)
+        if W.full_init is not None:
+            d_x2 = ops.cast_bf16(full_fddt_bwd(init_fddt, W.full_init, S.x2b, g, S.stno, 4 * T, G, rows, T, D))
+        else:
+            d_x2 = _e((rows, D), BF16, dev)
+            ops.fddt_ln_bwd(S.x2, rows, D, mode=mode, stno=S.stno, T=T, w=fw, b=fb, g_res=g, g_out_bf16=d_x2, dw=dw, db=db)
         if not conv_train:
             return
         d_pre2 = _e((rows, D), BF16, dev)

@@ -19,7 +19,7 @@ from torch import nn
 from . import _lib as L
 from . import ops
 from .config import DiCoWConfig
-from .engine import EncoderEngine, DecoderEngine, CtcEngine, GradSink, fddt_ptrs, CLS
+from .engine import EncoderEngine, DecoderEngine, CtcEngine, GradSink, fddt_ptrs, CLS, prep_full_fddt, full_fddt_fwd, full_fddt_bwd
 
 F32, BF16 = torch.float32, torch.bfloat16
 
@@ -246,48 +246,19 @@ class _FDDTFullFn(torch.autograd.Function):
         if D % 64 != 0:
             raise L.DicowError("full FDDT needs d_model % 64 == 0")
         dev = hidden.device
-        h = hidden.contiguous().to(F32)
+        h = hidden.contiguous().to(F32).view(B * T, D)
         st = stno.to(device=dev, dtype=F32).contiguous()
-        rows = B * T
-        hb = ops.cast_bf16(h)
-        Wc = torch.zeros(4 * D, D, dtype=BF16, device=dev)
-        Wct = torch.zeros(D, 4 * D, dtype=BF16, device=dev)
-        bias = torch.zeros(4 * D, dtype=F32, device=dev)
-        use = 0
-        for c, name in enumerate(CLS):
-            m = getattr(mod, name, None)
-            if m is not None:
-                use |= 1 << c
-                ops.cast_transpose_bf16(m.weight.detach(), out=Wc[c * D:(c + 1) * D], out_t=Wct[:, c * D:(c + 1) * D], ld=D, ld_t=4 * D)
-                bias[c * D:(c + 1) * D] = m.bias.detach()
-        y4 = torch.empty(rows, 4 * D, dtype=BF16, device=dev)
-        ops.gemm_nt(hb, Wc, y4, rows, 4 * D, D, bias=bias)
-        out = torch.empty(B, T, D, dtype=F32, device=dev)
-        L.call("dicow_fddt_full_combine_fwd", y4.data_ptr(), h.data_ptr(), 0, st.data_ptr(), 4 * T, use, out.data_ptr(), rows, T, D, L.stream())
-        ctx.mod, ctx.hb, ctx.st, ctx.Wct, ctx.use, ctx.params, ctx.shape = mod, hb, st, Wct, use, params, (B, T, D)
-        return out
+        w = prep_full_fddt(mod, dev)
+        out, hb = full_fddt_fwd(w, h, st, 4 * T, B * T, T, D)
+        ctx.mod, ctx.w, ctx.hb, ctx.st, ctx.params, ctx.shape = mod, w, hb, st, params, (B, T, D)
+        return out.view(B, T, D)
 
     @staticmethod
     def backward(ctx, g):
-        mod, hb, st, Wct, use = ctx.mod, ctx.hb, ctx.st, ctx.Wct, ctx.use
         B, T, D = ctx.shape
-        rows, dev = B * T, hb.device
-        g = g.contiguous().to(F32)
-        G = GradSink(ctx.params, dev)
-        d_y4 = torch.zeros(rows, 4 * D, dtype=BF16, device=dev)
-        gh = torch.empty(B, T, D, dtype=F32, device=dev)
-        L.call("dicow_fddt_full_combine_bwd", g.data_ptr(), st.data_ptr(), 4 * T, use, d_y4.data_ptr(), gh.data_ptr(), rows, T, D, L.stream())
-        ops.gemm_nt(d_y4, Wct, gh, rows, D, 4 * D, flags=L.EPI_ACCUM)
-        for c, name in enumerate(CLS):
-            m = getattr(mod, name, None)
-            if m is None:
-                continue
-            sl = d_y4[:, c * D:(c + 1) * D]
-            if G.get(m.bias) is not None:
-                ops.colsum_bf16(sl, G.get(m.bias))
-            if G.get(m.weight) is not None:
-                ops.gemm_tn(sl, hb, G.get(m.weight), rows, D, D, lda=4 * D, ldb=D, ldc=D)
-        return (None, gh, None) + tuple(G.result(p) for p in ctx.params)
+        G = GradSink(ctx.params, g.device)
+        gh = full_fddt_bwd(ctx.mod, ctx.w, ctx.hb, g.contiguous().to(F32).view(B * T, D), ctx.st, 4 * T, G, B * T, T, D)
+        return (None, gh.view(B, T, D), None) + tuple(G.result(p) for p in ctx.params)
 
 
 # ------------------------------------------------------------------------------------------------ encoder
@@ -343,9 +314,6 @@ class DiCoWEncoder(nn.Module):
                 self.initial_fddt = mk(config.non_target_fddt_value)
         if config.use_enrollments and config.scb_layers is not None:
             self.ca_enrolls = nn.ModuleList([SpeakerCommunicationBlock(config) for _ in range(config.scb_layers)])
-        if config.use_fddt and not (config.fddt_is_diagonal or config.fddt_bias_only):
-            raise NotImplementedError("full (D x D) FDDT is available as the standalone FDDT module; the fused encoder "
-                                      "path implements the recipe's diagonal and bias-only variants")
         self._eng = None
         self._sig = None
         self._ctc_eng = None
