@@ -234,6 +234,32 @@ def main():
         "step_tflops": round(((6.99 if not a.se else 10.7) if not a.preheat else (6.99 - 2.2738 if not a.se else 10.7 - 3.51)) * utts, 1),
     }
     out["step_mfma_frac"] = round(out["step_tflops"] / peak, 4)
+    # north-star headline: MFMA utilisation of the FDDT-conditioned ENCODER FORWARD alone (no activations kept), same batch
+    try:
+        T_, D_, F_, Le, Mm = cfg.max_source_positions, cfg.d_model, cfg.encoder_ffn_dim, cfg.encoder_layers, cfg.num_mel_bins
+        enc_flops = (Le * (8 * T_ * D_ * D_ + 4 * T_ * T_ * D_ + 4 * T_ * D_ * F_) + 6 * (2 * T_) * Mm * D_ + 6 * T_ * D_ * D_) * a.batch
+        b0 = batches[0]
+        kw_e = dict(stno_mask=b0["stno_mask"])
+        if a.se:
+            kw_e["enrollments"] = b0["enrollments"]
+            enc_flops = None                                   # (the SE encoder's count differs; report the time only)
+        with torch.no_grad():
+            for _ in range(2):
+                model.model.encoder(b0["input_features"], **kw_e)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                model.model.encoder(b0["input_features"], **kw_e)
+            e1.record()
+            torch.cuda.synchronize()
+        enc_ms = e0.elapsed_time(e1) / 5
+        out["encoder_forward"] = {"ms": round(enc_ms, 2), "batch": a.batch,
+                                  "tflops": None if enc_flops is None else round(enc_flops / enc_ms / 1e9, 1),
+                                  "mfma_frac": None if enc_flops is None else round(enc_flops / enc_ms / 1e9 / peak, 4),
+                                  "note": "encoder forward only, torch.no_grad(), algorithmic FLOPs of SURVEY 8d / dense bf16 peak 2.5 PF"}
+    except Exception as ex:
+        out["encoder_forward"] = {"ms": None, "note": f"failed: {ex!r}"}
     if not a.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(a.model, a.labels)
