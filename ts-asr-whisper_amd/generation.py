@@ -9,10 +9,14 @@ Mirrors, for the in-training evaluation the reference runs every ``eval_steps``:
                             SuppressTokens / SuppressTokensAtBegin processors the reference wires (generation.py:286-306),
                             finished rows are padded, decoding stops when every row has produced eos.
 
-Every matrix product, attention and LayerNorm is a C-ABI kernel call (the same ones the training step uses; single-row
-queries go through dicow_attn_fwd with Lq = 1).  Not here: beam search, temperature fallback, the timestamp logits
-processor, CTC-prefix rescoring (decoding.py) and the long-form seek loop of HF's generate -- control flow around
-this step function, out of the measured path.  No CPU fallback.
+  * ``timestamp_rules``     WhisperTimeStampLogitsProcessorCustom (src/models/dicow/utils.py:5-14) as one kernel per step;
+  * joint CTC / attention   ``ctc=dict(...)`` switches on ctc_decoding.CtcRescorer (decoding.py) after a log-softmax, as the
+                            reference wires it for greedy search (generation.py:249-268).
+
+Every matrix product, attention and LayerNorm is a C-ABI kernel call (the training step's kernels; single-row queries go
+through dicow_attn_fwd with Lq = 1, the <= 16-row products through the weight-streaming gemm_nt_skinny_kernel).  Not here:
+beam search, temperature fallback and the long-form seek loop of HF's generate -- host control flow around this step
+function.  No CPU fallback.
 """
 from types import SimpleNamespace as NS
 
