@@ -9,7 +9,8 @@ Mirrors reference src/models/dicow/decoding.py:
 The glue (top-k candidate selection, scatter of the candidate scores into the vocabulary row, state selection) is a handful
 of small torch tensor ops on [B, V]; states are kept for the scored candidates only ([B, T, 2, k]) where the reference
 scatters them into a [B, V, T, 2] buffer.  Everything stays on the device with fixed shapes (finished rows are scored
-and then masked instead of being filtered out), so a decoding step adds no host synchronisation.  No CPU fallback.
+and then masked instead of being filtered out); after the first call, which inspects the prompt layout, a decoding step adds
+no host synchronisation.  No CPU fallback.
 """
 import torch
 
@@ -86,14 +87,21 @@ class CtcRescorer:
         self.score_prev = torch.zeros(self.B, 1, dtype=F32, device=dev)
         self.rows = torch.arange(self.B, device=dev)
         self.cand = self.cand_states = self.full = None
+        self._cut = None
 
     def __call__(self, input_ids, scores):
         ids = input_ids.clone()
-        if ids.shape[1] < 1 or bool((ids[:, 0] != self.bos).any()):          # decoding.py:266-269: cut everything before bos
-            cut = [int((row == self.bos).nonzero()[0]) for row in ids]
-            if len(set(ids.shape[1] - c for c in cut)) != 1:
-                raise L.DicowError("CtcRescorer: rows have different lengths after removing the prompt before bos")
-            ids = torch.stack([row[c:] for row, c in zip(ids, cut)])
+        if self._cut is None:                         # decoding.py:266-269: drop whatever precedes bos (checked once: the
+            first = ids[:, 0].tolist()                # prompt layout does not change while a window is being decoded)
+            if all(t == self.bos for t in first):
+                self._cut = 0
+            else:
+                cut = [int((row == self.bos).nonzero()[0]) for row in ids]
+                if len(set(cut)) != 1:
+                    raise L.DicowError("CtcRescorer: rows carry prompts of different lengths before bos")
+                self._cut = cut[0]
+        if self._cut:
+            ids = ids[:, self._cut:].clone()
         if self.prefix_len > 1:
             ids = ids[:, self.prefix_len - 1:].clone()
         ids[:, 0] = self.blank
