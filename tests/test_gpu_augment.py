@@ -122,3 +122,29 @@ def test_augment_throughput_note(paug):
     assert bool(live.all()) and float((s - 1).abs().max()) < 1e-3
     frac0 = float((out["input_features"] == 0).float().mean())
     assert 0.02 < frac0 < 0.6
+
+
+def test_augment_edge_cases(paug):
+    """Degenerate plans: no row selected (no draw consumed), no segment changed, every frame in one changed segment, inputs too
+    short for the warp and the ratio time mask, a single-row batch."""
+    st = torch.softmax(torch.randn(1, 4, 40), 1)
+    torch.manual_seed(1)
+    a = float(torch.rand(1))
+    torch.manual_seed(1)
+    out = paug.add_gaussian_noise_and_rescale(st.cuda(), 0.2, 0.75)            # int(1 * 0.75) == 0 rows
+    assert torch.equal(out.cpu(), st) and float(torch.rand(1)) == a
+    torch.manual_seed(2)
+    assert torch.equal(paug.soft_segment_augmentation(st.cuda(), 0.0, 5, 9).cpu(), st)
+    torch.manual_seed(3)
+    got = paug.soft_segment_augmentation(st.cuda(), 1.0, 40, 40).cpu().numpy()
+    torch.manual_seed(3)
+    want = oaug.soft_segment_augmentation(st.numpy(), 1.0, 40, 40)
+    assert np.array_equal(got, want) and not np.array_equal(got, st.numpy())
+    mel = torch.from_numpy(hashed_mel(1, 128, 10))
+    st5 = torch.softmax(torch.randn(1, 4, 5), 1)
+    torch.manual_seed(4)
+    mo, so = paug.spec_aug_joint(mel.cuda(), st5.cuda())
+    torch.manual_seed(4)
+    omel, ostno = oaug.spec_aug_joint(mel.numpy(), st5.numpy())
+    assert np.array_equal(mo.cpu().numpy(), omel) and np.array_equal(so.cpu().numpy(), ostno)    # masks only: exact
+    assert torch.equal(so.cpu(), st5)

@@ -156,3 +156,23 @@ def test_greedy_decode_with_ctc_rescoring(cd):
         # candidate sets can differ where attention scores tie within bf16 noise: compare where both scored the label
         assert float(np.abs(got[real] - want[real]).max()) < 8e-2, n
         orc.update_state(seq_c[:, prompt.shape[1] + n], np.arange(B))
+
+
+def test_prefix_scorer_edge_sizes(cd):
+    """No active hypothesis, one candidate, two frames, a repeated label at the last possible frame."""
+    g = torch.Generator().manual_seed(8)
+    x = torch.log_softmax(torch.randn(2, 2, 6, generator=g), -1)
+    sc = cd.CtcPrefixScorer(x.cuda(), 5, 4)
+    r0 = sc.initial_state()
+    psi, r = sc(torch.zeros(0, dtype=torch.long).cuda(), torch.zeros(0, 3, dtype=torch.long).cuda(), torch.zeros(0).cuda(),
+                torch.zeros(0).cuda(), r0[:0])
+    assert psi.shape == (0, 3) and r.shape == (0, 2, 2, 3)
+    cs = torch.tensor([[2], [4]])
+    psi, r = sc(torch.arange(2).cuda(), cs.cuda(), torch.tensor([0, 0]).cuda(), torch.tensor([5, 5]).cuda(), r0)
+    opsi, orr = ocp.prefix_score(x.numpy(), np.arange(2), cs.numpy(), np.array([0, 0]), np.array([5, 5]), r0.cpu().numpy(), 5, 4)
+    assert close_with_logzero(psi.cpu(), opsi, 1e-5) and close_with_logzero(r.cpu(), orr, 1e-5)
+    # a 2-label prefix in 2 frames: the last frame is the only place the next label could start
+    r1 = r[:, :, :, 0].contiguous()
+    psi2, r2 = sc(torch.arange(2).cuda(), cs.cuda(), torch.tensor([1, 1]).cuda(), cs[:, 0].cuda(), r1)
+    opsi2, orr2 = ocp.prefix_score(x.numpy(), np.arange(2), cs.numpy(), np.array([1, 1]), cs[:, 0].numpy(), orr[:, :, :, 0], 5, 4)
+    assert close_with_logzero(psi2.cpu(), opsi2, 1e-5) and close_with_logzero(r2.cpu(), orr2, 1e-5)

@@ -376,3 +376,20 @@ def test_logmel_vs_reference_golden(ops):
     padded, am = features.pad_to_30s(w2)
     out = features.log_mel(padded.cuda(), 80)
     assert out.shape == (2, 80, 6000) and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("B,H,Lk", [(2, 3, 1), (16, 20, 448), (3, 2, 1500)])
+def test_attn_fwd_single_query_row(ops, B, H, Lk):
+    """Lq = 1: the decoding step's attention over a KV cache (strided cache views, batch stride > Lk rows)."""
+    g = torch.Generator().manual_seed(Lk)
+    D, Lmax = H * 64, Lk + 7
+    q = (torch.randn(B, 1, H, 64, generator=g) * 0.3).bfloat16()
+    kc = torch.randn(B, Lmax, D, generator=g).bfloat16()
+    vc = torch.randn(B, Lmax, D, generator=g).bfloat16()
+    qd, kd, vd = q.cuda(), kc.cuda(), vc.cuda()
+    o = torch.empty(B, 1, H, 64, dtype=torch.bfloat16, device="cuda")
+    ops.attn_fwd(qd, kd[:, :Lk].view(B, Lk, H, 64), vd[:, :Lk].view(B, Lk, H, 64), o)
+    k, v = kc[:, :Lk].view(B, Lk, H, 64).float(), vc[:, :Lk].view(B, Lk, H, 64).float()
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k)
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v)
+    assert maxdiff(o.float().cpu(), ref) < 2e-2

@@ -175,11 +175,12 @@ extern "C" int dicow_ctc_prefix_init(const void* logits, int in_bf16, int64_t ld
 }
 
 extern "C" int dicow_ctc_prefix_score(const dicow_ctc_prefix_args* a, void* stream) {
-    DICOW_REQUIRE(a && a->logits && a->lse && a->rows && a->cs && a->decoded_len && a->last && a->r_prev && a->psi && a->r,
-                  "ctc_prefix_score: null pointer");
+    DICOW_REQUIRE(a, "ctc_prefix_score: null argument block");
     DICOW_REQUIRE(a->n >= 0 && a->C > 0 && a->T > 0 && a->T <= 8192, "ctc_prefix_score: bad sizes n=%d C=%d T=%d", a->n, a->C, a->T);
+    if (a->n == 0) return DICOW_OK;                       // no active hypothesis: nothing to score (empty tensors have no storage)
+    DICOW_REQUIRE(a->logits && a->lse && a->rows && a->cs && a->decoded_len && a->last && a->r_prev && a->psi && a->r,
+                  "ctc_prefix_score: null pointer");
     DICOW_REQUIRE(a->blank >= 0 && a->blank < a->ld && a->eos >= 0, "ctc_prefix_score: blank %d / eos %d out of range", a->blank, a->eos);
-    if (a->n == 0) return DICOW_OK;
     const size_t lds = (size_t)a->T * 4 * sizeof(float);
     static bool attr = false;
     if (!attr) {
