@@ -286,3 +286,26 @@ def test_dense_fddt_inside_the_encoder_vs_oracle(pkg, se):
     assert any("fddts.1.target_linear.weight" in n for n in grads) and grads["model.encoder.initial_fddt.silence_linear.weight"].shape == (128, 128)
     worst = _check_grads(model, grads, tol_rel=6e-2, min_checked=60)
     print("worst grad rel err (dense FDDT):", worst)
+
+
+def test_label_edge_cases_vs_oracle(pkg):
+    """Ragged / degenerate label batches on the golden F7 model: a fully padded row, labels as long as max_target_positions,
+    no upper-cased alternative -- hard-label fallback loss (mean over all positions, padding contributes 0) vs the oracle."""
+    z = load_golden("f7_e2e_small")
+    model, cfg = build_model(pkg, z)
+    ocfg, p = golden_cfg(z), golden_params(z)
+    x, st = T(z, "x"), T(z, "stno")
+    g = torch.Generator().manual_seed(12)
+    Lmax = cfg.max_target_positions
+    lab_full = torch.randint(0, 400, (2, Lmax), generator=g)
+    lab_pad = torch.randint(0, 400, (2, 9), generator=g)
+    lab_pad[1] = -100                                        # one utterance without any target
+    lab_pad[0, 6:] = -100
+    for lab, upp in ((lab_full, lab_full.clone()), (lab_pad, None), (lab_pad, lab_pad.clone())):
+        out = model(input_features=x.cuda(), stno_mask=st.cuda(), labels=lab.cuda(), upp_labels=None if upp is None else upp.cuda())
+        ref = O.model_forward(p, ocfg, x, st, lab, upp, emu=True)
+        assert float(out.loss) == float(out.loss) and abs(float(out.loss) - float(ref["loss"])) < 6e-3, (lab.shape, upp is None)
+        assert maxdiff(out.logits.float().cpu(), ref["logits"].detach()) < 5e-2
+    with pytest.raises(ValueError):
+        too_long = torch.randint(0, 400, (2, Lmax + 1), generator=g)
+        model(input_features=x.cuda(), stno_mask=st.cuda(), labels=too_long.cuda())
