@@ -11,7 +11,7 @@
 #include <vector>
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-template <int DEPTH>     // DEPTH k-steps in flight before the oldest is waited for (1 = the GEMM's scheme)
+template <int DEPTH, int AUX = 0>     // DEPTH k-steps in flight before the oldest is waited for (1 = the GEMM's scheme); AUX = cache-policy bits
 __global__ void __launch_bounds__(256) k(const char* base, long long ld_bytes, int nsteps, int mode, long long* cyc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -35,7 +35,7 @@ __global__ void __launch_bounds__(256) k(const char* base, long long ld_bytes, i
 #pragma unroll
             for (int d = 0; d < 16; ++d)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(s + (d < 8 ? 0 : 32768) + (wave * 8 + (d & 7)) * 1024), 16,
-                                                         off[d], t * 128, 0, 0);
+                                                         off[d], t * 128, 0, AUX);
         }
         if (t >= DEPTH - 1) {
             if (DEPTH == 1 || t >= nsteps - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -175,6 +175,16 @@ int main() {
                    mode, depth, us, mean / nsteps, 65536.0 / (mean / nsteps), 256 * 65536.0 * nsteps / us / 1e6);
         }
     }
+    // cache-policy bits of the DMA loads (aux: 1 = sc0, 2 = nt, 16 = sc1), GEMM sharing pattern, two k-steps in flight
+#define AUXRUN(AX) { hipFuncSetAttribute((const void*)k<2, AX>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);            \
+        hipEventRecord(e0);                                                                                                      \
+        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((k<2, AX>), dim3(256), dim3(256), 131072, 0, buf, ld, nsteps, 1, cyc); \
+        hipEventRecord(e1); hipEventSynchronize(e1);                                                                             \
+        float ms; hipEventElapsedTime(&ms, e0, e1);                                                                              \
+        std::vector<long long> h(256); hipMemcpy(h.data(), cyc, 256 * 8, hipMemcpyDeviceToHost);                                 \
+        double mean = 0; for (auto v : h) mean += v; mean /= 256;                                                                \
+        printf("aux %2d: %.1f us per launch, %.0f clocks per 64 KiB = %.1f B/clk/CU\n", AX, ms * 100.0, mean / nsteps, 65536.0 / (mean / nsteps)); }
+    AUXRUN(0) AUXRUN(1) AUXRUN(2) AUXRUN(3) AUXRUN(16) AUXRUN(17) AUXRUN(18) AUXRUN(19)
     unsigned* sink; hipMalloc(&sink, 4096);
     for (int mode = 0; mode < 2; ++mode) {
         for (int depth = 1; depth <= 2; ++depth) {
