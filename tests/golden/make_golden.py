@@ -634,9 +634,83 @@ def f14_timestamp_rules():
     save("f14_timestamp_rules", **arrs)
 
 
+# ----------------------------------------------------------------------------- F15: beam-search bookkeeping
+def f15_beam_search():
+    """The beam bookkeeping the reference's `_beam_search` (src/models/dicow/generation.py:815-1153) performs each step through
+    the helpers it inherits from transformers' GenerationMixin (_get_top_k_continuations, _get_running_beams_for_next_iteration,
+    _update_finished_beams, _check_early_stop_heuristic, _beam_search_has_unfinished_sequences), driven here in the reference's
+    order on synthetic per-step log-probabilities.  Every state tensor after every step and the final selection are stored."""
+    from transformers.generation.utils import GenerationMixin as G
+    me = types.SimpleNamespace(_gather_beams=G._gather_beams)
+    arrs = {}
+    cases = [dict(B=2, K=3, V=17, P=2, max_length=9, eos=5, length_penalty=1.0, early_stopping=False, seed=1, eos_boost=2.0),
+             dict(B=3, K=5, V=29, P=3, max_length=12, eos=7, length_penalty=1.0, early_stopping=True, seed=2, eos_boost=3.5),
+             dict(B=1, K=4, V=11, P=1, max_length=7, eos=2, length_penalty=0.6, early_stopping="never", seed=3, eos_boost=1.0)]
+    for ci, c in enumerate(cases):
+        B, K, V, P, max_length, eos = c["B"], c["K"], c["V"], c["P"], c["max_length"], c["eos"]
+        lp_, es = c["length_penalty"], c["early_stopping"]
+        g = torch.Generator().manual_seed(c["seed"])
+        beams_to_keep = 2 * K
+        top_mask = torch.cat((torch.ones(K, dtype=torch.bool), torch.zeros(beams_to_keep - K, dtype=torch.bool)))
+        cur_len = P
+        running_sequences = torch.full((B, K, max_length), eos, dtype=torch.int64)
+        running_sequences[:, :, :P] = torch.randint(8, V, (B, 1, P), generator=g).expand(B, K, P)
+        sequences = running_sequences.clone()
+        running_beam_scores = torch.zeros(B, K)
+        running_beam_scores[:, 1:] = -1e9
+        beam_scores = torch.full((B, K), -1e9)
+        is_sent_finished = torch.zeros(B, K, dtype=torch.bool)
+        unsat = torch.ones(B, 1, dtype=torch.bool)
+        running_beam_indices = torch.full((B, K, max_length - P), -1, dtype=torch.int32)
+        beam_indices = running_beam_indices.clone()
+        arrs[f"c{ci}.cfg"] = np.array([B, K, V, P, max_length, eos])
+        arrs[f"c{ci}.length_penalty"] = np.array(lp_)
+        arrs[f"c{ci}.early_stopping"] = np.array({False: 0, True: 1, "never": 2}[es])
+        arrs[f"c{ci}.prompt"] = running_sequences[:, 0, :P].clone()
+        step = 0
+        finished = False
+        while not finished:
+            logits = torch.randn(B * K, V, generator=g) * 2.0
+            logits[:, eos] += c["eos_boost"] * (step - 1)               # eos becomes attractive as decoding goes on
+            log_probs = torch.log_softmax(logits, dim=-1)
+            arrs[f"c{ci}.s{step}.log_probs"] = log_probs.clone()
+            lp = log_probs.view(B, K, V) + running_beam_scores[:, :, None]
+            lp = lp.reshape(B, K * V)
+            tk_lp, tk_seq, tk_idx = G._get_top_k_continuations(me, accumulated_log_probs=lp, running_sequences=running_sequences,
+                                                               running_beam_indices=running_beam_indices, cur_len=cur_len,
+                                                               decoder_prompt_len=P, do_sample=False, beams_to_keep=beams_to_keep,
+                                                               num_beams=K, vocab_size=V, batch_size=B)
+            hits = (tk_seq[:, :, cur_len] == eos) | (cur_len + 1 >= max_length)       # EosTokenCriteria | MaxLengthCriteria
+            running_sequences, running_beam_scores, running_beam_indices = G._get_running_beams_for_next_iteration(
+                me, topk_log_probs=tk_lp, topk_running_sequences=tk_seq, topk_running_beam_indices=tk_idx,
+                next_token_hits_stopping_criteria=hits, num_beams=K)
+            sequences, beam_scores, beam_indices, is_sent_finished = G._update_finished_beams(
+                me, sequences=sequences, topk_running_sequences=tk_seq, beam_scores=beam_scores, topk_log_probs=tk_lp,
+                beam_indices=beam_indices, topk_running_beam_indices=tk_idx, is_early_stop_heuristic_unsatisfied=unsat,
+                is_sent_finished=is_sent_finished, next_token_hits_stopping_criteria=hits, top_num_beam_mask=top_mask,
+                num_beams=K, cur_len=cur_len, decoder_prompt_len=P, length_penalty=lp_, early_stopping=es)
+            beam_idx = running_beam_indices[..., cur_len - P].flatten()
+            cur_len += 1
+            unsat = G._check_early_stop_heuristic(is_early_stop_heuristic_unsatisfied=unsat, running_beam_scores=running_beam_scores,
+                                                  beam_scores=beam_scores, is_sent_finished=is_sent_finished, cur_len=cur_len,
+                                                  max_length=max_length, decoder_prompt_len=P, early_stopping=es, length_penalty=lp_)
+            finished = not bool(G._beam_search_has_unfinished_sequences(unsat, is_sent_finished, hits, es))
+            for nm, t in (("running_sequences", running_sequences), ("running_beam_scores", running_beam_scores),
+                          ("sequences", sequences), ("beam_scores", beam_scores), ("is_sent_finished", is_sent_finished),
+                          ("unsat", unsat), ("beam_idx", beam_idx)):
+                arrs[f"c{ci}.s{step}.{nm}"] = t.clone()
+            step += 1
+        arrs[f"c{ci}.steps"] = np.array(step)
+        max_gen = int(((beam_indices[:, :1] + 1).bool()).sum(dim=2).max())
+        arrs[f"c{ci}.final"] = sequences[:, 0, :P + max_gen].clone()
+        arrs[f"c{ci}.final_scores"] = beam_scores[:, 0].clone()
+    arrs["n_cases"] = np.array(len(cases))
+    save("f15_beam_search", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12", "f13", "f14"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12", "f13", "f14", "f15"]
     fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
-           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules}
+           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules, "f15": f15_beam_search}
     for w in which:
         fns[w]()

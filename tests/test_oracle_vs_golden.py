@@ -299,3 +299,29 @@ def test_f14_timestamp_rules_bit_exact():
         mi = int(z[f"c{i}.max_init"])
         got = timestamp_rules(z[f"c{i}.ids"], z[f"c{i}.scores"], begin, eos, no_ts, None if mi < 0 else mi)
         assert np.array_equal(got, z[f"c{i}.out"]), i
+
+
+# ------------------------------------------------------------------------------------------------ F15: beam search bookkeeping
+def test_f15_beam_search_bookkeeping():
+    """Every step's running / finished beams, scores, flags and cache indices follow transformers' helpers in the reference's
+    order (slots still holding the -1e9 placeholder are unordered in torch.topk and are not compared)."""
+    from oracle.beam_search import BeamState
+    z = load_golden("f15_beam_search")
+    for ci in range(int(z["n_cases"])):
+        B, K, V, P, ml, eos = (int(v) for v in z[f"c{ci}.cfg"])
+        es = {0: False, 1: True, 2: "never"}[int(z[f"c{ci}.early_stopping"])]
+        st = BeamState(z[f"c{ci}.prompt"], K, V, ml, eos, float(z[f"c{ci}.length_penalty"]), es)
+        for s in range(int(z[f"c{ci}.steps"])):
+            assert not st.done
+            bi = st.step(z[f"c{ci}.s{s}.log_probs"])
+            live = z[f"c{ci}.s{s}.running_beam_scores"] > -1e8
+            assert np.array_equal(st.running_sequences[live], z[f"c{ci}.s{s}.running_sequences"][live])
+            assert np.array_equal(bi.reshape(B, K)[live], z[f"c{ci}.s{s}.beam_idx"].reshape(B, K)[live])
+            fin = z[f"c{ci}.s{s}.beam_scores"] > -1e8
+            assert np.array_equal(fin, st.beam_scores > -1e8) and np.array_equal(st.sequences[fin], z[f"c{ci}.s{s}.sequences"][fin])
+            assert np.array_equal(st.is_sent_finished, z[f"c{ci}.s{s}.is_sent_finished"]) and np.array_equal(st.unsat, z[f"c{ci}.s{s}.unsat"])
+            assert np.allclose(st.running_beam_scores, z[f"c{ci}.s{s}.running_beam_scores"], rtol=1e-6, atol=1e-6)
+            assert np.allclose(st.beam_scores, z[f"c{ci}.s{s}.beam_scores"], rtol=1e-6, atol=1e-6)
+        assert st.done
+        seq, sc = st.result()
+        assert np.array_equal(seq, z[f"c{ci}.final"]) and np.allclose(sc, z[f"c{ci}.final_scores"], atol=1e-6)

@@ -37,3 +37,14 @@ t2 = time.perf_counter()
 tot_ms = (t2 - t1) * 1e3
 print(f"B={B}: encoder + cross K/V {enc_ms:.1f} ms; generate({N} tokens) {tot_ms:.1f} ms -> {(tot_ms - enc_ms) / (N + 3):.3f} ms per decoder step, "
       f"{B * N / tot_ms * 1e3:.0f} tokens/s, {B / tot_ms * 1e3:.1f} windows/s")
+
+if len(sys.argv) > 4:                                           # beam search, K = argv[4]
+    K = int(sys.argv[4])
+    d2 = GreedyDecoder(model)
+    d2.beam_search(b["input_features"], b["stno_mask"], prompt, 4 + 8, K, eos_token_id=-1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    seq, sc = d2.beam_search(b["input_features"], b["stno_mask"], prompt, 4 + N, K, eos_token_id=-1)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) * 1e3
+    print(f"beam search K={K}: B={B}, {seq.shape[1] - 4} tokens in {dt:.1f} ms ({B / dt * 1e3:.1f} windows/s)")

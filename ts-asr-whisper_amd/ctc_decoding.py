@@ -73,19 +73,21 @@ class CtcRescorer:
     (tokenizer.upper_cased_tokens.items()); ``prefix_len`` = len(tokenizer.prefix_tokens); ``first_timestamp`` =
     tokenizer.get_vocab()["<|0.00|>"]; rows of a beam search are hypotheses (repeat the logits num_beams times)."""
 
-    def __init__(self, enc_logits, blank, eos, bos, first_timestamp, upper_cased, prefix_len, ctc_weight, n_score=500):
+    def __init__(self, enc_logits, blank, eos, bos, first_timestamp, upper_cased, prefix_len, ctc_weight, n_score=500, num_beams=1):
         dev = enc_logits.device
         V1 = enc_logits.shape[-1]
         alias = torch.arange(V1, dtype=I32)
         for lo, up in upper_cased:
             alias[int(up)] = int(lo)
         self.scorer = CtcPrefixScorer(enc_logits, blank, eos, alias.to(dev))
-        self.B, self.T, self.V = enc_logits.shape[0], enc_logits.shape[1], V1 - 1
+        # hypotheses = batch rows x beams (beam-major within a row, like HF's flattened beam dimension); the reference repeats
+        # the logits num_beams times (generation.py:257), here every hypothesis just points at its batch row
+        self.B, self.T, self.V = enc_logits.shape[0] * int(num_beams), enc_logits.shape[1], V1 - 1
         self.blank, self.eos, self.bos, self.ts0 = int(blank), int(eos), int(bos), int(first_timestamp)
         self.prefix_len, self.w, self.k = int(prefix_len), float(ctc_weight), int(n_score)
-        self.state_prev = self.scorer.initial_state()
+        self.rows = torch.arange(self.B, device=dev) // int(num_beams)
+        self.state_prev = self.scorer.initial_state()[self.rows]
         self.score_prev = torch.zeros(self.B, 1, dtype=F32, device=dev)
-        self.rows = torch.arange(self.B, device=dev)
         self.cand = self.cand_states = self.full = None
         self._cut = None
 

@@ -114,15 +114,18 @@ class GreedyDecoder:
         return logits[:, :cfg.vocab_size]
 
     @torch.no_grad()
-    def encode(self, input_features, stno_mask, enrollments=None):
-        """Encoder once + the cross-attention K/V of every decoder layer once.  Returns the decoding state."""
+    def encode(self, input_features, stno_mask, enrollments=None, num_beams=1):
+        """Encoder once + the cross-attention K/V of every decoder layer once.  Returns the decoding state.
+        num_beams > 1: the decoding state has batch x num_beams rows (the encoder and the K/V projections still run once per
+        window; their result is repeated per beam)."""
         model, cfg = self.model, self.cfg
         if not input_features.is_cuda:
             raise L.DicowError("GreedyDecoder: tensors must be on the GPU (no CPU fallback)")
         enc_out = model.model.encoder(input_features, stno_mask=stno_mask, enrollments=enrollments).last_hidden_state
-        B, T, D = enc_out.shape
+        B0, T, D = enc_out.shape
+        B = B0 * num_beams
         W = model._engine().W
-        enc_bf = ops.cast_bf16(enc_out.contiguous().to(F32)).view(B * T, D)
+        enc_bf = ops.cast_bf16(enc_out.contiguous().to(F32)).view(B0 * T, D)
         Lmax = cfg.max_target_positions
         dev = enc_out.device
         st = self._persist.get(B) if self.use_graphs else None
@@ -137,8 +140,109 @@ class GreedyDecoder:
                 self._persist[B] = st
         st.enc_out = enc_out
         for w, c in zip(W.layers, st.layers):
-            linear_fwd(enc_bf, w.ca.kv, B * T, out=c.ckv)
+            if num_beams == 1:
+                linear_fwd(enc_bf, w.ca.kv, B * T, out=c.ckv)
+            else:
+                kv = linear_fwd(enc_bf, w.ca.kv, B0 * T)
+                c.ckv.view(B0, num_beams, T, -1).copy_(kv.view(B0, 1, T, -1).expand(B0, num_beams, T, kv.shape[1]))
         return st
+
+    @torch.no_grad()
+    def beam_search(self, input_features, stno_mask, decoder_input_ids, max_length, num_beams, eos_token_id=None, pad_token_id=None,
+                    length_penalty=1.0, early_stopping=False, suppress_tokens=None, begin_suppress_tokens=None, enrollments=None,
+                    timestamps=None, ctc=None):
+        """Beam search as the reference runs it (DiCoWGenerationMixin._beam_search, generation.py:815-1153, on transformers'
+        vectorised beam helpers): per step the top 2K continuations over beams x vocabulary, the K best unfinished keep running,
+        finished ones compete for the K result slots with length-penalised scores; processors act on log-probabilities
+        (suppress lists, timestamp rules, joint CTC term without a second log-softmax, generation.py:249-268); KV caches and
+        the CTC states follow ``beam_idx``.  Returns (sequences [B, <= max_length], scores [B]) of the best hypothesis."""
+        cfg, K = self.cfg, int(num_beams)
+        eos = cfg.eos_token_id if eos_token_id is None else eos_token_id
+        pad = cfg.pad_token_id if pad_token_id is None else pad_token_id
+        if self.use_graphs:
+            raise L.DicowError("beam_search reorders the KV caches every step: use a decoder without graph capture")
+        st = self.encode(input_features, stno_mask, enrollments, num_beams=K)
+        dev = st.enc_out.device
+        prompt = decoder_input_ids.to(dev)
+        B, P = prompt.shape
+        V = cfg.vocab_size
+        max_length = min(int(max_length), cfg.max_target_positions)
+        if P < 1 or P >= max_length:
+            raise ValueError(f"prompt length {P} leaves no room below max_length {max_length}")
+        sup = None if not suppress_tokens else torch.as_tensor(list(suppress_tokens), device=dev)
+        bsup = None if not begin_suppress_tokens else torch.as_tensor(list(begin_suppress_tokens), device=dev)
+        rescorer = None
+        if ctc is not None and ctc.get("weight", 0.0) > 0.0:
+            from .ctc_decoding import CtcRescorer
+            rescorer = CtcRescorer(self.model.get_enc_logits(st.enc_out), V, eos, prompt[0, 0].item(), ctc["first_timestamp"],
+                                   ctc.get("upper_cased", ()), ctc.get("prefix_len", P), ctc["weight"], ctc.get("n_score", 500), num_beams=K)
+        fill = pad if pad is not None else eos
+        run_seq = torch.full((B, K, max_length), fill, dtype=torch.long, device=dev)
+        run_seq[:, :, :P] = prompt[:, None, :]
+        seqs = run_seq.clone()
+        run_sc = torch.zeros(B, K, dtype=F32, device=dev)
+        run_sc[:, 1:] = -1e9
+        fin_sc = torch.full((B, K), -1e9, dtype=F32, device=dev)
+        is_fin = torch.zeros(B, K, dtype=torch.bool, device=dev)
+        unsat = torch.ones(B, 1, dtype=torch.bool, device=dev)
+        run_idx = torch.full((B, K, max_length - P), -1, dtype=torch.int32, device=dev)
+        fin_idx = run_idx.clone()
+        top_mask = (torch.arange(2 * K, device=dev) < K)[None, :]
+        offs = (torch.arange(B, device=dev) * K)[:, None]
+
+        def gather(t, idx):
+            while idx.dim() < t.dim():
+                idx = idx.unsqueeze(-1)
+            return torch.take_along_dim(t, idx, dim=1)
+
+        for t in range(P - 1):                                       # prefill: every beam of a row starts from the same prompt
+            self._step(run_seq[:, :, t].reshape(-1), t, st)
+        cur = P
+        while True:
+            flat = run_seq[:, :, :cur].reshape(B * K, cur)
+            logp = torch.log_softmax(self._step(flat[:, -1].contiguous(), cur - 1, st).float(), dim=-1)
+            if sup is not None:
+                logp[:, sup] = -float("inf")
+            if bsup is not None and cur == P:
+                logp[:, bsup] = -float("inf")
+            if timestamps is not None:
+                logp = timestamp_rules(flat, logp, P, eos, timestamps["no_timestamps_token_id"], timestamps.get("max_initial_timestamp_index"))
+            if rescorer is not None:
+                logp = rescorer(flat, logp)
+            acc = (logp.view(B, K, V) + run_sc[:, :, None]).reshape(B, K * V)
+            tk_lp, tk = torch.topk(acc, k=2 * K)
+            src = tk // V
+            tk_seq, tk_idx = gather(run_seq, src).clone(), gather(run_idx, src).clone()
+            tk_seq[:, :, cur] = tk % V
+            tk_idx[:, :, cur - P] = (src + offs).to(torch.int32)
+            hits = (tk_seq[:, :, cur] == eos) | (cur + 1 >= max_length)
+            run_lp = tk_lp + hits.float() * -1e9
+            nxt = torch.topk(run_lp, k=K)[1]
+            run_seq, run_sc, run_idx = gather(tk_seq, nxt), gather(run_lp, nxt), gather(tk_idx, nxt)
+            just = hits & top_mask
+            fin = tk_lp / float((cur + 1 - P) ** length_penalty)
+            fin = fin + (is_fin.all(dim=-1, keepdim=True) & (early_stopping is True)).float() * -1e9
+            fin = fin + (~unsat).float() * -1e9 + (~just).float() * -1e9
+            m_sc = torch.cat((fin_sc, fin), dim=1)
+            top = torch.topk(m_sc, k=K)[1]
+            seqs, fin_sc = gather(torch.cat((seqs, tk_seq), dim=1), top), gather(m_sc, top)
+            fin_idx, is_fin = gather(torch.cat((fin_idx, tk_idx), dim=1), top), gather(torch.cat((is_fin, just), dim=1), top)
+            beam_idx = run_idx[..., cur - P].reshape(-1).long()
+            for c in st.layers:                                      # the caches follow their beams
+                c.k[:, :cur].copy_(c.k[:, :cur].index_select(0, beam_idx))
+                c.v[:, :cur].copy_(c.v[:, :cur].index_select(0, beam_idx))
+            if rescorer is not None:
+                rescorer.update_state(run_seq.reshape(B * K, -1)[:, cur], beam_idx)
+            cur += 1
+            hyp_len = (max_length - P) if (early_stopping == "never" and length_penalty > 0.0) else (cur - P)
+            best = run_sc[:, :1] / float(hyp_len ** length_penalty)
+            worst = torch.where(is_fin, fin_sc.min(dim=1, keepdim=True)[0], torch.full_like(fin_sc, -1e9))
+            unsat = unsat & (best > worst).any(dim=-1, keepdim=True)
+            go_on = bool(unsat.any()) and not (bool(is_fin.all()) and early_stopping is True) and not bool(hits.all())
+            if not go_on:
+                break
+        gen = int(((fin_idx[:, :1] + 1) != 0).sum(dim=2).max())
+        return seqs[:, 0, :P + gen], fin_sc[:, 0]
 
     @torch.no_grad()
     def generate(self, input_features, stno_mask, decoder_input_ids, max_new_tokens, eos_token_id=None, pad_token_id=None,

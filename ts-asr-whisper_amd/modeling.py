@@ -650,15 +650,15 @@ class DiCoWForConditionalGeneration(nn.Module):
 
     def generate(self, input_features=None, stno_mask=None, attention_mask=None, decoder_input_ids=None, max_new_tokens=None,
                  max_length=None, generation_config=None, enrollments=None, num_beams=1, return_timestamps=None, **kwargs):
-        """Short-form (one 30 s window) greedy decoding with the reference's logits-processor chain (generation.GreedyDecoder).
+        """Short-form (one 30 s window) greedy or beam-search decoding with the reference's logits-processor chain
+        (generation.GreedyDecoder.generate / .beam_search).
         ``generation_config``: any object with the HF / reference attribute names (eos_token_id, pad_token_id, suppress_tokens,
         begin_suppress_tokens, return_timestamps, no_timestamps_token_id, max_initial_timestamp_index, ctc_weight, ...).
         The prompt is ``decoder_input_ids`` or [decoder_start_token_id] + the tokenizer's prefix tokens."""
         from .generation import GreedyDecoder
         gc = generation_config if generation_config is not None else self.generation_config
         get = (lambda k, d=None: getattr(gc, k, d) if gc is not None else d)
-        if (num_beams or 1) > 1 or (get("num_beams", 1) or 1) > 1:
-            raise NotImplementedError("beam search is outside this build's decoding path (greedy only)")
+        beams = max(num_beams or 1, get("num_beams", 1) or 1)
         if input_features.shape[-1] != 2 * self.config.max_source_positions:
             raise NotImplementedError("long-form inputs: cut 30 s windows with generation.stno_seek_windows and decode each")
         cfg = self.config
@@ -684,6 +684,13 @@ class DiCoWForConditionalGeneration(nn.Module):
                        upper_cased=list(getattr(tok, "upper_cased_tokens", {}).items()), prefix_len=len(tok.prefix_tokens))
         if not hasattr(self, "_decoder"):
             self._decoder = GreedyDecoder(self)
+        if beams > 1:                                        # reference: generation_num_beams 5 in configs/decode/*_beam_joint.yaml
+            seq, _ = self._decoder.beam_search(input_features, stno_mask, decoder_input_ids, P + max_new_tokens, beams,
+                                               eos_token_id=get("eos_token_id", cfg.eos_token_id), pad_token_id=get("pad_token_id", cfg.pad_token_id),
+                                               length_penalty=get("length_penalty", 1.0), early_stopping=get("early_stopping", False),
+                                               suppress_tokens=get("suppress_tokens"), begin_suppress_tokens=get("begin_suppress_tokens"),
+                                               enrollments=enrollments, timestamps=timestamps, ctc=ctc)
+            return seq
         return self._decoder.generate(input_features, stno_mask, decoder_input_ids, max_new_tokens,
                                       eos_token_id=get("eos_token_id", cfg.eos_token_id), pad_token_id=get("pad_token_id", cfg.pad_token_id),
                                       suppress_tokens=get("suppress_tokens"), begin_suppress_tokens=get("begin_suppress_tokens"),
