@@ -337,7 +337,9 @@ int dicow_whisper_timestamp_rules(float* scores, int64_t ld, int B, int V, const
 
 /* ------------------------------------------------------------------------------------------------ optimizer
  * Fused AdamW + global-norm clipping on flat fp32 regions (src/models/containers.py:100-114 two param groups;
- * HF Trainer max_grad_norm 1.0).  dicow_sumsq_f32 accumulates sum(x^2) into out[0]; dicow_adamw_f32 applies
+ * HF Trainer max_grad_norm 1.0).  dicow_sumsq_f32 accumulates sum(x^2) into out[0], DETERMINISTICALLY for a given input
+ * (fixed summation order: data-parallel replicas must derive the same clip coefficient); one call in flight per device;
+ * dicow_adamw_f32 applies
  *   g' = g * min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6));  decoupled weight decay; bias-corrected moments.   */
 int dicow_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
 int dicow_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -1,0 +1,84 @@
+"""Data-parallel TrainStep on the GPU kernels with two ranks sharing one device over gloo (the RCCL transport itself needs two
+GPUs; the bucketed side-stream reduction, the preheat-only exchange and the optimizer run exactly as under "nccl"): two ranks
+with different micro-batches must end at the parameters of one process accumulating both micro-batches."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build():
+    import amd_pkg
+    pkg = amd_pkg.load()
+    from ts_asr_whisper_amd.trainer import TrainStep
+    from ts_asr_whisper_amd.data import synthetic_batch
+    cfg = pkg.DiCoWConfig.preset("whisper-tiny", use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True,
+                                 fddt_init="suppressive", non_target_fddt_value=0.5)
+    torch.manual_seed(0)
+    model = pkg.DiCoWForConditionalGeneration(cfg).cuda()
+    model.tie_weights()
+    ts = TrainStep(model, lr=1e-4, fddt_lr_multiplier=10.0, use_fddt_only_n_steps=1)
+    batches = [synthetic_batch(cfg, 2, 12, seed=40 + i) for i in range(2)]
+    return model, ts, batches
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model, ts, batches = _build()
+        assert ts.reducer.world == 2 and ts.reducer.stream is not None
+        losses = [float(ts.step(batches[rank])) for _ in range(3)]       # step 1: preheat-only exchange, then bucketed
+        q.put((rank, losses, {n: p.detach().cpu().numpy() for n, p in model.named_parameters() if p.requires_grad}))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_process_accumulating():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    model, ts, batches = _build()
+    for _ in range(3):
+        ts.step(batches)                                                 # gradient accumulation over the two micro-batches
+    single = {n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}
+    for n in single:
+        assert (res[0][2][n] == res[1][2][n]).all(), n                   # ranks stay in lock-step
+    num = sum(float((torch.from_numpy(res[0][2][n]) - single[n]).double().pow(2).sum()) for n in single) ** 0.5
+    den = sum(float((single[n] - start).double().pow(2).sum()) for n, start in _start_params().items()) ** 0.5
+    assert num < 0.05 * den, (num, den)                                   # same update up to bf16 / summation-order noise
+
+
+def _start_params():
+    import amd_pkg
+    pkg = amd_pkg.load()
+    cfg = pkg.DiCoWConfig.preset("whisper-tiny", use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True,
+                                 fddt_init="suppressive", non_target_fddt_value=0.5)
+    torch.manual_seed(0)
+    m = pkg.DiCoWForConditionalGeneration(cfg)
+    from ts_asr_whisper_amd.trainer import freeze_by_keyword
+    freeze_by_keyword(m, ("decoder",))
+    return {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}

@@ -401,8 +401,18 @@ extern "C" int dicow_conv2_col2im_gelu_bwd(const void* dA2, const void* pre1, vo
 }
 
 // ------------------------------------------------------------------------------------------------ optimizer
-__global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
+// Deterministic: the clip coefficient derived from this sum multiplies every gradient, and data-parallel replicas must apply
+// bit-identical updates (nothing ever re-synchronises their parameters).  fp32 atomics would add the workgroup partials in
+// arrival order; instead every workgroup stores its partial in a fixed slot and the last one to arrive (ticket counter) adds
+// the slots in index order.  The slots are module-level device storage (one sumsq in flight per device: calls are
+// stream-ordered on the training stream).
+#define SUMSQ_MAX_BLOCKS 2048
+__device__ float g_sumsq_part[SUMSQ_MAX_BLOCKS];
+__device__ unsigned g_sumsq_ticket = 0;
+
+__global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ out) {
     __shared__ float red[4];
+    __shared__ bool last;
     float s = 0.f;
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
@@ -414,12 +424,28 @@ __global__ void sumsq_kernel(const float* __restrict__ x, int64_t n, float* __re
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        g_sumsq_part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        last = atomicAdd(&g_sumsq_ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float t = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += __builtin_nontemporal_load(&g_sumsq_part[i]);
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] += (red[0] + red[1]) + (red[2] + red[3]);
+        g_sumsq_ticket = 0;
+    }
 }
 
 extern "C" int dicow_sumsq_f32(const float* x, int64_t n, float* out, void* stream) {
     DICOW_REQUIRE(x && out && n > 0, "sumsq_f32: bad args");
-    int grid = (int)((n / 4 + 255) / 256); if (grid < 1) grid = 1; if (grid > 2048) grid = 2048;
+    int grid = (int)((n / 4 + 255) / 256); if (grid < 1) grid = 1; if (grid > SUMSQ_MAX_BLOCKS) grid = SUMSQ_MAX_BLOCKS;
     hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, out);
     DICOW_CHECK_LAUNCH("sumsq_f32");
     return DICOW_OK;
