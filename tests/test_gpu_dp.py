@@ -20,63 +20,74 @@ def _free_port():
     return p
 
 
-def _build():
+def _cfg(pkg, variant):
+    kw = dict(use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True, fddt_init="suppressive", non_target_fddt_value=0.5)
+    if variant == "ctc_se":
+        kw.update(ctc_weight=0.3, pre_ctc_sub_sample=True, additional_self_attention_layer=True, use_enrollments=True, scb_layers=2)
+    return pkg.DiCoWConfig.preset("whisper-tiny", **kw)
+
+
+def _build(variant="preheat"):
     import amd_pkg
     pkg = amd_pkg.load()
     from ts_asr_whisper_amd.trainer import TrainStep
     from ts_asr_whisper_amd.data import synthetic_batch
-    cfg = pkg.DiCoWConfig.preset("whisper-tiny", use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True,
-                                 fddt_init="suppressive", non_target_fddt_value=0.5)
+    cfg = _cfg(pkg, variant)
     torch.manual_seed(0)
     model = pkg.DiCoWForConditionalGeneration(cfg).cuda()
     model.tie_weights()
-    ts = TrainStep(model, lr=1e-4, fddt_lr_multiplier=10.0, use_fddt_only_n_steps=1)
-    batches = [synthetic_batch(cfg, 2, 12, seed=40 + i) for i in range(2)]
+    se = variant == "ctc_se"
+    prefixes = ("model.encoder.fddts", "model.encoder.initial_fddt") + (("model.encoder.ca_enrolls", "model.encoder.lm_head") if se else ())
+    ts = TrainStep(model, lr=1e-4, fddt_lr_multiplier=10.0, use_fddt_only_n_steps=0 if se else 1, preheat_prefixes=prefixes)
+    batches = [synthetic_batch(cfg, 2, 12, seed=40 + i, enrollments=se) for i in range(4 if se else 2)]
     return model, ts, batches
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, variant):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        model, ts, batches = _build()
+        model, ts, batches = _build(variant)
         assert ts.reducer.world == 2 and ts.reducer.stream is not None
-        losses = [float(ts.step(batches[rank])) for _ in range(3)]       # step 1: preheat-only exchange, then bucketed
+        if variant == "ctc_se":                                          # two micro-batches per rank: exchange after the second only
+            losses = [float(ts.step([batches[2 * rank], batches[2 * rank + 1]])) for _ in range(2)]
+        else:
+            losses = [float(ts.step(batches[rank])) for _ in range(3)]   # step 1: preheat-only exchange, then bucketed
         q.put((rank, losses, {n: p.detach().cpu().numpy() for n, p in model.named_parameters() if p.requires_grad}))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_ranks_equal_one_process_accumulating():
+@pytest.mark.parametrize("variant", ["preheat", "ctc_se"])
+def test_two_ranks_equal_one_process_accumulating(variant):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, variant)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    model, ts, batches = _build()
-    for _ in range(3):
-        ts.step(batches)                                                 # gradient accumulation over the two micro-batches
+    model, ts, batches = _build(variant)
+    for _ in range(2 if variant == "ctc_se" else 3):
+        ts.step(batches)                                                 # gradient accumulation over all the micro-batches
     single = {n: p.detach().cpu() for n, p in model.named_parameters() if p.requires_grad}
     for n in single:
         assert (res[0][2][n] == res[1][2][n]).all(), n                   # ranks stay in lock-step
     num = sum(float((torch.from_numpy(res[0][2][n]) - single[n]).double().pow(2).sum()) for n in single) ** 0.5
-    den = sum(float((single[n] - start).double().pow(2).sum()) for n, start in _start_params().items()) ** 0.5
+    den = sum(float((single[n] - start).double().pow(2).sum()) for n, start in _start_params(variant).items()) ** 0.5
     assert num < 0.05 * den, (num, den)                                   # same update up to bf16 / summation-order noise
 
 
-def _start_params():
+def _start_params(variant):
     import amd_pkg
     pkg = amd_pkg.load()
-    cfg = pkg.DiCoWConfig.preset("whisper-tiny", use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True,
-                                 fddt_init="suppressive", non_target_fddt_value=0.5)
+    cfg = _cfg(pkg, variant)
     torch.manual_seed(0)
     m = pkg.DiCoWForConditionalGeneration(cfg)
     from ts_asr_whisper_amd.trainer import freeze_by_keyword
