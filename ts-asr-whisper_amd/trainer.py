@@ -237,6 +237,8 @@ class TrainStep:
         # every weight-gradient GEMM of a parameter that does not require grad, dgrad still flows down to layer 0's FDDT.
         self.use_fddt_only_n_steps = use_fddt_only_n_steps
         self.warmup_phase = use_fddt_only_n_steps > 0
+        names = {id(p): n for n, p in model.named_parameters()}
+        self._preheat_is_vectors_only = all(p.dim() == 1 and "fddt" in names[id(p)] for p, _, _, pre in self.store.entries if pre)
         if self.warmup_phase:
             self._set_phase(preheat_only=True)
 
@@ -262,10 +264,12 @@ class TrainStep:
         """Gradients are in the flat store: exchange (DP), clip, AdamW, invalidate the bf16 compute copies."""
         self.reducer.finish()
         self.opt.step(preheat_only=self.warmup_phase)
-        # the fused optimizer writes through raw pointers (no torch version bump): invalidate the bf16 weight copies
+        # the fused optimizer writes through raw pointers (no torch version bump): invalidate the bf16 weight copies --
+        # except in the preheat phase when only diagonal / bias FDDT vectors moved (the row kernels read those in fp32)
         enc = self.model.model.encoder
-        enc._sig = None
-        enc._ctc_sig = None
+        if not (self.warmup_phase and self._preheat_is_vectors_only):
+            enc._sig = None
+            enc._ctc_sig = None
         if any(p.requires_grad for p in self.model.model.decoder.parameters()):
             self.model._sig = None
 
