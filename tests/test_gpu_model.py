@@ -241,17 +241,29 @@ def test_ctc_pretraining_api_return_logits_and_get_loss(pkg):
     assert abs(float(loss2) - float(loss)) < 1e-3
 
 
-@pytest.mark.parametrize("se", [False, True])
-def test_dense_fddt_inside_the_encoder_vs_oracle(pkg, se):
-    """fddt_is_diagonal=False (FDDT.py:13-16: a D x D Linear per class) through the fused encoder path, plain and SE-DiCoW
-    (dense FDDT before the speaker-communication blocks), vs the oracle with the same bf16 rounding points: loss + gradients."""
+_VARIANTS = {
+    "dense": dict(fddt_is_diagonal=False),
+    "dense_se": dict(fddt_is_diagonal=False, use_enrollments=True, scb_layers=2),
+    "bias_only": dict(fddt_bias_only=True),
+    "first_layer_only_no_prepos": dict(apply_fddt_to_n_layers=1, use_pre_pos_fddt=False),
+    "no_silence_no_overlap": dict(fddt_use_silence=False, fddt_use_overlap=False),
+    "se_diag_three_scb": dict(use_enrollments=True, scb_layers=3),
+    "no_fddt": dict(use_fddt=False),
+}
+
+
+@pytest.mark.parametrize("variant", list(_VARIANTS))
+def test_config_variants_end_to_end_vs_oracle(pkg, variant):
+    """The hot-path switches of DiCoWConfig end to end vs the oracle with the same bf16 rounding points,
+    loss + every trainable gradient: dense D x D FDDT (plain and before the speaker-communication blocks), bias-only FDDT,
+    FDDT on the first layer only without the pre-positional one, disabled classes, three SCB layers, no FDDT at all."""
     from oracle.dicow_oracle import OracleConfig
     kw = dict(vocab_size=512, d_model=128, encoder_layers=3, encoder_attention_heads=2, decoder_layers=2, decoder_attention_heads=2,
               encoder_ffn_dim=256, decoder_ffn_dim=256, max_source_positions=100, max_target_positions=32, pad_token_id=500,
-              bos_token_id=500, eos_token_id=500, decoder_start_token_id=501, num_mel_bins=80, use_fddt=True, fddt_is_diagonal=False,
+              bos_token_id=500, eos_token_id=500, decoder_start_token_id=501, num_mel_bins=80, use_fddt=True, fddt_is_diagonal=True,
               use_pre_pos_fddt=True, fddt_init="suppressive", non_target_fddt_value=0.5)
-    if se:
-        kw.update(use_enrollments=True, scb_layers=2)
+    kw.update(_VARIANTS[variant])
+    se = bool(kw.get("use_enrollments"))
     cfg = pkg.DiCoWConfig(**kw)
     torch.manual_seed(3)
     model = pkg.DiCoWForConditionalGeneration(cfg)
@@ -283,9 +295,14 @@ def test_dense_fddt_inside_the_encoder_vs_oracle(pkg, se):
     assert abs(float(out.loss) - float(ref["loss"])) < 1e-2
     trainable = {n for n, q in model.named_parameters() if q.requires_grad}
     grads = {n: t.grad for n, t in p.items() if t.grad is not None and n in trainable}
-    assert any("fddts.1.target_linear.weight" in n for n in grads) and grads["model.encoder.initial_fddt.silence_linear.weight"].shape == (128, 128)
-    worst = _check_grads(model, grads, tol_rel=6e-2, min_checked=60)
-    print("worst grad rel err (dense FDDT):", worst)
+    if variant.startswith("dense"):
+        assert any("fddts.1.target_linear.weight" in n for n in grads) and grads["model.encoder.initial_fddt.silence_linear.weight"].shape == (128, 128)
+    if variant == "first_layer_only_no_prepos":
+        assert not any("initial_fddt" in n or "fddts.1." in n for n in grads) and any("fddts.0." in n for n in grads)
+    if variant == "no_silence_no_overlap":
+        assert not any("silence_linear" in n or "overlap_linear" in n for n in grads)
+    worst = _check_grads(model, grads, tol_rel=6e-2, min_checked=50)
+    print(f"worst grad rel err ({variant}):", worst)
 
 
 def test_label_edge_cases_vs_oracle(pkg):
