@@ -15,6 +15,8 @@ for s in $SRCS; do
     pids="$pids $!"
   fi
 done
-for p in $pids; do wait $p; done
+fail=0
+for p in $pids; do wait $p || fail=1; done
+if [ $fail -ne 0 ]; then echo "build.sh: a compilation failed" >&2; exit 1; fi
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT
 echo "built $(realpath $OUT)"
