@@ -1,4 +1,7 @@
 """Diagnostic: per-workgroup timeline of the 4-wave NT kernel (DICOW_HIP_LIB=<libdicow_hip.so built with -DNTW_PROFILE>).
+   NOTE: the -DNTW_PROFILE build of the current kernel crashes the ROCm 7.2 compiler (inliner segfault); the numbers quoted in
+   gemm.hip / DESIGN.md come from the commit that introduced the persistent kernel.  tools/sweep_k.py and tools/probe_dma.hip
+   give the same decomposition (k-loop slope, prologue + epilogue intercept, L2 -> LDS ceiling) without instrumentation.
    python tools/profile_ksteps.py M N K"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
