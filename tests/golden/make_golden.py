@@ -708,9 +708,52 @@ def f15_beam_search():
     save("f15_beam_search", **arrs)
 
 
+# ----------------------------------------------------------------------------- F16: long-form segment retrieval
+def f16_retrieve_segment():
+    """DiCoWGenerationMixin._retrieve_segment (src/models/dicow/generation.py:416-534, a static method): how one window's
+    decoded tokens become segments and how far the seek pointer moves.  Crafted token sequences cover every branch."""
+    from models.dicow.generation import DiCoWGenerationMixin as G
+    arrs = {}
+    tb = 100                                              # timestamp_begin: tokens >= 100 are timestamps (0.02 s each)
+    T = lambda x: tb + x
+    cases = [
+        [T(0), 5, 6, T(50), T(50), 7, 8, T(120), T(120), 9, T(400)],        # two closed segments + an open one -> seek to 120
+        [T(0), 5, 6, T(50), T(50), 7, 8, T(120)],                           # single timestamp ending -> whole window consumed
+        [T(10), 5, 6, 7, T(90), T(90), 8, 9, T(200), T(200)],               # ends on a timestamp pair
+        [5, 6, 7, 8],                                                       # no timestamps at all
+        [T(30), 5, 6, 7],                                                   # one timestamp early
+        [T(260), 5, 6, 7],                                                  # one timestamp late -> rollback, nothing emitted
+        [T(20), 5, 6, T(80), 7, 8, T(140)],                                 # separated timestamps, no consecutive pair
+        [T(0)],                                                             # a lone <|0.00|>
+    ]
+    time_offset = torch.tensor([12.5, 40.0], dtype=torch.float64)
+    seek_num_frames = torch.tensor([3000, 1800])
+    dec_ids = torch.zeros(1, 4, dtype=torch.long)
+    n = 0
+    for prev_idx in (0, 1):
+        for seq in cases:
+            try:
+                segs, off = G._retrieve_segment(seek_sequence=torch.tensor(seq), seek_outputs=[None, None], time_offset=time_offset,
+                                                timestamp_begin=tb, seek_num_frames=seek_num_frames, time_precision=0.02,
+                                                time_precision_features=0.01, input_stride=2, prev_idx=prev_idx, idx=prev_idx,
+                                                return_token_timestamps=False, decoder_input_ids=dec_ids)
+            except ValueError:
+                segs, off = None, -1
+            arrs[f"c{n}.seq"], arrs[f"c{n}.prev"] = np.array(seq), np.array(prev_idx)
+            arrs[f"c{n}.offset"] = np.array(int(off))
+            arrs[f"c{n}.nseg"] = np.array(-1 if segs is None else len(segs))
+            for j, sg in enumerate(segs or []):
+                arrs[f"c{n}.s{j}.start"], arrs[f"c{n}.s{j}.end"] = np.array(float(sg["start"])), np.array(float(sg["end"]))
+                arrs[f"c{n}.s{j}.tokens"] = np.array(sg["tokens"].tolist())
+            n += 1
+    arrs["n_cases"] = np.array(n)
+    arrs["time_offset"], arrs["seek_num_frames"], arrs["timestamp_begin"] = time_offset, seek_num_frames, np.array(tb)
+    save("f16_retrieve_segment", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12", "f13", "f14", "f15"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12", "f13", "f14", "f15", "f16"]
     fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
-           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules, "f15": f15_beam_search}
+           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules, "f15": f15_beam_search, "f16": f16_retrieve_segment}
     for w in which:
         fns[w]()

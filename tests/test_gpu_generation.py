@@ -252,3 +252,50 @@ def test_beam_search_with_ctc_and_timestamps_runs(pkg):
     assert bool(torch.isfinite(score).all()) and seq.shape[0] == x.shape[0] and seq.shape[1] <= 10
     for row in seq[:, 2:].tolist():
         assert row[0] == 5 or ts0 <= row[0] <= ts0 + 10
+
+
+def test_long_form_loop(pkg):
+    """Three recordings of different lengths (3.2, 1.4 and 2.0 windows of the small golden model's 2 s window): the loop
+    terminates, every window's tokens equal a direct generate() on that window, seeks advance by retrieve_segment's offsets,
+    segment times are non-decreasing and stay inside the recording."""
+    from ts_asr_whisper_amd.generation import LongFormDecoder, GreedyDecoder, stno_seek_windows, retrieve_segment
+    z, model, cfg, x, st, prompt = _setup(pkg)
+    W = 2 * cfg.max_source_positions                      # 200 feature frames = one window of the small model
+    g = torch.Generator().manual_seed(21)
+    B, total = 3, 3 * W + 40
+    feats = torch.randn(B, cfg.num_mel_bins, total, generator=g).clamp_(-1.5, 1.5).cuda()
+    stno = torch.softmax(torch.randn(B, 4, total // 2, generator=g) * 2, 1).cuda()
+    max_frames = [total, W + 80, 2 * W]
+    no_ts, eos = 399, 5
+    p1 = prompt[:1]
+    lf = LongFormDecoder(model)
+    segs = lf.transcribe(feats, stno, max_frames, p1, no_ts, eos_token_id=eos, pad_token_id=499, max_new_tokens=10)
+    assert len(segs) == B
+    for b in range(B):
+        times = [(s["start"], s["end"]) for s in segs[b]]
+        assert all(s <= e + 1e-9 for s, e in times) and all(times[i][0] <= times[i + 1][0] + 1e-9 for i in range(len(times) - 1))
+        assert all(e <= max_frames[b] * 0.01 + W * 0.01 + 1e-6 for _, e in times)     # a random model may stamp the window's end
+    # replay recording 0 window by window with the building blocks
+    dec, seek, replay = GreedyDecoder(model), 0, []
+    while seek < max_frames[0]:
+        left = min(max_frames[0] - seek, W)
+        win = feats.new_zeros(1, cfg.num_mel_bins, W)
+        win[0, :, :left] = feats[0, :, seek:seek + left]
+        sw = stno_seek_windows(stno, [seek, 0, 0], max_frames, [0], num_frames=cfg.max_source_positions)
+        out = dec.generate(win, sw, p1, 10, eos_token_id=eos, pad_token_id=499,
+                           timestamps=dict(no_timestamps_token_id=no_ts, max_initial_timestamp_index=50))
+        toks = out[0, p1.shape[1]:].tolist()
+        while toks and toks[-1] in (499, eos):
+            toks.pop()
+        if not toks:
+            seek += left
+            continue
+        sg, adv = retrieve_segment(toks, seek * 0.01, no_ts + 1, left)
+        replay.extend(sg)
+        seek += adv
+    assert [s["tokens"] for s in replay] == [s["tokens"] for s in segs[0]]
+    assert all(abs(a["start"] - b["start"]) < 1e-9 for a, b in zip(replay, segs[0]))
+    # beam search variant runs through the same loop
+    segs_b = LongFormDecoder(model, num_beams=2).transcribe(feats[:1], stno[:1], max_frames[:1], p1, no_ts, eos_token_id=eos,
+                                                            pad_token_id=499, max_new_tokens=8)
+    assert len(segs_b) == 1

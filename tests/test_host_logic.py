@@ -220,3 +220,9 @@ def test_from_pretrained_plain_whisper_checkpoint_keeps_fddt_init(tmp_path):
     assert torch.allclose(w, torch.full_like(w, 0.5))                           # suppressive init with non_target_fddt_value
     m3 = pkg.DiCoWForConditionalGeneration.from_pretrained("openai/whisper-tiny", use_fddt=True)
     assert m3.config.d_model == 384 and m3._load_report["missing"] is None
+
+
+def test_product_retrieve_segment_matches_reference_golden():
+    from tests.test_oracle_vs_golden import _check_retrieve
+    from ts_asr_whisper_amd.generation import retrieve_segment
+    _check_retrieve(retrieve_segment)

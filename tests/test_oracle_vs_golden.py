@@ -325,3 +325,25 @@ def test_f15_beam_search_bookkeeping():
         assert st.done
         seq, sc = st.result()
         assert np.array_equal(seq, z[f"c{ci}.final"]) and np.allclose(sc, z[f"c{ci}.final_scores"], atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ F16: long-form segment retrieval
+def _check_retrieve(fn):
+    z = load_golden("f16_retrieve_segment")
+    tb = int(z["timestamp_begin"])
+    for i in range(int(z["n_cases"])):
+        prev, seq = int(z[f"c{i}.prev"]), z[f"c{i}.seq"].tolist()
+        try:
+            segs, off = fn(seq, float(z["time_offset"][prev]), tb, int(z["seek_num_frames"][prev]))
+        except ValueError:
+            segs, off = None, -1
+        assert off == int(z[f"c{i}.offset"]), i
+        assert (-1 if segs is None else len(segs)) == int(z[f"c{i}.nseg"]), i
+        for j, sg in enumerate(segs or []):
+            assert abs(sg["start"] - float(z[f"c{i}.s{j}.start"])) < 1e-9 and abs(sg["end"] - float(z[f"c{i}.s{j}.end"])) < 1e-9
+            assert list(sg["tokens"]) == z[f"c{i}.s{j}.tokens"].tolist()
+
+
+def test_f16_retrieve_segment_oracle():
+    from oracle.longform import retrieve_segment
+    _check_retrieve(retrieve_segment)

@@ -302,3 +302,111 @@ class GreedyDecoder:
                 break
         out = torch.cat(seq, dim=1)
         return (out, torch.stack(scores)) if return_scores else out
+
+
+# ------------------------------------------------------------------------------------------------ long-form decoding
+def retrieve_segment(seq, time_offset, timestamp_begin, seek_num_frames, time_precision=0.02, input_stride=2):
+    """DiCoWGenerationMixin._retrieve_segment (reference src/models/dicow/generation.py:416-534) on a plain list of the tokens
+    decoded for one window (prompt removed): consecutive timestamp pairs close segments; a single trailing timestamp means
+    "no more speech in this window" (the whole window is consumed), otherwise the seek pointer moves to the last closed
+    segment; without any pair the window becomes one segment (or is rolled back when its only timestamp lies beyond 4 s from
+    the start).  Returns ([dict(start, end, tokens)], frames to advance); host control flow, pinned by golden F16."""
+    is_ts = [t >= timestamp_begin for t in seq]
+    single_ending = is_ts[-2:] == [False, True]
+    pairs = [i + 1 for i in range(len(seq) - 1) if is_ts[i] and is_ts[i + 1]]
+    segments = []
+    if pairs:
+        slices = list(pairs)
+        if single_ending:
+            slices.append(len(seq))
+        else:
+            slices[-1] += 1
+        last = 0
+        for i, cur in enumerate(slices):
+            tok = seq[last:cur]
+            end_tok = tok[-1 if (i < len(slices) - 1 or single_ending) else -2]
+            segments.append({"start": time_offset + (tok[0] - timestamp_begin) * time_precision,
+                             "end": time_offset + (end_tok - timestamp_begin) * time_precision, "tokens": tok})
+            last = cur
+        offset = seek_num_frames if single_ending else (seq[last - 2] - timestamp_begin) * input_stride
+    else:
+        stamps = [t for t, f in zip(seq, is_ts) if f]
+        start_pos, last_pos, skip, offset = 0.0, seek_num_frames // 2, False, seek_num_frames
+        if len(stamps) > 1:
+            start_pos, last_pos = stamps[-2] - timestamp_begin, stamps[-1] - timestamp_begin
+        elif len(stamps) == 1:
+            start_pos = stamps[-1] - timestamp_begin
+            if start_pos > 200:
+                offset, skip = start_pos * input_stride - 100, True
+        elif len(seq) <= 1:
+            skip = True
+        if not skip:
+            segments = [{"start": time_offset + start_pos * time_precision, "end": time_offset + last_pos * time_precision,
+                         "tokens": list(seq)}]
+            offset = seek_num_frames
+    if offset <= 0:
+        raise ValueError(f"Segment offset: {offset} <= 0. This should not happen!")
+    return segments, int(offset)
+
+
+class LongFormDecoder:
+    """Sequential long-form decoding of recordings longer than one window, the way the reference drives HF's Whisper
+    ``generate`` (temperature 0, no conditioning on previous text -- the reference raises for it, generation.py:545): every
+    still-active recording contributes its current 30 s window (features from ``seek``, zero-padded; STNO mask through
+    ``stno_seek_windows``), the windows are decoded as one batch (greedy or beam, timestamp rules on), each window's tokens go
+    through ``retrieve_segment`` and the recording's seek pointer advances by the returned offset."""
+
+    def __init__(self, model, num_beams=1):
+        self.model, self.cfg, self.num_beams = model, model.config, num_beams
+        self.decoder = GreedyDecoder(model)
+
+    @torch.no_grad()
+    def transcribe(self, input_features, stno_mask, max_frames, decoder_input_ids, no_timestamps_token_id, eos_token_id=None,
+                   pad_token_id=None, max_new_tokens=None, enrollments=None, **gen_kw):
+        """input_features [B, M, T_total] (T_total a multiple of nothing in particular), stno_mask [B, 4, T_total / 2],
+        max_frames [B] valid feature frames per recording, decoder_input_ids [1 or B, P] the forced prompt.
+        Returns per recording a list of segments dict(start, end, tokens) in seconds / token ids."""
+        cfg = self.cfg
+        eos = cfg.eos_token_id if eos_token_id is None else eos_token_id
+        pad = cfg.pad_token_id if pad_token_id is None else pad_token_id
+        ts0 = no_timestamps_token_id + 1
+        W = 2 * cfg.max_source_positions                           # feature frames per window
+        B, M, _ = input_features.shape
+        max_frames = [int(v) for v in max_frames]
+        seek = [0] * B
+        out = [[] for _ in range(B)]
+        prompt = decoder_input_ids if decoder_input_ids.shape[0] == B else decoder_input_ids.expand(B, -1)
+        P = prompt.shape[1]
+        n_new = (cfg.max_target_positions - P) if max_new_tokens is None else max_new_tokens
+        while True:
+            active = [b for b in range(B) if seek[b] < max_frames[b]]
+            if not active:
+                break
+            left = [min(max_frames[b] - seek[b], W) for b in active]
+            feats = input_features.new_zeros((len(active), M, W))
+            for i, b in enumerate(active):
+                feats[i, :, :left[i]] = input_features[b, :, seek[b]:seek[b] + left[i]]
+            stno = stno_seek_windows(stno_mask, seek, max_frames, active, num_frames=cfg.max_source_positions)
+            enr = None if enrollments is None else {k: v[active] for k, v in enrollments.items()}
+            kw = dict(eos_token_id=eos, pad_token_id=pad, enrollments=enr,
+                      timestamps=dict(no_timestamps_token_id=no_timestamps_token_id,
+                                      max_initial_timestamp_index=gen_kw.get("max_initial_timestamp_index", 50)),
+                      suppress_tokens=gen_kw.get("suppress_tokens"), begin_suppress_tokens=gen_kw.get("begin_suppress_tokens"),
+                      ctc=gen_kw.get("ctc"))
+            if self.num_beams > 1:
+                seqs, _ = self.decoder.beam_search(feats, stno, prompt[active], P + n_new, self.num_beams,
+                                                   length_penalty=gen_kw.get("length_penalty", 1.0),
+                                                   early_stopping=gen_kw.get("early_stopping", False), **kw)
+            else:
+                seqs = self.decoder.generate(feats, stno, prompt[active], n_new, **kw)
+            for i, b in enumerate(active):
+                toks = seqs[i, P:].tolist()
+                while toks and toks[-1] in (pad, eos):              # HF strips the eos / padding tail before segmenting
+                    toks.pop()
+                if not toks:
+                    seek[b] += left[i]
+                    continue
+                segs, adv = retrieve_segment(toks, seek[b] * 0.01, ts0, left[i])
+                out[b].extend(segs)
+                seek[b] += adv
+        return out
