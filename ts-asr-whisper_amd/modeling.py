@@ -660,7 +660,8 @@ class DiCoWForConditionalGeneration(nn.Module):
         get = (lambda k, d=None: getattr(gc, k, d) if gc is not None else d)
         beams = max(num_beams or 1, get("num_beams", 1) or 1)
         if input_features.shape[-1] != 2 * self.config.max_source_positions:
-            raise NotImplementedError("long-form inputs: cut 30 s windows with generation.stno_seek_windows and decode each")
+            raise NotImplementedError("long-form inputs: use generation.LongFormDecoder(model, num_beams).transcribe(...) "
+                                      "(sequential seek loop; returns timed segments per recording)")
         cfg = self.config
         B = input_features.shape[0]
         if decoder_input_ids is None:
