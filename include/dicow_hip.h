@@ -137,7 +137,7 @@ int dicow_fddt_full_combine_bwd(const float* g, const float* stno, int64_t stno_
  * fp32 accumulation on v_mfma_f32_32x32x16_bf16, 128x128x64 LDS tiles.
  * Requirements: K % 64 == 0, lda/ldb % 8 == 0, ldc % 4 == 0, N % 4 == 0; M, N tails handled.          */
 #define DICOW_EPI_BIAS      1    /* + bias[n] */
-#define DICOW_EPI_GELU      2    /* exact-erf GELU; pre-activation stored to aux (bf16) when aux != NULL */
+#define DICOW_EPI_GELU      2    /* exact-erf GELU of the bf16-ROUNDED pre-activation (AMP: the Linear output is bf16); the pre-activation is stored to aux (bf16) when aux != NULL */
 #define DICOW_EPI_RESIDUAL  4    /* + residual[m,n] (fp32, ld = ldr) */
 #define DICOW_EPI_OUT_F32   8    /* C is fp32 (else bf16) */
 #define DICOW_EPI_SCALE_N  16    /* columns n < scale_ncols multiplied by scale AFTER bias (q * head_dim^-0.5) */

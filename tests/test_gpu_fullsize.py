@@ -254,3 +254,166 @@ def test_recipe_pipeline_end_to_end():
     assert all(l == l and abs(l) < 1e4 for l in losses), losses
     assert not ts.warmup_phase and ts.global_step == 24
     assert sum(losses[-4:]) / 4 < sum(losses[1:5]) / 4 - 0.3, losses
+
+
+def test_full_size_encoder_consistency_properties():
+    """whisper-large-v3-turbo dimensions, 30 s inputs: (a) the inference-mode forward (nothing kept, plain GELU epilogue)
+    equals the training-mode forward bit for bit; (b) a sample's encoder output does not depend on what else is in the batch
+    (row-wise kernels and GEMM row tiles must not mix samples): B=1 vs the same sample inside B=3."""
+    import amd_pkg
+    pkg = amd_pkg.load()
+    from ts_asr_whisper_amd.data import synthetic_batch
+    cfg = pkg.DiCoWConfig.preset("whisper-large-v3-turbo", use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True,
+                                 fddt_init="suppressive", non_target_fddt_value=0.5)
+    torch.manual_seed(0)
+    model = pkg.DiCoWForConditionalGeneration(cfg).cuda()
+    model.tie_weights()
+    enc = model.model.encoder
+    b = synthetic_batch(cfg, 3, 8, seed=11)
+    x, st = b["input_features"], b["stno_mask"]
+    train = enc(x, stno_mask=st).last_hidden_state.detach()
+    with torch.no_grad():
+        infer = enc(x, stno_mask=st).last_hidden_state
+        single = enc(x[1:2].contiguous(), stno_mask=st[1:2].contiguous()).last_hidden_state
+    assert torch.equal(train, infer)
+    assert bool(torch.isfinite(train).all())
+    d = float((single[0] - train[1]).abs().max())
+    assert d < 2e-2 * max(1.0, float(train[1].abs().max())), d          # different row tiling of the bf16 GEMMs only
+    assert float((train[0] - train[1]).abs().max()) > 10 * max(d, 1e-6)  # while different samples do differ
+
+
+@pytest.mark.parametrize("rows,T", [(24000, 1500), (4500, 1500), (3000, 1500)])
+def test_layer_row_kernels_at_bench_size(ops, rows, T):
+    """The specialised / LDS-staged FDDT+LayerNorm kernels the encoder layers actually run at D = 1280 (no positional term, bf16
+    y, saved mean / rstd, fp32 h_out; backward with the residual gradient, bf16 copy and column sums) against plain torch fp32
+    on the GPU.  The generic test above passes `pos` / `y_f32` and therefore never reaches these variants; a store-data
+    register hazard in the staged forward (1.5 % of h_out wrong, y correct) went unnoticed until this test existed."""
+    D, B = 1280, rows // T
+    g = torch.Generator(device="cuda").manual_seed(rows)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    h, st = rnd(rows, D), torch.softmax(rnd(B, 4, T), 1)
+    w = [1 + 0.1 * rnd(D) for _ in range(4)]
+    b = [0.1 * rnd(D) for _ in range(4)]
+    lw, lb = 1 + 0.1 * rnd(D), 0.1 * rnd(D)
+    leaves = [h.clone().requires_grad_(True)] + [t.clone().requires_grad_(True) for t in w + b + [lw, lb]]
+    hr, wr, br, lwr, lbr = leaves[0], leaves[1:5], leaves[5:9], leaves[9], leaves[10]
+    x = sum((hr.view(B, T, D) * wr[c] + br[c]) * st[:, c, :, None] for c in range(4)).view(rows, D)
+    y = torch.nn.functional.layer_norm(x, (D,), lwr, lbr)
+    dy = rnd(rows, D).bfloat16()
+    gres = rnd(rows, D)
+    ((y * dy.float()).sum() + (x * gres).sum()).backward()
+    # ---- forward: FDDT + LN (staged) and LN only
+    ho, yb = torch.empty(rows, D, device="cuda"), torch.empty(rows, D, dtype=torch.bfloat16, device="cuda")
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    for trial in range(2):
+        ho.zero_()
+        ops.fddt_ln_fwd(h, rows, D, mode=ops.MODE_DIAG, stno=st, T=T, w=w, b=b, h_out=ho, ln_w=lw, ln_b=lb, y_bf16=yb, mean=mean, rstd=rstd)
+        assert float((ho - x.detach()).abs().max()) < 2e-6, trial
+        assert float((yb.float() - y.detach()).abs().max()) < 5e-2
+    y2, m2, r2 = torch.empty_like(yb), torch.empty_like(mean), torch.empty_like(rstd)
+    ops.fddt_ln_fwd(ho, rows, D, mode=ops.MODE_NONE, ln_w=lw, ln_b=lb, y_bf16=y2, mean=m2, rstd=r2)
+    assert float((y2.float() - y.detach()).abs().max()) < 5e-2 and float((m2 - mean).abs().max()) < 1e-5      # (another reduction order)
+    # ---- backward: LN + residual + FDDT, with and without the bf16 copy
+    for want_bf16 in (True, False):
+        g0 = torch.empty(rows, D, device="cuda")
+        g0b = torch.empty(rows, D, dtype=torch.bfloat16, device="cuda") if want_bf16 else None
+        dlw, dlb, cs = (torch.zeros(D, device="cuda") for _ in range(3))
+        dw, db = [torch.zeros(D, device="cuda") for _ in range(4)], [torch.zeros(D, device="cuda") for _ in range(4)]
+        ops.fddt_ln_bwd(h, rows, D, mode=ops.MODE_DIAG, stno=st, T=T, w=w, b=b, ln_w=lw, mean=mean, rstd=rstd, d_y=dy, g_res=gres,
+                        g_out=g0, g_out_bf16=g0b, dln_w=dlw, dln_b=dlb, dw=dw, db=db, colsum_out=cs)
+        assert float((g0 - hr.grad).abs().max()) < 5e-4, want_bf16
+        if want_bf16:
+            assert float((g0b.float() - hr.grad).abs().max()) < 5e-2
+        sc = rows ** 0.5
+        assert float((dlw - lwr.grad).abs().max()) < 5e-4 * sc and float((dlb - lbr.grad).abs().max()) < 5e-4 * sc
+        for c in range(4):
+            assert float((dw[c] - wr[c].grad).abs().max()) < 8e-4 * sc and float((db[c] - br[c].grad).abs().max()) < 8e-4 * sc, c
+        assert float((cs - hr.grad.sum(0)).abs().max()) < 8e-4 * sc
+    # ---- backward: LN only (the second LayerNorm of a layer) with the residual gradient
+    xl = x.detach().clone().requires_grad_(True)
+    lw2 = lw.clone().requires_grad_(True)
+    yl = torch.nn.functional.layer_norm(xl, (D,), lw2, lb)
+    ((yl * dy.float()).sum() + (xl * gres).sum()).backward()
+    g1, g1b = torch.empty(rows, D, device="cuda"), torch.empty(rows, D, dtype=torch.bfloat16, device="cuda")
+    dlw, dlb, cs = (torch.zeros(D, device="cuda") for _ in range(3))
+    ops.fddt_ln_bwd(x.detach(), rows, D, mode=ops.MODE_NONE, ln_w=lw, mean=mean, rstd=rstd, d_y=dy, g_res=gres, g_out=g1, g_out_bf16=g1b,
+                    dln_w=dlw, dln_b=dlb, colsum_out=cs)
+    assert float((g1 - xl.grad).abs().max()) < 5e-4 and float((g1b.float() - xl.grad).abs().max()) < 5e-2
+    assert float((dlw - lw2.grad).abs().max()) < 5e-4 * rows ** 0.5 and float((cs - xl.grad.sum(0)).abs().max()) < 8e-4 * rows ** 0.5
+
+
+def _bf(x):
+    return x.bfloat16()
+
+
+@pytest.mark.parametrize("N,K", [(3840, 1280), (1280, 1280), (5120, 1280), (1280, 5120)])
+def test_gemm_epilogues_at_bench_shapes_vs_torch(ops, N, K):
+    """The encoder layer's GEMMs at M = 24000 (B = 16) against torch fp32 on the GPU, every fused epilogue the step uses, full
+    element-wise comparison (a hazard that corrupts ~1 % of a big, HBM-saturating launch does not show at test-sized shapes)."""
+    from ts_asr_whisper_amd import _lib as L
+    M = 24000
+    g = torch.Generator(device="cuda").manual_seed(N + K)
+    A = _bf(torch.randn(M, K, device="cuda", generator=g) * 0.5)
+    W = _bf(torch.randn(N, K, device="cuda", generator=g) * K ** -0.5)
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    res = torch.randn(M, N, device="cuda", generator=g)
+    base = A.float() @ W.float().t()
+    C = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(A, W, C, M, N, K)
+    assert float((C.float() - base).abs().max()) < 3e-2
+    ops.gemm_nt(A, W, C, M, N, K, bias=bias, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=N // 2)     # (quad-granular: a multiple of 4)
+    ref = base + bias
+    ref[:, :N // 2] *= 0.125
+    assert float((C.float() - ref).abs().max()) < 3e-2
+    Cf = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(A, W, Cf, M, N, K, bias=bias, residual=res)
+    assert float((Cf - ((base + bias).bfloat16().float() + res)).abs().max()) < 3e-2
+    U = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(A, W, C, M, N, K, bias=bias, aux=U, flags=L.EPI_GELU | L.EPI_GELU_DAUX)
+    pre = (base + bias).bfloat16().float().requires_grad_(True)
+    act = torch.nn.functional.gelu(pre)
+    act.sum().backward()
+    assert float((C.float() - act.detach()).abs().max()) < 3e-2 and float((U.float() - pre.grad).abs().max()) < 2e-2
+    cs = torch.zeros(N, device="cuda")
+    ops.gemm_nt(A, W, C, M, N, K, aux=U, flags=L.EPI_MUL_AUX, colsum_out=cs)
+    want = base * U.float()
+    assert float((C.float() - want).abs().max()) < 3e-2
+    assert float((cs - want.sum(0)).abs().max()) < 2e-2 * M ** 0.5 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("N1,N2", [(3840, 1280), (5120, 1280), (1280, 5120)])
+def test_gemm_tn_at_bench_shapes_vs_torch(ops, N1, N2):
+    Mk = 24000
+    g = torch.Generator(device="cuda").manual_seed(N1 + N2)
+    A = _bf(torch.randn(Mk, N1, device="cuda", generator=g) * 0.1)
+    Bm = _bf(torch.randn(Mk, N2, device="cuda", generator=g) * 0.1)
+    C = torch.randn(N1, N2, device="cuda", generator=g)
+    ref = C + A.float().t() @ Bm.float()
+    ops.gemm_tn(A, Bm, C, Mk, N1, N2)
+    assert float((C - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_attention_at_bench_shape_vs_torch(ops):
+    """B = 16, H = 20, T = 1500 (one encoder layer's attention of the bench batch): forward and backward vs torch fp32 math."""
+    B, H, Tq = 16, 20, 1500
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda s: _bf(torch.randn(B, Tq, H, 64, device="cuda", generator=g) * s)
+    q, k, v, do = mk(0.35), mk(1.0), mk(1.0), mk(0.5)
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, Tq, device="cuda")
+    ops.attn_fwd(q, k, v, o, lse)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    delta = torch.empty(2, B, H, Tq, device="cuda")
+    ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv)
+    worst = 0.0
+    for b in (0, 7, 15):                                      # fp32 reference per batch row (2.9 GB of scores otherwise)
+        qf, kf, vf = (t[b].float().permute(1, 0, 2).requires_grad_(True) for t in (q, k, v))
+        s = qf @ kf.transpose(1, 2)
+        of = torch.softmax(s, -1) @ vf
+        of.backward(do[b].float().permute(1, 0, 2))
+        assert float((o[b].float().permute(1, 0, 2) - of.detach()).abs().max()) < 2e-2
+        for got, ref in ((dq, qf.grad), (dk, kf.grad), (dv, vf.grad)):
+            err = float((got[b].float().permute(1, 0, 2) - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
+            worst = max(worst, err)
+            assert err < 3e-2, err
+    print("attention bwd worst rel err at bench shape:", worst)

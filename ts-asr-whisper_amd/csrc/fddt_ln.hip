@@ -263,15 +263,16 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
         else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(9 * R) : "memory");
         float4 x[R];
         float sm[R];
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        u32x4_t ov[R];                               // store data: kept live until after the reductions (see below)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             x[r] = *reinterpret_cast<const float4*>(stg + (s * R + r) * row_lds + tid * 16);
 #define FD(e) fddt_diag_elem(x[r].e, w[0].e, b[0].e, w[1].e, b[1].e, w[2].e, b[2].e, w[3].e, b[3].e, m[r][0], m[r][1], m[r][2], m[r][3])
             F4_APPLY(x[r], FD);
 #undef FD
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-            const u32x4_t ov = {__float_as_uint(x[r].x), __float_as_uint(x[r].y), __float_as_uint(x[r].z), __float_as_uint(x[r].w)};
-            __builtin_amdgcn_raw_buffer_store_b128(ov, rsO, vo32, (row0 + r) * D * 4, 0);
+            ov[r] = u32x4_t{__float_as_uint(x[r].x), __float_as_uint(x[r].y), __float_as_uint(x[r].z), __float_as_uint(x[r].w)};
+            __builtin_amdgcn_raw_buffer_store_b128(ov[r], rsO, vo32, (row0 + r) * D * 4, 0);
             sm[r] = (x[r].x + x[r].y) + (x[r].z + x[r].w);
         }
         block_sum<R>(sm, red[0], nwaves);
@@ -283,6 +284,13 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
             q[r] = (dx * dx + dy * dy) + (dz * dz + dw * dw);
         }
         block_sum<R>(q, red[1], nwaves);
+        // The registers a 16-byte store reads its data from must not be rewritten while the store may still be queued: with
+        // the copy the compiler made for the last row (v_mov into a temporary quad that the DPP reduction right after the
+        // store reused) ~1.5 % of h_out came out wrong at D = 1280 -- lanes 12..15 of every 16, second dword -- while the
+        // values computed from the same registers (y, mean, rstd) were right.  Keeping the quads live across both block
+        // reductions removes the reuse.
+#pragma unroll
+        for (int r = 0; r < R; ++r) asm volatile("" :: "v"(ov[r]));
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const float rs = rsqrtf(q[r] * inv_d + a.eps);
@@ -566,6 +574,14 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
     const int stride = gridDim.x * R;
     int row0 = blockIdx.x * R, it = 0;
     if (row0 < a.rows) { load_scalars(row0); stage_rows(row0, 0); }
+    // Store data lives in these quads until the NEXT trip's reduction is over: rewriting the registers of a queued 16-byte store
+    // (the compiler reused its temporaries at once) corrupted ~1 % of g_out at D = 1280, exactly as in the staged forward.
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+    u32x4_t ov[R];
+    u32x2_t bv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { ov[r] = u32x4_t{0, 0, 0, 0}; bv[r] = u32x2_t{0, 0}; }
     for (; row0 < a.rows; row0 += stride, ++it) {
         const int s = it & 1;
         float sc[R][6];
@@ -610,6 +626,8 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
         }
         block_sum<2 * R>(sums, red[it & 1], nwaves);
 #pragma unroll
+        for (int r = 0; r < R; ++r) { asm volatile("" :: "v"(ov[r])); if (OUT_BF16) asm volatile("" :: "v"(bv[r])); }
+#pragma unroll
         for (int r = 0; r < R; ++r) {
             const char* base = stg + (s * R + r) * row_lds;
             float4 g = *reinterpret_cast<const float4*>(base + 4 * D + tid * 16);
@@ -629,14 +647,12 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
             }
             const float4 g0 = make_float4(g.x * scw[r].x, g.y * scw[r].y, g.z * scw[r].z, g.w * scw[r].w);
             F4_ADD(acc_cs, g0);
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
             const int so32 = (row0 + r) * D * 4;
-            const u32x4_t ov = {__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g0.z), __float_as_uint(g0.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(ov, rsO, vo32, so32, 0);
+            ov[r] = u32x4_t{__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g0.z), __float_as_uint(g0.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(ov[r], rsO, vo32, so32, 0);
             if (OUT_BF16) {
-                const u32x2_t bv = {pack_bf16x2(g0.x, g0.y), pack_bf16x2(g0.z, g0.w)};
-                __builtin_amdgcn_raw_buffer_store_b64(bv, rsB, (unsigned)(col * 2), (row0 + r) * D * 2, 0);
+                bv[r] = u32x2_t{pack_bf16x2(g0.x, g0.y), pack_bf16x2(g0.z, g0.w)};
+                __builtin_amdgcn_raw_buffer_store_b64(bv[r], rsB, (unsigned)(col * 2), (row0 + r) * D * 2, 0);
             }
         }
     }

@@ -104,12 +104,10 @@ __device__ __forceinline__ void nt_epilogue_math(const dicow_gemm_args& a, int r
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) dg[e] = v[e];         // aux receives the pre-activation
-            if (aux) {
+            // AMP: the Linear / conv output is a bf16 tensor, so the activation sees the ROUNDED value -- with or without a
+            // saved pre-activation (the inference forward and the decoder step must give what the training forward gives)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e]));
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(bf2f(f2bf(v[e])));
         }
     }
     if (flags & (DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) {
@@ -933,6 +931,7 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     DICOW_REQUIRE(!(a->flags & DICOW_EPI_MUL_AUX) || a->aux, "gemm_nt: MUL_AUX needs aux");
     DICOW_REQUIRE(!(a->flags & DICOW_EPI_GELU_DAUX) || ((a->flags & DICOW_EPI_GELU) && a->aux), "gemm_nt: GELU_DAUX needs GELU and aux");
     DICOW_REQUIRE(!(a->aux) || a->ldaux % 4 == 0, "gemm_nt: ldaux must be a multiple of 4");
+    DICOW_REQUIRE(!(a->flags & DICOW_EPI_SCALE_N) || a->scale_ncols % 4 == 0, "gemm_nt: SCALE_N works on column quads, scale_ncols=%d", a->scale_ncols);
     const int batch = a->batch > 0 ? a->batch : 1;
     const int ntm = dicow_cdiv(a->M, BM), ntn = dicow_cdiv(a->N, BN);
     static bool attr_set = false;
