@@ -417,3 +417,57 @@ def test_attention_at_bench_shape_vs_torch(ops):
             worst = max(worst, err)
             assert err < 3e-2, err
     print("attention bwd worst rel err at bench shape:", worst)
+
+
+def test_losses_at_real_vocabulary_vs_torch(ops):
+    """CE (hard labels, per-token min over the two label sets) at [2048, 51866] and CTC at [16, 375, 51867] against torch's own
+    losses on the GPU: values and logits gradients."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    V, rows = 51866, 2048
+    vpad = (V + 127) // 128 * 128
+    logits = torch.zeros(rows, vpad, dtype=bf, device="cuda")
+    logits[:, :V] = (torch.randn(rows, V, device="cuda", generator=g) * 2).bfloat16()
+    labels = torch.randint(0, V, (rows,), device="cuda", generator=g)
+    upp = torch.randint(0, V, (rows,), device="cuda", generator=g)
+    labels[::9] = -100
+    upp[::9] = -100
+    lse, rl = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ch = torch.empty(rows, dtype=torch.int32, device="cuda")
+    acc = torch.zeros(2, device="cuda")
+    a = ops.ce_args(logits, vpad, rows, V, labels, upp, False, None, lse, rl, ch, acc[0:1], acc[1:2])
+    ops.ce_loss_fwd(a)
+    lf = logits[:, :V].float().requires_grad_(True)
+    ce1 = torch.nn.functional.cross_entropy(lf, labels, reduction="none", ignore_index=-100)
+    ce2 = torch.nn.functional.cross_entropy(lf, upp, reduction="none", ignore_index=-100)
+    ref = torch.stack((ce1, ce2), dim=-1).min(dim=-1).values       # the reference's op (modeling_dicow.py:321): ties go to one label set
+    assert abs(float(acc[0]) - float(ref.sum())) < 2e-3 * float(ref.sum())
+    d = torch.empty(rows, vpad, dtype=bf, device="cuda")
+    a.d_logits = d.data_ptr()
+    ops.ce_loss_bwd(a, torch.ones(1, device="cuda"))
+    ref.sum().backward()
+    assert float((d[:, :V].float() - lf.grad).abs().max()) < 1e-2
+    # ---- CTC
+    B, Tn, C1, Lc = 16, 375, 51867, 40
+    cpad = (C1 + 127) // 128 * 128
+    zl = torch.zeros(B * Tn, cpad, dtype=bf, device="cuda")
+    zl[:, :C1] = (torch.randn(B * Tn, C1, device="cuda", generator=g) * 2).bfloat16()
+    lab = torch.randint(0, C1 - 1, (B, Lc), device="cuda", generator=g)
+    tl = torch.randint(5, Lc + 1, (B,), device="cuda", generator=g)
+    lab = torch.where(torch.arange(Lc, device="cuda")[None, :] < tl[:, None], lab, torch.full_like(lab, -100))
+    lse2, nll, tlen = torch.empty(B * Tn, device="cuda"), torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+    ab = torch.empty(2, B, Tn, 2 * Lc + 1, device="cuda")
+    acc2 = torch.zeros(1, device="cuda")
+    c = ops.ctc_args(zl, cpad, B, Tn, C1, lab, lse2, ab[0], ab[1], nll, tlen, acc2)
+    ops.ctc_loss_fwd(c)
+    zf = zl[:, :C1].float().view(B, Tn, C1).requires_grad_(True)
+    lp = torch.log_softmax(zf, -1).transpose(0, 1)
+    refc = torch.nn.functional.ctc_loss(lp, lab.clamp(min=0), torch.full((B,), Tn, device="cuda"), tl, blank=C1 - 1, reduction="mean",
+                                        zero_infinity=True)
+    assert abs(float(acc2[0]) / B - float(refc)) < 2e-3 * abs(float(refc))
+    dz = torch.empty(B * Tn, cpad, dtype=bf, device="cuda")
+    c.d_logits = dz.data_ptr()
+    ops.ctc_loss_bwd(c, torch.ones(1, device="cuda"))          # d(mean loss): the batch mean is part of the kernel's contract
+    refc.backward()
+    gref = zf.grad.view(B * Tn, C1)
+    assert float((dz[:, :C1].float() - gref).abs().max()) < 2e-2 * float(gref.abs().max()) + 1e-6
+    assert float(dz[:, C1:].float().abs().max()) == 0.0
