@@ -473,7 +473,8 @@ def test_losses_at_real_vocabulary_vs_torch(ops):
     assert float(dz[:, C1:].float().abs().max()) == 0.0
 
 
-def test_turbo_dims_training_step_vs_oracle():
+@pytest.mark.parametrize("variant", ["plain", "ctc", "se"])
+def test_turbo_dims_training_step_vs_oracle(variant):
     """whisper-large-v3-turbo dimensions end to end (B = 1, 30 s, L = 16): loss, encoder output and gradients of the product's
     forward + backward against the CPU oracle with the same bf16 rounding points (~25 s of CPU).  This is the configuration
     the bench runs, so every specialised kernel variant it selects (LDS-staged row kernels, persistent GEMM tile shapes, fused
@@ -481,14 +482,16 @@ def test_turbo_dims_training_step_vs_oracle():
     import amd_pkg
     pkg = amd_pkg.load()
     from oracle import dicow_oracle as O
+    extra = {"plain": {}, "ctc": dict(ctc_weight=0.3, pre_ctc_sub_sample=True, additional_self_attention_layer=True),
+             "se": dict(use_enrollments=True, scb_layers=8)}[variant]
     cfg = pkg.DiCoWConfig.preset("whisper-large-v3-turbo", use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True,
-                                 fddt_init="suppressive", non_target_fddt_value=0.5)
+                                 fddt_init="suppressive", non_target_fddt_value=0.5, **extra)
     torch.manual_seed(0)
     model = pkg.DiCoWForConditionalGeneration(cfg)
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
         for n, p_ in model.named_parameters():
-            if "fddt" in n:
+            if "fddt" in n or "cross_gate" in n:
                 p_.add_(torch.randn(p_.shape, generator=g) * 0.05)
     state = {n: t.detach().clone() for n, t in model.state_dict().items()}
     model = model.cuda()
@@ -496,17 +499,26 @@ def test_turbo_dims_training_step_vs_oracle():
     x = torch.randn(1, cfg.num_mel_bins, 3000, generator=g).clamp_(-1.5, 1.5)
     st = torch.softmax(torch.randn(1, 4, 1500, generator=g) * 2, 1)
     lab = torch.randint(0, 50257, (1, 16), generator=g)
-    out = model(input_features=x.cuda(), stno_mask=st.cuda(), labels=lab.cuda(), upp_labels=lab.cuda())
+    enr = None
+    if variant == "se":
+        enr = {"input_features": torch.randn(1, cfg.num_mel_bins, 3000, generator=g).clamp_(-1.5, 1.5),
+               "stno_mask": torch.softmax(torch.randn(1, 4, 1500, generator=g) * 2, 1)}
+    out = model(input_features=x.cuda(), stno_mask=st.cuda(), labels=lab.cuda(), upp_labels=lab.cuda(),
+                enrollments=None if enr is None else {k: v.cuda() for k, v in enr.items()})
     out.loss.backward()
     ocfg = O.OracleConfig(**{k: v for k, v in cfg.to_dict().items() if k in O.OracleConfig.__dataclass_fields__})
     watch = ["model.encoder.fddts.0.target_linear.weight", "model.encoder.fddts.31.non_target_linear.bias",
              "model.encoder.initial_fddt.silence_linear.weight", "model.encoder.layers.0.fc1.weight",
              "model.encoder.layers.31.self_attn.q_proj.weight", "model.encoder.layers.15.final_layer_norm.weight",
              "model.encoder.conv1.weight", "model.encoder.layers.7.fc2.bias"]
+    if variant == "ctc":
+        watch += ["model.encoder.lm_head.weight", "model.encoder.subsample_conv1.weight"]
+    if variant == "se":
+        watch += ["model.encoder.ca_enrolls.0.cae.cross_gate.gate", "model.encoder.ca_enrolls.7.cae.ffn.3.weight"]
     p = {n: (t.clone().requires_grad_(True) if n in watch else t) for n, t in state.items()}
     p["proj_out.weight"] = p["model.decoder.embed_tokens.weight"]
     torch.set_num_threads(min(64, torch.get_num_threads() * 8 or 64))
-    ref = O.model_forward(p, ocfg, x, st, lab, lab, emu=True)
+    ref = O.model_forward(p, ocfg, x, st, lab, lab, enrollments=enr, emu=True)
     ref["loss"].backward()
     enc_err = float((out.encoder_last_hidden_state.cpu() - ref["encoder_last_hidden_state"].detach()).abs().max())
     assert enc_err < 0.15, enc_err                                   # 32 layers of bf16 rounding; a corrupted row is O(1) off
