@@ -176,3 +176,49 @@ def test_prefix_scorer_edge_sizes(cd):
     psi2, r2 = sc(torch.arange(2).cuda(), cs.cuda(), torch.tensor([1, 1]).cuda(), cs[:, 0].cuda(), r1)
     opsi2, orr2 = ocp.prefix_score(x.numpy(), np.arange(2), cs.numpy(), np.array([1, 1]), cs[:, 0].numpy(), orr[:, :, :, 0], 5, 4)
     assert close_with_logzero(psi2.cpu(), opsi2, 1e-5) and close_with_logzero(r2.cpu(), orr2, 1e-5)
+
+
+def test_prefix_scorer_full_size_elementwise_vs_torch_loop(cd):
+    """Every state and score of a full-size call (16 hypotheses x 500 candidates x 375 frames, second decoding step with a
+    repeated label among the candidates) against the reference's own formulation -- a frame loop of torch ops -- on the GPU."""
+    g = torch.Generator().manual_seed(6)
+    B, Tn, V1, C, eos = 16, 375, 51867, 500, 50257
+    logits = (torch.randn(B, Tn, V1, generator=g) * 3).to(torch.bfloat16).cuda()
+    sc = cd.CtcPrefixScorer(logits, V1 - 1, eos)
+    r0 = sc.initial_state()
+    rows = torch.arange(B).cuda()
+    cs = torch.stack([torch.randperm(50364, generator=g)[:C] for _ in range(B)]).cuda()
+    cs[:, -1] = eos
+    zero, blank = torch.zeros(B, dtype=torch.long).cuda(), torch.full((B,), V1 - 1).cuda()
+    psi1, r1 = sc(rows, cs, zero, blank, r0)
+    last = cs[:, 3].clone()
+    r_prev = r1[:, :, :, 3].contiguous()
+    cs2 = cs.clone()
+    cs2[:, 7] = last                                           # the repeated-label rule applies to candidate 7
+    psi2, r2 = sc(rows, cs2, torch.ones(B, dtype=torch.long).cuda(), last, r_prev)
+    x = torch.log_softmax(logits.float(), -1)
+
+    def torch_loop(cand, d, last_tok, rp):
+        xs = torch.gather(x, 2, cand[:, None, :].expand(-1, Tn, -1))
+        xb = x[..., V1 - 1]
+        rsum = torch.logaddexp(rp[..., 0], rp[..., 1])
+        phi = rsum[..., None].expand(-1, -1, C).clone()
+        same = (cand == last_tok[:, None]) & (d > 0)[:, None]
+        phi = torch.where(same[:, None, :], rp[..., 1:2].expand(-1, -1, C), phi)
+        r = torch.full((B, Tn, 2, C), -1e10, device="cuda")
+        r[d == 0, 0, 0] = xs[d == 0, 0]
+        start = d.clamp(min=1)
+        psi = r[torch.arange(B), start - 1, 0]
+        mask = torch.arange(1, Tn, device="cuda")[None, :] >= d[:, None]
+        psi = torch.logaddexp(psi, torch.logsumexp(torch.where(mask[..., None], phi[:, :-1] + xs[:, 1:], torch.full_like(xs[:, 1:], -1e10)), dim=1))
+        for t in range(1, Tn):
+            r[:, t, 0] = torch.logaddexp(r[:, t - 1, 0], phi[:, t - 1]) + xs[:, t]
+            r[:, t, 1] = torch.logaddexp(r[:, t - 1, 0], r[:, t - 1, 1]) + xb[:, t][:, None]
+        psi = torch.where(cand == eos, rsum[:, -1][:, None].expand(-1, C), psi)
+        return psi, r
+
+    for (psi, r), args in (((psi1, r1), (cs, zero, blank, r0)), ((psi2, r2), (cs2, torch.ones(B, dtype=torch.long).cuda(), last, r_prev))):
+        wpsi, wr = torch_loop(*args)
+        real = wr > -1e9
+        assert torch.equal(real, r > -1e9)
+        assert float((r[real] - wr[real]).abs().max()) < 3e-3 and float((psi - wpsi).abs().max()) < 3e-3
