@@ -510,7 +510,12 @@ def test_turbo_dims_training_step_vs_oracle(variant):
     watch = ["model.encoder.fddts.0.target_linear.weight", "model.encoder.fddts.31.non_target_linear.bias",
              "model.encoder.initial_fddt.silence_linear.weight", "model.encoder.layers.0.fc1.weight",
              "model.encoder.layers.31.self_attn.q_proj.weight", "model.encoder.layers.15.final_layer_norm.weight",
-             "model.encoder.conv1.weight", "model.encoder.layers.7.fc2.bias"]
+             "model.encoder.conv1.weight", "model.encoder.layers.7.fc2.bias",
+             # bias gradients come out of fused column sums (dgrad epilogue, attention backward, LayerNorm backward)
+             "model.encoder.layers.3.self_attn.q_proj.bias", "model.encoder.layers.3.self_attn.v_proj.bias",
+             "model.encoder.layers.20.fc1.bias", "model.encoder.layers.20.self_attn.out_proj.bias",
+             "model.encoder.layers.0.self_attn_layer_norm.bias", "model.encoder.embed_positions.weight"]
+    watch = [n for n in watch if dict(model.named_parameters())[n].requires_grad]
     if variant == "ctc":
         watch += ["model.encoder.lm_head.weight", "model.encoder.subsample_conv1.weight"]
     if variant == "se":
