@@ -299,3 +299,33 @@ def test_long_form_loop(pkg):
     segs_b = LongFormDecoder(model, num_beams=2).transcribe(feats[:1], stno[:1], max_frames[:1], p1, no_ts, eos_token_id=eos,
                                                             pad_token_id=499, max_new_tokens=8)
     assert len(segs_b) == 1
+
+
+def test_greedy_decode_at_turbo_dims_vs_oracle(pkg):
+    """whisper-large-v3-turbo dimensions, one 30 s window, 3 cached decoder steps (skinny weight-streaming GEMMs at the real N / K,
+    single-query attention over 1500 encoder frames): per-step scores vs the oracle's full-prefix forward."""
+    from ts_asr_whisper_amd.generation import GreedyDecoder
+    from oracle.dicow_oracle import OracleConfig
+    cfg = pkg.DiCoWConfig.preset("whisper-large-v3-turbo", use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True,
+                                 fddt_init="suppressive", non_target_fddt_value=0.5)
+    torch.manual_seed(0)
+    model = pkg.DiCoWForConditionalGeneration(cfg).eval()
+    state = {n: t.detach().clone() for n, t in model.state_dict().items()}
+    model = model.cuda()
+    model.tie_weights()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(1, cfg.num_mel_bins, 3000, generator=g).clamp_(-1.5, 1.5)
+    st = torch.softmax(torch.randn(1, 4, 1500, generator=g) * 2, 1)
+    prompt = torch.tensor([[50258, 50259, 50360]])
+    seq, scores = GreedyDecoder(model).generate(x.cuda(), st.cuda(), prompt, 3, eos_token_id=-1, return_scores=True)
+    ocfg = OracleConfig(**{k: v for k, v in cfg.to_dict().items() if k in OracleConfig.__dataclass_fields__})
+    p = dict(state)
+    p["proj_out.weight"] = p["model.decoder.embed_tokens.weight"]
+    with torch.no_grad():
+        enc = O.encoder_forward(p, ocfg, x, st, emu=True)
+        full = O.linear(O.decoder_forward(p, ocfg, seq[:, :-1].cpu(), enc, emu=True), p["proj_out.weight"], None, True).float()
+    for n in range(3):
+        want = full[:, prompt.shape[1] - 1 + n]
+        got = scores[n].float().cpu()
+        assert float((got - want).abs().max()) < 0.12, n
+        assert float(want.gather(1, seq[:, prompt.shape[1] + n].cpu()[:, None])) >= float(want.max()) - 0.25
