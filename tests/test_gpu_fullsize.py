@@ -374,6 +374,16 @@ def test_gemm_epilogues_at_bench_shapes_vs_torch(ops, N, K):
     act = torch.nn.functional.gelu(pre)
     act.sum().backward()
     assert float((C.float() - act.detach()).abs().max()) < 3e-2 and float((U.float() - pre.grad).abs().max()) < 2e-2
+    # the remaining compile-time epilogues of the step and the runtime-flag fallback kernel
+    ops.gemm_nt(A, W, C, M, N, K, bias=bias)
+    assert float((C.float() - (base + bias)).abs().max()) < 3e-2
+    ops.gemm_nt(A, W, C, M, N, K, bias=bias, flags=L.EPI_GELU)
+    assert float((C.float() - act.detach()).abs().max()) < 3e-2
+    ops.gemm_nt(A, W, C, M, N, K, aux=U, flags=L.EPI_MUL_AUX)
+    assert float((C.float() - base * U.float()).abs().max()) < 3e-2
+    P = (base + bias).bfloat16()
+    ops.gemm_nt(A, W, C, M, N, K, aux=P, flags=L.EPI_GELU_BWD)                       # not a compile-time set: runtime flags
+    assert float((C.float() - base * pre.grad).abs().max()) < 4e-2
     cs = torch.zeros(N, device="cuda")
     ops.gemm_nt(A, W, C, M, N, K, aux=U, flags=L.EPI_MUL_AUX, colsum_out=cs)
     want = base * U.float()
