@@ -57,3 +57,17 @@ def greedy_decode(p, cfg, input_features, stno_mask, prompt_ids, max_new_tokens,
         if not bool(unfinished.any()):
             break
     return ids, torch.stack(scores)
+
+
+@torch.no_grad()
+def detect_language(p, cfg, input_features, stno_mask, decoder_start_token_id, lang_token_ids, enrollments=None, emu=False):
+    """DiCoWGenerationMixin.detect_language (reference generation.py:151-221): one decoder position on the start token, with
+    the window's STNO mask (and enrollments) conditioning the encoder; every non-language logit is masked and the argmax is
+    the language token.  Returns (language ids int64 [B], fp32 logits [B, V] before masking)."""
+    enc = O.encoder_forward(p, cfg, input_features, stno_mask, enrollments=enrollments, emu=emu)
+    ids = torch.full((input_features.shape[0], 1), decoder_start_token_id, dtype=torch.long)
+    logits = O.linear(O.decoder_forward(p, cfg, ids, enc, emu=emu)[:, -1, :], p["proj_out.weight"], None, emu).float()
+    masked = torch.full_like(logits, -float("inf"))
+    lang = torch.as_tensor(list(lang_token_ids), dtype=torch.long)
+    masked[:, lang] = logits[:, lang]
+    return masked.argmax(-1), logits

@@ -50,3 +50,67 @@ def retrieve_segment(seq, time_offset, timestamp_begin, seek_num_frames, time_pr
     if offset <= 0:
         raise ValueError(f"segment offset {offset} <= 0")
     return segments, int(offset)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Global-time segments -> per-window timestamp tokens (reference generation.py:313-415, _fix_timestamps_from_segmentation)
+
+def _ticks_half_up(x):
+    """Seconds -> 0.02 s ticks the way the reference rounds them (generation.py:314-320: Decimal(str(x)), ROUND_HALF_UP)."""
+    from decimal import Decimal, ROUND_HALF_UP
+    return (Decimal(str(x)) / Decimal("0.02")).to_integral_value(rounding=ROUND_HALF_UP) * Decimal("0.02")
+
+
+def fold_segments(segments, first_timestamp_token, filler_token):
+    """One recording's segments [dict(start, end, tokens)] in recording time -> [(start, tokens, end)] in window time
+    (0..30 s), with the filler entries the reference inserts when a 30 s block boundary is crossed or blocks are skipped.
+    Follows the reference's Decimal arithmetic literally, including its inexact ``Decimal(-0.02)`` carry (generation.py:392)."""
+    from decimal import Decimal
+    W = 30
+    live = [s for s in segments if len(s["tokens"]) > 0 and not (len(s["tokens"]) == 1 and s["tokens"][0] == first_timestamp_token)]
+    out, prev_end, carry = [], None, Decimal(0.0)
+    for seg in live:
+        t0, t1 = _ticks_half_up(float(seg["start"])), _ticks_half_up(float(seg["end"]))
+        if prev_end is None:
+            out += [(0, [filler_token], 30)] * int(t0 // W)
+        else:
+            here, before = (t0 + carry) // W, (prev_end - Decimal("0.001")) // W
+            if here > before:
+                out.append((30, [filler_token], 30))
+            out += [(0, [filler_token], 30)] * max(int(here - before - 1), 0)
+        a, b = t0 + carry, t1 + carry
+        if a // W == b // W:
+            out.append((a % W, seg["tokens"], b % W))
+        elif b % W == 0:
+            out.append((a % W, seg["tokens"], 30))
+            carry = Decimal(0.0)
+        else:
+            s_new, e_new = a % W, b % W
+            if t1 - t0 == 30.0:
+                if float(s_new) % 30.0 == 0.0:
+                    e_new, carry = Decimal(30.0), Decimal(0.0)
+                else:
+                    carry = Decimal(-0.02)
+                    e_new += carry
+            else:
+                carry = Decimal(0.0)
+            out.append((s_new, seg["tokens"], e_new))
+        prev_end = t1 + carry
+    return out
+
+
+def folded_to_ids(folded, first_timestamp_token):
+    """[(start, tokens, end)] -> token ids ``<|start|> text... <|end|>`` per entry.  The reference goes through the tokenizer
+    (generation.py:402-405: format '<|%.2f|>', decode, re-encode); with a tokenizer whose decode/encode round trip is the
+    identity on text tokens that equals this direct mapping (timestamp ids inside ``tokens`` are dropped by decode())."""
+    ids = []
+
+    def stamp(x):
+        text = f"{x:.2f}"
+        if text.startswith("-"):          # the inexact carry can leave -4e-19, printed '<|-0.00|>': not a timestamp token
+            return []
+        return [first_timestamp_token + int(round(float(text) / 0.02))]
+
+    for s, toks, e in folded:
+        ids += stamp(s) + [t for t in toks if t < first_timestamp_token] + stamp(e)
+    return ids

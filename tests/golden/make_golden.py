@@ -751,9 +751,81 @@ def f16_retrieve_segment():
     save("f16_retrieve_segment", **arrs)
 
 
+def f17_fix_timestamps():
+    """DiCoWGenerationMixin._fix_timestamps_from_segmentation (src/models/dicow/generation.py:313-415): recording-time segments
+    -> window-time (0..30 s) timestamp token sequences.  The method only touches ``self.tokenizer``; a stand-in tokenizer whose
+    decode/encode round trip is the identity on text ids makes the result a pure function of the segment times."""
+    import re
+    import types
+    from models.dicow.generation import DiCoWGenerationMixin as G
+    TS0, FILL, PAD = 1000, 7, 0
+
+    class Tok:
+        pad_token_id = PAD
+
+        def get_vocab(self):
+            return {"<|0.00|>": TS0, "\u0120": FILL}
+
+        def decode(self, ids):
+            return "".join(f"[{int(t)}]" for t in ids if int(t) < TS0)            # Whisper's decode() drops timestamp ids
+
+        def __call__(self, text):
+            ids = []
+            for m in re.finditer(r"<\|(\d+\.\d\d)\|>|\[(\d+)\]", text):
+                ids.append(TS0 + int(round(float(m.group(1)) / 0.02)) if m.group(1) is not None else int(m.group(2)))
+            return {"input_ids": ids}
+
+    me = types.SimpleNamespace(tokenizer=Tok(), round_to_nearest_0_02=G.round_to_nearest_0_02)
+    rng = np.random.default_rng(17)
+    arrs, n = {}, 0
+
+    def emit(segs):
+        nonlocal n
+        seqs = {"segments": [[{"start": torch.tensor(a, dtype=torch.float64), "end": torch.tensor(b, dtype=torch.float64),
+                               "tokens": torch.tensor(t, dtype=torch.long)} for a, b, t in segs]],
+                "sequences": torch.zeros(1, 1, dtype=torch.long)}
+        out = G._fix_timestamps_from_segmentation(me, seqs)
+        arrs[f"c{n}.start"], arrs[f"c{n}.end"] = np.array([a for a, _, _ in segs]), np.array([b for _, b, _ in segs])
+        arrs[f"c{n}.ntok"] = np.array([len(t) for _, _, t in segs])
+        arrs[f"c{n}.tokens"] = np.array([x for _, _, t in segs for x in t], dtype=np.int64)
+        arrs[f"c{n}.ids"] = out[0].numpy()
+        n += 1
+
+    def toks():
+        k = int(rng.integers(1, 5))
+        return [TS0 + 3] + [int(x) for x in rng.integers(10, 900, k)] + [TS0 + 40]
+
+    # crafted: boundary hits, exact 30 s segments, skipped blocks, late first segment, dropped segments, half-tick rounding
+    emit([(0.0, 30.0, toks()), (30.0, 60.0, toks()), (60.0, 61.5, toks())])
+    emit([(12.34, 42.34, toks()), (42.34, 50.0, toks()), (59.98, 60.02, toks())])
+    emit([(65.0, 70.0, toks()), (200.0, 201.0, toks())])
+    emit([(1.0, 2.0, []), (2.0, 3.0, [TS0]), (3.0, 29.5, toks()), (29.5, 30.5, toks()), (95.0, 125.0, toks())])
+    emit([(0.01, 0.03, toks()), (0.05, 29.99, toks()), (29.99, 30.01, toks())])
+    emit([(29.98, 59.98, toks()), (59.98, 89.98, toks()), (90.0, 90.5, toks())])
+    emit([(10.0, 40.0, toks()), (40.0, 70.0, toks()), (70.0, 70.02, toks()), (89.98, 119.98, toks())])
+    for _ in range(240):
+        t, segs = float(rng.integers(0, 2500)) * 0.02 * float(rng.random() < 0.7), []
+        for _ in range(int(rng.integers(1, 9))):
+            r = rng.random()
+            if r < 0.25:
+                t += float(rng.integers(0, 4000)) * 0.02                       # silence, possibly several blocks long
+            if rng.random() < 0.15:
+                t = max(float(np.ceil(t / 30.0)) * 30.0 - (0.02 if rng.random() < 0.4 else 0.0), 0.0)      # sit on / just before a boundary
+            r = rng.random()
+            d = 30.0 if r < 0.2 else (float(np.ceil((t + 0.02) / 30.0)) * 30.0 - t if r < 0.35 else float(rng.integers(1, 1400)) * 0.02)
+            a, b = round(t, 2), round(t + d, 2)
+            if rng.random() < 0.1:
+                a, b = a + 0.01, b + 0.01                                       # odd hundredths: the half-up rounding
+            segs.append((a, b, toks() if rng.random() > 0.08 else ([TS0] if rng.random() < 0.5 else [])))
+            t = b
+        emit(segs)
+    arrs["n_cases"], arrs["first_timestamp"], arrs["filler"], arrs["pad"] = np.array(n), np.array(TS0), np.array(FILL), np.array(PAD)
+    save("f17_fix_timestamps", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12", "f13", "f14", "f15", "f16"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12", "f13", "f14", "f15", "f16", "f17"]
     fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
-           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules, "f15": f15_beam_search, "f16": f16_retrieve_segment}
+           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules, "f15": f15_beam_search, "f16": f16_retrieve_segment, "f17": f17_fix_timestamps}
     for w in which:
         fns[w]()

@@ -329,3 +329,32 @@ def test_greedy_decode_at_turbo_dims_vs_oracle(pkg):
         got = scores[n].float().cpu()
         assert float((got - want).abs().max()) < 0.12, n
         assert float(want.gather(1, seq[:, prompt.shape[1] + n].cpu()[:, None])) >= float(want.max()) - 0.25
+
+
+def test_detect_language_vs_oracle(pkg):
+    """One decoder position on the start token, non-language logits masked (reference generation.py:151-221): logits within the
+    bf16-path tolerance of the oracle, the chosen language is the oracle's wherever its margin exceeds that tolerance, and
+    model.detect_language reuses the STNO mask kept by generate()."""
+    from types import SimpleNamespace
+    from ts_asr_whisper_amd.generation import GreedyDecoder
+    z, model, cfg, x, st, prompt = _setup(pkg)
+    langs = [30, 31, 32, 33, 40, 41]
+    got, logits = GreedyDecoder(model).detect_language(x.cuda(), st.cuda(), langs, return_logits=True)
+    ocfg, p = golden_cfg(z), golden_params(z)
+    want, ologits = ogen.detect_language(p, ocfg, x, st, cfg.decoder_start_token_id, langs, emu=True)
+    tol = 6e-2
+    assert float((logits.float().cpu() - ologits).abs().max()) < tol
+    assert all(int(g) in langs for g in got)
+    sub = ologits[:, langs]
+    top2 = sub.topk(2, dim=-1).values
+    for b in range(x.shape[0]):
+        if float(top2[b, 0] - top2[b, 1]) > 2 * tol:
+            assert int(got[b]) == int(want[b])
+        assert float(sub[b].max() - ologits[b, int(got[b])]) <= 2 * tol
+    gc = SimpleNamespace(lang_to_id={f"<|l{i}|>": t for i, t in enumerate(langs)}, decoder_start_token_id=cfg.decoder_start_token_id,
+                         eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id)
+    model.generate(input_features=x.cuda(), stno_mask=st.cuda(), decoder_input_ids=prompt, max_new_tokens=2, generation_config=gc)
+    again = model.detect_language(input_features=x.cuda(), generation_config=gc)
+    assert torch.equal(again.cpu(), got.cpu())
+    with pytest.raises(Exception):
+        GreedyDecoder(model).detect_language(x, st, langs)                      # CPU tensors: no fallback

@@ -226,3 +226,35 @@ def test_product_retrieve_segment_matches_reference_golden():
     from tests.test_oracle_vs_golden import _check_retrieve
     from ts_asr_whisper_amd.generation import retrieve_segment
     _check_retrieve(retrieve_segment)
+
+
+def test_product_fix_timestamps_matches_reference_golden_and_oracle():
+    """Integer-tick folding of recording-time segments into 30 s windows: exact against golden F17, and against the oracle's
+    Decimal restatement on a few thousand further random recordings (block boundaries, exact 30 s segments, long gaps)."""
+    from tests.test_oracle_vs_golden import _f17_cases
+    from oracle.longform import fold_segments, folded_to_ids
+    from ts_asr_whisper_amd.generation import fix_timestamps_from_segmentation
+    recs, wants = [], []
+    for c, segs, want, ts0, fill, pad in _f17_cases():
+        assert fix_timestamps_from_segmentation([segs], ts0, fill, pad)[0].tolist() == want, c
+        recs.append(segs), wants.append(want)
+    batch = fix_timestamps_from_segmentation(recs[:9], ts0, fill, pad, prefix_ids=(3, 4), suffix_ids=(5,))     # padding / specials
+    for row, want in zip(batch.tolist(), wants[:9]):
+        assert row[:len(want) + 3] == [3, 4] + want + [5] and all(x == pad for x in row[len(want) + 3:])
+    rng = np.random.default_rng(170)
+    for _ in range(3000):
+        t, segs = int(rng.integers(0, 3000)) * int(rng.random() < 0.6), []
+        for _ in range(int(rng.integers(1, 10))):
+            if rng.random() < 0.3:
+                t += int(rng.integers(0, 5000))
+            if rng.random() < 0.2:
+                t = max(-(-t // 1500) * 1500 - int(rng.integers(0, 3)), 0)
+            r = rng.random()
+            d = 1500 if r < 0.25 else (-(-(t + 1) // 1500) * 1500 - t if r < 0.4 else int(rng.integers(1, 1600)))
+            odd = 0.01 if rng.random() < 0.1 else 0.0
+            segs.append(dict(start=round(t * 0.02 + odd, 2), end=round((t + d) * 0.02 + odd, 2),
+                             tokens=[1003] + [int(x) for x in rng.integers(10, 900, 2)] + [1040]))
+            t += d
+        want = folded_to_ids(fold_segments(segs, 1000, 7), 1000)
+        assert fix_timestamps_from_segmentation([segs], 1000, 7, 0)[0].tolist() == want, segs
+    assert fix_timestamps_from_segmentation([[]], 1000, 7, 0).shape == (1, 0)

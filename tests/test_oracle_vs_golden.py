@@ -347,3 +347,25 @@ def _check_retrieve(fn):
 def test_f16_retrieve_segment_oracle():
     from oracle.longform import retrieve_segment
     _check_retrieve(retrieve_segment)
+
+
+# ------------------------------------------------------------------------------------------------ F17: window-relative timestamps
+def _f17_cases():
+    z = load_golden("f17_fix_timestamps")
+    for c in range(int(z["n_cases"])):
+        nt = z[f"c{c}.ntok"]
+        off = np.concatenate([[0], np.cumsum(nt)]).astype(int)
+        tk = z[f"c{c}.tokens"]
+        segs = [dict(start=float(z[f"c{c}.start"][i]), end=float(z[f"c{c}.end"][i]), tokens=[int(x) for x in tk[off[i]:off[i + 1]]])
+                for i in range(len(nt))]
+        yield c, segs, [int(x) for x in z[f"c{c}.ids"]], int(z["first_timestamp"]), int(z["filler"]), int(z["pad"])
+
+
+def test_f17_fix_timestamps_oracle():
+    """247 recordings folded by the reference's _fix_timestamps_from_segmentation (stand-in tokenizer): exact ids."""
+    from oracle.longform import fold_segments, folded_to_ids
+    n = 0
+    for c, segs, want, ts0, fill, _ in _f17_cases():
+        assert folded_to_ids(fold_segments(segs, ts0, fill), ts0) == want, c
+        n += 1
+    assert n > 200

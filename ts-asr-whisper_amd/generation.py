@@ -148,6 +148,24 @@ class GreedyDecoder:
         return st
 
     @torch.no_grad()
+    def detect_language(self, input_features, stno_mask, lang_token_ids, decoder_start_token_id=None, enrollments=None,
+                        return_logits=False):
+        """DiCoWGenerationMixin.detect_language (reference src/models/dicow/generation.py:151-221): the encoder runs on the
+        first window with its STNO mask (and enrollments), the decoder runs position 0 on the start token, every logit that is
+        not a language token (``generation_config.lang_to_id.values()``) is masked and the argmax is returned ([B] int64)."""
+        cfg = self.cfg
+        n = 2 * cfg.max_source_positions
+        st = self.encode(input_features[:, :, :n].contiguous(), stno_mask[:, :, :n // 2].contiguous(), enrollments)
+        start = cfg.decoder_start_token_id if decoder_start_token_id is None else decoder_start_token_id
+        ids = torch.full((st.B,), start, dtype=torch.long, device=input_features.device)
+        logits = self._step(ids, 0, st).float()
+        lang = torch.as_tensor(list(lang_token_ids), dtype=torch.long, device=logits.device)
+        masked = torch.full_like(logits, float("-inf"))
+        masked[:, lang] = logits[:, lang]
+        best = masked.argmax(-1)
+        return (best, logits) if return_logits else best
+
+    @torch.no_grad()
     def beam_search(self, input_features, stno_mask, decoder_input_ids, max_length, num_beams, eos_token_id=None, pad_token_id=None,
                     length_penalty=1.0, early_stopping=False, suppress_tokens=None, begin_suppress_tokens=None, enrollments=None,
                     timestamps=None, ctc=None):
@@ -347,6 +365,93 @@ def retrieve_segment(seq, time_offset, timestamp_begin, seek_num_frames, time_pr
     if offset <= 0:
         raise ValueError(f"Segment offset: {offset} <= 0. This should not happen!")
     return segments, int(offset)
+
+
+_UNITS_PER_TICK = 100                  # integer time base of fix_timestamps_from_segmentation: 0.02 s = 100 units
+_WINDOW_UNITS = 1500 * _UNITS_PER_TICK   # one 30 s window
+_CARRY = -(_UNITS_PER_TICK + 1)         # the reference's Decimal(-0.02): one tick and a hair (4e-19 s) below zero
+
+
+def _seconds_to_ticks(x):
+    """Seconds -> 0.02 s ticks, half-up on the shortest decimal form of the float (what Decimal(str(x)) / ROUND_HALF_UP of
+    reference generation.py:314-320 computes), in exact rational arithmetic."""
+    from fractions import Fraction
+    return int((Fraction(str(float(x))) * 50 + Fraction(1, 2)) // 1)
+
+
+def fold_segments_to_windows(segments, first_timestamp_token, filler_token):
+    """One recording's segments [dict(start, end, tokens)] (recording time, seconds) -> [(start, tokens, end)] with times in
+    window-relative 0.02 s ticks (0..1500) or None for a stamp the reference prints as '<|-0.00|>' (not a timestamp token).
+    Behaviour of DiCoWGenerationMixin._fix_timestamps_from_segmentation (reference generation.py:322-400) in integer
+    arithmetic: a (30, filler, 30) entry is inserted when a 30 s block boundary is crossed, (0, filler, 30) entries bridge
+    skipped blocks, a segment that is exactly 30 s long and would wrap is shortened by one tick and that tick is carried into
+    the following segments.  The reference's carry is the inexact Decimal(-0.02) (a hair more than one tick); it decides block
+    membership of times that land exactly on a boundary, so it is modelled as one extra unit at 100 units per tick.  Pinned by
+    golden F17 (247 recordings run through the reference method)."""
+    U, W = _UNITS_PER_TICK, _WINDOW_UNITS
+    filler = [filler_token]
+    out, prev_end, carry = [], None, 0
+
+    def tick(u):
+        return None if u < 0 else (u + U // 2) // U
+
+    for seg in segments:
+        toks = [int(t) for t in seg["tokens"]]
+        if not toks or toks == [first_timestamp_token]:
+            continue
+        t0, t1 = _seconds_to_ticks(seg["start"]), _seconds_to_ticks(seg["end"])
+        a, b = t0 * U + carry, t1 * U + carry
+        if a < 0:
+            raise ValueError("fold_segments_to_windows: negative segment start")
+        if prev_end is None:
+            out += [(0, filler, 1500)] * (t0 // 1500)
+        else:
+            here, before = a // W, max(prev_end - U // 20, 0) // W          # 1 ms below the previous end (generation.py:362)
+            if here > before:
+                out.append((1500, filler, 1500))
+            out += [(0, filler, 1500)] * max(here - before - 1, 0)
+        if a // W == b // W:
+            out.append((tick(a % W), toks, tick(b % W)))
+        elif b % W == 0:
+            out.append((tick(a % W), toks, 1500))
+            carry = 0
+        else:
+            lo, hi = a % W, b % W
+            if t1 - t0 == 1500:
+                if lo == 0 or lo >= W - 2:                                   # float(lo) % 30.0 == 0.0 in the reference
+                    hi, carry = W, 0
+                else:
+                    carry = _CARRY
+                    hi += carry
+            else:
+                carry = 0
+            out.append((tick(lo), toks, tick(hi)))
+        prev_end = t1 * U + carry
+    return out
+
+
+def fix_timestamps_from_segmentation(segments, first_timestamp_token, filler_token, pad_token_id, prefix_ids=(), suffix_ids=(),
+                                     device=None):
+    """segments: per recording, the [dict(start, end, tokens)] list LongFormDecoder.transcribe returns.  Returns a padded
+    LongTensor [recordings, L] of ``prefix <|start|> text <|end|> ... suffix`` with window-relative timestamp tokens
+    (reference generation.py:322-415).  The reference builds the text '<|s|>' + decode(tokens) + '<|e|>' and re-encodes it with the
+    tokenizer (which adds its prefix / eos: pass them as prefix_ids / suffix_ids); here the ids are written directly --
+    timestamp ids inside ``tokens`` are dropped exactly as Whisper's decode() drops them, text ids are kept as they are."""
+    rows = []
+    for rec in segments:
+        ids = list(prefix_ids)
+        for s, toks, e in fold_segments_to_windows(rec, first_timestamp_token, filler_token):
+            if s is not None:
+                ids.append(first_timestamp_token + s)
+            ids += [t for t in toks if t < first_timestamp_token]
+            if e is not None:
+                ids.append(first_timestamp_token + e)
+        rows.append(ids + list(suffix_ids))
+    L_ = max((len(r) for r in rows), default=0)
+    out = torch.full((len(rows), L_), pad_token_id, dtype=torch.long, device=device)
+    for i, r in enumerate(rows):
+        out[i, :len(r)] = torch.tensor(r, dtype=torch.long)
+    return out
 
 
 class LongFormDecoder:

@@ -659,6 +659,7 @@ class DiCoWForConditionalGeneration(nn.Module):
         gc = generation_config if generation_config is not None else self.generation_config
         get = (lambda k, d=None: getattr(gc, k, d) if gc is not None else d)
         beams = max(num_beams or 1, get("num_beams", 1) or 1)
+        self.stno_mask = stno_mask                            # reference generate() keeps it for detect_language (generation.py:556)
         if input_features.shape[-1] != 2 * self.config.max_source_positions:
             raise NotImplementedError("long-form inputs: use generation.LongFormDecoder(model, num_beams).transcribe(...) "
                                       "(sequential seek loop; returns timed segments per recording)")
@@ -696,6 +697,21 @@ class DiCoWForConditionalGeneration(nn.Module):
                                       eos_token_id=get("eos_token_id", cfg.eos_token_id), pad_token_id=get("pad_token_id", cfg.pad_token_id),
                                       suppress_tokens=get("suppress_tokens"), begin_suppress_tokens=get("begin_suppress_tokens"),
                                       enrollments=enrollments, ctc=ctc, timestamps=timestamps)
+
+    def detect_language(self, input_features=None, stno_mask=None, generation_config=None, enrollments=None,
+                        num_segment_frames=None, lang_token_ids=None):
+        """Language id per row from one decoder position (reference generation.py:151-221).  ``stno_mask`` defaults to the one
+        stored by the last generate() call, as in the reference; language tokens come from ``generation_config.lang_to_id``."""
+        from .generation import GreedyDecoder
+        gc = generation_config if generation_config is not None else self.generation_config
+        if lang_token_ids is None:
+            lang_token_ids = list(getattr(gc, "lang_to_id").values())
+        if stno_mask is None:
+            stno_mask = self.stno_mask
+        if not hasattr(self, "_decoder"):
+            self._decoder = GreedyDecoder(self)
+        start = getattr(gc, "decoder_start_token_id", None) if gc is not None else None
+        return self._decoder.detect_language(input_features, stno_mask, lang_token_ids, start, enrollments)
 
     def post_init(self):
         self.tie_weights()
