@@ -146,6 +146,9 @@ def pmc_traffic():
         return None
 
 
+PEAK_MEASURED = 2115.8      # TFLOP/s, MFMA-only micro-benchmark on the MI355X box (SURVEY 8d asks for both peaks)
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -224,6 +227,9 @@ def main():
         "loss": float(loss),
         "roofline": {"bound": "mfma", "kernel": "gemm_ntw_kernel (persistent 256x256 / 192x320) / gemm_nt_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
                      "achieved": round(nt["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(nt["tflops"] / peak, 4),
+                     "peak_measured": PEAK_MEASURED, "frac_of_measured": round(nt["tflops"] / PEAK_MEASURED, 4),
+                     "peak_measured_source": "profiles/r01_probe_clock.txt: register-resident 32x32x16 bf16 MFMA loop on 256 CUs, best of 3 "
+                                             "(32.0 cycles/MFMA; the shader clock settles at 2.0-2.1 GHz under full MFMA load)",
                      "traffic": pmc_traffic(), "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // a.steps,
                      "share_of_step": round(nt["total_ms"] / (dt * 1e3), 3),
                      "traffic_source": "profiles/r01g_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
@@ -257,6 +263,7 @@ def main():
         out["encoder_forward"] = {"ms": round(enc_ms, 2), "batch": a.batch,
                                   "tflops": None if enc_flops is None else round(enc_flops / enc_ms / 1e9, 1),
                                   "mfma_frac": None if enc_flops is None else round(enc_flops / enc_ms / 1e9 / peak, 4),
+                                  "mfma_frac_of_measured_peak": None if enc_flops is None else round(enc_flops / enc_ms / 1e9 / PEAK_MEASURED, 4),
                                   "note": "encoder forward only, torch.no_grad(), algorithmic FLOPs of SURVEY 8d / dense bf16 peak 2.5 PF"}
     except Exception as ex:
         out["encoder_forward"] = {"ms": None, "note": f"failed: {ex!r}"}
