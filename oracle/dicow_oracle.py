@@ -62,6 +62,7 @@ class OracleConfig:
     scb_layers: Optional[int] = None
     ctc_weight: float = 0.0
     additional_self_attention_layer: bool = False
+    additional_layer: bool = False
     pre_ctc_sub_sample: bool = False
     remove_timestamps_from_ctc: bool = False
     ctc_loss_reduction: str = "mean"
@@ -327,7 +328,10 @@ def ctc_logits(p: Dict[str, T], cfg: OracleConfig, enc: T, emu: bool = False) ->
     """get_enc_logits (modeling_dicow.py:242-246) -> possibly_update_last_hidden_states (encoder.py:87-106)."""
     e = "model.encoder."
     h = enc
-    if cfg.additional_self_attention_layer:
+    if cfg.additional_layer:
+        # a full pre-LN encoder layer (residuals included) takes precedence over the bare attention: encoder.py:88-94
+        h = encoder_layer(h, p, e + "additional_layer.", cfg.encoder_attention_heads, emu)
+    elif cfg.additional_self_attention_layer:
         # the attention output REPLACES the hidden states (no residual, no LayerNorm): encoder.py:95-101
         h = attention(h, h, p, e + "additional_self_attention_layer.", cfg.encoder_attention_heads, False, emu)
     if cfg.pre_ctc_sub_sample:

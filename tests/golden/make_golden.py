@@ -220,7 +220,7 @@ def small_cfg(**over):
     return DiCoWConfig(**kw)
 
 
-CFG_KEYS = ["additional_self_attention_layer", "pre_ctc_sub_sample", "remove_timestamps_from_ctc", "ctc_loss_reduction",
+CFG_KEYS = ["additional_self_attention_layer", "additional_layer", "pre_ctc_sub_sample", "remove_timestamps_from_ctc", "ctc_loss_reduction",
             "eos_token_id", "vocab_size", "num_mel_bins", "d_model", "encoder_layers", "encoder_attention_heads", "decoder_layers",
             "decoder_attention_heads", "encoder_ffn_dim", "decoder_ffn_dim", "max_source_positions",
             "max_target_positions", "pad_token_id", "decoder_start_token_id", "use_fddt", "fddt_is_diagonal",
@@ -413,6 +413,34 @@ def f10_ctc():
         if p.grad is not None and ("encoder" in n) and n != "proj_out.weight":
             arrs["g." + n] = p.grad
     save("f10_ctc", **arrs)
+
+
+def f10b_ctc_extra_layer():
+    """The other CTC-branch variant (encoder.py:16-17,88-94): ``additional_layer`` -- a full extra WhisperEncoderLayer between
+    the encoder output and the subsampling convolutions.  Same recipe as F10; the CTC logits are stored every 6th frame."""
+    cfg = small_cfg(vocab_size=2048, pad_token_id=2000, bos_token_id=2000, eos_token_id=2000, decoder_start_token_id=2001,
+                    ctc_weight=0.3, pre_ctc_sub_sample=True, additional_layer=True, additional_self_attention_layer=False,
+                    remove_timestamps_from_ctc=True, encoder_layers=1, decoder_layers=1)
+    torch.manual_seed(14)
+    model = DiCoWForConditionalGeneration(cfg).eval()
+    randomize_(model, 11)
+    tok = StubTokenizer(cfg.vocab_size, 600, 100)
+    tok.prefix_tokens = [2001]
+    model.set_tokenizer(tok)
+    x, st, lab, upp = make_inputs(cfg, B=2, L=10, seed=91, ts_range=(600, 100))
+    lab[1, 6:] = -100
+    upp[1, 6:] = -100
+    out = run_model(model, dict(input_features=x, stno_mask=st, labels=lab, upp_labels=upp))
+    out.loss.backward()
+    enc_logits = model.get_enc_logits(out.encoder_last_hidden_state)
+    arrs = {"cfg": np.array(repr(cfg_dict(cfg))), "x": x, "stno": st, "labels": lab, "upp_labels": upp, "loss": out.loss,
+            "enc_logits_sub": enc_logits[:, ::6], "ts_start": np.array(600), "ts_n": np.array(100), "prefix": np.array([2001])}
+    for n, p in model.state_dict().items():
+        arrs["p." + n] = p
+    for n, p in model.named_parameters():
+        if p.grad is not None and ("encoder" in n) and n != "proj_out.weight":
+            arrs["g." + n] = p.grad
+    save("f10b_ctc_extra_layer", **arrs)
 
 
 # ----------------------------------------------------------------------------- F11: collator augmentations (SURVEY 8 f3)
@@ -824,8 +852,8 @@ def f17_fix_timestamps():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f11", "f12", "f13", "f14", "f15", "f16", "f17"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f10b", "f11", "f12", "f13", "f14", "f15", "f16", "f17"]
     fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
-           "f8": f8_se, "f10": f10_ctc, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules, "f15": f15_beam_search, "f16": f16_retrieve_segment, "f17": f17_fix_timestamps}
+           "f8": f8_se, "f10": f10_ctc, "f10b": f10b_ctc_extra_layer, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules, "f15": f15_beam_search, "f16": f16_retrieve_segment, "f17": f17_fix_timestamps}
     for w in which:
         fns[w]()

@@ -184,9 +184,11 @@ def test_cpu_tensors_are_refused(pkg):
         m(torch.randn(1, 4, 128), torch.rand(1, 4, 4))
 
 
-def test_f10_ctc_branch(pkg):
-    """Recipe-default CTC auxiliary branch vs the reference golden (fp32) -- loss and every encoder gradient."""
-    z = load_golden("f10_ctc")
+@pytest.mark.parametrize("fixture", ["f10_ctc", "f10b_ctc_extra_layer"])
+def test_f10_ctc_branch(pkg, fixture):
+    """CTC auxiliary branch vs the reference golden (fp32) -- loss and every encoder gradient; F10: the recipe default (extra
+    self-attention), F10b: ``additional_layer`` (a full extra encoder layer, strict key surface incl. its parameters)."""
+    z = load_golden(fixture)
     model, cfg = build_model(pkg, z)
 
     class Tok:
@@ -209,10 +211,12 @@ def test_f10_ctc_branch(pkg):
     print("worst CTC-model grad rel err:", worst)
 
 
-def test_ctc_pretraining_api_return_logits_and_get_loss(pkg):
+@pytest.mark.parametrize("fixture", ["f10_ctc", "f10b_ctc_extra_layer"])
+def test_ctc_pretraining_api_return_logits_and_get_loss(pkg, fixture):
     """The encoder-only CTC pre-training path (src/utils/trainers.py:76-101): ``encoder(..., return_logits=True).logits`` ->
-    ``encoder.get_loss(logits, labels)`` -> backward, vs the oracle (pinned by golden F10) with the same bf16 rounding points."""
-    z = load_golden("f10_ctc")
+    ``encoder.get_loss(logits, labels)`` -> backward, vs the oracle (pinned by goldens F10 / F10b) with the same bf16 rounding
+    points."""
+    z = load_golden(fixture)
     model, cfg = build_model(pkg, z)
     enc = model.model.encoder
     x, st, lab = T(z, "x"), T(z, "stno"), T(z, "labels")

@@ -228,6 +228,61 @@ def heads(t, B, Lx, H):
 
 
 # ------------------------------------------------------------------------------------------------ encoder
+def plain_layer_fwd(lyr, w, h, B, T, H, F_):
+    """One pre-LN Whisper encoder layer without FDDT / SCB on fp32 rows ``h`` [B*T, D] (HF WhisperEncoderLayer; the CTC
+    branch's ``additional_layer``, reference encoder.py:16-17,88-94).  Returns (fp32 rows, saved activations)."""
+    rows, D = h.shape
+    dev = h.device
+    s = NS(h_in=h)
+    s.xln, s.mean, s.rstd = _e((rows, D), BF16, dev), _e((rows,), F32, dev), _e((rows,), F32, dev)
+    ln = lyr.self_attn_layer_norm
+    ops.fddt_ln_fwd(h, rows, D, mode=ops.MODE_NONE, ln_w=ln.weight.detach(), ln_b=ln.bias.detach(), y_bf16=s.xln, mean=s.mean,
+                    rstd=s.rstd)
+    s.qkv = linear_fwd(s.xln, w.att.qkv, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+    s.o, s.lse = _e((rows, D), BF16, dev), _e((B, H, T), F32, dev)
+    ops.attn_fwd(heads(s.qkv[:, :D], B, T, H), heads(s.qkv[:, D:2 * D], B, T, H), heads(s.qkv[:, 2 * D:], B, T, H),
+                 heads(s.o, B, T, H), s.lse)
+    s.h2 = linear_fwd(s.o, w.att.o, rows, out_dtype=F32, residual=h)
+    s.xln2, s.mean2, s.rstd2 = _e((rows, D), BF16, dev), _e((rows,), F32, dev), _e((rows,), F32, dev)
+    ln2 = lyr.final_layer_norm
+    ops.fddt_ln_fwd(s.h2, rows, D, mode=ops.MODE_NONE, ln_w=ln2.weight.detach(), ln_b=ln2.bias.detach(), y_bf16=s.xln2,
+                    mean=s.mean2, rstd=s.rstd2)
+    s.u = _e((rows, F_), BF16, dev)
+    s.a = linear_fwd(s.xln2, w.fc1, rows, gelu_aux=s.u)
+    return linear_fwd(s.a, w.fc2, rows, out_dtype=F32, residual=s.h2), s
+
+
+def plain_layer_bwd(lyr, w, s, gb, G, B, T, H):
+    """Backward of plain_layer_fwd.  gb: bf16 rows, gradient wrt the layer output.  Returns the fp32 gradient wrt its input."""
+    rows, D = gb.shape
+    dev = gb.device
+    g = gb.float()
+    bias_grad(gb, G.get(lyr.fc2.bias))
+    linear_wgrad(gb, s.a, G.get(lyr.fc2.weight), rows)
+    d_u = linear_dgrad(gb, w.fc2, rows, aux=s.u, colsum_out=G.get(lyr.fc1.bias))
+    linear_wgrad(d_u, s.xln2, G.get(lyr.fc1.weight), rows)
+    d_xln2 = linear_dgrad(d_u, w.fc1, rows)
+    g2, g2b = _e((rows, D), F32, dev), _e((rows, D), BF16, dev)
+    ln2, att = lyr.final_layer_norm, lyr.self_attn
+    ops.fddt_ln_bwd(s.h2, rows, D, mode=ops.MODE_NONE, ln_w=ln2.weight.detach(), mean=s.mean2, rstd=s.rstd2, d_y=d_xln2, g_res=g,
+                    g_out=g2, g_out_bf16=g2b, dln_w=G.get(ln2.weight), dln_b=G.get(ln2.bias), colsum_out=G.get(att.out_proj.bias))
+    linear_wgrad(g2b, s.o, G.get(att.out_proj.weight), rows)
+    d_o = linear_dgrad(g2b, w.att.o, rows)
+    d_qkv, delta = _e((rows, 3 * D), BF16, dev), _e((2, B, H, T), F32, dev)
+    qkv = s.qkv
+    ops.attn_bwd(heads(qkv[:, :D], B, T, H), heads(qkv[:, D:2 * D], B, T, H), heads(qkv[:, 2 * D:], B, T, H),
+                 heads(s.o, B, T, H), heads(d_o, B, T, H), s.lse, delta, heads(d_qkv[:, :D], B, T, H),
+                 heads(d_qkv[:, D:2 * D], B, T, H), heads(d_qkv[:, 2 * D:], B, T, H), dq_scale=0.125,
+                 dq_colsum=G.get(att.q_proj.bias), dv_colsum=G.get(att.v_proj.bias))
+    qkv_wgrad(d_qkv, s.xln, G.get(att.q_proj.weight), G.get(att.k_proj.weight), G.get(att.v_proj.weight), rows, D)
+    d_xln = linear_dgrad(d_qkv, w.att.qkv, rows)
+    g0 = _e((rows, D), F32, dev)
+    ln = lyr.self_attn_layer_norm
+    ops.fddt_ln_bwd(s.h_in, rows, D, mode=ops.MODE_NONE, ln_w=ln.weight.detach(), mean=s.mean, rstd=s.rstd, d_y=d_xln, g_res=g2,
+                    g_out=g0, dln_w=G.get(ln.weight), dln_b=G.get(ln.bias))
+    return g0
+
+
 class EncoderEngine:
     def __init__(self, enc):
         self.enc = enc
@@ -779,6 +834,12 @@ class CtcEngine:
         D = cfg.d_model
         W = NS()
         W.att = prep_attention(enc.additional_self_attention_layer, dev) if hasattr(enc, "additional_self_attention_layer") else None
+        W.lyr = None
+        if hasattr(enc, "additional_layer"):                 # takes precedence over the bare attention (encoder.py:88-95)
+            lyr = enc.additional_layer
+            W.lyr = NS(att=prep_attention(lyr.self_attn, dev), fc1=prep_linear([lyr.fc1.weight], [lyr.fc1.bias], dev),
+                       fc2=prep_linear([lyr.fc2.weight], [lyr.fc2.bias], dev))
+            W.att = None
         if hasattr(enc, "subsample_conv1"):
             W.c1, W.c1_t = ops.conv_weight_pack(enc.subsample_conv1.weight.detach(), 3 * D, want_t=True)
             W.c2, W.c2_t = ops.conv_weight_pack(enc.subsample_conv2.weight.detach(), 3 * D, want_t=True)
@@ -787,10 +848,10 @@ class CtcEngine:
         self.W = W
         return W
 
-    def forward(self, enc_bf, B, T, labels):
+    def forward(self, enc_bf, B, T, labels, enc_f32=None):
         cfg, W = self.cfg, self.W
         dev = enc_bf.device
-        S = self.encode_logits(enc_bf, B, T)
+        S = self.encode_logits(enc_bf, B, T, enc_f32)
         logits, Tn = S.logits, S.Tn
         Cc = cfg.vocab_size + 1
         lab = labels.contiguous()
@@ -806,8 +867,9 @@ class CtcEngine:
             raise L.DicowError("only ctc_loss_reduction='mean' (reference default) is implemented")
         return S.acc[0] / B, S
 
-    def encode_logits(self, enc_bf, B, T):
-        """The CTC branch up to its logits (encoder.py:87-106, get_enc_logits): S.logits bf16 [B * Tn, cpad]."""
+    def encode_logits(self, enc_bf, B, T, enc_f32=None):
+        """The CTC branch up to its logits (encoder.py:87-106, get_enc_logits): S.logits bf16 [B * Tn, cpad].
+        enc_f32: the fp32 rows enc_bf was rounded from (the residual stream of ``additional_layer``)."""
         enc, cfg, W = self.enc, self.cfg, self.W
         dev = enc_bf.device
         D, H = cfg.d_model, cfg.encoder_attention_heads
@@ -818,7 +880,14 @@ class CtcEngine:
             raise L.DicowError("pre_ctc_sub_sample needs max_source_positions % 4 == 0")
         h = enc_bf
         hpad = None
-        if W.att is not None:
+        if W.lyr is not None:
+            hf, S.lyr = plain_layer_fwd(enc.additional_layer, W.lyr, enc_f32 if enc_f32 is not None else enc_bf.float(), B, T, H,
+                                        cfg.encoder_ffn_dim)
+            h = ops.cast_bf16(hf)
+            if sub:
+                hpad = torch.zeros(B, T + 2, D, dtype=BF16, device=dev)
+                hpad[:, 1:T + 1].copy_(h.view(B, T, D))
+        elif W.att is not None:
             S.qkv = linear_fwd(enc_bf, W.att.qkv, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
             S.o, S.lse_a = _e((rows, D), BF16, dev), _e((B, H, T), F32, dev)
             ops.attn_fwd(heads(S.qkv[:, :D], B, T, H), heads(S.qkv[:, D:2 * D], B, T, H), heads(S.qkv[:, 2 * D:], B, T, H),
@@ -900,6 +969,8 @@ class CtcEngine:
             d_hid = _e((B, T, D), BF16, dev)
             ops.conv2_col2im_gelu_bwd(dA1, None, d_hid, B, T1, D)
             d_h = d_hid.view(rows, D)
+        if W.lyr is not None:
+            return plain_layer_bwd(enc.additional_layer, W.lyr, S.lyr, d_h.contiguous(), G, B, T, H)
         if W.att is None:
             return d_h.float()
         att = enc.additional_self_attention_layer

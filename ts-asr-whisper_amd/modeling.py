@@ -293,9 +293,8 @@ class DiCoWEncoder(nn.Module):
         self.layer_norm = nn.LayerNorm(d)
         self.ctc_weight = config.ctc_weight
         if config.ctc_weight > 0.0:                      # CTC auxiliary branch (reference encoder.py:15-44)
-            if config.additional_layer:
-                raise NotImplementedError("additional_layer (a full extra encoder layer before the CTC head) is not "
-                                          "implemented; the recipe uses additional_self_attention_layer")
+            if config.additional_layer:                  # a full extra encoder layer; wins over the bare attention below
+                self.additional_layer = EncoderLayer(d, f)
             if config.additional_self_attention_layer:
                 self.additional_self_attention_layer = Attention(d)
             if config.pre_ctc_sub_sample:
@@ -319,7 +318,7 @@ class DiCoWEncoder(nn.Module):
         self._ctc_eng = None
         self._ctc_sig = None
 
-    _CTC_PREFIXES = ("additional_self_attention_layer.", "subsample_conv", "lm_head.")
+    _CTC_PREFIXES = ("additional_layer.", "additional_self_attention_layer.", "subsample_conv", "lm_head.")
 
     def get_loss(self, logits, labels):
         """CTC loss of ``forward(..., return_logits=True).logits`` (reference encoder.py:108-135)."""
@@ -391,8 +390,9 @@ class _CtcFn(torch.autograd.Function):
     def forward(ctx, enc, enc_out, ctc_labels, *params):
         eng = enc._ctc_engine()
         B, T, D = enc_out.shape
-        enc_bf = ops.cast_bf16(enc_out.contiguous().to(F32)).view(B * T, D)
-        loss, S = eng.forward(enc_bf, B, T, ctc_labels)
+        enc_f = enc_out.contiguous().to(F32).view(B * T, D)
+        enc_bf = ops.cast_bf16(enc_f).view(B * T, D)
+        loss, S = eng.forward(enc_bf, B, T, ctc_labels, enc_f)
         ctx.enc, ctx.S, ctx.params = enc, S, params
         return loss
 
@@ -415,8 +415,9 @@ class _CtcLogitsFn(torch.autograd.Function):
     def forward(ctx, enc, enc_out, *params):
         eng = enc._ctc_engine()
         B, T, D = enc_out.shape
-        enc_bf = ops.cast_bf16(enc_out.contiguous().to(F32)).view(B * T, D)
-        S = eng.encode_logits(enc_bf, B, T)
+        enc_f = enc_out.contiguous().to(F32).view(B * T, D)
+        enc_bf = ops.cast_bf16(enc_f).view(B * T, D)
+        S = eng.encode_logits(enc_bf, B, T, enc_f)
         ctx.enc, ctx.S, ctx.params = enc, S, params
         return S.logits.view(B, S.Tn, -1)[:, :, :enc.config.vocab_size + 1]
 
@@ -728,8 +729,9 @@ class DiCoWForConditionalGeneration(nn.Module):
         _require_cuda(hidden_states, "get_enc_logits")
         B, T, D = hidden_states.shape
         with torch.no_grad():
-            enc_bf = ops.cast_bf16(hidden_states.detach().contiguous().to(F32)).view(B * T, D)
-            S = enc._ctc_engine().encode_logits(enc_bf, B, T)
+            enc_f = hidden_states.detach().contiguous().to(F32).view(B * T, D)
+            enc_bf = ops.cast_bf16(enc_f).view(B * T, D)
+            S = enc._ctc_engine().encode_logits(enc_bf, B, T, enc_f)
         return S.logits.view(B, S.Tn, -1)[:, :, :self.config.vocab_size + 1]
 
     def get_decoder(self):
