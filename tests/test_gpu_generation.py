@@ -189,8 +189,8 @@ def test_model_generate_wrapper(pkg):
     assert torch.equal(a, b) and a.shape[1] <= 14
     c = model.generate(input_features=x.cuda(), stno_mask=st.cuda(), generation_config=gc, num_beams=3)
     assert c.shape[0] == 2 and c.shape[1] <= 14 and torch.equal(c[:, :3].cpu(), want_prompt)
-    with pytest.raises(NotImplementedError):
-        model.generate(input_features=x.cuda()[:, :, :100], stno_mask=st.cuda(), generation_config=gc)      # not a 30 s window
+    with pytest.raises(ValueError):
+        model.generate(input_features=x.cuda()[:, :, :100], stno_mask=st.cuda(), generation_config=gc)      # shorter than a window
     model.tokenizer = None
 
 
@@ -358,3 +358,45 @@ def test_detect_language_vs_oracle(pkg):
     assert torch.equal(again.cpu(), got.cpu())
     with pytest.raises(Exception):
         GreedyDecoder(model).detect_language(x, st, langs)                      # CPU tensors: no fallback
+
+
+def test_model_generate_long_form_returns_window_relative_sequences(pkg):
+    """model.generate on recordings longer than one window = LongFormDecoder.transcribe + fix_timestamps_from_segmentation
+    (what the reference's generate() returns for long-form input, generation.py:536-564): padded ids with the tokenizer's prefix /
+    eos, segments kept in model.last_segments; short-form inputs still take the single-window path."""
+    from types import SimpleNamespace
+    from ts_asr_whisper_amd.generation import LongFormDecoder, fix_timestamps_from_segmentation
+    z, model, cfg, x, st, prompt = _setup(pkg)
+    W = 2 * cfg.max_source_positions
+    g = torch.Generator().manual_seed(33)
+    B, total = 2, 2 * W + 60
+    feats = torch.randn(B, cfg.num_mel_bins, total, generator=g).clamp_(-1.5, 1.5).cuda()
+    stno = torch.softmax(torch.randn(B, 4, total // 2, generator=g) * 2, 1).cuda()
+    amask = torch.zeros(B, total, dtype=torch.long)
+    amask[0, :total] = 1
+    amask[1, :W + 30] = 1
+    no_ts, eos, pad = 399, 5, 499
+
+    class Tok:
+        prefix_tokens = [int(t) for t in prompt[0]]
+        pad_token_id = pad
+
+        def get_vocab(self):
+            return {"<|0.00|>": no_ts + 1, "Ġ": 7}
+
+    model.set_tokenizer(Tok())
+    gc = SimpleNamespace(eos_token_id=eos, pad_token_id=pad, no_timestamps_token_id=no_ts, max_initial_timestamp_index=50,
+                         decoder_start_token_id=cfg.decoder_start_token_id)
+    out = model.generate(input_features=feats, stno_mask=stno, attention_mask=amask.cuda(), generation_config=gc, max_new_tokens=10)
+    segs = LongFormDecoder(model).transcribe(feats, stno, amask.sum(-1).tolist(), prompt[:1], no_ts, eos_token_id=eos,
+                                             pad_token_id=pad, max_new_tokens=10)
+    assert [[s["tokens"] for s in r] for r in model.last_segments] == [[s["tokens"] for s in r] for r in segs]
+    want = fix_timestamps_from_segmentation(segs, no_ts + 1, 7, pad, prefix_ids=Tok.prefix_tokens, suffix_ids=[eos])
+    assert out.is_cuda and torch.equal(out.cpu(), want)
+    assert out.shape[0] == B and all(int(v) == eos for v in [r[r != pad][-1] for r in out.cpu()])
+    with pytest.raises(ValueError):
+        model.generate(input_features=feats, stno_mask=stno, generation_config=gc)          # no attention_mask
+    short = model.generate(input_features=feats[:, :, :W].contiguous(), stno_mask=stno[:, :, :W // 2].contiguous(),
+                           decoder_input_ids=prompt, max_new_tokens=3, generation_config=gc)
+    assert short.shape == (B, prompt.shape[1] + 3)
+    model.tokenizer = None

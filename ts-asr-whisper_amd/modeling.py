@@ -661,10 +661,12 @@ class DiCoWForConditionalGeneration(nn.Module):
         get = (lambda k, d=None: getattr(gc, k, d) if gc is not None else d)
         beams = max(num_beams or 1, get("num_beams", 1) or 1)
         self.stno_mask = stno_mask                            # reference generate() keeps it for detect_language (generation.py:556)
-        if input_features.shape[-1] != 2 * self.config.max_source_positions:
-            raise NotImplementedError("long-form inputs: use generation.LongFormDecoder(model, num_beams).transcribe(...) "
-                                      "(sequential seek loop; returns timed segments per recording)")
         cfg = self.config
+        if input_features.shape[-1] > 2 * cfg.max_source_positions:
+            return self._generate_long_form(input_features, stno_mask, attention_mask, decoder_input_ids, max_new_tokens, get, beams,
+                                            enrollments)
+        if input_features.shape[-1] != 2 * cfg.max_source_positions:
+            raise ValueError("input_features shorter than one window: pad the features to 2 * max_source_positions frames")
         B = input_features.shape[0]
         if decoder_input_ids is None:
             prefix = list(getattr(self.tokenizer, "prefix_tokens", [])) if self.tokenizer is not None else []
@@ -698,6 +700,42 @@ class DiCoWForConditionalGeneration(nn.Module):
                                       eos_token_id=get("eos_token_id", cfg.eos_token_id), pad_token_id=get("pad_token_id", cfg.pad_token_id),
                                       suppress_tokens=get("suppress_tokens"), begin_suppress_tokens=get("begin_suppress_tokens"),
                                       enrollments=enrollments, ctc=ctc, timestamps=timestamps)
+
+    def _generate_long_form(self, input_features, stno_mask, attention_mask, decoder_input_ids, max_new_tokens, get, beams, enrollments):
+        """Recordings longer than one window (reference generate(), generation.py:536-564, with HF's seek loop underneath):
+        sequential windows at temperature 0 with timestamps, segments per recording, and -- what the reference returns for
+        such inputs -- the window-relative token sequences of ``_fix_timestamps_from_segmentation`` (padded LongTensor).  The
+        segments themselves are kept in ``self.last_segments``."""
+        from .generation import LongFormDecoder, fix_timestamps_from_segmentation
+        cfg, tok = self.config, self.tokenizer
+        if attention_mask is None:
+            raise ValueError("long-form generation needs attention_mask [B, frames] (valid feature frames per recording)")
+        if tok is None:
+            raise ValueError("long-form generation needs set_tokenizer(): the returned sequences carry its timestamp / prefix ids")
+        vocab = tok.get_vocab()
+        first_ts = vocab["<|0.00|>"]
+        no_ts = get("no_timestamps_token_id", first_ts - 1)
+        if decoder_input_ids is None:
+            prefix = [t for t in getattr(tok, "prefix_tokens", []) if t != no_ts]          # timestamps are predicted
+            start = get("decoder_start_token_id", cfg.decoder_start_token_id)
+            decoder_input_ids = torch.tensor([prefix if (prefix and prefix[0] == start) else [start] + prefix], dtype=torch.long)
+        ctc = None
+        if (get("ctc_weight", 0.0) or 0.0) > 0.0:
+            ctc = dict(weight=get("ctc_weight"), first_timestamp=first_ts,
+                       upper_cased=list(getattr(tok, "upper_cased_tokens", {}).items()), prefix_len=len(tok.prefix_tokens))
+        eos = get("eos_token_id", cfg.eos_token_id)
+        dec = LongFormDecoder(self, beams)
+        segs = dec.transcribe(input_features, stno_mask, attention_mask.sum(-1).cpu().tolist(), decoder_input_ids, no_ts,
+                              eos_token_id=eos, pad_token_id=get("pad_token_id", cfg.pad_token_id), max_new_tokens=max_new_tokens,
+                              enrollments=enrollments, suppress_tokens=get("suppress_tokens"),
+                              begin_suppress_tokens=get("begin_suppress_tokens"),
+                              max_initial_timestamp_index=get("max_initial_timestamp_index", 50),
+                              length_penalty=get("length_penalty", 1.0), early_stopping=get("early_stopping", False), ctc=ctc)
+        self.last_segments = segs
+        pad_id = getattr(tok, "pad_token_id", None)
+        return fix_timestamps_from_segmentation(segs, first_ts, vocab["\u0120"], cfg.pad_token_id if pad_id is None else pad_id,
+                                                prefix_ids=list(getattr(tok, "prefix_tokens", [])), suffix_ids=[eos],
+                                                device=input_features.device)
 
     def detect_language(self, input_features=None, stno_mask=None, generation_config=None, enrollments=None,
                         num_segment_frames=None, lang_token_ids=None):
