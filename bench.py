@@ -215,6 +215,17 @@ def main():
         timer.breakdown("gemm_nt", a.steps)
         timer.breakdown("gemm_tn", a.steps)
     peak = 2500.0
+    # algorithmic TFLOP per utterance of one step: 3 x encoder + 2 x (decoder + head) with the decoder frozen;
+    # turbo: 3 x 2.2738 + 2 x 0.0841 = 6.99.  SE-DiCoW: the survey's 10.7 (3.51 encoder) for the headline model only.
+    T_, D_, F_, Le, Ld = cfg.max_source_positions, cfg.d_model, cfg.encoder_ffn_dim, cfg.encoder_layers, cfg.decoder_layers
+    Lx, V_ = a.labels, cfg.vocab_size
+    enc_tf = (Le * (8 * T_ * D_ * D_ + 4 * T_ * T_ * D_ + 4 * T_ * D_ * F_) + 6 * (2 * T_) * cfg.num_mel_bins * D_ + 6 * T_ * D_ * D_) / 1e12
+    dec_tf = (Ld * (12 * Lx * D_ * D_ + 4 * Lx * Lx * D_ + 4 * T_ * D_ * D_ + 4 * Lx * T_ * D_ + 4 * Lx * D_ * cfg.decoder_ffn_dim)
+              + 2 * Lx * D_ * V_) / 1e12
+    if a.se:
+        tf_utt = (10.7 - (3.51 if a.preheat else 0.0)) if a.model.endswith("large-v3-turbo") else None
+    else:
+        tf_utt = (2 if a.preheat else 3) * enc_tf + 2 * dec_tf
     out = {
         "metric": f"train utterances/sec (30 s clips) {a.model} DiCoW" if not a.se else
                   "train utterances/sec (30 s clips) SE-DiCoW large-v3-turbo",
@@ -237,9 +248,9 @@ def main():
         "kernels": {"gemm_tn_kernel": {"tflops": round(tn["tflops"], 1), "frac": round(tn["tflops"] / peak, 4),
                                        "share_of_step": round(tn["total_ms"] / (dt * 1e3), 3)}} if tn else {},
         # preheat phase: forward + dgrad only (2 x encoder + 2 x decoder), no encoder weight gradients
-        "step_tflops": round(((6.99 if not a.se else 10.7) if not a.preheat else (6.99 - 2.2738 if not a.se else 10.7 - 3.51)) * utts, 1),
+        "step_tflops": None if tf_utt is None else round(tf_utt * utts, 1),
     }
-    out["step_mfma_frac"] = round(out["step_tflops"] / peak, 4)
+    out["step_mfma_frac"] = None if tf_utt is None else round(out["step_tflops"] / peak, 4)
     # north-star headline: MFMA utilisation of the FDDT-conditioned ENCODER FORWARD alone (no activations kept), same batch
     try:
         T_, D_, F_, Le, Mm = cfg.max_source_positions, cfg.d_model, cfg.encoder_ffn_dim, cfg.encoder_layers, cfg.num_mel_bins
