@@ -400,3 +400,32 @@ def test_model_generate_long_form_returns_window_relative_sequences(pkg):
                            decoder_input_ids=prompt, max_new_tokens=3, generation_config=gc)
     assert short.shape == (B, prompt.shape[1] + 3)
     model.tokenizer = None
+
+
+def test_generate_builds_the_prompt_from_language_and_task(pkg):
+    """generation_config.language None (what the reference sets for multilingual models, containers.py:58) -> per-row language
+    detection, then the task token and <|notimestamps|>; explicit language forms; the resulting sequences equal a generate() with
+    that prompt given explicitly."""
+    from types import SimpleNamespace
+    z, model, cfg, x, st, prompt = _setup(pkg)
+    model.tokenizer = None
+    langs = {"<|en|>": 30, "<|de|>": 31, "<|cs|>": 32}
+    gc = SimpleNamespace(lang_to_id=langs, task_to_id={"transcribe": 40, "translate": 41}, language=None, task="transcribe",
+                         no_timestamps_token_id=399, return_timestamps=False, decoder_start_token_id=cfg.decoder_start_token_id,
+                         eos_token_id=-1, pad_token_id=cfg.pad_token_id)
+    xc, sc = x.cuda(), st.cuda()
+    det = model.detect_language(xc, sc, gc).tolist()
+    init = model.retrieve_init_tokens(xc, sc, gc)
+    assert init.tolist() == [[cfg.decoder_start_token_id, l, 40, 399] for l in det]
+    auto = model.generate(input_features=xc, stno_mask=sc, generation_config=gc, max_new_tokens=4)
+    manual = model.generate(input_features=xc, stno_mask=sc, generation_config=gc, max_new_tokens=4, decoder_input_ids=init)
+    assert torch.equal(auto, manual) and auto.shape == (x.shape[0], 8)
+    for form, want in (("<|de|>", 31), ("de", 31), ("German", 31), (["cs", "en"], None)):
+        gc.language = form
+        got = model.retrieve_init_tokens(xc, sc, gc)[:, 1].tolist()
+        assert got == ([want] * 2 if want is not None else [32, 30])
+    gc.language, gc.task, gc.return_timestamps = "en", None, True
+    assert model.retrieve_init_tokens(xc, sc, gc).tolist() == [[cfg.decoder_start_token_id, 30, 40]] * 2   # transcribe by default
+    gc.language = "xx"
+    with pytest.raises(ValueError):
+        model.retrieve_init_tokens(xc, sc, gc)

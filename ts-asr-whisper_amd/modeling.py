@@ -664,11 +664,13 @@ class DiCoWForConditionalGeneration(nn.Module):
         cfg = self.config
         if input_features.shape[-1] > 2 * cfg.max_source_positions:
             return self._generate_long_form(input_features, stno_mask, attention_mask, decoder_input_ids, max_new_tokens, get, beams,
-                                            enrollments)
+                                            enrollments, gc)
         if input_features.shape[-1] != 2 * cfg.max_source_positions:
             raise ValueError("input_features shorter than one window: pad the features to 2 * max_source_positions frames")
         B = input_features.shape[0]
-        if decoder_input_ids is None:
+        if decoder_input_ids is None and get("lang_to_id") is not None:
+            decoder_input_ids = self.retrieve_init_tokens(input_features, stno_mask, gc, enrollments, return_timestamps)
+        elif decoder_input_ids is None:
             prefix = list(getattr(self.tokenizer, "prefix_tokens", [])) if self.tokenizer is not None else []
             start = get("decoder_start_token_id", cfg.decoder_start_token_id)
             prompt = prefix if (prefix and prefix[0] == start) else [start] + prefix
@@ -701,7 +703,55 @@ class DiCoWForConditionalGeneration(nn.Module):
                                       suppress_tokens=get("suppress_tokens"), begin_suppress_tokens=get("begin_suppress_tokens"),
                                       enrollments=enrollments, ctc=ctc, timestamps=timestamps)
 
-    def _generate_long_form(self, input_features, stno_mask, attention_mask, decoder_input_ids, max_new_tokens, get, beams, enrollments):
+    def retrieve_init_tokens(self, input_features, stno_mask, generation_config, enrollments=None, return_timestamps=None):
+        """The forced prompt per row the way the reference's evaluation gets it (DiCoWGenerationMixin._retrieve_init_tokens,
+        generation.py:121-149, falling through to HF's): ``forced_decoder_ids`` is not supported (the reference sets it to None,
+        containers.py:67); start token, then the language token -- ``generation_config.language`` (a '<|xx|>' key of
+        ``lang_to_id``, a language code, a language name, or one per row) or, when it is None (containers.py:58), the STNO-conditioned
+        ``detect_language`` of each row -- then the task token, then ``<|notimestamps|>`` unless timestamps are predicted."""
+        gc = generation_config
+        B = input_features.shape[0]
+        if getattr(gc, "forced_decoder_ids", None) is not None:
+            raise NotImplementedError("forced_decoder_ids: use generation_config.language / .task (the reference clears it)")
+        start = getattr(gc, "decoder_start_token_id", None)
+        start = self.config.decoder_start_token_id if start is None else start
+        lang_to_id, language, task = gc.lang_to_id, getattr(gc, "language", None), getattr(gc, "task", None)
+
+        def lang_id(name):
+            key = name.lower()
+            if key not in lang_to_id:
+                if f"<|{key}|>" in lang_to_id:
+                    key = f"<|{key}|>"
+                else:
+                    from transformers.models.whisper.tokenization_whisper import TO_LANGUAGE_CODE
+                    if key not in TO_LANGUAGE_CODE or f"<|{TO_LANGUAGE_CODE[key]}|>" not in lang_to_id:
+                        raise ValueError(f"Unsupported language: {name}")
+                    key = f"<|{TO_LANGUAGE_CODE[key]}|>"
+            return lang_to_id[key]
+
+        if isinstance(language, (list, tuple)):
+            if len(language) != B or any(l is None for l in language):
+                raise ValueError(f"a list of languages must name one language per row ({B})")
+            langs = [lang_id(l) for l in language]
+        elif language is not None:
+            langs = [lang_id(language)] * B
+        else:
+            langs = self.detect_language(input_features, stno_mask, gc, enrollments).tolist()
+        tail = []
+        if task is not None:
+            if task not in ("transcribe", "translate"):
+                raise ValueError(f"The `{task}` task is not supported")
+            tail.append(gc.task_to_id[task])
+        elif language is not None and getattr(gc, "task_to_id", None) is not None:
+            tail.append(gc.task_to_id["transcribe"])
+        ts = getattr(gc, "return_timestamps", False) if return_timestamps is None else return_timestamps
+        no_ts = getattr(gc, "no_timestamps_token_id", None)
+        if not ts and no_ts is not None:
+            tail.append(no_ts)
+        return torch.tensor([[start, l] + tail for l in langs], dtype=torch.long)
+
+    def _generate_long_form(self, input_features, stno_mask, attention_mask, decoder_input_ids, max_new_tokens, get, beams, enrollments,
+                            gc=None):
         """Recordings longer than one window (reference generate(), generation.py:536-564, with HF's seek loop underneath):
         sequential windows at temperature 0 with timestamps, segments per recording, and -- what the reference returns for
         such inputs -- the window-relative token sequences of ``_fix_timestamps_from_segmentation`` (padded LongTensor).  The
@@ -715,7 +765,9 @@ class DiCoWForConditionalGeneration(nn.Module):
         vocab = tok.get_vocab()
         first_ts = vocab["<|0.00|>"]
         no_ts = get("no_timestamps_token_id", first_ts - 1)
-        if decoder_input_ids is None:
+        if decoder_input_ids is None and get("lang_to_id") is not None:               # language from the first window
+            decoder_input_ids = self.retrieve_init_tokens(input_features, stno_mask, gc, enrollments, return_timestamps=True)
+        elif decoder_input_ids is None:
             prefix = [t for t in getattr(tok, "prefix_tokens", []) if t != no_ts]          # timestamps are predicted
             start = get("decoder_start_token_id", cfg.decoder_start_token_id)
             decoder_input_ids = torch.tensor([prefix if (prefix and prefix[0] == start) else [start] + prefix], dtype=torch.long)
