@@ -420,6 +420,9 @@ def test_generate_builds_the_prompt_from_language_and_task(pkg):
     auto = model.generate(input_features=xc, stno_mask=sc, generation_config=gc, max_new_tokens=4)
     manual = model.generate(input_features=xc, stno_mask=sc, generation_config=gc, max_new_tokens=4, decoder_input_ids=init)
     assert torch.equal(auto, manual) and auto.shape == (x.shape[0], 8)
+    graphed = model.generate(input_features=xc, stno_mask=sc, generation_config=gc, max_new_tokens=4, use_graphs=True)
+    again = model.generate(input_features=xc, stno_mask=sc, generation_config=gc, max_new_tokens=4, use_graphs=True)    # replay
+    assert torch.equal(graphed, auto) and torch.equal(again, auto)
     for form, want in (("<|de|>", 31), ("de", 31), ("German", 31), (["cs", "en"], None)):
         gc.language = form
         got = model.retrieve_init_tokens(xc, sc, gc)[:, 1].tolist()

@@ -650,7 +650,8 @@ class DiCoWForConditionalGeneration(nn.Module):
         save_file(sd, os.path.join(directory, "model.safetensors"))
 
     def generate(self, input_features=None, stno_mask=None, attention_mask=None, decoder_input_ids=None, max_new_tokens=None,
-                 max_length=None, generation_config=None, enrollments=None, num_beams=1, return_timestamps=None, **kwargs):
+                 max_length=None, generation_config=None, enrollments=None, num_beams=1, return_timestamps=None, use_graphs=False,
+                 **kwargs):
         """Short-form (one 30 s window) greedy or beam-search decoding with the reference's logits-processor chain
         (generation.GreedyDecoder.generate / .beam_search).
         ``generation_config``: any object with the HF / reference attribute names (eos_token_id, pad_token_id, suppress_tokens,
@@ -698,7 +699,12 @@ class DiCoWForConditionalGeneration(nn.Module):
                                                suppress_tokens=get("suppress_tokens"), begin_suppress_tokens=get("begin_suppress_tokens"),
                                                enrollments=enrollments, timestamps=timestamps, ctc=ctc)
             return seq
-        return self._decoder.generate(input_features, stno_mask, decoder_input_ids, max_new_tokens,
+        dec = self._decoder
+        if use_graphs:                                       # hipGraph replay of each decoder position (evaluation: fixed weights)
+            if not hasattr(self, "_decoder_graphed"):
+                self._decoder_graphed = GreedyDecoder(self, use_graphs=True)
+            dec = self._decoder_graphed
+        return dec.generate(input_features, stno_mask, decoder_input_ids, max_new_tokens,
                                       eos_token_id=get("eos_token_id", cfg.eos_token_id), pad_token_id=get("pad_token_id", cfg.pad_token_id),
                                       suppress_tokens=get("suppress_tokens"), begin_suppress_tokens=get("begin_suppress_tokens"),
                                       enrollments=enrollments, ctc=ctc, timestamps=timestamps)
