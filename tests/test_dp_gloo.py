@@ -60,8 +60,11 @@ def _worker(rank, world, port, q):
         for name, a, b in store.segments:
             red.segment_ready(name)
         red.finish()
+        from types import SimpleNamespace
+        from ts_asr_whisper_amd.trainer import TrainStep
+        logged = float(TrainStep.logged_loss(SimpleNamespace(reducer=red), torch.tensor(1.0 + rank)))   # mean over ranks
         q.put((rank, local.numpy(), full.numpy(), [s[0] for s in store.segments], store.grads.clone().numpy(),
-               [(a, b, pre) for a, b, pre in store.runs]))
+               [(a, b, pre) for a, b, pre in store.runs], logged))
     finally:
         dist.destroy_process_group()
 
@@ -79,7 +82,8 @@ def test_dp_allreduce_matches_mean_of_ranks():
         assert p.exitcode == 0
     res.sort(key=lambda t: t[0])
     mean = torch.from_numpy(res[0][1] + res[1][1]) / 2
-    for _, local, reduced, segs, pre_reduced, runs in res:
+    assert all(abs(r[6] - 1.5) < 1e-6 for r in res)           # the logged loss is the mean of the ranks' losses (1.0, 2.0)
+    for _, local, reduced, segs, pre_reduced, runs, _ in res:
         assert torch.allclose(torch.from_numpy(reduced), mean, atol=1e-6)
         want = torch.from_numpy(local).clone()
         for a, b, pre in runs:

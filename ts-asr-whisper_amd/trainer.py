@@ -294,6 +294,16 @@ class TrainStep:
         self.finish_step()
         return loss / len(micro)
 
+    def logged_loss(self, loss):
+        """The number the reference's trainer logs: the mean of the ranks' step losses (HF Trainer gathers the per-rank loss and
+        averages it).  One scalar all-reduce on the compute stream, only when called (logging_steps); identity at world 1."""
+        r = self.reducer
+        if r.world == 1:
+            return loss
+        t = loss.detach().clone().float().reshape(1)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=r.pg)
+        return (t / r.world)[0]
+
     # ---- checkpoint / resume of the optimizer side (the model side is model.state_dict(), reference key names)
     def state_dict(self):
         o = self.opt
