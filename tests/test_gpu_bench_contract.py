@@ -1,0 +1,38 @@
+"""The bench.py output contract the round driver parses (one JSON line on stdout; keys, types, derived values), on a small
+workload so that it runs in seconds.  Run with `pytest -m gpu`."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests.util import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", "whisper-tiny", "--batch", "2", "--labels", "16",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str),
+                 ("config", dict), ("roofline", dict)):
+        assert isinstance(d[k], t), (k, d[k])
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["dtype"] == "bf16" and d["unit"] == "utt/s"
+    assert "workload" in d["config"] and d["config"]["global_batch"] == 2 and "model" not in d["config"]
+    assert abs(d["value"] - 2 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]          # whole-job utterances / s
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0 and "traffic" in rf
+    assert d["loss"] == d["loss"]                                                        # finite
