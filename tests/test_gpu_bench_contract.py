@@ -36,3 +36,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0 and "traffic" in rf
     assert d["loss"] == d["loss"]                                                        # finite
+
+
+def test_graft_entry_smoke_runs_and_checks_against_the_oracle():
+    """__graft_entry__.smoke(): one small fwd+bwd of the hot path on cuda:0 compared with the oracle (raises on mismatch)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.smoke()

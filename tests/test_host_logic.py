@@ -258,3 +258,8 @@ def test_product_fix_timestamps_matches_reference_golden_and_oracle():
         want = folded_to_ids(fold_segments(segs, 1000, 7), 1000)
         assert fix_timestamps_from_segmentation([segs], 1000, 7, 0)[0].tolist() == want, segs
     assert fix_timestamps_from_segmentation([[]], 1000, 7, 0).shape == (1, 0)
+
+
+def test_graft_entry_exposes_build_and_smoke():
+    import __graft_entry__ as g
+    assert callable(g.build) and callable(g.smoke)
