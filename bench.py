@@ -25,8 +25,8 @@ import torch.distributed as dist
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--model", default="whisper-large-v3-turbo")
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch")
     ap.add_argument("--labels", type=int, default=128)
