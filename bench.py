@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the DiCoW training step on MI355X (contract: see the task description / DESIGN.md "Measurement").
 
-    python bench.py --gpus 1 --steps K --warmup W            (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: run it either under torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment; WORLD_SIZE must
+equal N) or plainly -- without a rendezvous in the environment `python bench.py --gpus N` spawns the N ranks itself (one process
+per GPU, LOCAL_RANK -> device, RCCL rendezvous on 127.0.0.1; what scripts/submit_slurm.sh:34 does with torchrun in the reference).
 
 One "step" = forward + backward + gradient all-reduce + clip + AdamW on one synthetic batch of 30 s clips
 (whisper-large-v3-turbo dims, per-GPU batch 16, decoder frozen, L=128: BASELINE.json configs[2]/[3]); inputs are
@@ -36,7 +40,42 @@ def parse():
                     help="time the recipe's first phase instead (use_fddt_only_n_steps: only FDDT parameters train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="turbo-b1")
+    ap.add_argument("--profile-steps", type=int, default=5,
+                    help="instrumented steps run AFTER the timed region (per-launch HIP events of the dominant kernel: roofline)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (launch-bound configs)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher self-test: rendezvous + one all-reduce per rank, no training step (runs without a GPU over gloo)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` with no rendezvous in the environment: start one process per GPU and relay rank 0's JSON line."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DICOW_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
+    out0, _ = procs[0].communicate()
+    rcs = [p.wait() for p in procs]
+    if any(rcs):
+        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.exit(1)
+    sys.stdout.write(out0)
+    sys.stdout.flush()
 
 
 class KernelTimer:
@@ -131,10 +170,40 @@ def cpu_baseline(cfg_name, labels):
                       f"best {best:.2f} s, host has {cores} logical cores"}
 
 
+def cpu_config1():
+    """BASELINE.json configs[0] on the host cores: whisper-tiny + FDDT, one synthetic 30 s clip, forward only (oracle, fp32)."""
+    import amd_pkg
+    pkg = amd_pkg.load()
+    from oracle import dicow_oracle as O
+    cfg = pkg.DiCoWConfig.preset("whisper-tiny", use_pre_pos_fddt=True, non_target_fddt_value=0.5)
+    ocfg = O.OracleConfig(**{k: getattr(cfg, k) for k in O.OracleConfig.__dataclass_fields__ if hasattr(cfg, k)})
+    p = O.init_state(ocfg, seed=0)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, cfg.num_mel_bins, 3000, generator=g).clamp_(-1.5, 1.5)
+    st = torch.softmax(torch.randn(1, 4, 1500, generator=g), 1)
+    lab = torch.randint(0, 50257, (1, 64), generator=g)
+    times = []
+    with torch.no_grad():
+        for _ in range(3):
+            t0 = time.time()
+            O.model_forward(p, ocfg, x, st, lab, lab)
+            times.append(time.time() - t0)
+    return {"value": round(1.0 / min(times), 3), "unit": "utt/s (forward only)", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"configs[0]: whisper-tiny + FDDT, B=1, L=64, fp32 oracle forward, best of {len(times)}: {min(times):.3f} s"}
+
+
+PMC_FILES = ("r02_pmc_hbm_traffic.json", "r01g_pmc_hbm_traffic.json")      # newest first
+TRAFFIC_SOURCE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/prof_pmc.sh; fabric-side bytes "
+                  "per persistent NT GEMM launch, FETCH_SIZE x2 per the gfx950 correction)")
+
+
 def pmc_traffic():
     """HBM-side bytes per launch of the dominant kernel from the committed PMC summary (counters cannot be read live)."""
+    global TRAFFIC_SOURCE
     try:
-        with open(os.path.join(ROOT, "profiles", "r01g_pmc_hbm_traffic.json")) as f:
+        name = next(n for n in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        TRAFFIC_SOURCE = TRAFFIC_SOURCE % name
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
         tot = n = 0
         for k, v in d.items():
@@ -146,21 +215,51 @@ def pmc_traffic():
         return None
 
 
-PEAK_MEASURED = 2115.8      # TFLOP/s, MFMA-only micro-benchmark on the MI355X box (SURVEY 8d asks for both peaks)
+
+def dry_launch(a, world, rank, local):
+    """Launcher self-test (no training step): every rank joins the process group, checks its size, all-reduces its rank id."""
+    use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
+    if use_gpu:
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        t = torch.tensor([float(rank + 1)], device="cuda")
+    else:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)])
+    assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": dist.get_world_size(), "backend": dist.get_backend(),
+                          "allreduce_sum": float(t), "expected_sum": a.gpus * (a.gpus + 1) / 2,
+                          "config": {"global_batch": a.batch * a.gpus, "parallelism": f"dp{a.gpus}"}}))
+    dist.destroy_process_group()
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(a)                       # self-launch: one process per GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    if world != a.gpus and (a.gpus > 1 or world > 1):
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} in the environment")
+    if a.dry_launch:
+        return dry_launch(a, world, rank, local)
+    # DICOW_BENCH_SHARE_GPU=1 (tests on a one-GPU box): every rank uses device 0 and the exchange runs over gloo
+    share = os.environ.get("DICOW_BENCH_SHARE_GPU") == "1"
+    torch.cuda.set_device(0 if share else local)
     if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # the gradient all-reduce overlaps the backward pass and needs few channels; every RCCL channel is a workgroup that
         # keeps a CU from the persistent GEMM (trainer.GradReducer reserves DICOW_RCCL_CUS = 16 CUs for them)
         os.environ.setdefault("NCCL_MAX_NCHANNELS", "16")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
     import amd_pkg
     pkg = amd_pkg.load()
     from ts_asr_whisper_amd import ops
@@ -178,7 +277,8 @@ def main():
     model.tie_weights()
     prefixes = ("model.encoder.fddts", "model.encoder.initial_fddt") + (("model.encoder.ca_enrolls",) if a.se else ())
     ts = TrainStep(model, lr=2e-6, fddt_lr_multiplier=100.0, max_grad_norm=1.0, warmup_steps=2000, max_steps=40000,
-                   preheat_prefixes=prefixes, use_fddt_only_n_steps=10 ** 9 if a.preheat else 0)
+                   preheat_prefixes=prefixes, use_fddt_only_n_steps=10 ** 9 if a.preheat else 0,
+                   **({"graph": True} if a.graph else {}))
     batches = [synthetic_batch(cfg, a.batch, a.labels, seed=1000 + rank * 17 + i, mixed_length=a.se, enrollments=a.se)
                for i in range(2)]
     timer = KernelTimer(ops, ["gemm_nt", "gemm_tn"])
@@ -193,17 +293,36 @@ def main():
     for i in range(a.warmup):
         loss = ts.step(batches[i % 2])
     sync()
-    timer.on = True
+    # ---- the timed region: exactly K steps, no per-launch instrumentation (one event per step boundary for the median)
+    ts.reducer.time_exposed = True
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(a.steps):
         loss = ts.step(batches[i % 2])
+        marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
-    timer.on = False
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    med_ms = step_ms[len(step_ms) // 2] if a.steps % 2 else 0.5 * (step_ms[a.steps // 2 - 1] + step_ms[a.steps // 2])
+    exposed_ms = ts.reducer.exposed_ms()
+    ts.reducer.time_exposed = False
+    rank_ms = [dt / a.steps * 1e3]
+    rank_exposed = [exposed_ms]
     if world > 1:
-        t = torch.tensor([dt], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t)
+        t = torch.tensor([dt, -dt, exposed_ms], device="cuda", dtype=torch.float64)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        dt = max(float(e[0]) for e in every)
+        rank_ms = [round(float(e[0]) / a.steps * 1e3, 3) for e in every]
+        rank_exposed = [round(float(e[2]), 3) for e in every]
+    # ---- instrumented steps OUTSIDE the timed region: per-launch HIP events of the GEMM classes (roofline)
+    nprof = max(1, min(a.profile_steps, a.steps))
+    timer.on = True
+    for i in range(nprof):
+        ts.step(batches[i % 2], **({"eager": True} if a.graph else {}))
+    sync()
+    timer.on = False
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -211,10 +330,12 @@ def main():
     ms = dt / a.steps * 1e3
     utts = a.batch * world * a.steps / dt
     nt, tn = timer.summary("gemm_nt"), timer.summary("gemm_tn")
+    prof_ms = sum(r[0].elapsed_time(r[1]) for r in timer.rec["gemm_nt"])
     if os.environ.get("DICOW_BENCH_BREAKDOWN"):
-        timer.breakdown("gemm_nt", a.steps)
-        timer.breakdown("gemm_tn", a.steps)
+        timer.breakdown("gemm_nt", nprof)
+        timer.breakdown("gemm_tn", nprof)
     peak = 2500.0
+    TRAFFIC = pmc_traffic()
     # algorithmic TFLOP per utterance of one step: 3 x encoder + 2 x (decoder + head) with the decoder frozen;
     # turbo: 3 x 2.2738 + 2 x 0.0841 = 6.99.  SE-DiCoW: the survey's 10.7 (3.51 encoder) for the headline model only.
     T_, D_, F_, Le, Ld = cfg.max_source_positions, cfg.d_model, cfg.encoder_ffn_dim, cfg.encoder_layers, cfg.decoder_layers
@@ -230,23 +351,28 @@ def main():
         "metric": f"train utterances/sec (30 s clips) {a.model} DiCoW" if not a.se else
                   "train utterances/sec (30 s clips) SE-DiCoW large-v3-turbo",
         "value": round(utts, 3), "unit": "utt/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "ms_per_step": round(ms, 3), "ms_per_step_median": round(med_ms, 3),
+        "value_at_median_step": round(a.batch * world * 1e3 / med_ms, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
         "data": "synthetic (random-init weights, N(0,1) mel clamped to [-1.5,1.5], 3-speaker STNO process, random labels)",
         "config": {"workload": f"{a.model} DiCoW fine-tune step, per-GPU batch {a.batch}, L={a.labels}, decoder frozen, "
-                               f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}{', CTC 0.3' if a.ctc else ''}{', preheat phase (FDDT-only training)' if a.preheat else ''}",
+                               f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}{', CTC 0.3' if a.ctc else ''}{', preheat phase (FDDT-only training)' if a.preheat else ''}"
+                               f"{', step replayed from a hipGraph' if a.graph else ''}",
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "trainable_params": sum(n for q, _, n, _ in ts.store.entries if q.requires_grad)},
         "loss": float(loss),
+        "per_rank_ms_per_step": rank_ms,
+        "allreduce": {"exposed_ms_per_step": rank_exposed,
+                      "note": "time the compute stream waits for the side-stream RCCL buckets before the optimizer (0 at one rank)",
+                      "backend": dist.get_backend() if dist.is_initialized() else None,
+                      "bytes_per_step": 4 * ts.store.n_trainable if world > 1 else 0},
         "roofline": {"bound": "mfma", "kernel": "gemm_ntw_kernel (persistent 256x256 / 192x320) / gemm_nt_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
                      "achieved": round(nt["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(nt["tflops"] / peak, 4),
-                     "peak_measured": PEAK_MEASURED, "frac_of_measured": round(nt["tflops"] / PEAK_MEASURED, 4),
-                     "peak_measured_source": "profiles/r01_probe_clock.txt: register-resident 32x32x16 bf16 MFMA loop on 256 CUs, best of 3 "
-                                             "(32.0 cycles/MFMA; the shader clock settles at 2.0-2.1 GHz under full MFMA load)",
-                     "traffic": pmc_traffic(), "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // a.steps,
-                     "share_of_step": round(nt["total_ms"] / (dt * 1e3), 3),
-                     "traffic_source": "profiles/r01g_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                       "command; fabric-side bytes per gemm_nt256w launch, FETCH_SIZE x2 per the gfx950 correction)"},
+                     "traffic": TRAFFIC, "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // nprof,
+                     "share_of_step": round(prof_ms / nprof / ms, 3),
+                     "measured_over": f"{nprof} instrumented steps after the timed region (HIP events around every launch, on the launch stream)",
+                     "traffic_source": TRAFFIC_SOURCE},
         "kernels": {"gemm_tn_kernel": {"tflops": round(tn["tflops"], 1), "frac": round(tn["tflops"] / peak, 4),
-                                       "share_of_step": round(tn["total_ms"] / (dt * 1e3), 3)}} if tn else {},
+                                       "share_of_step": round(tn["total_ms"] / nprof / ms, 3)}} if tn else {},
         # preheat phase: forward + dgrad only (2 x encoder + 2 x decoder), no encoder weight gradients
         "step_tflops": None if tf_utt is None else round(tf_utt * utts, 1),
     }
@@ -274,7 +400,6 @@ def main():
         out["encoder_forward"] = {"ms": round(enc_ms, 2), "batch": a.batch,
                                   "tflops": None if enc_flops is None else round(enc_flops / enc_ms / 1e9, 1),
                                   "mfma_frac": None if enc_flops is None else round(enc_flops / enc_ms / 1e9 / peak, 4),
-                                  "mfma_frac_of_measured_peak": None if enc_flops is None else round(enc_flops / enc_ms / 1e9 / PEAK_MEASURED, 4),
                                   "note": "encoder forward only, torch.no_grad(), algorithmic FLOPs of SURVEY 8d / dense bf16 peak 2.5 PF"}
     except Exception as ex:
         out["encoder_forward"] = {"ms": None, "note": f"failed: {ex!r}"}
@@ -283,6 +408,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(a.model, a.labels)
         except Exception as ex:      # the bench line must still be printed
             out["cpu_baseline"] = {"value": None, "unit": "utt/s", "cores": 0, "kind": "port", "sample": f"failed: {ex!r}"}
+        try:
+            out["cpu_baseline"]["config1"] = cpu_config1()
+        except Exception as ex:
+            out["cpu_baseline"]["config1"] = {"value": None, "sample": f"failed: {ex!r}"}
     print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()

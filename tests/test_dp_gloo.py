@@ -119,3 +119,25 @@ def test_flat_store_views_and_groups():
     # writing through the flat buffer is visible in the parameter (same storage)
     store.params.zero_()
     assert float(names["model.encoder.layers.0.fc1.weight"].abs().sum()) == 0.0
+
+
+def test_bench_launcher_spawns_the_ranks_itself():
+    """`python bench.py --gpus 2` without a rendezvous in the environment starts two ranks (scripts/submit_slurm.sh:34 uses
+    torchrun for this); --dry-launch stops after the process-group checks, so it runs here over gloo without a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
+                       text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["allreduce_sum"] == d["expected_sum"] == 3.0
+    assert d["config"]["global_batch"] == 32 and d["config"]["parallelism"] == "dp2"
+    # a rendezvous of another size in the environment is refused instead of silently running one rank
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
+                       text=True, timeout=120, cwd=root, env=dict(env, RANK="0", WORLD_SIZE="3"))
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr

@@ -35,7 +35,29 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     rf = d["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and rf["peak"] == 2500.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0 and "traffic" in rf
+    assert d["ms_per_step_median"] > 0 and d["per_rank_ms_per_step"] == [d["ms_per_step"]]
     assert d["loss"] == d["loss"]                                                        # finite
+
+
+def test_bench_gpus_2_launches_two_ranks_by_itself():
+    """`bench.py --gpus 2` with no rendezvous in the environment: the launcher starts both ranks; on this one-GPU box they share
+    device 0 and exchange over gloo (DICOW_BENCH_SHARE_GPU=1), on a multi-GPU node the same command runs RCCL."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=ROOT, DICOW_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "whisper-tiny", "--batch", "2",
+                        "--labels", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["config"]["parallelism"] == "dp2"
+    assert len(d["per_rank_ms_per_step"]) == 2 and len(d["allreduce"]["exposed_ms_per_step"]) == 2
+    assert d["allreduce"]["bytes_per_step"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 4 * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]          # whole-job utterances / s over both ranks
+    assert "cpu_baseline" not in d                                                      # rank 0 at N = 1 only
 
 
 def test_graft_entry_smoke_runs_and_checks_against_the_oracle():

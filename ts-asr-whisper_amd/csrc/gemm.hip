@@ -774,6 +774,8 @@ __global__ void __launch_bounds__(256) gemm_ntw_kernel(const dicow_gemm_args a) 
 #undef NTW_RSRC
 #undef NTW_DMA
 
+#include "gemm_ntr.inc"
+
 // ------------------------------------------------------------------------------------------------ NT, 256x256, staggered
 // Same tile / wave grid as gemm_nt256_kernel, but the contraction advances in 32-deep PHASES through a 4-stage LDS ring
 // (4 x 32 KiB) and the two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run ONE PHASE APART: in barrier
@@ -957,6 +959,12 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
         NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTW_ATTR(DICOW_EPI_MUL_AUX);
         NTW_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
 #undef NTW_ATTR
+#define NTR_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS)
+        NTR_ATTR(-1); NTR_ATTR(0); NTR_ATTR(DICOW_EPI_BIAS); NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N);
+        NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU); NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32);
+        NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTR_ATTR(DICOW_EPI_MUL_AUX);
+        NTR_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
+#undef NTR_ATTR
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
         (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
@@ -972,7 +980,7 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     const bool big = off32 && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
         const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
-        if (variant == 0 || variant == 11 || variant == 12 || variant == 13) {
+        if (variant == 0 || variant == 11 || variant == 12 || variant == 13 || variant == 20) {
             static int ncu_all = 0;
             if (!ncu_all) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); ncu_all = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
             const int ncu = (g_gemm_cus > 0 && g_gemm_cus < ncu_all) ? g_gemm_cus : ncu_all;   // CUs left to us (dicow_set_gemm_cus)
@@ -983,7 +991,9 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             const int64_t t44 = (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch;
             const int64_t t35 = (int64_t)dicow_cdiv(a->M, 192) * dicow_cdiv(a->N, 320) * batch;
             const int64_t w44 = dicow_cdiv(t44, ncu) * 256 * 256, w35 = dicow_cdiv(t35, ncu) * 192 * 320;
-            const bool use35 = variant == 13 || (variant != 12 && a->N >= 320 && a->N <= 2048 && w35 < w44);
+            // gemm_ntr_kernel (LDS ring, 256 x 256 tiles) is the default; DICOW_NT_VARIANT 12 / 13 force the two-stage kernels
+            const bool ring = (variant == 0 || variant == 20) && a->K >= 2 * BK;
+            const bool use35 = !ring && (variant == 13 || (variant != 12 && a->N >= 320 && a->N <= 2048 && w35 < w44));
             const int total = (int)(use35 ? t35 : t44);
             // balanced grid: with r = ceil(total / ncu) rounds needed anyway, ceil(total / r) workgroups each take r (or
             // r - 1) tiles -- e.g. 470 tiles run on 235 workgroups x 2 instead of 214 x 2 + 42 x 1: same makespan, fewer
@@ -991,7 +1001,8 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             const int rounds = dicow_cdiv(total, ncu);
             const dim3 gp(dicow_cdiv(total, rounds));
             if (colsum_rows) *colsum_rows = 2 * dicow_cdiv(a->M, use35 ? 192 : 256);
-#define NTW_LAUNCH(F) { if (use35) hipLaunchKernelGGL((gemm_ntw_kernel<F, 3, 5>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); \
+#define NTW_LAUNCH(F) { if (ring) hipLaunchKernelGGL((gemm_ntr_kernel<F>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); \
+                        else if (use35) hipLaunchKernelGGL((gemm_ntw_kernel<F, 3, 5>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); \
                         else hipLaunchKernelGGL((gemm_ntw_kernel<F, 4, 4>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); }
             if (want_colsum && variant != 11 && a->flags == DICOW_EPI_MUL_AUX) { a->flags |= DICOW_EPI_COLSUM; *fused_colsum = true; }
             switch (variant == 11 ? -1 : a->flags) {   // compile-time epilogues for the flag sets the training step uses

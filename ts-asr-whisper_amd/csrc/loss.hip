@@ -78,14 +78,23 @@ __global__ void __launch_bounds__(LOSS_THREADS) ce_fwd_kernel(const dicow_ce_arg
     const float gs = block_reduce_sum(m == -INFINITY ? 0.f : s * __expf(m - gm), red);
     const float lse = gm + __logf(gs);
 
-    const int64_t lab = a.labels[r];
-    const int64_t upp = a.upp_labels ? a.upp_labels[r] : lab;
-    const bool valid_lo = lab != -100, valid_up = upp != -100;
+    int64_t lab = a.labels[r];
+    int64_t upp = a.upp_labels ? a.upp_labels[r] : lab;
+    // labels outside [0, V) other than the ignore index: torch's CrossEntropyLoss / one_hot raise; here the row loss is
+    // poisoned (NaN -> the step's loss is NaN) instead of reading logits / timestamp tables out of bounds
+    const bool bad = (lab != -100 && (lab < 0 || lab >= a.V)) || (upp != -100 && (upp < 0 || upp >= a.V));
+    if (bad) { lab = -100; upp = -100; }
+    const bool valid_lo = lab != -100;
+    // soft path: the reference clamps an ignored label to token 0 and masks BOTH losses by the lower-case labels' padding
+    // only (SoftLabelCreator._get_soft_distribution / compute_loss, modeling_dicow.py:79,130-136): a row whose upper-case
+    // label alone is -100 competes with -log p(token 0)
+    if (a.soft && valid_lo && upp == -100) upp = 0;
+    const bool valid_up = upp != -100;
     float lo = valid_lo ? lse - target_dot(row, lab, a, red) : 0.f;
     float up = lo;
     if (a.upp_labels) up = valid_up ? lse - target_dot(row, upp, a, red) : 0.f;
-    // soft path masks BOTH losses by the lower-case labels' padding (modeling_dicow.py:130-136)
     if (a.soft && !valid_lo) { lo = 0.f; up = 0.f; }
+    if (bad) lo = up = __int_as_float(0x7fc00000);
     const int choice = (up < lo) ? 1 : 0;
     const float l = choice ? up : lo;
     if (threadIdx.x == 0) {
@@ -102,9 +111,10 @@ __global__ void __launch_bounds__(LOSS_THREADS) ce_bwd_kernel(const dicow_ce_arg
     const unsigned short* row = reinterpret_cast<const unsigned short*>(a.logits) + (int64_t)r * a.ld;
     unsigned short* drow = reinterpret_cast<unsigned short*>(a.d_logits) + (int64_t)r * a.ld;
     const int64_t lab = a.labels[r];
-    const int64_t upp = a.upp_labels ? a.upp_labels[r] : lab;
+    int64_t upp = a.upp_labels ? a.upp_labels[r] : lab;
+    if (a.soft && lab != -100 && upp == -100) upp = 0;          // as in the forward: the reference's clamp of an ignored label
     const int64_t sel = a.choice[r] ? upp : lab;
-    bool active = sel != -100;
+    bool active = sel != -100 && sel >= 0 && sel < a.V;         // out-of-range labels poisoned the loss in the forward
     if (a.soft && lab == -100) active = false;
     const float sc = active ? grad_scale[0] : 0.f;
     const float lse = a.lse[r];

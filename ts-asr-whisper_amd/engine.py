@@ -43,7 +43,7 @@ class GradSink:
         for p in params:
             if p is None or not p.requires_grad or id(p) in self.index or id(p) in self.direct:
                 continue
-            if getattr(p, "_direct_grad", None) is not None and extra_rows.get(id(p), 0) == 0:
+            if getattr(p, "_direct_grad", None) is not None:
                 self.direct[id(p)] = p._direct_grad
                 continue
             n = p.numel() + extra_rows.get(id(p), 0)
@@ -65,7 +65,14 @@ class GradSink:
         """What autograd should receive for p: None when the gradient was accumulated in place."""
         return None if (p is None or id(p) in self.direct) else self.get(p)
 
+    def is_direct(self, p):
+        return p is not None and id(p) in self.direct
+
     def raw(self, p, n):
+        if id(p) in self.direct:
+            d = self.direct[id(p)]
+            assert d.numel() == n, "GradSink.raw: a flat-store gradient has no padding rows"
+            return d.view(-1)
         off, _, _ = self.index[id(p)]
         return self.flat[off:off + n]
 
@@ -746,7 +753,15 @@ class DecoderEngine:
         # tied LM head (modeling_dicow.py:302): d_x = d_logits @ E ; dE += d_logits^T @ x
         ge = G.get(model.proj_out.weight)
         if ge is not None:
-            ops.gemm_tn(d_logits, S.xf, G.raw(model.proj_out.weight, W.vpad * D).view(W.vpad, D), rows, W.vpad, D)
+            if G.is_direct(model.proj_out.weight) and W.vpad != cfg.vocab_size:
+                # flat-store gradient (trainer.FlatStore) of a vocabulary that is not a multiple of 128: the padded rows go
+                # through a temporary so that the tied weight's gradient is COMPLETE in the flat store before the "decoder"
+                # segment is handed to the data-parallel all-reduce (it used to reach p.grad only after autograd returned)
+                tmp = torch.zeros(W.vpad, D, dtype=F32, device=dev)
+                ops.gemm_tn(d_logits, S.xf, tmp, rows, W.vpad, D)
+                ge.add_(tmp[:cfg.vocab_size])
+            else:
+                ops.gemm_tn(d_logits, S.xf, G.raw(model.proj_out.weight, W.vpad * D).view(W.vpad, D), rows, W.vpad, D)
         d_xf = linear_dgrad(d_logits, W.head, rows)
         g = _e((rows, D), F32, dev)
         gb = _e((rows, D), BF16, dev)

@@ -261,6 +261,14 @@ class _FDDTFullFn(torch.autograd.Function):
         return (None, gh.view(B, T, D), None) + tuple(G.result(p) for p in ctx.params)
 
 
+def _refuse_unsupported(where, **kw):
+    """Arguments of the HF / reference signatures that this path does not implement must not be dropped silently."""
+    bad = [k for k, v in kw.items() if v is not None]
+    if bad:
+        raise NotImplementedError(f"{where}: {', '.join(bad)} not supported by the HIP path (per-head masks, attention / "
+                                  "hidden-state outputs, decoder masks / positions have no kernels here)")
+
+
 # ------------------------------------------------------------------------------------------------ encoder
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
@@ -268,7 +276,6 @@ class _EncoderFn(torch.autograd.Function):
         eng = enc._engine()
         out, S = eng.forward(input_features, stno, enrollments, need_grad=need_grad)
         ctx.enc, ctx.S, ctx.params = enc, (S if need_grad else None), params
-        enc._last_state = S if need_grad else None
         return out
 
     @staticmethod
@@ -368,6 +375,8 @@ class DiCoWEncoder(nn.Module):
         _require_cuda(input_features, "DiCoWEncoder")
         if stno_mask is None:
             raise ValueError("stno_mask is required")
+        _refuse_unsupported("DiCoWEncoder.forward", head_mask=head_mask, output_attentions=output_attentions or None,
+                            output_hidden_states=output_hidden_states or None)
         ctc_ids = {id(p) for p in self.ctc_parameters()} if self.ctc_weight > 0.0 else set()
         params = [p for p in self.parameters() if id(p) not in ctc_ids]
         # under torch.no_grad() (evaluation / decoding) no activation is kept for a backward pass
@@ -863,6 +872,14 @@ class DiCoWForConditionalGeneration(nn.Module):
             decoder_input_ids = shift_tokens_right(labels, cfg.pad_token_id, cfg.decoder_start_token_id)
         if decoder_inputs_embeds is not None or past_key_values is not None:
             raise NotImplementedError("decoder_inputs_embeds / KV-cache decoding are outside the training-step path")
+        # arguments of the HF signature this path has no kernels for: refuse instead of silently computing something else
+        # (attention_mask is accepted and unused exactly as in HF Whisper, whose encoder does not mask)
+        _refuse_unsupported("DiCoWForConditionalGeneration.forward", decoder_attention_mask=decoder_attention_mask,
+                            head_mask=head_mask, decoder_head_mask=decoder_head_mask, cross_attn_head_mask=cross_attn_head_mask,
+                            decoder_position_ids=decoder_position_ids, cache_position=cache_position,
+                            forced_decoder_ids=forced_decoder_ids, output_attentions=output_attentions or None,
+                            output_hidden_states=output_hidden_states or None,
+                            use_cache=(use_cache or None) if labels is None else None)
         if encoder_outputs is None:
             _require_cuda(input_features, "DiCoWForConditionalGeneration")
             enc_out = self.model.encoder(input_features, stno_mask=stno_mask, enrollments=enrollments).last_hidden_state

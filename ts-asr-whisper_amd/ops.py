@@ -248,6 +248,9 @@ def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0
 
 # ------------------------------------------------------------------------------------------------ loss / embedding / misc
 def ce_args(logits, ld, rows, V, labels, upp_labels, soft, ts, lse, row_loss, choice, loss_sum, count, d_logits=None):
+    _req(labels, torch.int64, "ce.labels")
+    if upp_labels is not None:
+        _req(upp_labels, torch.int64, "ce.upp_labels")
     a = L.CeArgs()
     a.logits, a.ld, a.rows, a.V = logits.data_ptr(), ld, rows, V
     a.labels, a.upp_labels, a.soft = labels.data_ptr(), _p(upp_labels), int(soft)
@@ -285,6 +288,7 @@ def conv2_col2im_gelu_bwd(dA2, pre1, d_pre1, B, T2, Cc):
 
 
 def ctc_args(logits, ld, B, Tn, Cc, labels, lse, alpha, beta, nll, tlen, loss_sum):
+    _req(labels, torch.int64, "ctc.labels")
     a = L.CtcArgs()
     a.logits, a.ld, a.B, a.Tn, a.C = logits.data_ptr(), ld, B, Tn, Cc
     a.labels, a.Lc, a.blank = labels.data_ptr(), labels.shape[1], Cc - 1

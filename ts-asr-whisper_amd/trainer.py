@@ -175,6 +175,8 @@ class GradReducer:
             ops.set_gemm_cus(max(ncu - reserve, ncu // 2))
         self.seg = {name: (a, b) for name, a, b in store.segments}
         self.pending = []
+        self.time_exposed = False     # bench: record how long the compute stream waits for the side-stream buckets
+        self._exposed = []
         self.preheat_only = False     # staged freezing, phase 1: only the preheat runs carry gradients
         self.hold = False             # gradient accumulation: not the last micro-batch yet, nothing to exchange
 
@@ -214,7 +216,23 @@ class GradReducer:
         if self.preheat_only and (self.world > 1 or self.force):
             self._reduce_preheat_runs()
         if self.stream is not None:
-            torch.cuda.current_stream().wait_stream(self.stream)
+            if self.time_exposed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                torch.cuda.current_stream().wait_stream(self.stream)
+                e1.record()
+                self._exposed.append((e0, e1))
+            else:
+                torch.cuda.current_stream().wait_stream(self.stream)
+
+    def exposed_ms(self):
+        """Mean per-step time the compute stream spent waiting for the gradient exchange (time_exposed = True steps)."""
+        if not self._exposed:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b in self._exposed) / len(self._exposed)
+        self._exposed = []
+        return ms
 
 
 class TrainStep:
