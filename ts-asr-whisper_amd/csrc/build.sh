@@ -10,7 +10,11 @@ pids=""
 for s in $SRCS; do
   o=build/${s%.hip}.o
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/dicow_hip.h -nt "$o" ]; then
+  stale=0
+  for dep in "$s" common.h ../../include/dicow_hip.h $(ls *.inc 2>/dev/null); do
+    if [ ! -f "$o" ] || [ "$dep" -nt "$o" ]; then stale=1; fi
+  done
+  if [ $stale -eq 1 ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c "$s" -o "$o" "$@" &
     pids="$pids $!"
   fi

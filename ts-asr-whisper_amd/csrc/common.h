@@ -79,6 +79,66 @@ __device__ __forceinline__ void gelu_erf_both(float x, float& g, float& dg) {
     dg = fmaf(x, pdf, cdf);
 }
 
+// N elements at once, STAGE-MAJOR and PACKED.  The GEMM epilogues run ONE wave per SIMD, and a SIMD gets one issue slot every
+// four cycles: a lone wave retires at most one instruction per 4 cycles whatever its type, so the epilogue's cost is its
+// INSTRUCTION COUNT x 4 cycles (measured: 26 scalar VALU instructions per element x 256 elements per lane = 15.6 us per
+// 256 x 256 tile at 1.7 GHz, against 3.6 us for the same epilogue without the GELU).  Hence
+//   * packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two elements per issue slot) wherever the formula
+//     allows it -- the transcendental, sign and conversion steps stay per element;
+//   * every step of the formula applied to all N values before the next step starts, so that N independent dependency
+//     chains sit side by side (element by element, hipcc emits one ~12-deep chain of dependent operations after the other
+//     and the wave also idles for the VALU latency between them).  Empty asm statements naming a stage's values as in/out
+//     operands pin that order: left alone hipcc re-serialises the chains to save registers, and
+//     __builtin_amdgcn_sched_barrier does not hold pure arithmetic in place.
+template <int NP>
+__device__ __forceinline__ void stage_fence2(f32x2_t (&a)[NP]) {
+    static_assert(NP % 4 == 0, "stage_fence2: multiples of 4 pairs");
+#pragma unroll
+    for (int i = 0; i < NP; i += 4) asm volatile("" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
+}
+// x: NP pairs -> cdf = Phi(x), pdf = phi(x)  (same erfc form and coefficients as gelu_cdf_pdf)
+template <int NP, bool WANT_PDF>
+__device__ __forceinline__ void gelu_cdf_pdf_p(const f32x2_t (&x)[NP], f32x2_t (&cdf)[NP], f32x2_t (&pdf)[NP]) {
+    f32x2_t z[NP], t[NP], e[NP], p[NP];
+    const f32x2_t one = {1.0f, 1.0f}, half = {0.5f, 0.5f};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) z[i] = __builtin_elementwise_abs(x[i]) * 0.84932180028801907f;
+    stage_fence2(z);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { t[i] = __builtin_elementwise_fma(z[i], f32x2_t{0.27273748087922245f, 0.27273748087922245f}, one); e[i] = -(z[i] * z[i]); }
+    stage_fence2(t); stage_fence2(e);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { t[i].x = __builtin_amdgcn_rcpf(t[i].x); t[i].y = __builtin_amdgcn_rcpf(t[i].y);
+                                    e[i].x = __builtin_amdgcn_exp2f(e[i].x); e[i].y = __builtin_amdgcn_exp2f(e[i].y); }
+    stage_fence2(t); stage_fence2(e);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(t[i], f32x2_t{0.5307027145f, 0.5307027145f}, f32x2_t{-0.7265760135f, -0.7265760135f});
+    stage_fence2(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2_t{0.7107068705f, 0.7107068705f});
+    stage_fence2(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2_t{-0.142248368f, -0.142248368f});
+    stage_fence2(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = __builtin_elementwise_fma(p[i], t[i], f32x2_t{0.127414796f, 0.127414796f});
+    stage_fence2(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = p[i] * t[i];
+    stage_fence2(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) p[i] = half - p[i] * e[i];                          // 0.5 - Phi(-|x|) >= 0
+    stage_fence2(p);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) cdf[i] = half + __builtin_elementwise_copysign(p[i], x[i]);    // Phi(x) = 0.5 + sign(x) (0.5 - Phi(-|x|))
+    stage_fence2(cdf);
+    if (WANT_PDF) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pdf[i] = e[i] * 0.3989422804014327f;
+        stage_fence2(pdf);
+    }
+}
+
 // ---- wave / block reductions (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -129,6 +129,71 @@ __device__ __forceinline__ void nt_epilogue_math(const dicow_gemm_args& a, int r
     }
 }
 
+// NQ quads of one pass at once (compile-time flags only), stage-major like gelu_cdf_pdf_n: v / dg hold 4 * NQ values, quad u
+// at [4u, 4u + 4).  All quads share the column quad n (one bias quad); pre_aux / pre_res point at NQ consecutive entries.
+template <int FLAGS, int NQ>
+__device__ __forceinline__ void nt_epilogue_math_n(const dicow_gemm_args& a, float (&v)[4 * NQ], float (&dg)[4 * NQ], int n,
+                                                   const float4& bv, const uint2* pre_aux, const float4* pre_res) {
+    constexpr int NE = 4 * NQ;
+    if (FLAGS & DICOW_EPI_BIAS) {
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) { v[4 * u] += bv.x; v[4 * u + 1] += bv.y; v[4 * u + 2] += bv.z; v[4 * u + 3] += bv.w; }
+    }
+    if (FLAGS & DICOW_EPI_SCALE_N) {
+        if (n < a.scale_ncols) {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) v[e] *= a.scale;
+        }
+    }
+    if (FLAGS & DICOW_EPI_GELU) {
+        constexpr int NP = NE / 2;
+        f32x2_t x[NP], cdf[NP], pdf[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {                                  // AMP: the activation sees the bf16-rounded Linear output
+            const unsigned w = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+            x[i] = f32x2_t{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+        }
+        gelu_cdf_pdf_p<NP, (FLAGS & DICOW_EPI_GELU_DAUX) != 0>(x, cdf, pdf);
+        if (FLAGS & DICOW_EPI_GELU_DAUX) {
+#pragma unroll
+            for (int i = 0; i < NP; ++i) { const f32x2_t d = __builtin_elementwise_fma(x[i], pdf[i], cdf[i]); dg[2 * i] = d.x; dg[2 * i + 1] = d.y; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < NE; ++e) dg[e] = v[e];                  // aux receives the pre-activation
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) { const f32x2_t g = x[i] * cdf[i]; v[2 * i] = g.x; v[2 * i + 1] = g.y; }
+    }
+    if (FLAGS & (DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) {
+        float f[NE];
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const uint2 w = pre_aux[u];
+            f[4 * u] = __uint_as_float(w.x << 16); f[4 * u + 1] = __uint_as_float(w.x & 0xffff0000u);
+            f[4 * u + 2] = __uint_as_float(w.y << 16); f[4 * u + 3] = __uint_as_float(w.y & 0xffff0000u);
+        }
+        if (FLAGS & DICOW_EPI_GELU_BWD) {
+            constexpr int NP = NE / 2;
+            f32x2_t x[NP], cdf[NP], pdf[NP];
+#pragma unroll
+            for (int i = 0; i < NP; ++i) x[i] = f32x2_t{f[2 * i], f[2 * i + 1]};
+            gelu_cdf_pdf_p<NP, true>(x, cdf, pdf);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) { const f32x2_t d = __builtin_elementwise_fma(x[i], pdf[i], cdf[i]); f[2 * i] = d.x; f[2 * i + 1] = d.y; }
+        }
+#pragma unroll
+        for (int e = 0; e < NE; ++e) v[e] *= f[e];
+    }
+    if (FLAGS & DICOW_EPI_RESIDUAL) {
+#pragma unroll
+        for (int u = 0; u < NQ; ++u) {
+            const float4 rv = pre_res[u];                               // AMP: the Linear output is rounded to bf16 before the fp32 residual add
+            v[4 * u] = bf2f(f2bf(v[4 * u])) + rv.x; v[4 * u + 1] = bf2f(f2bf(v[4 * u + 1])) + rv.y;
+            v[4 * u + 2] = bf2f(f2bf(v[4 * u + 2])) + rv.z; v[4 * u + 3] = bf2f(f2bf(v[4 * u + 3])) + rv.w;
+        }
+    }
+}
+
 template <int FLAGS = -1>
 __device__ __forceinline__ void nt_epilogue_quad(const dicow_gemm_args& a, int rflags, float (&v)[4], int m, int n,
                                                  unsigned short* Cb, float* Cf, unsigned short* aux,
@@ -632,8 +697,8 @@ __global__ void __launch_bounds__(256) gemm_ntw_kernel(const dicow_gemm_args a) 
                 if (TAIL && nokt) voCt = (unsigned)((tr8 * (int)a.ldc + 128 + 4 * tq) * ESZ);
                 if (AUX_IO) {
                     rsX = __builtin_amdgcn_make_buffer_rsrc(aux, 0, (unsigned)(((int64_t)(a.M - 1) * a.ldaux + a.N) * 2), 0x00020000);
-                    if (nok) voX = (unsigned)((hh * (int)a.ldaux + 4 * ml) * 2);
-                    if (TAIL && nokt) voXt = (unsigned)((tr8 * (int)a.ldaux + 128 + 4 * tq) * 2);
+                    if (nok && aux) voX = (unsigned)((hh * (int)a.ldaux + 4 * ml) * 2);          // no aux: stores dropped (no branch per quad)
+                    if (TAIL && nokt && aux) voXt = (unsigned)((tr8 * (int)a.ldaux + 128 + 4 * tq) * 2);
                 }
                 if (PRE_RES) {
                     rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual), 0,
@@ -668,7 +733,7 @@ __global__ void __launch_bounds__(256) gemm_ntw_kernel(const dicow_gemm_args a) 
         }                                                                                                    \
         if ((FLAGS & DICOW_EPI_GELU) != 0) {                                                                 \
             const u32x2_t xv = {pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3])};                       \
-            if (aux) __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (TL) ? voXt : voX, NTW_SOFF(J, IT, a.ldaux, 2), 0); \
+            __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (TL) ? voXt : voX, NTW_SOFF(J, IT, a.ldaux, 2), 0); \
         }                                                                                                    \
         if (ESZ == 4) {                                                                                      \
             const u32x4_t ov = {__float_as_uint(vv[0]), __float_as_uint(vv[1]), __float_as_uint(vv[2]), __float_as_uint(vv[3])}; \
@@ -959,7 +1024,8 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
         NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTW_ATTR(DICOW_EPI_MUL_AUX);
         NTW_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
 #undef NTW_ATTR
-#define NTR_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS)
+#define NTR_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS); \
+                    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS)
         NTR_ATTR(-1); NTR_ATTR(0); NTR_ATTR(DICOW_EPI_BIAS); NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N);
         NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU); NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32);
         NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTR_ATTR(DICOW_EPI_MUL_AUX);
@@ -980,7 +1046,7 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     const bool big = off32 && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
         const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
-        if (variant == 0 || variant == 11 || variant == 12 || variant == 13 || variant == 20) {
+        if (variant == 0 || variant == 11 || variant == 12 || variant == 13 || variant >= 20) {
             static int ncu_all = 0;
             if (!ncu_all) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); ncu_all = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
             const int ncu = (g_gemm_cus > 0 && g_gemm_cus < ncu_all) ? g_gemm_cus : ncu_all;   // CUs left to us (dicow_set_gemm_cus)
@@ -992,8 +1058,9 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             const int64_t t35 = (int64_t)dicow_cdiv(a->M, 192) * dicow_cdiv(a->N, 320) * batch;
             const int64_t w44 = dicow_cdiv(t44, ncu) * 256 * 256, w35 = dicow_cdiv(t35, ncu) * 192 * 320;
             // gemm_ntr_kernel (LDS ring, 256 x 256 tiles) is the default; DICOW_NT_VARIANT 12 / 13 force the two-stage kernels
-            const bool ring = (variant == 0 || variant == 20) && a->K >= 2 * BK;
-            const bool use35 = !ring && (variant == 13 || (variant != 12 && a->N >= 320 && a->N <= 2048 && w35 < w44));
+            // DICOW_NT_VARIANT 21 / 22 force the ring kernel's 256 x 256 / 192 x 320 tiles
+            const bool ring = (variant == 0 || variant >= 20) && a->K >= 2 * BK;
+            const bool use35 = variant == 13 || variant == 22 || (variant != 12 && variant != 21 && a->N >= 320 && a->N <= 2048 && w35 < w44);
             const int total = (int)(use35 ? t35 : t44);
             // balanced grid: with r = ceil(total / ncu) rounds needed anyway, ceil(total / r) workgroups each take r (or
             // r - 1) tiles -- e.g. 470 tiles run on 235 workgroups x 2 instead of 214 x 2 + 42 x 1: same makespan, fewer
@@ -1001,7 +1068,8 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             const int rounds = dicow_cdiv(total, ncu);
             const dim3 gp(dicow_cdiv(total, rounds));
             if (colsum_rows) *colsum_rows = 2 * dicow_cdiv(a->M, use35 ? 192 : 256);
-#define NTW_LAUNCH(F) { if (ring) hipLaunchKernelGGL((gemm_ntr_kernel<F>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); \
+#define NTW_LAUNCH(F) { if (ring && use35) hipLaunchKernelGGL((gemm_ntr_kernel<F, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); \
+                        else if (ring) hipLaunchKernelGGL((gemm_ntr_kernel<F, 4, 4>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); \
                         else if (use35) hipLaunchKernelGGL((gemm_ntw_kernel<F, 3, 5>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); \
                         else hipLaunchKernelGGL((gemm_ntw_kernel<F, 4, 4>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); }
             if (want_colsum && variant != 11 && a->flags == DICOW_EPI_MUL_AUX) { a->flags |= DICOW_EPI_COLSUM; *fused_colsum = true; }
