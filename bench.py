@@ -307,8 +307,8 @@ def main():
     med_ms = step_ms[len(step_ms) // 2] if a.steps % 2 else 0.5 * (step_ms[a.steps // 2 - 1] + step_ms[a.steps // 2])
     exposed_ms = ts.reducer.exposed_ms()
     ts.reducer.time_exposed = False
-    rank_ms = [dt / a.steps * 1e3]
-    rank_exposed = [exposed_ms]
+    rank_ms = [round(dt / a.steps * 1e3, 3)]
+    rank_exposed = [round(exposed_ms, 3)]
     if world > 1:
         t = torch.tensor([dt, -dt, exposed_ms], device="cuda", dtype=torch.float64)
         every = [torch.zeros_like(t) for _ in range(world)]
