@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""Real-dimension goldens: the REAL reference (imported from /root/reference, build container only) run at whisper-tiny,
+whisper-base and whisper-large-v3-turbo dimensions -- BASELINE.json configs[0], [1], [2] and the mixed-length SE-DiCoW of
+configs[4] -- on integer-hashed weights and inputs (tests/util.py: hashed_init_, hashed_mel, hashed_stno, hashed_labels), so
+that the fixtures hold OUTPUTS only (a few hundred KB each) and the GPU tests regenerate identical weights:
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_realdims.py [rd_tiny rd_base rd_turbo rd_turbo_se]
+
+Per case: fp32 loss (hard-label and soft-label), encoder output / logits sub-samples and per-frame statistics, every watched
+parameter gradient as (sub-sample, L2 norm, sum), and the deviation of the reference's OWN bf16-autocast run from its fp32 run
+for each of those (the yard-stick the GPU tolerances are written against, like F9 at toy dimensions).
+"""
+import os
+import sys
+import time
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import make_golden as MG                      # installs the transformers-5 tuple shim and imports the reference model classes
+
+import numpy as np
+import torch
+
+from tests.util import hashed_init_, hashed_mel, hashed_stno, hashed_labels, subsample, sketch
+
+DIMS = {
+    "whisper-tiny": dict(d_model=384, encoder_layers=4, encoder_attention_heads=6, decoder_layers=4, decoder_attention_heads=6,
+                         encoder_ffn_dim=1536, decoder_ffn_dim=1536, num_mel_bins=80, vocab_size=51865),
+    "whisper-base": dict(d_model=512, encoder_layers=6, encoder_attention_heads=8, decoder_layers=6, decoder_attention_heads=8,
+                         encoder_ffn_dim=2048, decoder_ffn_dim=2048, num_mel_bins=80, vocab_size=51865),
+    "whisper-large-v3-turbo": dict(d_model=1280, encoder_layers=32, encoder_attention_heads=20, decoder_layers=4,
+                                   decoder_attention_heads=20, encoder_ffn_dim=5120, decoder_ffn_dim=5120, num_mel_bins=128,
+                                   vocab_size=51866),
+}
+COMMON = dict(max_source_positions=1500, max_target_positions=448, pad_token_id=50257, bos_token_id=50257, eos_token_id=50257,
+              decoder_start_token_id=50258, use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True, fddt_init="suppressive",
+              non_target_fddt_value=0.5)
+CASES = {
+    # name: (preset, B, L, extra config, mixed_length, soft-label run too)
+    "rd_tiny": ("whisper-tiny", 1, 32, {}, False, True),
+    "rd_base": ("whisper-base", 8, 64, {}, False, True),
+    "rd_turbo": ("whisper-large-v3-turbo", 1, 128, {}, False, True),
+    "rd_turbo_se": ("whisper-large-v3-turbo", 1, 64, dict(use_enrollments=True, scb_layers=8), True, False),
+}
+TS_N = 1501                                  # <|0.00|> .. <|30.00|>: the last 1501 ids of the multilingual Whisper vocabularies
+
+
+def ts_start(preset):
+    return DIMS[preset]["vocab_size"] - TS_N
+
+
+def watched(names, n_layers, n_dec, se):
+    mid, last = n_layers // 2, n_layers - 1
+    want = [f"model.encoder.fddts.0.target_linear.weight", f"model.encoder.fddts.0.target_linear.bias",
+            f"model.encoder.fddts.{last}.overlap_linear.weight", f"model.encoder.fddts.{mid}.non_target_linear.bias",
+            "model.encoder.initial_fddt.silence_linear.weight", "model.encoder.initial_fddt.target_linear.bias",
+            "model.encoder.layers.0.self_attn.q_proj.weight", "model.encoder.layers.0.self_attn.q_proj.bias",
+            "model.encoder.layers.0.self_attn.k_proj.weight", "model.encoder.layers.0.self_attn.v_proj.bias",
+            "model.encoder.layers.0.self_attn.out_proj.bias", f"model.encoder.layers.{mid}.self_attn.out_proj.weight",
+            f"model.encoder.layers.{mid}.fc1.weight", f"model.encoder.layers.{mid}.fc1.bias", f"model.encoder.layers.{mid}.fc2.weight",
+            f"model.encoder.layers.{mid}.fc2.bias", f"model.encoder.layers.{last}.self_attn_layer_norm.weight",
+            f"model.encoder.layers.{last}.final_layer_norm.bias", f"model.encoder.layers.{last}.fc2.bias",
+            "model.encoder.layer_norm.weight", "model.encoder.conv1.weight", "model.encoder.conv1.bias", "model.encoder.conv2.weight",
+            "model.encoder.conv2.bias", "model.decoder.layers.0.encoder_attn.q_proj.weight",
+            f"model.decoder.layers.{n_dec - 1}.fc1.bias", "model.decoder.layer_norm.weight", "model.decoder.embed_tokens.weight",
+            "model.decoder.embed_positions.weight"]
+    if se:
+        want += [n for n in names if n.startswith(("model.encoder.ca_enrolls.0.", "model.encoder.ca_enrolls.7."))]
+    return [n for n in want if n in names]
+
+
+def inputs(preset, B, L, mixed, se, tag):
+    d = DIMS[preset]
+    TS_START = ts_start(preset)
+    M, T = d["num_mel_bins"], 1500
+    x = torch.from_numpy(hashed_mel(B * (2 if se else 1), M, 2 * T)).clone() * 1.5
+    st = hashed_stno(B * (2 if se else 1), T, tag + ".stno")
+    lens = [T] * (B * (2 if se else 1))
+    if mixed:                                 # 10-30 s mixtures, 5-30 s enrollments; pad-as-silence (collators.py:157-161)
+        lens = [int(T * f) for f in ([0.55] * B + [0.3] * B)][:len(lens)]
+        for i, n in enumerate(lens):
+            x[i, :, 2 * n:] = -1.5
+            st[i, :, n:] = 0.0
+            st[i, 0, n:] = 1.0
+    lab = hashed_labels(B, L, 0, 50257, tag + ".labels", pad_rows=(B - 1,))
+    lab[:, 0] = TS_START + 7                  # timestamp tokens: the soft-label rows
+    lab[:, L // 2] = TS_START + 311
+    upp = lab.clone()
+    chg = hashed_labels(B, L, 0, 10, tag + ".chg") < 3
+    upp[chg & (lab >= 0) & (lab < TS_START)] = (lab[chg & (lab >= 0) & (lab < TS_START)] + 7) % 50257
+    return x, st, lab, upp, lens
+
+
+def summarise(prefix, t, n=1024, sk=None):
+    t = t.detach().float()
+    d = {prefix + ".sub": subsample(t, n), prefix + ".norm": t.double().norm().float(), prefix + ".sum": t.double().sum().float(),
+         prefix + ".absmax": t.abs().max()}
+    if sk is not None:
+        d[prefix + ".sketch"] = sketch(t, sk)
+    return d
+
+
+def run_case(name):
+    preset, B, L, extra, mixed, do_soft = CASES[name]
+    se = bool(extra.get("use_enrollments"))
+    kw = dict(COMMON)
+    kw.update(DIMS[preset])
+    kw.update(extra)
+    cfg = MG.DiCoWConfig(**kw)
+    t0 = time.time()
+    torch.manual_seed(0)
+    model = MG.DiCoWForConditionalGeneration(cfg).eval()
+    hashed_init_(model)
+    with torch.no_grad():                     # Whisper's sinusoidal table, as HF computes it
+        model.model.encoder.embed_positions.weight.copy_(MG.mw.sinusoids(1500, cfg.d_model))
+    x, st, lab, upp, lens = inputs(preset, B, L, mixed, se, name)
+    batch = dict(input_features=x[:B], stno_mask=st[:B], labels=lab, upp_labels=upp)
+    if se:
+        batch["enrollments"] = {"input_features": x[B:], "stno_mask": st[B:], "attention_mask": torch.ones(B, 3000)}
+    names = [n for n, _ in model.named_parameters()]
+    W = watched(set(names), cfg.encoder_layers, cfg.decoder_layers, se)
+    params = dict(model.named_parameters())
+    arrs = {"preset": np.array(preset), "B": np.array(B), "L": np.array(L), "extra": np.array(repr(extra)), "mixed": np.array(mixed),
+            "lens": np.array(lens), "stno": st, "labels": lab, "upp_labels": upp, "watched": np.array("\n".join(W)),
+            "ts_start": np.array(ts_start(preset)), "ts_n": np.array(TS_N)}
+    print(f"[{name}] model built in {time.time() - t0:.1f} s; {sum(p.numel() for p in model.parameters()) / 1e6:.0f} M parameters", flush=True)
+
+    # ---- fp32, hard-label loss, all gradients
+    t0 = time.time()
+    out = MG.run_model(model, batch)
+    out.loss.backward()
+    print(f"[{name}] fp32 fwd+bwd {time.time() - t0:.1f} s, loss {float(out.loss):.6f}", flush=True)
+    enc, logits = out.encoder_last_hidden_state.detach(), out.logits.detach()
+    arrs["hard.loss"] = out.loss.detach()
+    arrs.update(summarise("enc", enc, 4096))
+    arrs["enc.frame_mean"], arrs["enc.frame_absmean"] = enc.mean(-1), enc.abs().mean(-1)
+    arrs.update(summarise("logits", logits, 4096))
+    arrs["logits.lse"] = torch.logsumexp(logits.float(), -1)
+    arrs["logits.argmax"] = logits.argmax(-1)
+    g32 = {}
+    for n in W:
+        g32[n] = params[n].grad.detach().clone()
+        arrs.update(summarise("hard.g." + n, g32[n], 512, sk=n))
+    # ---- the reference's own bf16-autocast deviation from the above
+    t0 = time.time()
+    ob = MG.run_model(model, batch, autocast=True)
+    ob.loss.backward()
+    print(f"[{name}] bf16-autocast fwd+bwd {time.time() - t0:.1f} s, loss {float(ob.loss):.6f}", flush=True)
+    eb, lb = ob.encoder_last_hidden_state.detach().float(), ob.logits.detach().float()
+    arrs["bf16.loss"] = ob.loss.detach().float()
+    arrs["bf16.enc.maxdev"], arrs["bf16.enc.reldev"] = (eb - enc).abs().max(), (eb - enc).double().norm().float() / enc.double().norm().float()
+    arrs["bf16.logits.maxdev"] = (lb - logits).abs().max()
+    arrs["bf16.logits.reldev"] = (lb - logits).double().norm().float() / logits.double().norm().float()
+    for n in W:
+        gb = params[n].grad.detach().float()
+        arrs["bf16.g.reldev." + n] = (gb - g32[n]).double().norm().float() / g32[n].double().norm().clamp_min(1e-30).float()
+        arrs["bf16.g.maxrel." + n] = (gb - g32[n]).abs().max() / g32[n].abs().max().clamp_min(1e-30)
+        arrs["bf16.g.subdev." + n] = (subsample(gb, 512) - subsample(g32[n], 512)).double().norm().float() / subsample(g32[n], 512).double().norm().clamp_min(1e-30).float()
+        arrs["bf16.g.sketch." + n] = sketch(gb, n)
+    # ---- soft-label loss (timestamp smoothing over the real timestamp range)
+    if do_soft:
+        model.set_tokenizer(MG.StubTokenizer(cfg.vocab_size, ts_start(preset), TS_N))
+        t0 = time.time()
+        os_ = MG.run_model(model, batch)
+        os_.loss.backward()
+        print(f"[{name}] soft-label fwd+bwd {time.time() - t0:.1f} s, loss {float(os_.loss):.6f}", flush=True)
+        arrs["soft.loss"] = os_.loss.detach()
+        for n in W[:12]:
+            arrs.update(summarise("soft.g." + n, params[n].grad.detach(), 512))
+    MG.save(name, **arrs)
+
+
+if __name__ == "__main__":
+    for c in (sys.argv[1:] or list(CASES)):
+        run_case(c)

@@ -1,0 +1,147 @@
+"""The HIP path against the REAL reference at real Whisper dimensions (goldens rd_*: tests/golden/make_golden_realdims.py).
+
+whisper-tiny B=1 (BASELINE.json configs[0]), whisper-base B=8 (configs[1]), whisper-large-v3-turbo B=1 L=128 (configs[2]'s model)
+and the mixed-length SE-DiCoW large-v3-turbo with 8 speaker-communication layers (configs[4]'s model).  Weights and inputs are
+regenerated from integer hashes (tests/util.py), the fixtures hold only the reference's fp32 outputs and -- as the yard-stick --
+how far the reference's OWN bf16-autocast run strays from them.
+
+Tolerances (the HIP path follows the reference's bf16 AMP recipe, the goldens are fp32):
+  * encoder output: max |diff| over the sub-sample and the per-frame means within max(6e-2, 3 x the reference's bf16 max deviation);
+    relative L2 error of the sub-sample within max(2e-2, 3 x the reference's relative L2 deviation);
+  * logits: same form with 6e-2 / 3 x; loss within max(2e-2, 3 x |bf16 loss - fp32 loss|);
+  * gradients, per watched parameter (>= 8 incl. the bias gradients produced by fused column sums): relative L2 error of the
+    sub-sample AND of the norm within max(5e-2, 4 x the reference's own bf16 relative deviation for that parameter).
+Run with `pytest -m gpu`."""
+import ast
+
+import numpy as np
+import pytest
+import torch
+
+import amd_pkg
+from tests.util import load_golden, hashed_init_, hashed_mel, subsample, sketch
+
+pytestmark = pytest.mark.gpu
+amd_pkg.load()
+
+
+def _build(z):
+    import ts_asr_whisper_amd as pkg
+    from ts_asr_whisper_amd.modeling import sinusoids
+    preset, extra = str(z["preset"]), ast.literal_eval(str(z["extra"]))
+    cfg = pkg.DiCoWConfig.preset(preset, use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True, fddt_init="suppressive",
+                                 non_target_fddt_value=0.5, **extra)
+    torch.manual_seed(0)
+    model = pkg.DiCoWForConditionalGeneration(cfg).cuda()
+    hashed_init_(model)                                   # identical parameter names -> identical hashed values as the reference run
+    with torch.no_grad():
+        model.model.encoder.embed_positions.weight.copy_(sinusoids(cfg.max_source_positions, cfg.d_model))
+    model.tie_weights()
+    for p in model.parameters():
+        p.requires_grad_(True)
+    model.model.encoder.embed_positions.weight.requires_grad_(False)      # HF: the sinusoidal table is frozen
+    return model, cfg
+
+
+def _batch(z, cfg):
+    B, L = int(z["B"]), int(z["L"])
+    se = bool(cfg.use_enrollments)
+    lens = z["lens"]
+    x = torch.from_numpy(hashed_mel(B * (2 if se else 1), cfg.num_mel_bins, 3000)).clone() * 1.5
+    if bool(z["mixed"]):
+        for i, n in enumerate(lens):
+            x[i, :, 2 * int(n):] = -1.5
+    st = torch.from_numpy(z["stno"])
+    batch = dict(input_features=x[:B].cuda(), stno_mask=st[:B].cuda(), labels=torch.from_numpy(z["labels"]).cuda(),
+                 upp_labels=torch.from_numpy(z["upp_labels"]).cuda())
+    if se:
+        batch["enrollments"] = {"input_features": x[B:].cuda(), "stno_mask": st[B:].cuda()}
+    return batch
+
+
+def _rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def _check_forward(z, out):
+    enc, logits = out.encoder_last_hidden_state.float().cpu(), out.logits.float().cpu()
+    ref_sub = torch.from_numpy(z["enc.sub"])
+    got_sub = subsample(enc, 4096)
+    dmax, drel = float(z["bf16.enc.maxdev"]), float(z["bf16.enc.reldev"])
+    assert float((got_sub - ref_sub).abs().max()) < max(6e-2, 3 * dmax), ("enc sub", float((got_sub - ref_sub).abs().max()), dmax)
+    assert _rel_l2(got_sub, ref_sub) < max(2e-2, 3 * drel), ("enc rel", _rel_l2(got_sub, ref_sub), drel)
+    assert float((enc.mean(-1) - torch.from_numpy(z["enc.frame_mean"])).abs().max()) < max(2e-2, 3 * dmax)
+    assert float((enc.abs().mean(-1) - torch.from_numpy(z["enc.frame_absmean"])).abs().max()) < max(2e-2, 3 * dmax)
+    lmax, lrel = float(z["bf16.logits.maxdev"]), float(z["bf16.logits.reldev"])
+    got_l, ref_l = subsample(logits, 4096), torch.from_numpy(z["logits.sub"])
+    assert float((got_l - ref_l).abs().max()) < max(6e-2, 3 * lmax), ("logits sub", float((got_l - ref_l).abs().max()), lmax)
+    assert _rel_l2(got_l, ref_l) < max(2e-2, 3 * lrel)
+    lse = torch.logsumexp(logits, -1)
+    assert float((lse - torch.from_numpy(z["logits.lse"])).abs().max()) < max(6e-2, 3 * lmax)
+    dloss = abs(float(z["bf16.loss"]) - float(z["hard.loss"]))
+    assert abs(float(out.loss) - float(z["hard.loss"])) < max(2e-2, 3 * dloss), (float(out.loss), float(z["hard.loss"]), dloss)
+
+
+def _check_grads(z, model, prefix, names, min_checked):
+    named = dict(model.named_parameters())
+    worst, n = (0.0, None), 0
+    for name in names:
+        key = f"{prefix}.g.{name}"
+        if key + ".sub" not in z.files:
+            continue
+        g = named[name].grad
+        assert g is not None, name
+        g = g.float().cpu()
+        ref_sub, ref_norm = torch.from_numpy(z[key + ".sub"]), float(z[key + ".norm"])
+        dev = max(float(z["bf16.g.reldev." + name]), float(z["bf16.g.subdev." + name])) if prefix == "hard" else float(z["bf16.g.reldev." + name])
+        tol = max(5e-2, 4 * dev)
+        r_sub = _rel_l2(subsample(g, 512), ref_sub)
+        r_norm = abs(float(g.double().norm()) - ref_norm) / max(ref_norm, 1e-30)
+        assert r_sub < tol and r_norm < tol, (name, r_sub, r_norm, tol, dev)
+        if key + ".sketch" in z.files:                         # whole-tensor direction: 4 hashed +-1 projections
+            ref_sk, bf_sk = torch.from_numpy(z[key + ".sketch"]), torch.from_numpy(z["bf16.g.sketch." + name])
+            sk = sketch(named[name].grad.float(), name).cpu()
+            # a projection of an N-element tensor is ~ |g| in size: errors are measured against the norm, not the projection
+            e_ours, e_ref = float((sk - ref_sk).abs().max()) / max(ref_norm, 1e-30), float((bf_sk - ref_sk).abs().max()) / max(ref_norm, 1e-30)
+            assert e_ours < max(5e-2, 4 * e_ref), (name, "sketch", e_ours, e_ref)
+        if r_sub > worst[0]:
+            worst = (r_sub, name)
+        n += 1
+    assert n >= min_checked, n
+    return worst
+
+
+class _Tok:
+    def __init__(self, V, ts_start, n_ts):
+        self.V, self.s, self.n = V, ts_start, n_ts
+        self.prefix_tokens = [50258]
+
+    def get_vocab(self):
+        v = {f"tok{i}": i for i in range(self.V)}
+        for j in range(self.n):
+            v.pop(f"tok{self.s + j}")
+            v[f"<|{0.02 * j:.2f}|>"] = self.s + j
+        return v
+
+
+@pytest.mark.parametrize("case", ["rd_tiny", "rd_base", "rd_turbo", "rd_turbo_se"])
+def test_real_dimension_step_vs_reference_golden(case):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    z = load_golden(case)
+    model, cfg = _build(z)
+    batch = _batch(z, cfg)
+    out = model(**batch)
+    _check_forward(z, out)
+    out.loss.backward()
+    names = str(z["watched"]).split("\n")
+    worst = _check_grads(z, model, "hard", names, min_checked=20)
+    print(case, "worst gradient sub-sample rel-L2 error vs the reference's fp32 gradient:", worst)
+    if "soft.loss" in z.files:                                  # soft-label (timestamp-smoothed) loss over the real timestamp range
+        model.zero_grad(set_to_none=True)
+        model.set_tokenizer(_Tok(cfg.vocab_size, int(z["ts_start"]), int(z["ts_n"])))
+        out = model(**batch)
+        dloss = abs(float(z["bf16.loss"]) - float(z["hard.loss"]))
+        assert abs(float(out.loss) - float(z["soft.loss"])) < max(2e-2, 3 * dloss), (float(out.loss), float(z["soft.loss"]))
+        out.loss.backward()
+        _check_grads(z, model, "soft", names, min_checked=8)

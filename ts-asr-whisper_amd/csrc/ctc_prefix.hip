@@ -182,12 +182,12 @@ extern "C" int dicow_ctc_prefix_score(const dicow_ctc_prefix_args* a, void* stre
                   "ctc_prefix_score: null pointer");
     DICOW_REQUIRE(a->blank >= 0 && a->blank < a->ld && a->eos >= 0, "ctc_prefix_score: blank %d / eos %d out of range", a->blank, a->eos);
     const size_t lds = (size_t)a->T * 4 * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
+    static const bool attr = [] {
         (void)hipFuncSetAttribute((const void*)ctc_prefix_score_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16);
         (void)hipFuncSetAttribute((const void*)ctc_prefix_score_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 16);
-        attr = true;
-    }
+        return true;
+    }();
+    (void)attr;
     const dim3 grid((a->C + CPS_BLOCK - 1) / CPS_BLOCK, a->n);
     if (a->in_bf16) ctc_prefix_score_kernel<1><<<grid, CPS_BLOCK, lds, (hipStream_t)stream>>>(*a);
     else ctc_prefix_score_kernel<0><<<grid, CPS_BLOCK, lds, (hipStream_t)stream>>>(*a);

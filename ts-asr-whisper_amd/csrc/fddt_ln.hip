@@ -312,12 +312,12 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
 // once and every workgroup strides over rows, so no partial tail wave runs at low occupancy.
 template <typename K>
 static int resident_grid(K kernel, int block, int* cache) {
-    if (*cache == 0) {
-        int nb = 0;
+    int nb = __atomic_load_n(cache, __ATOMIC_RELAXED);      // (any host thread may get here first: the query is idempotent)
+    if (nb == 0) {
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) nb = 1;
-        *cache = nb;
+        __atomic_store_n(cache, nb, __ATOMIC_RELAXED);
     }
-    return 256 * *cache;
+    return 256 * nb;
 }
 
 static int pick_block(int D) {
@@ -341,8 +341,8 @@ extern "C" int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream) 
                         a->y_bf16 && !a->y_f32 && a->mean && a->rstd && !a->pos && a->w[0] && a->w[1] && a->w[2] && a->w[3] &&
                         a->b[0] && a->b[1] && a->b[2] && a->b[3] && (int64_t)a->rows * a->D * 4 < (1ll << 31);
     if (staged) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)fddt_ln_fwd_staged_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 4 * 2048); attr = true; }
+        static const bool attr = [] { (void)hipFuncSetAttribute((const void*)fddt_ln_fwd_staged_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 4 * 2048); return true; }();
+        (void)attr;
         const int cap = 256 * 3;                      // three resident workgroups per CU (40 KiB of staging each at D = 1280)
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL((fddt_ln_fwd_staged_kernel<4>), dim3(grid), dim3(block), 2 * R * 4 * a->D, (hipStream_t)stream, *a);

@@ -350,13 +350,18 @@ __global__ void __launch_bounds__(256) gemm_nt_skinny_kernel(const dicow_gemm_ar
     nt_epilogue_quad(a, a.flags, v, m, n, Cb, Cf, aux);
 }
 
+// The product's big-problem kernel is gemm_ntr_kernel (gemm_ntr.inc).  Its predecessors -- the 8-wave 256 x 256 kernel with its
+// ablation switches, the two-stage persistent 4-wave kernel (gemm_ntw_kernel: its header explains the one-wave-per-SIMD layout,
+// the tile shapes and the LDS-transposed epilogue that the ring kernel keeps) and the staggered 4-stage experiment -- are only
+// compiled into diagnostic builds (-DDICOW_ABLATIONS, selected at run time with DICOW_NT_VARIANT; tools/build_variants.sh).
+#define NT256_STAGE (2 * 256 * BK * 2)       // A + B = 64 KiB
+#define NT256_LDS (2 * NT256_STAGE)
+#ifdef DICOW_ABLATIONS
 // ------------------------------------------------------------------------------------------------ NT, 256x256 tile
 // 512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 (M) x 64 (N) = 4x2 MFMA tiles (128 fp32 accumulators/lane).
 // Twice the arithmetic intensity of the 128x128 kernel (128 flop per LDS-staged byte): at ~0.7 PFLOP/s the small
 // tile already pulls ~11 TB/s through L2 -> LDS.  Two 64 KiB stages (128 KiB of the CU's 160 KiB LDS), one workgroup
 // per CU with two waves per SIMD.
-#define NT256_STAGE (2 * 256 * BK * 2)       // A + B = 64 KiB
-#define NT256_LDS (2 * NT256_STAGE)
 
 template <int ABL>   // ablation: 0 = real kernel, 1 = no DMA after the first tile, 2 = no MFMA, 3 = no LDS fragment reads
 __global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_args a) {
@@ -839,8 +844,11 @@ __global__ void __launch_bounds__(256) gemm_ntw_kernel(const dicow_gemm_args a) 
 #undef NTW_RSRC
 #undef NTW_DMA
 
+#endif  // DICOW_ABLATIONS
+
 #include "gemm_ntr.inc"
 
+#ifdef DICOW_ABLATIONS
 // ------------------------------------------------------------------------------------------------ NT, 256x256, staggered
 // Same tile / wave grid as gemm_nt256_kernel, but the contraction advances in 32-deep PHASES through a 4-stage LDS ring
 // (4 x 32 KiB) and the two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run ONE PHASE APART: in barrier
@@ -954,10 +962,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt256s_kernel(const dicow_gemm_ar
     }
 }
 
-static int g_gemm_cus = 0;                 // dicow_set_gemm_cus(): CUs the persistent kernel may occupy (0 = all)
-extern "C" int dicow_set_gemm_cus(int n) { const int old = g_gemm_cus; g_gemm_cus = n > 0 ? n : 0; return old; }
+#endif  // DICOW_ABLATIONS
 
-// ws for DICOW_EPI_COLSUM: the fused path needs 2 * ceil(M/256) partial rows; the fallback runs dicow_colsum_bf16 on C
+#include <atomic>
+#include <mutex>
+static std::atomic<int> g_gemm_cus{0};     // dicow_set_gemm_cus(): CUs the persistent kernel may occupy (0 = all)
+extern "C" int dicow_set_gemm_cus(int n) { return g_gemm_cus.exchange(n > 0 ? n : 0); }
+
+// ws for DICOW_EPI_COLSUM: the fused path needs 2 * ceil(M/192) partial rows; the fallback runs dicow_colsum_bf16 on C
 extern "C" int64_t dicow_gemm_nt_colsum_ws_bytes(int M, int N) {
     const int64_t fused = (int64_t)2 * dicow_cdiv(M, 192) * N * 4, fb = dicow_colsum_ws_bytes(M, N);
     return fused > fb ? fused : fb;
@@ -981,6 +993,40 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     return dicow_colsum_bf16(a->C, a->ldc, a->colsum_out, a->M, a->N, a->colsum_ws, a->colsum_ws_bytes, stream);
 }
 
+// one-time kernel attributes (dynamic LDS sizes) and device properties; the C ABI may be entered from any host thread -- the
+// forward thread and autograd's backward thread both launch GEMMs -- so this runs under std::call_once
+static int g_ncu_all = 256;
+static void gemm_nt_setup() {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+#define NTR_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS); \
+                    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS)
+    NTR_ATTR(-1); NTR_ATTR(0); NTR_ATTR(DICOW_EPI_BIAS); NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N);
+    NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU); NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32);
+    NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTR_ATTR(DICOW_EPI_MUL_AUX);
+    NTR_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
+#undef NTR_ATTR
+#ifdef DICOW_ABLATIONS
+    (void)hipFuncSetAttribute((const void*)gemm_nt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NTS_LDS);
+#define NTW_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntw_kernel<F, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS); \
+                    (void)hipFuncSetAttribute((const void*)gemm_ntw_kernel<F, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS)
+    NTW_ATTR(-1); NTW_ATTR(0); NTW_ATTR(DICOW_EPI_BIAS); NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N);
+    NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU); NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32);
+    NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTW_ATTR(DICOW_EPI_MUL_AUX);
+    NTW_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
+#undef NTW_ATTR
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
+#endif
+    hipDeviceProp_t pr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (hipGetDeviceProperties(&pr, dev) == hipSuccess) g_ncu_all = pr.multiProcessorCount;
+}
+
 static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_colsum, int* colsum_rows) {
     dicow_gemm_args a_copy = *a_in;
     dicow_gemm_args* a = &a_copy;
@@ -1001,65 +1047,36 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     DICOW_REQUIRE(!(a->flags & DICOW_EPI_SCALE_N) || a->scale_ncols % 4 == 0, "gemm_nt: SCALE_N works on column quads, scale_ncols=%d", a->scale_ncols);
     const int batch = a->batch > 0 ? a->batch : 1;
     const int ntm = dicow_cdiv(a->M, BM), ntn = dicow_cdiv(a->N, BN);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
-        attr_set = true;
-    }
-    static const int variant = getenv("DICOW_NT_VARIANT") ? atoi(getenv("DICOW_NT_VARIANT")) : 0;     // tuning knob
+    static std::once_flag once;
+    std::call_once(once, gemm_nt_setup);
+#ifdef DICOW_ABLATIONS
+    static const int variant = getenv("DICOW_NT_VARIANT") ? atoi(getenv("DICOW_NT_VARIANT")) : 0;     // diagnostic builds only
+#else
+    constexpr int variant = 0;
+#endif
     if (a->M <= 16 && batch == 1 && variant == 0) {       // a decoding step: stream the weights once (gemm_nt_skinny_kernel)
         hipLaunchKernelGGL(gemm_nt_skinny_kernel, dim3(dicow_cdiv(a->N, 16)), dim3(256), 0, (hipStream_t)stream, *a);
         DICOW_CHECK_LAUNCH("gemm_nt_skinny_kernel");
         if (fused_colsum) *fused_colsum = false;
         return DICOW_OK;
     }
-    static bool attr256 = false;
-    if (!attr256) {
-        (void)hipFuncSetAttribute((const void*)gemm_nt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NTS_LDS);
-#define NTW_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntw_kernel<F, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS); \
-                    (void)hipFuncSetAttribute((const void*)gemm_ntw_kernel<F, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS)
-        NTW_ATTR(-1); NTW_ATTR(0); NTW_ATTR(DICOW_EPI_BIAS); NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N);
-        NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU); NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32);
-        NTW_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTW_ATTR(DICOW_EPI_MUL_AUX);
-        NTW_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
-#undef NTW_ATTR
-#define NTR_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS); \
-                    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS)
-        NTR_ATTR(-1); NTR_ATTR(0); NTR_ATTR(DICOW_EPI_BIAS); NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N);
-        NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU); NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32);
-        NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTR_ATTR(DICOW_EPI_MUL_AUX);
-        NTR_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
-#undef NTR_ATTR
-        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_nt256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, NT256_LDS);
-        attr256 = true;
-    }
-    // the 256x256 kernel wins once it can put ~one workgroup on every CU; smaller problems keep the 128x128 tiles
-    // the persistent kernel addresses its operands with 32-bit byte offsets from a per-batch base
+    // the persistent kernel wins once it can put ~one workgroup on every CU; smaller problems keep the 128x128 tiles.
+    // It addresses its operands with 32-bit byte offsets from a per-batch base and needs at least two 64-deep k-steps
     const bool off32 = (int64_t)a->M * a->lda * 2 < (1ll << 31) && (int64_t)a->N * a->ldb * 2 < (1ll << 31) &&
                        (int64_t)a->M * a->ldc * 4 < (1ll << 31) && (int64_t)a->M * a->ldaux * 2 < (1ll << 31) &&
                        (int64_t)a->M * a->ldr * 4 < (1ll << 31);
-    const bool big = off32 && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
+    const bool big = off32 && a->K >= 2 * BK && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
-        const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
-        if (variant == 0 || variant == 11 || variant == 12 || variant == 13 || variant >= 20) {
-            static int ncu_all = 0;
-            if (!ncu_all) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); ncu_all = hipGetDeviceProperties(&pr, dev) == hipSuccess ? pr.multiProcessorCount : 256; }
-            const int ncu = (g_gemm_cus > 0 && g_gemm_cus < ncu_all) ? g_gemm_cus : ncu_all;   // CUs left to us (dicow_set_gemm_cus)
+        if (variant == 0 || variant >= 11) {
+            const int lim = g_gemm_cus.load();
+            const int ncu = (lim > 0 && lim < g_ncu_all) ? lim : g_ncu_all;   // CUs left to us (dicow_set_gemm_cus)
             // tile shape: 192x320 where its whole rounds of `ncu` workgroups pad the problem less than 256x256 does AND the
-            // output is narrow (measured at M = 24000: N = 1280 shapes gain 2-4.5 %; N = 3840 is neutral and N = 5120 with
-            // the GELU epilogue loses 5 % -- more, smaller tiles mean more epilogues); DICOW_NT_VARIANT 12 / 13 force
-            // 256x256 / 192x320
+            // output is narrow (M = 24000: the N = 1280 shapes gain 2-5 %; N = 3840 is neutral and N = 5120 with the GELU
+            // epilogue loses -- more, smaller tiles mean more epilogues).  Diagnostic builds: DICOW_NT_VARIANT 21 / 22 force the
+            // ring kernel's 256x256 / 192x320 tiles, 12 / 13 the two-stage kernel's, 11 its run-time-flag epilogue
             const int64_t t44 = (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch;
             const int64_t t35 = (int64_t)dicow_cdiv(a->M, 192) * dicow_cdiv(a->N, 320) * batch;
             const int64_t w44 = dicow_cdiv(t44, ncu) * 256 * 256, w35 = dicow_cdiv(t35, ncu) * 192 * 320;
-            // gemm_ntr_kernel (LDS ring, 256 x 256 tiles) is the default; DICOW_NT_VARIANT 12 / 13 force the two-stage kernels
-            // DICOW_NT_VARIANT 21 / 22 force the ring kernel's 256 x 256 / 192 x 320 tiles
-            const bool ring = (variant == 0 || variant >= 20) && a->K >= 2 * BK;
             const bool use35 = variant == 13 || variant == 22 || (variant != 12 && variant != 21 && a->N >= 320 && a->N <= 2048 && w35 < w44);
             const int total = (int)(use35 ? t35 : t44);
             // balanced grid: with r = ceil(total / ncu) rounds needed anyway, ceil(total / r) workgroups each take r (or
@@ -1068,10 +1085,16 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             const int rounds = dicow_cdiv(total, ncu);
             const dim3 gp(dicow_cdiv(total, rounds));
             if (colsum_rows) *colsum_rows = 2 * dicow_cdiv(a->M, use35 ? 192 : 256);
-#define NTW_LAUNCH(F) { if (ring && use35) hipLaunchKernelGGL((gemm_ntr_kernel<F, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); \
-                        else if (ring) hipLaunchKernelGGL((gemm_ntr_kernel<F, 4, 4>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); \
-                        else if (use35) hipLaunchKernelGGL((gemm_ntw_kernel<F, 3, 5>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); \
-                        else hipLaunchKernelGGL((gemm_ntw_kernel<F, 4, 4>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); }
+#ifdef DICOW_ABLATIONS
+            const bool two_stage = variant >= 11 && variant <= 13;
+#define NTW_LAUNCH(F) { if (two_stage && use35) hipLaunchKernelGGL((gemm_ntw_kernel<F, 3, 5>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); \
+                        else if (two_stage) hipLaunchKernelGGL((gemm_ntw_kernel<F, 4, 4>), gp, dim3(256), NTW_LDS, (hipStream_t)stream, *a); \
+                        else if (use35) hipLaunchKernelGGL((gemm_ntr_kernel<F, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); \
+                        else hipLaunchKernelGGL((gemm_ntr_kernel<F, 4, 4>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); }
+#else
+#define NTW_LAUNCH(F) { if (use35) hipLaunchKernelGGL((gemm_ntr_kernel<F, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); \
+                        else hipLaunchKernelGGL((gemm_ntr_kernel<F, 4, 4>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); }
+#endif
             if (want_colsum && variant != 11 && a->flags == DICOW_EPI_MUL_AUX) { a->flags |= DICOW_EPI_COLSUM; *fused_colsum = true; }
             switch (variant == 11 ? -1 : a->flags) {   // compile-time epilogues for the flag sets the training step uses
                 case 0: NTW_LAUNCH(0); break;
@@ -1086,20 +1109,28 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             }
 #undef NTW_LAUNCH
         }
-        else if (variant == 9) hipLaunchKernelGGL(gemm_nt256s_kernel, g256, dim3(512), NTS_LDS, (hipStream_t)stream, *a);
-        else if (variant == 5) hipLaunchKernelGGL(gemm_nt256_kernel<1>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
-        else if (variant == 6) hipLaunchKernelGGL(gemm_nt256_kernel<2>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
-        else if (variant == 7) hipLaunchKernelGGL(gemm_nt256_kernel<3>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
-        else if (variant == 8) hipLaunchKernelGGL(gemm_nt256_kernel<4>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
-        else hipLaunchKernelGGL(gemm_nt256_kernel<0>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
-        DICOW_CHECK_LAUNCH("gemm_nt256");
+#ifdef DICOW_ABLATIONS
+        else {
+            const dim3 g256(dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256), 1, batch);
+            if (variant == 9) hipLaunchKernelGGL(gemm_nt256s_kernel, g256, dim3(512), NTS_LDS, (hipStream_t)stream, *a);
+            else if (variant == 5) hipLaunchKernelGGL(gemm_nt256_kernel<1>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
+            else if (variant == 6) hipLaunchKernelGGL(gemm_nt256_kernel<2>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
+            else if (variant == 7) hipLaunchKernelGGL(gemm_nt256_kernel<3>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
+            else if (variant == 8) hipLaunchKernelGGL(gemm_nt256_kernel<4>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
+            else hipLaunchKernelGGL(gemm_nt256_kernel<0>, g256, dim3(512), NT256_LDS, (hipStream_t)stream, *a);
+        }
+#endif
+        DICOW_CHECK_LAUNCH("gemm_nt (persistent)");
         return DICOW_OK;
     }
     const dim3 grid(ntm * ntn, 1, batch);
+#ifdef DICOW_ABLATIONS
     if (variant == 1) hipLaunchKernelGGL((gemm_nt_kernel<1, false>), grid, dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, *a);
     else if (variant == 2) hipLaunchKernelGGL((gemm_nt_kernel<2, true>), grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
     else if (variant == 3) hipLaunchKernelGGL((gemm_nt_kernel<1, true>), grid, dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<2, false>), grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
+    else
+#endif
+    hipLaunchKernelGGL((gemm_nt_kernel<2, false>), grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("gemm_nt");
     return DICOW_OK;
 }
@@ -1507,8 +1538,10 @@ static void tn_plan(const dicow_gemm_tn_args* a, int& tpb, int& total, int& nt, 
             if (tsec < best) { best = tsec; tile = tl; splits = sp; nt = n; }
         }
     }
-    if (const char* ev = getenv("DICOW_TN_SPLITS")) splits = atoi(ev);        // tuning knobs (tools/bench_gemm.py)
+#ifdef DICOW_ABLATIONS
+    if (const char* ev = getenv("DICOW_TN_SPLITS")) splits = atoi(ev);        // tuning knobs of diagnostic builds (tools/bench_gemm.py)
     if (const char* ev = getenv("DICOW_TN_TILE")) { tile = atoi(ev); nt = dicow_cdiv(a->N1, tile) * dicow_cdiv(a->N2, tile); }
+#endif
     if (splits < 1) splits = 1;
     tps = dicow_cdiv(total, splits);
     splits = dicow_cdiv(total, tps);
@@ -1531,12 +1564,12 @@ extern "C" int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream) {
     tn_plan(a, tpb, total, nt, splits, tps, tile);
     DICOW_REQUIRE(splits == 1 || (a->ws && a->ws_bytes >= (int64_t)splits * a->N1 * a->N2 * 4),
                   "gemm_tn: workspace too small (need %ld bytes)", (long)splits * a->N1 * a->N2 * 4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static const bool attr_set = [] {       // (a function-local static initialiser runs once, under the runtime's lock)
         (void)hipFuncSetAttribute((const void*)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS_BYTES);
         (void)hipFuncSetAttribute((const void*)gemm_tn256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
-        attr_set = true;
-    }
+        return true;
+    }();
+    (void)attr_set;
     if (tile == 256)
         hipLaunchKernelGGL(gemm_tn256_kernel, dim3(nt, 1, splits), dim3(512), TN256_LDS, (hipStream_t)stream, *a, tpb, total, tps);
     else
