@@ -344,6 +344,17 @@ int dicow_whisper_timestamp_rules(float* scores, int64_t ld, int B, int V, const
 int dicow_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
 int dicow_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, const float* gnorm_sq, float max_norm, void* stream);
+/* The same update with the step-dependent scalars read from device memory, hyper = {lr, 1 - beta1^t, 1 - beta2^t}: a training
+ * step captured in a hipGraph (reference counterpart: HF Trainer.training_step, src/utils/trainers.py:116-139, re-run every
+ * step) replays with fixed kernel arguments.  dicow_adamw_hyper keeps the counters on the device (counters[0] = optimizer steps
+ * taken, counters[1 + i] = updates received by run i; torch keeps state['step'] per parameter), advances them and writes
+ * hyper[3 i ..] for every active run: HF's LambdaLR indexing (the k-th step uses lambda(k - 1)), linear warm-up, cosine decay
+ * to max_steps (configs/train/dicow_v3.yaml:66-68) or constant, x `mult` for preheat runs (containers.py:109-111);
+ * preheat_only: the other runs are frozen (trainers.py:122-137) and neither counted nor written. */
+int dicow_adamw_hyper(int* counters, float* hyper, const int* is_pre, int n_runs, int preheat_only, float lr, float mult,
+                      int warmup_steps, int max_steps, int cosine, float beta1, float beta2, void* stream);
+int dicow_adamw_f32_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1, float beta2,
+                        float eps, float weight_decay, const float* gnorm_sq, float max_norm, void* stream);
 
 #ifdef __cplusplus
 }

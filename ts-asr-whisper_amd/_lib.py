@@ -115,6 +115,8 @@ _SIGS = {
     "dicow_whisper_timestamp_rules": [c_vp, c_i64, c_i, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "dicow_sumsq_f32": [c_vp, c_i64, c_vp, c_vp],
     "dicow_adamw_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_f, c_vp],
+    "dicow_adamw_hyper": [c_vp, c_vp, c_vp, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_vp],
+    "dicow_adamw_f32_dev": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f, c_f, c_f, c_f, c_vp, c_f, c_vp],
 }
 
 

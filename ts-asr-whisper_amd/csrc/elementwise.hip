@@ -453,7 +453,8 @@ extern "C" int dicow_sumsq_f32(const float* x, int64_t n, float* out, void* stre
 
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
-                             const float* __restrict__ gnorm_sq, float max_norm) {
+                             const float* __restrict__ gnorm_sq, float max_norm, const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }      // step-dependent scalars read from the device (graph replay)
     float clip = 1.f;
     if (gnorm_sq && max_norm > 0.f) {
         const float c = max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f);
@@ -490,7 +491,59 @@ extern "C" int dicow_adamw_f32(float* p, const float* g, float* m, float* v, int
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     int grid = (int)((n / 4 + 255) / 256); if (grid < 1) grid = 1; if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                       weight_decay, bc1, bc2, gnorm_sq, max_norm);
+                       weight_decay, bc1, bc2, gnorm_sq, max_norm, (const float*)nullptr);
     DICOW_CHECK_LAUNCH("adamw_f32");
+    return DICOW_OK;
+}
+
+// Step counters and schedule ON THE DEVICE: counters[0] = optimizer steps taken (HF state.global_step), counters[1 + i] =
+// updates run i has received.  One launch advances them and writes hyper[i] = {lr_i, 1 - beta1^t_i, 1 - beta2^t_i} for every
+// active run: lr_i = base lr at scheduler step k - 1 (LambdaLR steps after the optimizer; linear warm-up, then cosine to zero
+// at max_steps or constant) x the group multiplier for preheat runs.  Both the launch-by-launch step and its captured
+// hipGraph go through this kernel, so they apply bit-identical updates.
+__global__ void adamw_hyper_kernel(int* __restrict__ counters, float* __restrict__ hyper, const int* __restrict__ is_pre, int n_runs,
+                                   int preheat_only, float lr, float mult, int warmup, int max_steps, int cosine, float b1, float b2) {
+    const int i = threadIdx.x;
+    const int k = counters[0] + 1;
+    __syncthreads();
+    if (i == 0) counters[0] = k;
+    if (i >= n_runs) return;
+    const int pre = is_pre[i];
+    if (preheat_only && !pre) return;
+    const int t = counters[1 + i] + 1;
+    counters[1 + i] = t;
+    const int ss = k - 1;
+    float l = lr;
+    if (ss < warmup) l = lr * (float)ss / (float)(warmup > 1 ? warmup : 1);
+    else if (cosine && max_steps > 0) {
+        const float prog = (float)(ss - warmup) / (float)((max_steps - warmup) > 1 ? (max_steps - warmup) : 1);
+        const float c = 0.5f * (1.0f + cosf(3.14159265358979323846f * prog));
+        l = lr * (c > 0.f ? c : 0.f);
+    }
+    hyper[3 * i] = l * (pre ? mult : 1.0f);
+    hyper[3 * i + 1] = 1.0f - powf(b1, (float)t);
+    hyper[3 * i + 2] = 1.0f - powf(b2, (float)t);
+}
+
+extern "C" int dicow_adamw_hyper(int* counters, float* hyper, const int* is_pre, int n_runs, int preheat_only, float lr, float mult,
+                                 int warmup_steps, int max_steps, int cosine, float beta1, float beta2, void* stream) {
+    DICOW_REQUIRE(counters && hyper && is_pre && n_runs > 0 && n_runs <= 1024, "adamw_hyper: bad args (at most 1024 runs)");
+    const int block = (n_runs + 63) / 64 * 64;
+    hipLaunchKernelGGL(adamw_hyper_kernel, dim3(1), dim3(block), 0, (hipStream_t)stream, counters, hyper, is_pre, n_runs, preheat_only,
+                       lr, mult, warmup_steps, max_steps, cosine, beta1, beta2);
+    DICOW_CHECK_LAUNCH("adamw_hyper");
+    return DICOW_OK;
+}
+
+// The same update with the step-dependent scalars (learning rate after the schedule and the group multiplier, the two bias
+// corrections 1 - beta^t) read from DEVICE memory: hyper = {lr, 1 - beta1^t, 1 - beta2^t}.  A training step captured in a
+// hipGraph replays with fixed kernel arguments; the host rewrites these three floats before each replay instead.
+extern "C" int dicow_adamw_f32_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
+                                   float beta2, float eps, float weight_decay, const float* gnorm_sq, float max_norm, void* stream) {
+    DICOW_REQUIRE(p && g && m && v && n > 0 && hyper, "adamw_f32_dev: bad args");
+    int grid = (int)((n / 4 + 255) / 256); if (grid < 1) grid = 1; if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1, beta2, eps,
+                       weight_decay, 1.f, 1.f, gnorm_sq, max_norm, hyper);
+    DICOW_CHECK_LAUNCH("adamw_f32_dev");
     return DICOW_OK;
 }

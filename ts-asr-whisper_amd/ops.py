@@ -312,3 +312,9 @@ def sumsq(x, out):
 def adamw(p, g, m, v, lr, beta1, beta2, eps, wd, step, gnorm_sq=None, max_norm=0.0):
     L.call("dicow_adamw_f32", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, beta1, beta2, eps, wd,
            step, _p(gnorm_sq), max_norm, L.stream())
+
+
+def adamw_dev(p, g, m, v, hyper, beta1, beta2, eps, wd, gnorm_sq=None, max_norm=0.0):
+    """adamw with {lr, 1 - beta1^t, 1 - beta2^t} read from the 3-float device tensor `hyper` (hipGraph replay)."""
+    L.call("dicow_adamw_f32_dev", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), hyper.data_ptr(), beta1, beta2,
+           eps, wd, _p(gnorm_sq), max_norm, L.stream())

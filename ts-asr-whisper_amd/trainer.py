@@ -127,9 +127,20 @@ class FusedAdamW:
         self.t = 0                                        # optimizer steps taken (= HF state.global_step)
         self.run_t = [0] * len(store.runs)                # updates received per run
         self.gnorm_sq = torch.zeros(1, dtype=F32, device=store.params.device)
+        # step counters and this step's scalars live on the DEVICE (dicow_adamw_hyper): counters[0] = optimizer steps,
+        # counters[1 + i] = updates of run i, hyper[i] = {lr, 1 - beta1^t, 1 - beta2^t}; the host mirrors (t, run_t) advance
+        # in lock-step and serve checkpointing and the phase switch
+        dev = store.params.device
+        self.counters = torch.zeros(1 + len(store.runs), dtype=torch.int32, device=dev)
+        self.hyper = torch.zeros(len(store.runs), 3, dtype=F32, device=dev)
+        self.is_pre = torch.tensor([int(pre) for _, _, pre in store.runs], dtype=torch.int32, device=dev)
+
+    def sync_counters(self):
+        """Host mirrors -> device counters (after load_state_dict)."""
+        self.counters.copy_(torch.tensor([self.t] + list(self.run_t), dtype=torch.int32))
 
     def lr_at(self, k):
-        """Learning rate of the k-th optimizer step (k = 1, 2, ...)."""
+        """Learning rate of the k-th optimizer step (k = 1, 2, ...) -- what dicow_adamw_hyper computes on the device."""
         sched_step = k - 1
         if sched_step < self.warmup:
             return self.lr * sched_step / max(1, self.warmup)
@@ -138,20 +149,33 @@ class FusedAdamW:
             return self.lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
         return self.lr
 
-    def step(self, preheat_only=False):
-        """preheat_only: update only the runs of the preheat group (the others are frozen: no gradient, no update)."""
-        s = self.s
+    def advance(self, preheat_only=False):
+        """Host mirrors of the device counters, one optimizer step on (the device side is launch())."""
         self.t += 1
-        lr = self.lr_at(self.t)
+        for i, (a, b, pre) in enumerate(self.s.runs):
+            if not (preheat_only and not pre):
+                self.run_t[i] += 1
+
+    def launch(self, preheat_only=False):
+        """Device side of one optimizer step (what a captured graph holds): counters + schedule, gradient norm, one fused
+        clip + AdamW launch per run.  No host value that changes from step to step is a kernel argument."""
+        s = self.s
+        L_ = ops.L
+        L_.call("dicow_adamw_hyper", self.counters.data_ptr(), self.hyper.data_ptr(), self.is_pre.data_ptr(), len(s.runs),
+                int(preheat_only), self.lr, self.mult, int(self.warmup), int(self.max_steps), int(self.schedule == "cosine"),
+                self.betas[0], self.betas[1], L_.stream())
         self.gnorm_sq.zero_()
         ops.sumsq(s.grads, self.gnorm_sq)                 # frozen runs hold zeros
         for i, (a, b, pre) in enumerate(s.runs):
             if preheat_only and not pre:
                 continue
-            self.run_t[i] += 1
-            ops.adamw(s.params[a:b], s.grads[a:b], s.exp_avg[a:b], s.exp_avg_sq[a:b], lr * (self.mult if pre else 1.0),
-                      self.betas[0], self.betas[1], self.eps, 0.0 if pre else self.wd, self.run_t[i], gnorm_sq=self.gnorm_sq,
-                      max_norm=self.max_norm)
+            ops.adamw_dev(s.params[a:b], s.grads[a:b], s.exp_avg[a:b], s.exp_avg_sq[a:b], self.hyper[i], self.betas[0], self.betas[1],
+                          self.eps, 0.0 if pre else self.wd, gnorm_sq=self.gnorm_sq, max_norm=self.max_norm)
+
+    def step(self, preheat_only=False):
+        """preheat_only: update only the runs of the preheat group (the others are frozen: no gradient, no update)."""
+        self.advance(preheat_only)
+        self.launch(preheat_only)
 
 
 class GradReducer:
@@ -240,8 +264,16 @@ class TrainStep:
 
     def __init__(self, model, lr=2e-6, fddt_lr_multiplier=100.0, weight_decay=0.0, max_grad_norm=1.0, warmup_steps=0,
                  max_steps=0, frozen_keywords=("decoder",), preheat_prefixes=("model.encoder.fddts", "model.encoder.initial_fddt"),
-                 process_group=None, augmenter=None, use_fddt_only_n_steps=0):
+                 process_group=None, augmenter=None, use_fddt_only_n_steps=0, graph=False):
         self.model = model
+        # graph=True: after one eager step per phase the whole step (zero-grad, forward, backward, clip, AdamW, bf16 weight
+        # refresh) is captured in ONE hipGraph per phase and replayed: small configurations (whisper-base, B = 8: ~1000 launches
+        # of a few microseconds each) are bound by the host's launch rate, not by the GPU.  The step has no host-side data
+        # dependence: the clip coefficient stays on the device, the schedule's scalars are rewritten in device memory
+        # before each replay (FusedAdamW.advance).
+        self.graph = bool(graph)
+        self._graphs = {}             # (phase, batch signature) -> (CUDAGraph, static batch, static loss)
+        self._eager_done = set()
         self.augmenter = augmenter          # augment.BatchAugmenter: the collator's training-time block, on the GPU
         freeze_by_keyword(model, frozen_keywords)
         self.store = FlatStore(model, preheat_prefixes)
@@ -298,11 +330,78 @@ class TrainStep:
         (out.loss if scale == 1.0 else out.loss * scale).backward()
         return out.loss.detach()
 
-    def step(self, batch):
+    # ---- whole-step hipGraph
+    @staticmethod
+    def _sig_of(batch):
+        out = []
+        for k in sorted(batch):
+            v = batch[k]
+            out.append((k, TrainStep._sig_of(v)) if isinstance(v, dict) else (k, tuple(v.shape), str(v.dtype)))
+        return tuple(out)
+
+    @staticmethod
+    def _clone(batch):
+        return {k: (TrainStep._clone(v) if isinstance(v, dict) else v.clone()) for k, v in batch.items()}
+
+    @staticmethod
+    def _copy_into(dst, src):
+        for k, v in src.items():
+            if isinstance(v, dict):
+                TrainStep._copy_into(dst[k], v)
+            else:
+                dst[k].copy_(v, non_blocking=True)
+
+    def _invalidate_weight_copies(self):
+        enc = self.model.model.encoder
+        enc._sig = None
+        enc._ctc_sig = None
+        if any(p.requires_grad for p in self.model.model.decoder.parameters()):
+            self.model._sig = None
+
+    def _graph_step(self, batch):
+        if self.reducer.world > 1:
+            raise NotImplementedError("TrainStep(graph=True) captures the single-GPU step; the bucketed side-stream exchange is not captured")
+        if self.model.config.ctc_weight > 0.0 or self.augmenter is not None:
+            raise NotImplementedError("TrainStep(graph=True): the CTC label preparation / the augmentation planner read device data on "
+                                      "the host; their steps cannot be captured")
+        if self.warmup_phase and self.global_step >= self.use_fddt_only_n_steps:
+            self._set_phase(preheat_only=False)
+            self.warmup_phase = False
+        key = (self.warmup_phase, self._sig_of(batch))
+        if key not in self._eager_done:                 # first step of a phase runs eagerly (allocator, one-time setup)
+            self._eager_done.add(key)
+            return self._eager_step([batch])
+        if key not in self._graphs:
+            static = self._clone(batch)
+            self._invalidate_weight_copies()            # the capture must contain the bf16 weight refresh
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.store.zero_grad()
+                out = self.model(**static)
+                out.loss.backward()
+                self.opt.launch(preheat_only=self.warmup_phase)
+                loss = out.loss.detach()
+            self._graphs[key] = (g, static, loss)
+            # (capturing does not execute: the replay below is this step)
+        g, static, loss = self._graphs[key]
+        self._copy_into(static, batch)
+        self.opt.advance(preheat_only=self.warmup_phase)
+        g.replay()
+        self._invalidate_weight_copies()                # an eager step that follows must re-cast, too
+        return loss.clone()
+
+    def step(self, batch, eager=False):
         """One optimizer step on one batch, or -- given a list / tuple of batches -- on their accumulated gradients
         (HF Trainer gradient_accumulation_steps: each micro-batch's mean loss is divided by the number of micro-batches,
-        gradients sum in place in the flat store, ranks exchange them once, after the last micro-batch's backward)."""
+        gradients sum in place in the flat store, ranks exchange them once, after the last micro-batch's backward).
+        With graph=True a single batch replays the captured step (`eager=True` forces the launch-by-launch path)."""
         micro = list(batch) if isinstance(batch, (list, tuple)) else [batch]
+        if self.graph and not eager and len(micro) == 1:
+            return self._graph_step(micro[0])
+        return self._eager_step(micro)
+
+    def _eager_step(self, micro):
         self.begin_step()
         loss = None
         for i, b in enumerate(micro):
@@ -333,6 +432,7 @@ class TrainStep:
         if [tuple(r) for r in sd["layout"]] != [tuple(r) for r in self.store.runs]:
             raise ValueError("optimizer state was saved for a different set of trainable parameters")
         self.opt.t, self.opt.run_t = int(sd["global_step"]), list(sd["run_t"])
+        self.opt.sync_counters()
         self.store.exp_avg.copy_(sd["exp_avg"])
         self.store.exp_avg_sq.copy_(sd["exp_avg_sq"])
         if bool(sd["warmup_phase"]) != self.warmup_phase:
