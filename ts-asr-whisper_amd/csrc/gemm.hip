@@ -1027,6 +1027,12 @@ static void gemm_nt_setup() {
     if (hipGetDeviceProperties(&pr, dev) == hipSuccess) g_ncu_all = pr.multiProcessorCount;
 }
 
+// 256 x 256 tiles from which the persistent ring kernel takes over from the 128 x 128 tiles (two workgroups per CU, two barriers
+// per k-step): a ring workgroup runs a tile ~2.5x faster than the small kernel runs a quarter of it, so the persistent kernel
+// wins long before it can fill the chip (whisper-base, B = 8: the N = 512 GEMMs are 94 tiles)
+#ifndef NT_BIG_TILES
+#define NT_BIG_TILES 200
+#endif
 static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_colsum, int* colsum_rows) {
     dicow_gemm_args a_copy = *a_in;
     dicow_gemm_args* a = &a_copy;
@@ -1065,7 +1071,12 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     const bool off32 = (int64_t)a->M * a->lda * 2 < (1ll << 31) && (int64_t)a->N * a->ldb * 2 < (1ll << 31) &&
                        (int64_t)a->M * a->ldc * 4 < (1ll << 31) && (int64_t)a->M * a->ldaux * 2 < (1ll << 31) &&
                        (int64_t)a->M * a->ldr * 4 < (1ll << 31);
-    const bool big = off32 && a->K >= 2 * BK && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= 200;
+#ifdef DICOW_ABLATIONS
+    static const int big_tiles = getenv("DICOW_NT_BIG") ? atoi(getenv("DICOW_NT_BIG")) : NT_BIG_TILES;
+#else
+    constexpr int big_tiles = NT_BIG_TILES;
+#endif
+    const bool big = off32 && a->K >= 2 * BK && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= big_tiles;
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
         if (variant == 0 || variant >= 11) {
             const int lim = g_gemm_cus.load();
@@ -1328,7 +1339,7 @@ __global__ void __launch_bounds__(256, 2) gemm_tn_kernel(const dicow_gemm_tn_arg
 // from ds_read_b64_tr_b16.  LDS image per operand: [64 m][256 n] bf16, 512-B rows, chunk c of row m at c ^ ((m&3)<<2).
 #define TN256_OP (TK * 256 * 2)              // 32 KiB per operand per stage
 #define TN256_STAGE (2 * TN256_OP)
-#define TN256_LDS (2 * TN256_STAGE)
+#define TN256_LDS (5 * TN256_OP)              // ring of five halves
 
 __device__ __forceinline__ unsigned tn256_tr_addr(const char* s, int m, int n) {
     return (unsigned)(uintptr_t)(s + m * 512 + ((((n >> 3) ^ ((m & 3) << 2))) << 4) + ((n & 7) << 1));
@@ -1415,29 +1426,45 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_
         voA[i] = (unsigned)(((int64_t)row * a.lda + ca) * 2);
         voB[i] = (unsigned)(((int64_t)row * a.ldb + cb) * 2);
     }
-    auto dma2 = [&](int kt, int i0) {                 // two DMA instruction pairs of contraction tile kt
+    // LDS ring of five 32-KiB halves (all 160 KiB): contraction tile t (relative to kt0) keeps its A half in slot 2t mod 5 and
+    // its B half in slot (2t + 1) mod 5.  At the top of step t (the barrier releases the halves of step t-1) the wave issues
+    // B(t+1) and A(t+2): like gemm_ntr_kernel, the loop no longer drains its own DMA at every step (two stages + vmcnt(0) left
+    // ONE stage in flight, and its latency -- not the matrix pipe -- set the step time); the counted wait lets the four newest
+    // instructions (A(t+1)) stay in flight across the barrier.
+    auto dma_half = [&](int kt, int half) {            // the four DMA instructions of this wave for one half of tile kt
         const int b = kt / tiles_per_batch, lt = kt - b * tiles_per_batch;
-        char* sA = smem + ((kt - kt0) & 1) * TN256_STAGE;
-        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned short*>(A + (int64_t)b * a.strideA), 0, (unsigned)((int64_t)a.Mk * a.lda * 2), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<unsigned short*>(B + (int64_t)b * a.strideB), 0, (unsigned)((int64_t)a.Mk * a.ldb * 2), 0x00020000);
-        const int soA = (int)((int64_t)lt * TK * a.lda * 2), soB = (int)((int64_t)lt * TK * a.ldb * 2);
+        const int rel = kt - kt0;
+        const int slot = (2 * rel + half) % 5;
+        char* dst = smem + slot * TN256_OP;
+        if (half == 0) {
+            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned short*>(A + (int64_t)b * a.strideA), 0, (unsigned)((int64_t)a.Mk * a.lda * 2), 0x00020000);
+            const int soA = (int)((int64_t)lt * TK * a.lda * 2);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int q = wave * 4 + i0 + e;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(sA + q * 1024), 16, voA[i0 + e], soA, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sA + TN256_OP + q * 1024), 16, voB[i0 + e], soB, 0, 0);
+            for (int e = 0; e < 4; ++e)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(dst + (wave * 4 + e) * 1024), 16, voA[e], soA, 0, 0);
+        } else {
+            const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<unsigned short*>(B + (int64_t)b * a.strideB), 0, (unsigned)((int64_t)a.Mk * a.ldb * 2), 0x00020000);
+            const int soB = (int)((int64_t)lt * TK * a.ldb * 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(dst + (wave * 4 + e) * 1024), 16, voB[e], soB, 0, 0);
         }
     };
-    dma2(kt0, 0);
-    dma2(kt0, 2);
+    dma_half(kt0, 0);
+    dma_half(kt0, 1);
+    if (kt0 + 1 < kt1) dma_half(kt0 + 1, 0);
     tn256_frag_t f0, f1;
+    int sa = 0;                                       // slot of the A half of the step being computed
     for (int kt = kt0; kt < kt1; ++kt) {
-        char* sA = smem + ((kt - kt0) & 1) * TN256_STAGE;
-        char* sB = sA + TN256_OP;
-        const bool more = kt + 1 < kt1, first = kt == kt0;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const int sb = sa + 1 >= 5 ? sa - 4 : sa + 1;
+        char* sA = smem + sa * TN256_OP;
+        char* sB = smem + sb * TN256_OP;
+        const bool first = kt == kt0;
+        // everything but A(t+1) -- the four newest DMA instructions, when that tile exists -- has landed
+        if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         unsigned ad[6];
@@ -1446,18 +1473,19 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_
 #pragma unroll
         for (int j = 0; j < 4; ++j) ad[2 + j] = tn256_tr_addr(sA, tr_row, w1 * 128 + j * 32 + tr_col);
         tn256_issue<0>(f0, ad);
-        if (more) dma2(kt + 1, 0);
+        if (kt + 1 < kt1) dma_half(kt + 1, 1);
         if (!first) tn256_mfma(acc, f1);              // slice 3 of the previous tile (landed before the barrier)
         tn256_issue<8192>(f1, ad);
-        if (more) dma2(kt + 1, 2);
         tn256_wait<12>(f0);
         tn256_mfma(acc, f0);
         tn256_issue<16384>(f0, ad);
+        if (kt + 2 < kt1) dma_half(kt + 2, 0);
         tn256_wait<12>(f1);
         tn256_mfma(acc, f1);
         tn256_issue<24576>(f1, ad);
         tn256_wait<12>(f0);
         tn256_mfma(acc, f0);
+        sa = sa + 2 >= 5 ? sa - 3 : sa + 2;
     }
     tn256_wait<0>(f1);
     tn256_mfma(acc, f1);
