@@ -851,9 +851,98 @@ def f17_fix_timestamps():
     save("f17_fix_timestamps", **arrs)
 
 
+# ----------------------------------------------------------------------------- F18: temperature fallback control flow
+def f18_fallback():
+    """transformers' WhisperGenerationMixin.generate_with_fallback / _need_fallback / _retrieve_* (what the reference's
+    generate_with_fallback, generation.py:567-611, delegates to) driven with SCRIPTED decoder outputs: fixed logits => fixed
+    fallback decisions.  The stub generate() looks the active windows up by a row id planted in the prompt."""
+    import copy
+    from transformers import GenerationConfig
+    from transformers.generation import GenerationMixin
+    from transformers.generation.utils import GenerateEncoderDecoderOutput
+    from transformers.generation.logits_process import WhisperNoSpeechDetection
+    from transformers.models.whisper.generation_whisper import WhisperGenerationMixin
+
+    V, eos, P, NMAX = 64, 60, 3, 48
+    temps = (0.0, 0.2, 0.4, 1.0)
+    g = torch.Generator().manual_seed(18)
+    R = 5
+
+    def script(row, k):
+        """(tokens incl. eos, scores [n, V]) of window `row` at temperature index k."""
+        gg = torch.Generator().manual_seed(1000 * row + k)
+        if row == 0 or (row == 1 and k >= 2) or (row == 4 and k >= 1):      # varied tokens, confident scores
+            n = 12 + row
+            toks = torch.randint(0, 50, (n,), generator=gg).tolist() + [eos]
+            peak = 9.0
+        elif row == 1 or row == 4:                                         # repetitive (high compression ratio), confident
+            toks = ([7, 8] * 20) + [eos]
+            peak = 9.0
+        else:                                                              # rows 2, 3: varied but unsure (low average log-probability)
+            n = 10 + k
+            toks = torch.randint(0, 50, (n,), generator=gg).tolist() + [eos]
+            peak = 0.5
+        sc = torch.randn(len(toks), V, generator=gg)
+        for i, t in enumerate(toks):
+            sc[i, t] += peak
+        t_ = temps[k]
+        if t_ > 0:
+            sc = sc / t_                                                    # what the temperature warper leaves in `scores`
+        return toks, sc
+
+    class Stub(GenerationMixin):
+        def generate(self, segment_input, generation_config=None, decoder_input_ids=None, **kw):
+            k = self.calls
+            self.calls += 1
+            rows = (decoder_input_ids[:, 1] - 10).tolist()
+            self.log.append((k, rows, bool(generation_config.do_sample), float(generation_config.temperature)))
+            outs = [script(r, k) for r in rows]
+            n = max(len(t) for t, _ in outs)
+            seqs = torch.full((len(rows), P + n), eos, dtype=torch.long)
+            seqs[:, :P] = decoder_input_ids
+            scores = torch.zeros(n, len(rows), V)
+            for i, (t, sc) in enumerate(outs):
+                seqs[i, P:P + len(t)] = torch.tensor(t)
+                scores[:len(t), i] = sc
+            return GenerateEncoderDecoderOutput(sequences=seqs, scores=tuple(scores[i] for i in range(n)))
+
+    class Dummy(WhisperGenerationMixin, Stub):
+        pass
+
+    d = Dummy.__new__(Dummy)
+    d.config = types.SimpleNamespace(vocab_size=V, decoder_layers=1)
+    d.calls, d.log = 0, []
+    nsd = WhisperNoSpeechDetection.__new__(WhisperNoSpeechDetection)
+    no_speech_prob = torch.tensor([0.1, 0.2, 0.3, 0.9, 0.05])
+    nsd.no_speech_prob_holder = no_speech_prob
+    type(nsd).no_speech_prob = property(lambda self_: self_.no_speech_prob_holder)
+    nsd.set_inputs = lambda inputs: None
+    gc = GenerationConfig(pad_token_id=eos, eos_token_id=eos)
+    gc.no_speech_threshold, gc.compression_ratio_threshold, gc.logprob_threshold = 0.6, 2.4, -1.0
+    gc.condition_on_prev_tokens, gc.cache_implementation, gc.num_beams = False, None, 1
+    prompt = torch.tensor([[61, 10 + r, 62] for r in range(R)])
+    seek_sequences, seek_outputs, should_skip, do_cond, _ = d.generate_with_fallback(
+        segment_input=torch.zeros(R, 4, 8), decoder_input_ids=prompt, cur_bsz=R, seek=torch.zeros(R, dtype=torch.long),
+        batch_idx_map=list(range(R)), temperatures=temps, generation_config=gc, logits_processor=[nsd], stopping_criteria=None,
+        prefix_allowed_tokens_fn=None, synced_gpus=False, return_token_timestamps=False, do_condition_on_prev_tokens=[False] * R,
+        is_shortform=False, batch_size=R, attention_mask=None, kwargs={})
+    arrs = {"V": np.array(V), "eos": np.array(eos), "P": np.array(P), "temps": np.array(temps), "n_rows": np.array(R),
+            "thr": np.array([gc.compression_ratio_threshold, gc.logprob_threshold, gc.no_speech_threshold]),
+            "no_speech_prob": no_speech_prob, "should_skip": np.array(should_skip),
+            "calls": np.array(repr([(k, rows, ds, t) for k, rows, ds, t in d.log]))}
+    for r in range(R):
+        arrs[f"final_{r}"] = np.array(seek_sequences[r].tolist(), dtype=np.int64)
+        for k in range(len(temps)):
+            t, sc = script(r, k)
+            arrs[f"tok_{r}_{k}"], arrs[f"sc_{r}_{k}"] = np.array(t, dtype=np.int64), sc
+            arrs[f"cr_{r}_{k}"] = np.array(WhisperGenerationMixin._retrieve_compression_ratio(torch.tensor(t), V))
+            arrs[f"lp_{r}_{k}"] = np.array(float(WhisperGenerationMixin._retrieve_avg_logprobs([s_ for s_ in sc], torch.tensor(t), temps[k])))
+    save("f18_fallback", **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f10b", "f11", "f12", "f13", "f14", "f15", "f16", "f17"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f10b", "f11", "f12", "f13", "f14", "f15", "f16", "f17", "f18"]
     fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
-           "f8": f8_se, "f10": f10_ctc, "f10b": f10b_ctc_extra_layer, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules, "f15": f15_beam_search, "f16": f16_retrieve_segment, "f17": f17_fix_timestamps}
+           "f8": f8_se, "f10": f10_ctc, "f10b": f10b_ctc_extra_layer, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules, "f15": f15_beam_search, "f16": f16_retrieve_segment, "f17": f17_fix_timestamps, "f18": f18_fallback}
     for w in which:
         fns[w]()

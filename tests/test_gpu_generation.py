@@ -432,3 +432,52 @@ def test_generate_builds_the_prompt_from_language_and_task(pkg):
     gc.language = "xx"
     with pytest.raises(ValueError):
         model.retrieve_init_tokens(xc, sc, gc)
+
+
+def test_temperature_fallback_on_the_decoder(pkg):
+    """generate_with_fallback on the real KV-cached decoder (control flow pinned by golden F18 in the CPU / host tests):
+      * thresholds nothing can fail -> one greedy pass, identical to generate();
+      * a log-probability threshold nothing can meet -> every window climbs the whole ladder, sampling is reproducible with a
+        seeded generator, and the per-window average log-probability / compression ratio computed on the GPU scores agree with
+        the oracle's restatement of transformers' formulas;
+      * with the no-speech test armed and a threshold of 0, unlikely windows are skipped instead of re-decoded."""
+    from ts_asr_whisper_amd.generation import GreedyDecoder, sequence_avg_logprob, token_compression_ratio
+    from oracle import fallback as OF
+    z, model, cfg, x, st, prompt = _setup(pkg)
+    dec = GreedyDecoder(model)
+    n_new, eos = 8, cfg.eos_token_id
+    kw = dict(eos_token_id=eos, pad_token_id=cfg.pad_token_id)
+    plain = dec.generate(x.cuda(), st.cuda(), prompt, n_new, **kw)[:, prompt.shape[1]:].tolist()
+    fin, skip, used = dec.generate_with_fallback(x.cuda(), st.cuda(), prompt, n_new, temperatures=(0.0, 0.5, 1.0),
+                                                 compression_ratio_threshold=1e9, logprob_threshold=-1e9, **kw)
+    assert used == [0, 0] and skip == [False, False]
+    for r in range(2):
+        want = list(plain[r])
+        while want and want[-1] == cfg.pad_token_id and cfg.pad_token_id != eos:
+            want.pop()
+        want = OF.strip_padding(want, cfg.pad_token_id, eos)
+        if want and want[-1] == eos:
+            want = want[:-1]
+        assert fin[r] == want
+    # nothing passes: the ladder is climbed to its end, reproducibly
+    runs = []
+    for _ in range(2):
+        g = torch.Generator(device="cuda").manual_seed(5)
+        runs.append(dec.generate_with_fallback(x.cuda(), st.cuda(), prompt, n_new, temperatures=(0.0, 0.7, 1.3),
+                                               compression_ratio_threshold=None, logprob_threshold=1.0, generator=g, **kw))
+    assert runs[0] == runs[1] and runs[0][2] == [2, 2] and runs[0][1] == [False, False]
+    # the statistics the decisions rest on, from real scores, vs the oracle's formulas
+    g = torch.Generator(device="cuda").manual_seed(7)
+    seqs, scores = dec.generate(x.cuda(), st.cuda(), prompt, n_new, return_scores=True, temperature=0.7, generator=g, **kw)
+    for r in range(2):
+        toks = OF.strip_padding(seqs[r, prompt.shape[1]:].tolist(), cfg.pad_token_id, eos)
+        lp = sequence_avg_logprob(scores[:, r], toks, 0.7)
+        assert abs(lp - OF.avg_logprob(scores[:, r].float().cpu(), toks, 0.7)) < 1e-4
+        assert abs(token_compression_ratio(toks, cfg.vocab_size) - OF.compression_ratio(toks, cfg.vocab_size)) < 1e-12
+        assert lp < 0.0
+    # silence: unlikely (threshold 1.0) and no_speech_prob > 0 -> skipped at the first temperature, never re-decoded
+    fin, skip, used = dec.generate_with_fallback(x.cuda(), st.cuda(), prompt, n_new, temperatures=(0.0, 0.7),
+                                                 compression_ratio_threshold=None, logprob_threshold=1.0, no_speech_threshold=0.0,
+                                                 no_speech_token_id=3, **kw)
+    assert skip == [True, True] and used == [0, 0]
+    assert dec.no_speech_prob is not None and dec.no_speech_prob.shape == (2,) and bool((dec.no_speech_prob > 0).all())

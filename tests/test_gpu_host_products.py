@@ -29,3 +29,7 @@ def test_f17_fix_timestamps_on_the_gpu_box():
 def test_library_symbols_and_no_cpu_fallback_on_the_gpu_box():
     H.test_library_exports_every_declared_symbol()
     H.test_no_cpu_fallback_and_oracle_not_imported_by_product()
+
+
+def test_f18_temperature_fallback_decisions_on_the_gpu_box():
+    H.test_product_temperature_fallback_matches_transformers_golden()

@@ -260,6 +260,14 @@ def test_product_fix_timestamps_matches_reference_golden_and_oracle():
     assert fix_timestamps_from_segmentation([[]], 1000, 7, 0).shape == (1, 0)
 
 
+def test_product_temperature_fallback_matches_transformers_golden():
+    """generation.decode_with_fallback / token_compression_ratio / sequence_avg_logprob against golden F18: transformers' own
+    generate_with_fallback (what reference generation.py:567-611 delegates to) driven with scripted decoder outputs."""
+    from tests.test_oracle_vs_golden import _check_fallback
+    from ts_asr_whisper_amd.generation import decode_with_fallback, token_compression_ratio, sequence_avg_logprob
+    _check_fallback(decode_with_fallback, token_compression_ratio, sequence_avg_logprob)
+
+
 def test_graft_entry_exposes_build_and_smoke():
     import __graft_entry__ as g
     assert callable(g.build) and callable(g.smoke)

@@ -375,3 +375,42 @@ def test_f17_fix_timestamps_oracle():
         assert folded_to_ids(fold_segments(segs, ts0, fill), ts0) == want, c
         n += 1
     assert n > 200
+
+
+# ----------------------------------------------------------------------------- F18: temperature fallback (transformers' own decisions)
+def _check_fallback(loop, ratio, avglp):
+    """loop(decode, n, temps, V, pad, eos, cr_thr, lp_thr, ns_thr) -> (final, skip, used); decode(rows, temp) -> (toks, scores, nsp)."""
+    import ast
+    z = load_golden("f18_fallback")
+    V, eos, R = int(z["V"]), int(z["eos"]), int(z["n_rows"])
+    temps = [float(t) for t in z["temps"]]
+    thr = [float(t) for t in z["thr"]]
+    for r in range(R):
+        for k in range(len(temps)):
+            tok, sc = z[f"tok_{r}_{k}"].tolist(), torch.from_numpy(z[f"sc_{r}_{k}"])
+            assert abs(ratio(tok, V) - float(z[f"cr_{r}_{k}"])) < 1e-12
+            assert abs(avglp(sc, tok, temps[k]) - float(z[f"lp_{r}_{k}"])) < 2e-5
+    calls = []
+
+    def decode(rows, temp):
+        k = temps.index(temp)
+        calls.append((k, list(rows), temp > 0.0, temp if temp > 0.0 else 1.0))
+        toks = [z[f"tok_{r}_{k}"].tolist() for r in rows]
+        n = max(len(t) for t in toks)
+        return [t + [eos] * (n - len(t)) for t in toks], [torch.from_numpy(z[f"sc_{r}_{k}"]) for r in rows], torch.from_numpy(z["no_speech_prob"])[:len(rows)]
+
+    final, skip, used = loop(decode, R, temps, V, eos, eos, thr[0], thr[1], thr[2])
+    assert calls == ast.literal_eval(str(z["calls"]))                     # the same windows re-decoded at the same temperatures
+    assert list(skip) == [bool(x) for x in z["should_skip"]]
+    for r in range(R):
+        assert final[r] == z[f"final_{r}"].tolist(), r
+    assert used == [0, 2, 3, 0, 1]
+
+
+def test_f18_fallback_oracle():
+    from oracle import fallback as OF
+
+    def loop(decode, n, temps, V, pad, eos, a, b, c):
+        nsp = torch.from_numpy(load_golden("f18_fallback")["no_speech_prob"])
+        return OF.fallback_loop(lambda rows, t: decode(rows, t)[:2], n, temps, V, pad, eos, a, b, c, nsp)
+    _check_fallback(loop, OF.compression_ratio, OF.avg_logprob)

@@ -265,12 +265,16 @@ class GreedyDecoder:
     @torch.no_grad()
     def generate(self, input_features, stno_mask, decoder_input_ids, max_new_tokens, eos_token_id=None, pad_token_id=None,
                  suppress_tokens=None, begin_suppress_tokens=None, enrollments=None, return_scores=False, ctc=None,
-                 timestamps=None):
+                 timestamps=None, temperature=0.0, generator=None, no_speech_token_id=None):
         """decoder_input_ids int64 [B, P]: the forced prefix (start token, language / task / timestamp tokens).
         ctc: dict(weight=..., first_timestamp=..., upper_cased=[(lo, up), ...], prefix_len=..., n_score=500) switches on the
         joint CTC / attention scoring of generation.py:249-268 (log-softmax, then ctc_decoding.CtcRescorer on the model's CTC head).
         timestamps: dict(no_timestamps_token_id=..., max_initial_timestamp_index=...) applies Whisper's timestamp rules
         (return_timestamps=True in the reference, generation.py:272-281), after the suppress lists and before the CTC term.
+        temperature > 0: multinomial sampling from softmax(processed scores / temperature) (HF's sample mode, what Whisper's
+        temperature fallback decodes with; `generator` makes it reproducible); the returned scores are then the temperature-scaled
+        ones, as HF's are.  no_speech_token_id: also keep softmax(logits of the position after the start token)[that id] per row
+        in ``self.no_speech_prob`` (HF WhisperNoSpeechDetection).
         Returns sequences [B, P + n] (and the processed fp32 scores [n, B, V] of the generated positions)."""
         cfg = self.cfg
         eos = cfg.eos_token_id if eos_token_id is None else eos_token_id
@@ -291,13 +295,18 @@ class GreedyDecoder:
                                    ctc.get("prefix_len", P), ctc["weight"], ctc.get("n_score", 500))
             rows = torch.arange(B, device=dev)
         step = self._step_graphed if self.use_graphs else self._step
+        self.no_speech_prob = None
         for t in range(P - 1):                                       # prefill the caches with the prefix
-            step(ids[:, t], t, st)
+            lg = step(ids[:, t], t, st)
+            if t == 0 and no_speech_token_id is not None:
+                self.no_speech_prob = torch.softmax(lg.float(), dim=-1)[:, no_speech_token_id].clone()
         unfinished = torch.ones(B, dtype=torch.bool, device=dev)
         seq, scores = [ids], []
         cur = ids[:, P - 1]
         for n in range(max_new_tokens):
             logits = step(cur, P - 1 + n, st)
+            if n == 0 and P == 1 and no_speech_token_id is not None:
+                self.no_speech_prob = torch.softmax(logits.float(), dim=-1)[:, no_speech_token_id].clone()
             if sup is not None:
                 logits[:, sup] = -float("inf")
             if bsup is not None and n == 0:
@@ -307,9 +316,14 @@ class GreedyDecoder:
                                          timestamps.get("max_initial_timestamp_index"))
             if rescorer is not None:
                 logits = rescorer(torch.cat(seq, dim=1), torch.log_softmax(logits, dim=-1))
+            if temperature and temperature > 0.0:
+                logits = logits / temperature
             if return_scores:
                 scores.append(logits.clone())
-            nxt = logits.argmax(-1)
+            if temperature and temperature > 0.0:
+                nxt = torch.multinomial(torch.softmax(logits.float(), dim=-1), 1, generator=generator)[:, 0]
+            else:
+                nxt = logits.argmax(-1)
             nxt = torch.where(unfinished, nxt, torch.full_like(nxt, pad))
             if rescorer is not None:
                 rescorer.update_state(nxt, rows)
@@ -320,6 +334,105 @@ class GreedyDecoder:
                 break
         out = torch.cat(seq, dim=1)
         return (out, torch.stack(scores)) if return_scores else out
+
+    @torch.no_grad()
+    def generate_with_fallback(self, input_features, stno_mask, decoder_input_ids, max_new_tokens, temperatures=(0.0, 0.2, 0.4, 0.6, 0.8, 1.0),
+                               compression_ratio_threshold=1.35, logprob_threshold=-1.0, no_speech_threshold=None,
+                               no_speech_token_id=None, generator=None, enrollments=None, **gen_kw):
+        """Whisper's temperature fallback over one batch of windows (reference generation.py:567-611 -> transformers'
+        generate_with_fallback): greedy first; windows whose output is too repetitive (zlib compression ratio) or too unlikely
+        (average log-probability) are decoded again -- encoder included, as in HF -- with sampling at the next temperature; a
+        window that is unlikely AND looks like silence (no_speech_prob) is skipped instead.  gen_kw: generate()'s processor
+        arguments (eos / pad ids, suppress lists, timestamps, ctc).
+        Returns (token lists of the generated positions without the eos, should_skip flags, temperature index per window)."""
+        cfg = self.cfg
+        eos = gen_kw.get("eos_token_id", None)
+        eos = cfg.eos_token_id if eos is None else eos
+        pad = gen_kw.get("pad_token_id", None)
+        pad = cfg.pad_token_id if pad is None else pad
+        B, P = decoder_input_ids.shape
+        if no_speech_threshold is not None and no_speech_token_id is None:
+            raise ValueError("no_speech_threshold needs no_speech_token_id")
+
+        def decode(rows, temperature):
+            idx = torch.as_tensor(rows, device=input_features.device)
+            enr = None if enrollments is None else {k: v[idx] for k, v in enrollments.items()}
+            seqs, scores = self.generate(input_features[idx], stno_mask[idx], decoder_input_ids[idx.to(decoder_input_ids.device)],
+                                         max_new_tokens, enrollments=enr, return_scores=True, temperature=temperature,
+                                         generator=generator, no_speech_token_id=no_speech_token_id, **gen_kw)
+            toks = seqs[:, P:].tolist()
+            return toks, [scores[:, i] for i in range(len(rows))], self.no_speech_prob
+
+        return decode_with_fallback(decode, B, tuple(temperatures), cfg.vocab_size, pad, eos, compression_ratio_threshold,
+                                    logprob_threshold, no_speech_threshold)
+
+
+# ------------------------------------------------------------------------------------------------ temperature fallback
+# The reference's generate_with_fallback (src/models/dicow/generation.py:567-611) cuts the STNO masks to the active windows and
+# hands over to transformers' WhisperGenerationMixin.generate_with_fallback; these are that method's decisions (golden F18 is
+# taken from the transformers code itself, driven with scripted decoder outputs).
+def token_compression_ratio(tokens, vocab_size):
+    """Raw bytes / zlib-compressed bytes of the token ids (HF _retrieve_compression_ratio): repetition detector."""
+    import math
+    import zlib
+    width = int(math.log2(vocab_size) / 8) + 1
+    raw = b"".join(int(t).to_bytes(width, "little") for t in tokens)
+    return len(raw) / len(zlib.compress(raw))
+
+
+def sequence_avg_logprob(scores, tokens, temperature):
+    """Mean log-probability of the generated tokens, eos included (HF _retrieve_avg_logprobs).  scores [n, V]: the processed
+    scores of the generated positions as generate(return_scores=True) returns them, i.e. divided by the temperature when
+    sampling -- undone here before the fp32 log-softmax."""
+    tok = torch.as_tensor(list(tokens), dtype=torch.long, device=scores.device)
+    n = min(scores.shape[0], tok.numel())
+    sc, tk = scores[:n], (tok if scores.shape[0] > tok.numel() else tok[-n:])[:n]
+    if temperature and temperature > 0.0:
+        sc = sc * temperature
+    lp = torch.log_softmax(sc.float(), dim=-1).to(scores.dtype)
+    return float(lp.gather(1, tk[:, None]).sum() / tok.numel())
+
+
+def window_needs_fallback(tokens, scores, temperature, vocab_size, compression_ratio_threshold, logprob_threshold,
+                          no_speech_threshold=None, no_speech_prob=None):
+    """(needs_fallback, should_skip) of one decoded window (HF _need_fallback)."""
+    needs = compression_ratio_threshold is not None and token_compression_ratio(tokens, vocab_size) > compression_ratio_threshold
+    low = False
+    if logprob_threshold is not None:
+        low = sequence_avg_logprob(scores, tokens, temperature) < logprob_threshold
+        needs = needs or low
+    if no_speech_threshold is not None and low and no_speech_prob is not None and no_speech_prob > no_speech_threshold:
+        return False, True
+    return needs, False
+
+
+def decode_with_fallback(decode, n_windows, temperatures, vocab_size, pad_token_id, eos_token_id, compression_ratio_threshold=1.35,
+                         logprob_threshold=-1.0, no_speech_threshold=None):
+    """Temperature ladder over a batch of windows.  decode(rows, temperature) -> (token lists of the generated positions,
+    [n, V] score tensors, no-speech probabilities or None) for the listed windows.  Every window keeps its latest result;
+    those that fail the compression / log-probability test are decoded again at the next temperature.
+    Returns (token lists without the eos, should_skip flags, index of the temperature each window ended with)."""
+    final, used, skip = [None] * n_windows, [None] * n_windows, [False] * n_windows
+    rows = list(range(n_windows))
+    for k, temp in enumerate(temperatures):
+        toks, scores, nsp = decode(list(rows), temp)
+        again = []
+        for i, row in enumerate(rows):
+            seq = list(toks[i])
+            if seq and seq[-1] == pad_token_id:       # drop the padding tail; with pad == eos one eos stays (it is scored)
+                npad = sum(1 for t in seq if t == pad_token_id) - (1 if pad_token_id == eos_token_id else 0)
+                if npad:
+                    seq = seq[:-npad]
+            needs, sk = window_needs_fallback(seq, scores[i], temp, vocab_size, compression_ratio_threshold, logprob_threshold,
+                                              no_speech_threshold, None if nsp is None else float(nsp[i]))
+            skip[i] = sk                              # (transformers indexes this list by the position in the CURRENT batch)
+            final[row], used[row] = (seq[:-1] if seq and seq[-1] == eos_token_id else seq), k
+            if needs:
+                again.append(row)
+        rows = again
+        if not rows or k == len(temperatures) - 1:
+            break
+    return final, skip, used
 
 
 # ------------------------------------------------------------------------------------------------ long-form decoding
@@ -498,14 +611,26 @@ class LongFormDecoder:
                                       max_initial_timestamp_index=gen_kw.get("max_initial_timestamp_index", 50)),
                       suppress_tokens=gen_kw.get("suppress_tokens"), begin_suppress_tokens=gen_kw.get("begin_suppress_tokens"),
                       ctc=gen_kw.get("ctc"))
-            if self.num_beams > 1:
+            skip = [False] * len(active)
+            if gen_kw.get("temperatures") is not None and self.num_beams == 1:
+                # temperature fallback (reference generation.py:567-611): per-window ladder, silent windows skipped
+                fb = {k: gen_kw[k] for k in ("compression_ratio_threshold", "logprob_threshold", "no_speech_threshold",
+                                             "no_speech_token_id", "generator") if k in gen_kw}
+                tok_lists, skip, _ = self.decoder.generate_with_fallback(feats, stno, prompt[active], n_new,
+                                                                         temperatures=gen_kw["temperatures"], **fb, **kw)
+            elif self.num_beams > 1:
                 seqs, _ = self.decoder.beam_search(feats, stno, prompt[active], P + n_new, self.num_beams,
                                                    length_penalty=gen_kw.get("length_penalty", 1.0),
                                                    early_stopping=gen_kw.get("early_stopping", False), **kw)
+                tok_lists = [seqs[i, P:].tolist() for i in range(len(active))]
             else:
                 seqs = self.decoder.generate(feats, stno, prompt[active], n_new, **kw)
+                tok_lists = [seqs[i, P:].tolist() for i in range(len(active))]
             for i, b in enumerate(active):
-                toks = seqs[i, P:].tolist()
+                if skip[i]:                                          # HF: a skipped (silent) window only moves the seek pointer
+                    seek[b] += left[i]
+                    continue
+                toks = list(tok_lists[i])
                 while toks and toks[-1] in (pad, eos):              # HF strips the eos / padding tail before segmenting
                     toks.pop()
                 if not toks:

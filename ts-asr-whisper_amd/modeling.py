@@ -668,7 +668,8 @@ class DiCoWForConditionalGeneration(nn.Module):
         The prompt is ``decoder_input_ids`` or [decoder_start_token_id] + the tokenizer's prefix tokens."""
         from .generation import GreedyDecoder
         gc = generation_config if generation_config is not None else self.generation_config
-        get = (lambda k, d=None: getattr(gc, k, d) if gc is not None else d)
+        # (explicit keyword arguments win over the generation config, as in HF's generate)
+        get = (lambda k, d=None: kwargs[k] if kwargs.get(k) is not None else (getattr(gc, k, d) if gc is not None else d))
         beams = max(num_beams or 1, get("num_beams", 1) or 1)
         self.stno_mask = stno_mask                            # reference generate() keeps it for detect_language (generation.py:556)
         cfg = self.config
@@ -792,12 +793,18 @@ class DiCoWForConditionalGeneration(nn.Module):
                        upper_cased=list(getattr(tok, "upper_cased_tokens", {}).items()), prefix_len=len(tok.prefix_tokens))
         eos = get("eos_token_id", cfg.eos_token_id)
         dec = LongFormDecoder(self, beams)
+        fb = {}
+        temps = get("temperature")
+        if isinstance(temps, (tuple, list)):          # HF: a tuple of temperatures switches the fallback ladder on
+            fb = dict(temperatures=tuple(float(t) for t in temps), compression_ratio_threshold=get("compression_ratio_threshold"),
+                      logprob_threshold=get("logprob_threshold"), no_speech_threshold=get("no_speech_threshold"),
+                      no_speech_token_id=no_ts - 1, generator=get("generator"))   # HF: <|nospeech|> = <|notimestamps|> - 1
         segs = dec.transcribe(input_features, stno_mask, attention_mask.sum(-1).cpu().tolist(), decoder_input_ids, no_ts,
                               eos_token_id=eos, pad_token_id=get("pad_token_id", cfg.pad_token_id), max_new_tokens=max_new_tokens,
                               enrollments=enrollments, suppress_tokens=get("suppress_tokens"),
                               begin_suppress_tokens=get("begin_suppress_tokens"),
                               max_initial_timestamp_index=get("max_initial_timestamp_index", 50),
-                              length_penalty=get("length_penalty", 1.0), early_stopping=get("early_stopping", False), ctc=ctc)
+                              length_penalty=get("length_penalty", 1.0), early_stopping=get("early_stopping", False), ctc=ctc, **fb)
         self.last_segments = segs
         pad_id = getattr(tok, "pad_token_id", None)
         return fix_timestamps_from_segmentation(segs, first_ts, vocab["\u0120"], cfg.pad_token_id if pad_id is None else pad_id,
