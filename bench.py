@@ -207,7 +207,7 @@ def pmc_traffic():
             d = json.load(f)
         tot = n = 0
         for k, v in d.items():
-            if k.startswith(("gemm_nt256w", "gemm_ntw")) and v.get("hbm_read_bytes_per_launch_corrected") is not None:
+            if k.startswith(("gemm_ntr", "gemm_nt256w", "gemm_ntw")) and v.get("hbm_read_bytes_per_launch_corrected") is not None:
                 tot += (v["hbm_read_bytes_per_launch_corrected"] + (v.get("hbm_write_bytes_per_launch") or 0)) * v["launches"]
                 n += v["launches"]
         return round(tot / n) if n else None
@@ -365,7 +365,7 @@ def main():
                       "note": "time the compute stream waits for the side-stream RCCL buckets before the optimizer (0 at one rank)",
                       "backend": dist.get_backend() if dist.is_initialized() else None,
                       "bytes_per_step": 4 * ts.store.n_trainable if world > 1 else 0},
-        "roofline": {"bound": "mfma", "kernel": "gemm_ntw_kernel (persistent 256x256 / 192x320) / gemm_nt_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_ntr_kernel (persistent LDS-ring 256x256 / 192x320) / gemm_nt_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
                      "achieved": round(nt["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(nt["tflops"] / peak, 4),
                      "traffic": TRAFFIC, "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // nprof,
                      "share_of_step": round(prof_ms / nprof / ms, 3),
