@@ -44,7 +44,9 @@ if os.environ.get("ATTN_PROFILE"):
 if os.environ.get("ATTN_PROFILE"):
     ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=bool(causal), dq_scale=0.125); torch.cuda.synchronize()
     nblk = B * H * ((Lk + 127) // 128)
-    pr = delta.view(-1).view(torch.int64)[:nblk * 8].view(-1, 8).double().cpu()
-    nt = pr[:, 6].mean()
-    names = ["stage+wait+barrier", "q-block 0 (16 MFMA + softmax + 16 MFMA)", "q-block 1", "lgkm + end barrier"]
-    print(f"dkv per q-tile cycles (wave 0, {nt:.1f} tiles): " + ", ".join(f"{n} {pr[:, i].mean() / nt:.0f}" for i, n in enumerate(names)) + f"; total {pr[:,5].mean()/nt:.0f}/tile")
+    rows = (nblk + 39) // 40
+    raw = dqkv.view(-1, 3 * D)[:rows, :D].contiguous().view(torch.int64).view(-1, 8)[:nblk].double().cpu()   # 64-byte records in the dq columns
+    nt = raw[:, 3].mean()
+    names = ["vmcnt wait + barrier + DMA issue", "q-block 0", "q-block 1"]
+    print(f"dkv per q-tile cycles (wave 0, {nt:.1f} tiles): " + ", ".join(f"{n} {raw[:, i].mean() / nt:.0f}" for i, n in enumerate(names)) +
+          f"; sum {raw[:, :3].sum(1).mean() / nt:.0f}/tile")

@@ -14,7 +14,7 @@ while [ $# -gt 1 ]; do
 done
 for p in $pids; do wait $p; done
 for n in "${names[@]}"; do
-  objs=$(ls build/*.o | grep -v "gemm_v_" | grep -v "build/gemm.o")
+  objs=$(ls build/*.o | grep -v "_v_" | grep -v "build/gemm.o")
   hipcc --offload-arch=gfx950 -shared -fPIC $objs build/gemm_v_$n.o -o ../../tools/libv_$n.so
   echo "built tools/libv_$n.so"
 done

@@ -22,6 +22,9 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)lds_dst, 16, 0, 0);
 }
 
+#ifndef ATTN_ABL
+#define ATTN_ABL 0             // diagnostic builds only (tools/build_attn_variants.sh): bit mask of pieces left out of the dkv loop
+#endif
 #define HD 64
 #define KV_TILE 64
 #define TILE_BYTES (KV_TILE * HD * 2)        // 8 KiB
@@ -180,6 +183,41 @@ __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& s, int r0) {
     return o;
 }
 
+// Packed fp32 helpers (v_pk_fma_f32 / v_pk_add_f32: two lanes-worth of arithmetic per issue slot).  Plain VALU work is paid
+// in matrix-pipe time on this machine (SQ counters of these loops: MFMA-busy cycles + VALU-active cycles ~= SIMD cycles), so
+// the softmax (re)compute is written to the instruction: per 32x32 score block 8 packed scales + 16 exp2 + 8 packed products
+// + 16 packed converts in the backward kernels, 8 packed fma + 16 exp2 + 8 packed adds + 8 max3 in the forward.
+// The products are written as fma(x, y, z) with a zero the optimiser cannot see: a plain vector multiply is split into two
+// v_mul_f32 about half of the time, and inline asm is not an option for values an MFMA has just produced (the compiler
+// pads MFMA -> VALU read hazards with s_nop only for instructions it emitted itself; an asm v_pk_mul_f32 read garbage).
+__device__ __forceinline__ f32x2_t opaque_zero2() {
+    f32x2_t z = {0.f, 0.f};
+    asm volatile("" : "+v"(z));
+    return z;
+}
+typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+// (pairs are taken and put back as SUB-VECTORS -- shufflevector, not element extracts: a pair built from two extracted
+// scalars is what the instruction selector splits again)
+#define PK_PAIR(v, i) __builtin_shufflevector(v, v, 2 * (i), 2 * (i) + 1)
+__device__ __forceinline__ f32x16_t pk_join16(f32x2_t p0, f32x2_t p1, f32x2_t p2, f32x2_t p3, f32x2_t p4, f32x2_t p5, f32x2_t p6,
+                                              f32x2_t p7) {
+    const f32x4_t q0 = __builtin_shufflevector(p0, p1, 0, 1, 2, 3), q1 = __builtin_shufflevector(p2, p3, 0, 1, 2, 3);
+    const f32x4_t q2 = __builtin_shufflevector(p4, p5, 0, 1, 2, 3), q3 = __builtin_shufflevector(p6, p7, 0, 1, 2, 3);
+    const f32x8_t h0 = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), h1 = __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}
+__device__ __forceinline__ void pk_scale16(f32x16_t& s, float c, f32x2_t z2) {
+    const f32x2_t c2 = {c, c};
+#define PK_(i) __builtin_elementwise_fma(PK_PAIR(s, i), c2, z2)
+    s = pk_join16(PK_(0), PK_(1), PK_(2), PK_(3), PK_(4), PK_(5), PK_(6), PK_(7));
+#undef PK_
+}
+__device__ __forceinline__ f32x16_t pk_mul16(const f32x16_t& x, const f32x16_t& y, f32x2_t z2) {
+#define PK_(i) __builtin_elementwise_fma(PK_PAIR(x, i), PK_PAIR(y, i), z2)
+    return pk_join16(PK_(0), PK_(1), PK_(2), PK_(3), PK_(4), PK_(5), PK_(6), PK_(7));
+#undef PK_
+}
+
 // XCD-aware workgroup -> (row block, head, batch) map.  Workgroups are dealt round-robin to the 8 XCDs (dispatch id L
 // lands on XCD L % 8), each with a private 4 MiB L2; the natural (x = row block fastest) order therefore scatters the
 // row blocks that share one head's K/V (or Q/dO) over all 8 L2s and every one of them fetches the panels again
@@ -324,16 +362,21 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
             m_ref = m_new;
         }
         const float mL = (m_ref == -INFINITY) ? 0.f : m_ref * LOG2E;
-        float psum = 0.f;
+        {   // packed: 16 v_pk_fma_f32 + 32 v_exp_f32 + 16 v_pk_add_f32 for the 32 scores of a lane
+            const f32x2_t c2 = {LOG2E, LOG2E}, m2 = {-mL, -mL};
+            f32x2_t ps2 = {0.f, 0.f};
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mL));
-                s[kb][r] = p;
-                psum += p;
-            }
-        l_run += psum;
+                for (int i = 0; i < 8; ++i) {
+                    f32x2_t e = __builtin_elementwise_fma(f32x2_t{s[kb][2 * i], s[kb][2 * i + 1]}, c2, m2);
+                    e.x = __builtin_amdgcn_exp2f(e.x);
+                    e.y = __builtin_amdgcn_exp2f(e.y);
+                    s[kb][2 * i] = e.x; s[kb][2 * i + 1] = e.y;
+                    ps2 = ps2 + e;
+                }
+            l_run += ps2.x + ps2.y;
+        }
 
         PT(3)
         // ---- O^T += V^T . P^T
@@ -468,13 +511,14 @@ __device__ __forceinline__ void tr_read_block_u(bf16x8_t (&f)[2][2], unsigned a0
 
 // ------------------------------------------------------------------------------------------------ dQ
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bwd_args a) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];      // K0 V0 K1 V1 (U images)
+    __shared__ __attribute__((aligned(16))) char smem[6 * TILE_BYTES];      // three (K, V) slots (U images)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
     int qblk, h, b;
     attn_block_coords((a.Lq + 127) / 128, a.H, a.B, qblk, h, b);
     const int q0 = qblk * 128;
+    const f32x2_t z2 = opaque_zero2();
     const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
     const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
     const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
@@ -527,27 +571,38 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
     // lane bases of the transposing reads, once (the stage only adds a scalar)
     const unsigned kb00 = tr_base_u(smem, lane, 0, 0), kb01 = tr_base_u(smem, lane, 0, 1);
     const unsigned kb10 = tr_base_u(smem, lane, 1, 0), kb11 = tr_base_u(smem, lane, 1, 1);
+    // Three-slot ring, ONE barrier per key tile (see attn_fwd_kernel): tile t+1 stays in flight across the barrier that
+    // publishes tile t, tile t+2 is requested into the slot tile t-1 just left.  LDS addresses = eight lane registers
+    // (fragment / transposing-read bases + slot offset) plus immediates.
     stage_tile(srcK, 0, smem, wave);
     stage_tile(srcV, 0, smem + TILE_BYTES, wave);
+    if (nt > 1) {
+        stage_tile(srcK, KV_TILE, smem + 2 * TILE_BYTES, wave);
+        stage_tile(srcV, KV_TILE, smem + 3 * TILE_BYTES, wave);
+    }
+    unsigned fo[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fo[kk] = (unsigned)uswz(lane & 31, kk * 2 + hh);
+    int slot = 0;
     for (int t = 0; t < nt; ++t) {
-        char* sK = smem + (t & 1) * 2 * TILE_BYTES;
-        char* sV = sK + TILE_BYTES;
-        if (t + 1 < nt) {
-            char* nK = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile(srcK, (t + 1) * KV_TILE, nK, wave);
-            stage_tile(srcV, (t + 1) * KV_TILE, nK + TILE_BYTES, wave);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (t + 2 < nt) {
+            char* nK = smem + (slot == 0 ? 2 : slot - 1) * 2 * TILE_BYTES;
+            stage_tile(srcK, (t + 2) * KV_TILE, nK, wave);
+            stage_tile(srcV, (t + 2) * KV_TILE, nK + TILE_BYTES, wave);
+        }
 
         const int k0 = t * KV_TILE;
         const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
         // K^T fragments for the dQ product: issued now, consumed after S / dP / dS
-        const unsigned stg = (unsigned)((t & 1) * 2 * TILE_BYTES);
+        const unsigned stg = (unsigned)(slot * 2 * TILE_BYTES);
         const unsigned k00 = kb00 + stg, k01 = kb01 + stg, k10 = kb10 + stg, k11 = kb11 + stg;
+        const char* fs[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fs[kk] = smem + fo[kk] + stg;
         tr8_t tk0, tk1;
         tr_issue_u<0>(tk0, k00, k01, k10, k11);
         tr_issue_u<4096>(tk1, k00, k01, k10, k11);
@@ -559,13 +614,14 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
             f32x16_t s = seed_s, dp = seed_p;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + uswz(kb * 32 + (lane & 31), kk * 2 + hh));
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + uswz(kb * 32 + (lane & 31), kk * 2 + hh));
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(fs[kk] + kb * 4096);
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(fs[kk] + (TILE_BYTES + kb * 4096));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dp, 0, 0, 0);
             }
+            pk_scale16(s, LOG2E, z2);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E);
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
             if (need_mask) {                          // one branch per block: a test inside the score loop becomes 16
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -573,8 +629,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
                     if (key >= a.Lk || (a.causal && key > qrow)) s[r] = 0.f;
                 }
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ds[kb][r] = s[r] * dp[r];
+            ds[kb] = pk_mul16(s, dp, z2);
         }
         // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
         {
@@ -596,9 +651,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
                 for (int d = 0; d < 2; ++d) dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[x][d], pf, dq[d], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        slot = slot == 2 ? 0 : slot + 1;
     }
     if (a.dq_colsum) {        // q_proj bias gradient, fused: partial row (b, q block, wave) of the first workspace plane
         const int nqb = (a.Lq + 127) / 128;
@@ -621,28 +674,33 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-// lse / delta of a 64-query tile -> LDS (one 4-byte DMA per lane; waves 0/2 fetch lse, waves 1/3 delta, so every wave
-// issues the same number of VMEM ops and one counted vmcnt serves all)
-__device__ __forceinline__ void stage_stats64(const float* lse, const float* delta, int q0, int Lq, char* dst, int wave, int lane) {
-    int q = q0 + lane; q = q < Lq ? q : Lq - 1;
-    const float* src = (wave & 1) ? delta + q : lse + q;
-    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + (wave & 1) * 256), 4, 0, 0);
+// -lse / -delta of a 64-query tile -> LDS (one 4-byte DMA per lane through a buffer descriptor: waves 0/2 fetch the -lse
+// plane, waves 1/3 the -delta plane, so every wave issues the same number of VMEM ops and one counted vmcnt serves all;
+// queries past the end read as zero -- their scores are masked).  No per-tile VALU address arithmetic: the tile only moves
+// the scalar offset.
+__device__ __forceinline__ void stage_stats64(__amdgpu_buffer_rsrc_t rs, int q0, char* dst, int wave, int lane) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + (wave & 1) * 256), 4, (unsigned)(lane * 4), q0 * 4, 0, 0);
 }
 
+#define DKV_SLOT (2 * TILE_BYTES)                 // one ring slot: Q tile | dO tile (U images)
+#define DKV_STATS (3 * DKV_SLOT)                  // three 512-B (-lse | -delta) slots behind the ring
 __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_bwd_args a) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 1024];   // Q0 dO0 Q1 dO1 (U images) + lse/delta x2
+    __shared__ __attribute__((aligned(16))) char smem[3 * DKV_SLOT + 3 * 512 + ((ATTN_ABL & 16) ? 40960 : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
     int kblk, h, b;
     attn_block_coords((a.Lk + 127) / 128, a.H, a.B, kblk, h, b);
     const int kblk0 = kblk * 128;
+    const f32x2_t z2 = opaque_zero2();
     const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
     const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
     const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
     const unsigned short* dO = reinterpret_cast<const unsigned short*>(a.d_o) + (int64_t)b * a.do_bs + h * HD;
     const float* lse = a.delta + (int64_t)a.B * a.H * a.Lq + ((int64_t)b * a.H + h) * a.Lq;     // -lse plane of the workspace
     const float* delta = a.delta + ((int64_t)b * a.H + h) * a.Lq;                                // -delta plane
+    const __amdgpu_buffer_rsrc_t rsStat = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>((wave & 1) ? delta : lse), 0, (unsigned)(a.Lq * 4), 0x00020000);
 
     // this wave's 32 keys as B operands (column = key, k-slots = d)
     const int key = kblk0 + wave * 32 + (lane & 31);
@@ -662,68 +720,64 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
     const int t0 = a.causal ? (kblk0 / KV_TILE) : 0;                 // query tiles entirely before the key block see none of it
     const int nt = (a.Lq + KV_TILE - 1) / KV_TILE;
     const tile_src_t srcQ = make_tile_src<SWZ_U>(Q, a.q_rs, a.Lq, wave, lane), srcdO = make_tile_src<SWZ_U>(dO, a.do_rs, a.Lq, wave, lane);
+    // Three-slot ring, ONE barrier per query tile (as in the forward kernel): the barrier that publishes tile t also proves
+    // every wave has left tile t-1, whose slot is refilled with tile t+2.  Every LDS address of a tile is one of nine lane
+    // registers (base + slot offset, 9 v_add_u32 per tile) plus an immediate: the q-block / operand / half offsets are
+    // compile-time (the two-slot form spent 43 v_add_u32 per tile, a quarter of the loop's VALU instructions, on them).
     if (t0 < nt) {
         stage_tile(srcQ, t0 * KV_TILE, smem, wave);
         stage_tile(srcdO, t0 * KV_TILE, smem + TILE_BYTES, wave);
-        stage_stats64(lse, delta, t0 * KV_TILE, a.Lq, smem + 4 * TILE_BYTES, wave, lane);
+        stage_stats64(rsStat, t0 * KV_TILE, smem + DKV_STATS, wave, lane);
+        if (t0 + 1 < nt) {
+            stage_tile(srcQ, (t0 + 1) * KV_TILE, smem + DKV_SLOT, wave);
+            stage_tile(srcdO, (t0 + 1) * KV_TILE, smem + DKV_SLOT + TILE_BYTES, wave);
+            stage_stats64(rsStat, (t0 + 1) * KV_TILE, smem + DKV_STATS + 512, wave, lane);
+        }
     }
-    // lane-derived row-fragment offsets (swizzle XORs) computed once: plain VALU instructions share the SIMD's issue port
-    // with the MFMAs, so per-tile address arithmetic is pure loss
-    int fo[2][4];
+    // lane-derived fragment offsets inside a slot, once
+    unsigned fo[4];
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fo[qb][kk] = uswz(qb * 32 + (lane & 31), kk * 2 + hh);
+    for (int kk = 0; kk < 4; ++kk) fo[kk] = (unsigned)uswz(lane & 31, kk * 2 + hh);
     const unsigned qb00 = tr_base_u(smem, lane, 0, 0), qb01 = tr_base_u(smem, lane, 0, 1);
     const unsigned qb10 = tr_base_u(smem, lane, 1, 0), qb11 = tr_base_u(smem, lane, 1, 1);
-    for (int t = t0; t < nt; ++t) {
-        char* sQ = smem + ((t - t0) & 1) * 2 * TILE_BYTES;
-        char* sdO = sQ + TILE_BYTES;
-        if (t + 1 < nt) {
-            char* nQ = smem + ((t - t0 + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile(srcQ, (t + 1) * KV_TILE, nQ, wave);
-            stage_tile(srcdO, (t + 1) * KV_TILE, nQ + TILE_BYTES, wave);
-            stage_stats64(lse, delta, (t + 1) * KV_TILE, a.Lq, smem + 4 * TILE_BYTES + ((t - t0 + 1) & 1) * 512, wave, lane);
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+    const char* statl = smem + DKV_STATS + 16 * hh;
 
-        const int qt0 = t * KV_TILE;
-        const float* sStat = reinterpret_cast<const float*>(smem + 4 * TILE_BYTES + ((t - t0) & 1) * 512);
-        const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + 128 > a.Lk) || (a.causal && (kblk0 + wave * 32 + 31 > qt0));
-        const unsigned stg = (unsigned)(((t - t0) & 1) * 2 * TILE_BYTES);
-        const unsigned q00 = qb00 + stg, q01 = qb01 + stg, q10 = qb10 + stg, q11 = qb11 + stg;
-        const unsigned o00 = q00 + TILE_BYTES, o01 = q01 + TILE_BYTES, o10 = q10 + TILE_BYTES, o11 = q11 + TILE_BYTES;
+#if ATTN_ABL & 1        /* ablation: no softmax arithmetic (results are garbage) */
+#define DKV_SOFTMAX_HEAD f32x16_t pv = s;
+#define DKV_SOFTMAX_TAIL const f32x16_t dsv = dp;
+#else
+#define DKV_SOFTMAX_HEAD pk_scale16(s, LOG2E, z2); f32x16_t pv; _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r]);
+#define DKV_SOFTMAX_TAIL const f32x16_t dsv = pk_mul16(pv, dp, z2);
+#endif
 #define DKV_QBLOCK(QB)                                                                                                  \
         {                                                                                                               \
             tr8_t tdo, tq;                                                                                              \
-            tr_issue_u<(QB) * 4096>(tdo, o00, o01, o10, o11);                                                           \
+            tr_issue_u<TILE_BYTES + (QB) * 4096>(tdo, q00, q01, q10, q11);                                              \
             tr_issue_u<(QB) * 4096>(tq, q00, q01, q10, q11);                                                            \
             f32x16_t s, dp;                       /* accumulators seeded with -lse[q], -delta[q] (see attn_bwd_dq_kernel) */ \
             _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                          \
-                const float4 lv = *reinterpret_cast<const float4*>(sStat + (QB) * 32 + 8 * q4 + 4 * hh);                 \
-                const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 64 + (QB) * 32 + 8 * q4 + 4 * hh);          \
+                const float4 lv = *reinterpret_cast<const float4*>(sStat + ((QB) * 32 + 8 * q4) * 4);                   \
+                const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 256 + ((QB) * 32 + 8 * q4) * 4);            \
                 s[4 * q4] = lv.x; s[4 * q4 + 1] = lv.y; s[4 * q4 + 2] = lv.z; s[4 * q4 + 3] = lv.w;                     \
                 dp[4 * q4] = dv4.x; dp[4 * q4 + 1] = dv4.y; dp[4 * q4 + 2] = dv4.z; dp[4 * q4 + 3] = dv4.w;             \
             }                                                                                                           \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
-                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(sQ + fo[QB][kk]);                                 \
-                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(sdO + fo[QB][kk]);                                \
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(fs[kk] + (QB) * 4096);                           \
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(fs[kk] + (TILE_BYTES + (QB) * 4096));            \
+                if (ATTN_ABL & 8) { s[kk] += bfbits2f(qa[0]) * bfbits2f(kf[kk][0]); dp[kk] += bfbits2f(da[0]) * bfbits2f(vf[kk][0]); continue; } \
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);                                    \
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
             }                                                                                                           \
-            f32x16_t pv, dsv;                                                                                           \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E);                \
+            pk_scale16(s, LOG2E, z2);                                                                                       \
+            f32x16_t pv;                                                                                                \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r]);                        \
             if (need_mask) {                      /* ONE branch per block: a test inside the score loop becomes 16 */   \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
                     const int qq = qt0 + (QB) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);                                   \
                     if (qq >= a.Lq || key >= a.Lk || (a.causal && key > qq)) pv[r] = 0.f;                               \
                 }                                                                                                       \
             }                                                                                                           \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) dsv[r] = pv[r] * dp[r];                                      \
+            const f32x16_t dsv = pk_mul16(pv, dp, z2);                                                                      \
             bf16x8_t qtf[2][2], dotf[2][2];                                                                             \
             tr_wait<0>(tdo);                                                                                            \
             tr_wait<0>(tq);                                                                                             \
@@ -733,18 +787,59 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
                 const bf16x8_t pf = pack8(pv, 8 * x);                                                                   \
                 const bf16x8_t df = pack8(dsv, 8 * x);                                                                  \
                 _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                         \
+                    if (ATTN_ABL & 2) { dv[d][x] += bfbits2f(pf[d]) + bfbits2f(dotf[x][d][0]); dk[d][x] += bfbits2f(df[d]) + bfbits2f(qtf[x][d][0]); continue; } \
                     dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[x][d], pf, dv[d], 0, 0, 0);                    \
                     dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[x][d], df, dk[d], 0, 0, 0);                     \
                 }                                                                                                       \
             }                                                                                                           \
         }
-        DKV_QBLOCK(0)
-        DKV_QBLOCK(1)
-#undef DKV_QBLOCK
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef ATTN_PROFILE
+    long long kacc[4] = {0, 0, 0, 0}, kt_[5];
+#define KT(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt_[i]) :: "memory");
+#else
+#define KT(i)
+#endif
+    int slot = 0;
+    for (int t = t0; t < nt; ++t) {
+        KT(0)
+        // tile t lives in `slot`; tile t+1 (issued one tile ago) may stay in flight; tile t+2 goes to the slot tile t-1 left
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        if (t + 2 < nt && !(ATTN_ABL & 4)) {
+            const int ns = slot == 0 ? 2 : slot - 1;
+            char* nQ = smem + ns * DKV_SLOT;
+            stage_tile(srcQ, (t + 2) * KV_TILE, nQ, wave);
+            stage_tile(srcdO, (t + 2) * KV_TILE, nQ + TILE_BYTES, wave);
+            stage_stats64(rsStat, (t + 2) * KV_TILE, smem + DKV_STATS + ns * 512, wave, lane);
+        }
+        const int qt0 = t * KV_TILE;
+        const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + 128 > a.Lk) || (a.causal && (kblk0 + wave * 32 + 31 > qt0));
+        const unsigned stg = (unsigned)(slot * DKV_SLOT);
+        const unsigned q00 = qb00 + stg, q01 = qb01 + stg, q10 = qb10 + stg, q11 = qb11 + stg;
+        const char* fs[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fs[kk] = smem + fo[kk] + stg;
+        const char* sStat = statl + slot * 512;
+        KT(1)
+        DKV_QBLOCK(0)
+        KT(2)
+        DKV_QBLOCK(1)
+        KT(3)
+        slot = slot == 2 ? 0 : slot + 1;
+#ifdef ATTN_PROFILE
+        for (int i = 0; i < 3; ++i) kacc[i] += kt_[i + 1] - kt_[i];
+#endif
     }
+#undef DKV_QBLOCK
+#ifdef ATTN_PROFILE
+    if (tid == 0) {     // diagnostic build: per-workgroup phase cycles of wave 0 go to the dq columns (this kernel never writes them)
+        const int rec = blockIdx.x;
+        long long* pr = reinterpret_cast<long long*>(reinterpret_cast<char*>(a.dq) + (int64_t)(rec / 40) * a.dq_rs * 2 + (rec % 40) * 64);
+        pr[0] = kacc[0]; pr[1] = kacc[1]; pr[2] = kacc[2]; pr[3] = nt - t0;
+    }
+#endif
     if (a.dv_colsum) {        // v_proj bias gradient, fused: second workspace plane, partial row (b, key block, wave)
         const int nqb = (a.Lq + 127) / 128, nkb = (a.Lk + 127) / 128;
         float* wsr = reinterpret_cast<float*>(a.cs_ws) + (int64_t)a.B * nqb * 4 * a.H * HD +

@@ -1389,10 +1389,28 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt1 = (a.N1 + 255) / 256, nt2 = (a.N2 + 255) / 256;
-    int t1, t2;
-    tile_coords(nt1, nt2, t1, t2);
+    // (split, tile) pairs in split-major order, dealt to the XCDs in contiguous chunks (flat 1-D grid, block L lands on XCD
+    // L % 8): the ~32 workgroups an XCD runs at a time then belong to ONE split -- the same rows of A and B -- and cover a
+    // compact block of output tiles, so every 64-row slice of an operand panel is fetched into that L2 once and hit by the
+    // other tiles of its row / column.  (With the split on gridDim.z an XCD held 3 tiles of each of 10 splits: a third of the
+    // reuse, 3.5x the algorithmic bytes on the fabric side of L2.)
+    const int ntile = nt1 * nt2;
+    int split, t1, t2;
+    {
+        const int nwg = (int)gridDim.x, L = (int)blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, loc = L >> 3;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        split = id / ntile;
+        const int tid_ = id - split * ntile;
+        const int GM = 8, per_group = GM * nt2;
+        const int group = tid_ / per_group, rem = tid_ - group * per_group;
+        const int first = group * GM;
+        const int gsize = (nt1 - first) < GM ? (nt1 - first) : GM;
+        t1 = first + rem % gsize;
+        t2 = rem / gsize;
+    }
     const int n1_0 = t1 * 256, n2_0 = t2 * 256;
-    const int kt0 = blockIdx.z * tiles_per_split;
+    const int kt0 = split * tiles_per_split;
     int kt1 = kt0 + tiles_per_split; kt1 = kt1 < total_tiles ? kt1 : total_tiles;
     if (kt0 >= kt1) return;
     const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A);
@@ -1491,8 +1509,8 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_
     tn256_mfma(acc, f1);
 
     const int hh = lane >> 5;
-    const bool to_ws = gridDim.z > 1;
-    float* wsz = reinterpret_cast<float*>(a.ws) + (int64_t)blockIdx.z * a.N1 * a.N2;
+    const bool to_ws = (int)gridDim.x > ntile;
+    float* wsz = reinterpret_cast<float*>(a.ws) + (int64_t)split * a.N1 * a.N2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n1 = n1_0 + w1 * 128 + j * 32 + (lane & 31);
@@ -1599,7 +1617,7 @@ extern "C" int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream) {
     }();
     (void)attr_set;
     if (tile == 256)
-        hipLaunchKernelGGL(gemm_tn256_kernel, dim3(nt, 1, splits), dim3(512), TN256_LDS, (hipStream_t)stream, *a, tpb, total, tps);
+        hipLaunchKernelGGL(gemm_tn256_kernel, dim3(nt * splits), dim3(512), TN256_LDS, (hipStream_t)stream, *a, tpb, total, tps);
     else
         hipLaunchKernelGGL(gemm_tn_kernel, dim3(nt, 1, splits), dim3(256), TN_LDS_BYTES, (hipStream_t)stream, *a, tpb, total, tps);
     DICOW_CHECK_LAUNCH("gemm_tn");
