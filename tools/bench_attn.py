@@ -47,6 +47,7 @@ if os.environ.get("ATTN_PROFILE"):
     rows = (nblk + 39) // 40
     raw = dqkv.view(-1, 3 * D)[:rows, :D].contiguous().view(torch.int64).view(-1, 8)[:nblk].double().cpu()   # 64-byte records in the dq columns
     nt = raw[:, 3].mean()
-    names = ["vmcnt wait + barrier + DMA issue", "q-block 0", "q-block 1"]
+    names = ["vmcnt wait + barrier", "q-block 0", "q-block 1"]
     print(f"dkv per q-tile cycles (wave 0, {nt:.1f} tiles): " + ", ".join(f"{n} {raw[:, i].mean() / nt:.0f}" for i, n in enumerate(names)) +
-          f"; sum {raw[:, :3].sum(1).mean() / nt:.0f}/tile")
+          f"; sum {raw[:, :3].sum(1).mean() / nt:.0f}/tile; loop total {raw[:, 4].mean():.0f} cycles in {raw[:, 5].mean() / 100:.1f} us "
+          f"(100 MHz s_memrealtime) = {raw[:, 4].mean() / raw[:, 5].mean() * 0.1:.2f} GHz")

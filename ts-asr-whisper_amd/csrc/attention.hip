@@ -683,9 +683,56 @@ __device__ __forceinline__ void stage_stats64(__amdgpu_buffer_rsrc_t rs, int q0,
 }
 
 #define DKV_SLOT (2 * TILE_BYTES)                 // one ring slot: Q tile | dO tile (U images)
-#define DKV_STATS (3 * DKV_SLOT)                  // three 512-B (-lse | -delta) slots behind the ring
+#define DKV_NSLOT 4
+#define DKV_STATS (DKV_NSLOT * DKV_SLOT)          // (-lse | -delta) slots, 512 B each, behind the ring
+
+// Row fragments (A operands of S = Q K^T and dP = dO V^T: 4 + 4 ds_read_b128) and the seed values (-lse, -delta of the 32
+// queries of a q-block, as the accumulator layout wants them: 4 + 4 broadcast ds_read_b128) of ONE q-block, issued as one
+// asm statement and waited for later (same split issue / wait form as tr8_t above).
+struct dkv_pre_t { bf16x8_t q[4], d[4]; f32x4_t sl[4], sd[4]; };
+template <int OFF_Q>                     // q-block offset inside the slot (dO = +TILE_BYTES)
+__device__ __forceinline__ void dkv_pre_issue_frags(dkv_pre_t& p, const unsigned (&fa)[4]) {
+    asm volatile(
+        "ds_read_b128 %0, %8 offset:%12\n\t"  "ds_read_b128 %4, %8 offset:%13\n\t"
+        "ds_read_b128 %1, %9 offset:%12\n\t"  "ds_read_b128 %5, %9 offset:%13\n\t"
+        "ds_read_b128 %2, %10 offset:%12\n\t" "ds_read_b128 %6, %10 offset:%13\n\t"
+        "ds_read_b128 %3, %11 offset:%12\n\t" "ds_read_b128 %7, %11 offset:%13"
+        : "=&v"(p.q[0]), "=&v"(p.q[1]), "=&v"(p.q[2]), "=&v"(p.q[3]), "=&v"(p.d[0]), "=&v"(p.d[1]), "=&v"(p.d[2]), "=&v"(p.d[3])
+        : "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "i"(OFF_Q), "i"(OFF_Q + TILE_BYTES)
+        : "memory");
+}
+template <int OFF_S>                     // q-block offset inside the stats slot
+__device__ __forceinline__ void dkv_pre_issue_stats(dkv_pre_t& p, unsigned sa) {
+    asm volatile(
+        "ds_read_b128 %0, %8 offset:%9\n\t"  "ds_read_b128 %4, %8 offset:%13\n\t"
+        "ds_read_b128 %1, %8 offset:%10\n\t" "ds_read_b128 %5, %8 offset:%14\n\t"
+        "ds_read_b128 %2, %8 offset:%11\n\t" "ds_read_b128 %6, %8 offset:%15\n\t"
+        "ds_read_b128 %3, %8 offset:%12\n\t" "ds_read_b128 %7, %8 offset:%16"
+        : "=&v"(p.sl[0]), "=&v"(p.sl[1]), "=&v"(p.sl[2]), "=&v"(p.sl[3]), "=&v"(p.sd[0]), "=&v"(p.sd[1]), "=&v"(p.sd[2]), "=&v"(p.sd[3])
+        : "v"(sa), "i"(OFF_S), "i"(OFF_S + 32), "i"(OFF_S + 64), "i"(OFF_S + 96),
+          "i"(OFF_S + 256), "i"(OFF_S + 256 + 32), "i"(OFF_S + 256 + 64), "i"(OFF_S + 256 + 96)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void dkv_pre_wait(dkv_pre_t& p) {
+    asm volatile("s_waitcnt lgkmcnt(%16)"
+                 : "+v"(p.q[0]), "+v"(p.q[1]), "+v"(p.q[2]), "+v"(p.q[3]), "+v"(p.d[0]), "+v"(p.d[1]), "+v"(p.d[2]), "+v"(p.d[3]),
+                   "+v"(p.sl[0]), "+v"(p.sl[1]), "+v"(p.sl[2]), "+v"(p.sl[3]), "+v"(p.sd[0]), "+v"(p.sd[1]), "+v"(p.sd[2]), "+v"(p.sd[3])
+                 : "i"(N) : "memory");
+}
+__device__ __forceinline__ f32x16_t join4x4(const f32x4_t (&v)[4]) {
+    const f32x8_t h0 = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7), h1 = __builtin_shufflevector(v[2], v[3], 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}
+
+// Software-pipelined over q-blocks (32 queries): SQ counters and an MFMA-free build showed the two-slot form bound by its
+// own skeleton -- per q-block every wave issued its LDS reads, WAITED for them behind the other seven waves' reads, ran the
+// S / dP MFMAs, waited, did the softmax arithmetic, ran the dV / dK MFMAs; with two waves per SIMD little of that
+// overlapped (3900 cycles per 64-query tile against 2048 of matrix-pipe work per SIMD, and 3700 with no MFMAs at all).
+// Here the row fragments and seeds of q-block n+1 are requested while q-block n's dV / dK MFMAs run, the transposed
+// fragments of q-block n while its S / dP MFMAs run: no LDS round trip is left on a wave's critical path.
 __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_bwd_args a) {
-    __shared__ __attribute__((aligned(16))) char smem[3 * DKV_SLOT + 3 * 512 + ((ATTN_ABL & 16) ? 40960 : 0)];
+    __shared__ __attribute__((aligned(16))) char smem[DKV_NSLOT * DKV_SLOT + DKV_NSLOT * 512];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
@@ -720,55 +767,53 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
     const int t0 = a.causal ? (kblk0 / KV_TILE) : 0;                 // query tiles entirely before the key block see none of it
     const int nt = (a.Lq + KV_TILE - 1) / KV_TILE;
     const tile_src_t srcQ = make_tile_src<SWZ_U>(Q, a.q_rs, a.Lq, wave, lane), srcdO = make_tile_src<SWZ_U>(dO, a.do_rs, a.Lq, wave, lane);
-    // Three-slot ring, ONE barrier per query tile (as in the forward kernel): the barrier that publishes tile t also proves
-    // every wave has left tile t-1, whose slot is refilled with tile t+2.  Every LDS address of a tile is one of nine lane
-    // registers (base + slot offset, 9 v_add_u32 per tile) plus an immediate: the q-block / operand / half offsets are
-    // compile-time (the two-slot form spent 43 v_add_u32 per tile, a quarter of the loop's VALU instructions, on them).
-    if (t0 < nt) {
-        stage_tile(srcQ, t0 * KV_TILE, smem, wave);
-        stage_tile(srcdO, t0 * KV_TILE, smem + TILE_BYTES, wave);
-        stage_stats64(rsStat, t0 * KV_TILE, smem + DKV_STATS, wave, lane);
-        if (t0 + 1 < nt) {
-            stage_tile(srcQ, (t0 + 1) * KV_TILE, smem + DKV_SLOT, wave);
-            stage_tile(srcdO, (t0 + 1) * KV_TILE, smem + DKV_SLOT + TILE_BYTES, wave);
-            stage_stats64(rsStat, (t0 + 1) * KV_TILE, smem + DKV_STATS + 512, wave, lane);
-        }
-    }
-    // lane-derived fragment offsets inside a slot, once
+    // Four-slot ring, ONE barrier per 64-query tile, placed between its two q-blocks: the barrier of tile t publishes tile
+    // t+1 (whose first fragments are requested during tile t's second q-block) and proves that every wave has left tile
+    // t-1, whose slot then receives tile t+3.  A tile's DMA therefore has two tile times to land.
+    auto dma_tile = [&](int t) {
+        const int sl = (t - t0) & (DKV_NSLOT - 1);
+        stage_tile(srcQ, t * KV_TILE, smem + sl * DKV_SLOT, wave);
+        stage_tile(srcdO, t * KV_TILE, smem + sl * DKV_SLOT + TILE_BYTES, wave);
+        stage_stats64(rsStat, t * KV_TILE, smem + DKV_STATS + sl * 512, wave, lane);
+    };
+    // lane-derived LDS addresses inside slot 0, once; a tile adds its slot offset (9 v_add_u32 per tile), q-block / operand /
+    // half offsets are immediates
     unsigned fo[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) fo[kk] = (unsigned)uswz(lane & 31, kk * 2 + hh);
+    for (int kk = 0; kk < 4; ++kk) fo[kk] = (unsigned)(uintptr_t)(smem + uswz(lane & 31, kk * 2 + hh));
     const unsigned qb00 = tr_base_u(smem, lane, 0, 0), qb01 = tr_base_u(smem, lane, 0, 1);
     const unsigned qb10 = tr_base_u(smem, lane, 1, 0), qb11 = tr_base_u(smem, lane, 1, 1);
-    const char* statl = smem + DKV_STATS + 16 * hh;
+    const unsigned statl = (unsigned)(uintptr_t)(smem + DKV_STATS + 16 * hh);
 
-#if ATTN_ABL & 1        /* ablation: no softmax arithmetic (results are garbage) */
-#define DKV_SOFTMAX_HEAD f32x16_t pv = s;
-#define DKV_SOFTMAX_TAIL const f32x16_t dsv = dp;
-#else
-#define DKV_SOFTMAX_HEAD pk_scale16(s, LOG2E, z2); f32x16_t pv; _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r]);
-#define DKV_SOFTMAX_TAIL const f32x16_t dsv = pk_mul16(pv, dp, z2);
-#endif
-#define DKV_QBLOCK(QB)                                                                                                  \
+    dkv_pre_t pre;
+    if (t0 < nt) {
+        dma_tile(t0);
+        if (t0 + 1 < nt) dma_tile(t0 + 1);
+        if (t0 + 2 < nt) dma_tile(t0 + 2);
+        if (t0 + 2 < nt) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (t0 + 1 < nt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        dkv_pre_issue_frags<0>(pre, fo);                             // q-block 0 of tile t0 (slot 0)
+        dkv_pre_issue_stats<0>(pre, statl);
+    }
+
+    // one q-block: QB = 0/1; fs/qs/ss = this tile's addresses; the NEXT q-block's fragments / seeds are requested with NEXT_FRAGS / NEXT_STATS
+#define DKV_QBLOCK(QB, NEXT_FRAGS, NEXT_STATS, MID_WORK)                                                                                      \
         {                                                                                                               \
-            tr8_t tdo, tq;                                                                                              \
+            tr8_t tdo, tq;                        /* (lgkmcnt counts to 15: issue and wait in groups of eight) */       \
             tr_issue_u<TILE_BYTES + (QB) * 4096>(tdo, q00, q01, q10, q11);                                              \
+            dkv_pre_wait<8>(pre);                 /* LDS returns in order: the 8 transposing reads stay in flight */    \
             tr_issue_u<(QB) * 4096>(tq, q00, q01, q10, q11);                                                            \
-            f32x16_t s, dp;                       /* accumulators seeded with -lse[q], -delta[q] (see attn_bwd_dq_kernel) */ \
-            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                          \
-                const float4 lv = *reinterpret_cast<const float4*>(sStat + ((QB) * 32 + 8 * q4) * 4);                   \
-                const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 256 + ((QB) * 32 + 8 * q4) * 4);            \
-                s[4 * q4] = lv.x; s[4 * q4 + 1] = lv.y; s[4 * q4 + 2] = lv.z; s[4 * q4 + 3] = lv.w;                     \
-                dp[4 * q4] = dv4.x; dp[4 * q4 + 1] = dv4.y; dp[4 * q4 + 2] = dv4.z; dp[4 * q4 + 3] = dv4.w;             \
-            }                                                                                                           \
+            /* accumulators seeded with -lse[q], -delta[q]: the first MFMA of a chain takes the seed registers as C */  \
+            f32x16_t s = join4x4(pre.sl), dp = join4x4(pre.sd);                                                         \
             _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
-                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(fs[kk] + (QB) * 4096);                           \
-                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(fs[kk] + (TILE_BYTES + (QB) * 4096));            \
-                if (ATTN_ABL & 8) { s[kk] += bfbits2f(qa[0]) * bfbits2f(kf[kk][0]); dp[kk] += bfbits2f(da[0]) * bfbits2f(vf[kk][0]); continue; } \
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);                                    \
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pre.q[kk], kf[kk], s, 0, 0, 0);                             \
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pre.d[kk], vf[kk], dp, 0, 0, 0);                           \
             }                                                                                                           \
-            pk_scale16(s, LOG2E, z2);                                                                                       \
+            MID_WORK                                                                                                    \
+            pk_scale16(s, LOG2E, z2);                                                                                   \
             f32x16_t pv;                                                                                                \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r]);                        \
             if (need_mask) {                      /* ONE branch per block: a test inside the score loop becomes 16 */   \
@@ -777,69 +822,83 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
                     if (qq >= a.Lq || key >= a.Lk || (a.causal && key > qq)) pv[r] = 0.f;                               \
                 }                                                                                                       \
             }                                                                                                           \
-            const f32x16_t dsv = pk_mul16(pv, dp, z2);                                                                      \
+            const f32x16_t dsv = pk_mul16(pv, dp, z2);                                                                  \
+            bf16x8_t pf[2], df[2];                                                                                      \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x) { pf[x] = pack8(pv, 8 * x); df[x] = pack8(dsv, 8 * x); }      \
+            asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(df[0]), "+v"(df[1]));   /* scores are dead from here */   \
+            NEXT_FRAGS                                                                                                  \
             bf16x8_t qtf[2][2], dotf[2][2];                                                                             \
-            tr_wait<0>(tdo);                                                                                            \
-            tr_wait<0>(tq);                                                                                             \
+            tr_wait<8>(tdo);                      /* (8 = the younger fragment reads just issued) */                    \
+            tr_wait<8>(tq);                                                                                             \
+            NEXT_STATS                                                                                                  \
             tr_pack(dotf, tdo);                                                                                         \
             tr_pack(qtf, tq);                                                                                           \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                             \
-                const bf16x8_t pf = pack8(pv, 8 * x);                                                                   \
-                const bf16x8_t df = pack8(dsv, 8 * x);                                                                  \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                               \
                 _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                         \
-                    if (ATTN_ABL & 2) { dv[d][x] += bfbits2f(pf[d]) + bfbits2f(dotf[x][d][0]); dk[d][x] += bfbits2f(df[d]) + bfbits2f(qtf[x][d][0]); continue; } \
-                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[x][d], pf, dv[d], 0, 0, 0);                    \
-                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[x][d], df, dk[d], 0, 0, 0);                     \
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[x][d], pf[x], dv[d], 0, 0, 0);                 \
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[x][d], df[x], dk[d], 0, 0, 0);                  \
                 }                                                                                                       \
-            }                                                                                                           \
         }
 #ifdef ATTN_PROFILE
-    long long kacc[4] = {0, 0, 0, 0}, kt_[5];
+    long long kacc[4] = {0, 0, 0, 0}, kt_[5], kc0, kr0, kc1, kr1;
 #define KT(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt_[i]) :: "memory");
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(kc0), "=s"(kr0) :: "memory");
 #else
 #define KT(i)
 #endif
     int slot = 0;
     for (int t = t0; t < nt; ++t) {
         KT(0)
-        // tile t lives in `slot`; tile t+1 (issued one tile ago) may stay in flight; tile t+2 goes to the slot tile t-1 left
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 2 < nt && !(ATTN_ABL & 4)) {
-            const int ns = slot == 0 ? 2 : slot - 1;
-            char* nQ = smem + ns * DKV_SLOT;
-            stage_tile(srcQ, (t + 2) * KV_TILE, nQ, wave);
-            stage_tile(srcdO, (t + 2) * KV_TILE, nQ + TILE_BYTES, wave);
-            stage_stats64(rsStat, (t + 2) * KV_TILE, smem + DKV_STATS + ns * 512, wave, lane);
-        }
         const int qt0 = t * KV_TILE;
         const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + 128 > a.Lk) || (a.causal && (kblk0 + wave * 32 + 31 > qt0));
         const unsigned stg = (unsigned)(slot * DKV_SLOT);
         const unsigned q00 = qb00 + stg, q01 = qb01 + stg, q10 = qb10 + stg, q11 = qb11 + stg;
-        const char* fs[4];
+        unsigned fs[4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fs[kk] = smem + fo[kk] + stg;
-        const char* sStat = statl + slot * 512;
+        for (int kk = 0; kk < 4; ++kk) fs[kk] = fo[kk] + stg;
+        const unsigned ss = statl + slot * 512;
+        DKV_QBLOCK(0, (dkv_pre_issue_frags<4096>(pre, fs));, (dkv_pre_issue_stats<128>(pre, ss));, )
         KT(1)
-        DKV_QBLOCK(0)
+        // ---- mid-tile: publish tile t+1, recycle the slot of tile t-1
+        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          // tile t+2 (5 DMA instructions) may stay in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         KT(2)
-        DKV_QBLOCK(1)
+#ifdef DKV_DMA_AT_BARRIER
+        if (t + 3 < nt) dma_tile(t + 3);
+#define DKV_DMA_MID
+#else
+        // the DMA instructions of tile t+3 go BEHIND the S / dP MFMAs of the second q-block: issued right after the barrier,
+        // next to the fragment reads, each of them held the wave for ~150 cycles (a fifth of the tile); among MFMAs in flight
+        // the issue costs a third of that and the matrix pipe is busy meanwhile
+#define DKV_DMA_MID if (t + 3 < nt) dma_tile(t + 3);
+#endif
+        const int nslot = (slot + 1) & (DKV_NSLOT - 1);
+        const unsigned nstg = (unsigned)(nslot * DKV_SLOT);
+        unsigned fn[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fn[kk] = fo[kk] + nstg;
+        const unsigned sn = statl + nslot * 512;
+        // (past the last tile this reads a stale slot; the values are never used -- the counted waits need the 16 reads)
+        DKV_QBLOCK(1, (dkv_pre_issue_frags<0>(pre, fn));, (dkv_pre_issue_stats<0>(pre, sn));, DKV_DMA_MID)
+#undef DKV_DMA_MID
         KT(3)
-        slot = slot == 2 ? 0 : slot + 1;
+        slot = nslot;
 #ifdef ATTN_PROFILE
-        for (int i = 0; i < 3; ++i) kacc[i] += kt_[i + 1] - kt_[i];
+        kacc[0] += kt_[2] - kt_[1]; kacc[1] += kt_[1] - kt_[0]; kacc[2] += kt_[3] - kt_[2];
 #endif
     }
-#undef DKV_QBLOCK
 #ifdef ATTN_PROFILE
     if (tid == 0) {     // diagnostic build: per-workgroup phase cycles of wave 0 go to the dq columns (this kernel never writes them)
         const int rec = blockIdx.x;
         long long* pr = reinterpret_cast<long long*>(reinterpret_cast<char*>(a.dq) + (int64_t)(rec / 40) * a.dq_rs * 2 + (rec % 40) * 64);
-        pr[0] = kacc[0]; pr[1] = kacc[1]; pr[2] = kacc[2]; pr[3] = nt - t0;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(kc1), "=s"(kr1) :: "memory");
+        pr[0] = kacc[0]; pr[1] = kacc[1]; pr[2] = kacc[2]; pr[3] = nt - t0; pr[4] = kc1 - kc0; pr[5] = kr1 - kr0;
     }
 #endif
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#undef DKV_QBLOCK
     if (a.dv_colsum) {        // v_proj bias gradient, fused: second workspace plane, partial row (b, key block, wave)
         const int nqb = (a.Lq + 127) / 128, nkb = (a.Lk + 127) / 128;
         float* wsr = reinterpret_cast<float*>(a.cs_ws) + (int64_t)a.B * nqb * 4 * a.H * HD +
