@@ -1449,40 +1449,58 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_
     // B(t+1) and A(t+2): like gemm_ntr_kernel, the loop no longer drains its own DMA at every step (two stages + vmcnt(0) left
     // ONE stage in flight, and its latency -- not the matrix pipe -- set the step time); the counted wait lets the four newest
     // instructions (A(t+1)) stay in flight across the barrier.
-    auto dma_half = [&](int kt, int half) {            // the four DMA instructions of this wave for one half of tile kt
-        const int b = kt / tiles_per_batch, lt = kt - b * tiles_per_batch;
-        const int rel = kt - kt0;
-        const int slot = (2 * rel + half) % 5;
-        char* dst = smem + slot * TN256_OP;
-        if (half == 0) {
-            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<unsigned short*>(A + (int64_t)b * a.strideA), 0, (unsigned)((int64_t)a.Mk * a.lda * 2), 0x00020000);
-            const int soA = (int)((int64_t)lt * TK * a.lda * 2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(dst + (wave * 4 + e) * 1024), 16, voA[e], soA, 0, 0);
-        } else {
-            const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<unsigned short*>(B + (int64_t)b * a.strideB), 0, (unsigned)((int64_t)a.Mk * a.ldb * 2), 0x00020000);
-            const int soB = (int)((int64_t)lt * TK * a.ldb * 2);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(dst + (wave * 4 + e) * 1024), 16, voB[e], soB, 0, 0);
-        }
+    // The DMA of a half: four instructions per wave, addressed through a buffer descriptor whose num_records is ZERO once the
+    // stream has run past the split's last tile -- the loop then needs no branch around its DMA (a branch ends the scheduling
+    // region the instructions are threaded through) and the counted waits stay uniform; the dead loads fetch nothing.
+    // (batch, tile-in-batch) of each stream advance incrementally: the division per half cost ~40 SALU instructions a step.
+    struct tn_stream_t { int b, lt, rel, slot; };
+    auto stream_next = [&](tn_stream_t& st) {
+        if (++st.lt == tiles_per_batch) { st.lt = 0; ++st.b; }
+        ++st.rel;
+        st.slot = st.slot + 2 >= 5 ? st.slot - 3 : st.slot + 2;
     };
-    dma_half(kt0, 0);
-    dma_half(kt0, 1);
-    if (kt0 + 1 < kt1) dma_half(kt0 + 1, 0);
+    const int b0 = kt0 / tiles_per_batch;
+    tn_stream_t stA = {b0, kt0 - b0 * tiles_per_batch, 0, 0}, stB = {b0, kt0 - b0 * tiles_per_batch, 0, 1};
+    const int nrel = kt1 - kt0;
+    auto dmaA = [&](const tn_stream_t& st, int e0, int e1) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(A + (int64_t)st.b * a.strideA), 0, st.rel < nrel ? (unsigned)((int64_t)a.Mk * a.lda * 2) : 0u, 0x00020000);
+        const int so = (int)((int64_t)st.lt * TK * a.lda * 2);
+        char* dst = smem + st.slot * TN256_OP;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e >= e0 && e < e1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + (wave * 4 + e) * 1024), 16, voA[e], so, 0, 0);
+    };
+    auto dmaB = [&](const tn_stream_t& st, int e0, int e1) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned short*>(B + (int64_t)st.b * a.strideB), 0, st.rel < nrel ? (unsigned)((int64_t)a.Mk * a.ldb * 2) : 0u, 0x00020000);
+        const int so = (int)((int64_t)st.lt * TK * a.ldb * 2);
+        char* dst = smem + st.slot * TN256_OP;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (e >= e0 && e < e1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + (wave * 4 + e) * 1024), 16, voB[e], so, 0, 0);
+    };
+    dmaA(stA, 0, 4); stream_next(stA);                // A(0)
+    dmaB(stB, 0, 4); stream_next(stB);                // B(0)
+    dmaA(stA, 0, 4); stream_next(stA);                // A(1)   (empty descriptor when the split has a single tile)
     tn256_frag_t f0, f1;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) f1.r[i] = bf16x4_t{0, 0, 0, 0};      // "slice 3 of the tile before the first": adds nothing
     int sa = 0;                                       // slot of the A half of the step being computed
+    // The eight DMA instructions of a step -- B(t+1), then A(t+2) -- are threaded between the MFMAs, two per slice: issued in
+    // two batches next to the fragment reads each of them held the wave for ~100 cycles (a build without the DMA ran 25 %
+    // faster, one that issued it and never waited ran no faster); among MFMAs in flight the issue costs a fraction of that.
+#define TN_SPREAD() { __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+                      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); \
+                      __builtin_amdgcn_sched_group_barrier(0x008, 2, 0); }
     for (int kt = kt0; kt < kt1; ++kt) {
         const int sb = sa + 1 >= 5 ? sa - 4 : sa + 1;
         char* sA = smem + sa * TN256_OP;
         char* sB = smem + sb * TN256_OP;
-        const bool first = kt == kt0;
-        // everything but A(t+1) -- the four newest DMA instructions, when that tile exists -- has landed
-        if (kt + 1 < kt1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // everything but A(t+1) -- the four newest DMA instructions -- has landed
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         unsigned ad[6];
@@ -1491,20 +1509,27 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_
 #pragma unroll
         for (int j = 0; j < 4; ++j) ad[2 + j] = tn256_tr_addr(sA, tr_row, w1 * 128 + j * 32 + tr_col);
         tn256_issue<0>(f0, ad);
-        if (kt + 1 < kt1) dma_half(kt + 1, 1);
-        if (!first) tn256_mfma(acc, f1);              // slice 3 of the previous tile (landed before the barrier)
+        tn256_mfma(acc, f1);                          // slice 3 of the previous tile (landed before the barrier)
+        dmaB(stB, 0, 2);
+        TN_SPREAD()
         tn256_issue<8192>(f1, ad);
         tn256_wait<12>(f0);
         tn256_mfma(acc, f0);
+        dmaB(stB, 2, 4); stream_next(stB);
+        TN_SPREAD()
         tn256_issue<16384>(f0, ad);
-        if (kt + 2 < kt1) dma_half(kt + 2, 0);
         tn256_wait<12>(f1);
         tn256_mfma(acc, f1);
+        dmaA(stA, 0, 2);
+        TN_SPREAD()
         tn256_issue<24576>(f1, ad);
         tn256_wait<12>(f0);
         tn256_mfma(acc, f0);
+        dmaA(stA, 2, 4); stream_next(stA);
+        TN_SPREAD()
         sa = sa + 2 >= 5 ? sa - 3 : sa + 2;
     }
+#undef TN_SPREAD
     tn256_wait<0>(f1);
     tn256_mfma(acc, f1);
 
