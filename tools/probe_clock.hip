@@ -4,16 +4,24 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-template <int NACC>
+template <int NACC, bool RANDOM = false>
 __global__ void __launch_bounds__(256) mfma_loop(float* out, long long* clk, int iters) {
     f32x16_t acc[NACC];
     for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
     bf16x8_t a, b;
     for (int r = 0; r < 8; ++r) { a[r] = (short)(0x3f80 + threadIdx.x); b[r] = (short)(0x3f00 + r); }
+    if (RANDOM) {     // operands with random sign / mantissa / small exponent spread per lane (N(0,1)-like bit toggling)
+        unsigned x = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+        for (int r = 0; r < 8; ++r) {
+            x = x * 1664525u + 1013904223u; a[r] = (short)(((x >> 16) & 0x807f) | (0x3e00 + ((x >> 9) & 0x180)));
+            x = x * 1664525u + 1013904223u; b[r] = (short)(((x >> 16) & 0x807f) | (0x3e00 + ((x >> 9) & 0x180)));
+        }
+    }
     const long long c0 = clock64(), w0 = wall_clock64();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -26,8 +34,26 @@ __global__ void __launch_bounds__(256) mfma_loop(float* out, long long* clk, int
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = w1 - w0; }
 }
 
-int main() {
+int main(int argc, char** argv) {
     const int blocks = 256, iters = 20000;
+    if (argc > 1) {   // sustained mode: tools/probe_clock <seconds> [random]   (sample rocm-smi from another shell meanwhile)
+        const double secs = atof(argv[1]); const bool rnd = argc > 2;
+        float* out; long long* clk; hipMalloc(&out, blocks * 256 * 4); hipMalloc(&clk, blocks * 16);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        double total_ms = 0; int n = 0;
+        while (total_ms < secs * 1e3) {
+            hipEventRecord(e0);
+            for (int k = 0; k < 10; ++k) {
+                if (rnd) hipLaunchKernelGGL((mfma_loop<8, true>), dim3(blocks), dim3(256), 0, 0, out, clk, iters);
+                else hipLaunchKernelGGL((mfma_loop<8, false>), dim3(blocks), dim3(256), 0, 0, out, clk, iters);
+            }
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); total_ms += ms; n += 10;
+            if (n % 200 == 0) printf("%s operands, after %.1f s: %.1f TF sustained over the last 10 launches\n", rnd ? "random" : "constant", total_ms * 1e-3,
+                                     10.0 * blocks * 4 * iters * 8 * 32768.0 / (ms * 1e-3) * 1e-12);
+        }
+        return 0;
+    }
     float* out; long long* clk;
     hipMalloc(&out, blocks * 256 * 4); hipMalloc(&clk, blocks * 16);
     std::vector<long long> h(2 * blocks);

@@ -48,6 +48,20 @@ __device__ __forceinline__ float fddt_bias_elem(float h, float b0, float b1, flo
     return h;
 }
 
+// The same evaluation order on a PAIR of columns: v_pk_mul_f32 / v_pk_add_f32 are the IEEE operations of the scalar form
+// (no contraction), two columns per issue slot.  The staged row kernels are VALU-bound without it: ~500 VALU instructions
+// per thread and 4-row trip against ~8800 cycles per trip and CU.
+typedef __attribute__((ext_vector_type(2))) float f32x2r_t;
+__device__ __forceinline__ f32x2r_t fddt_diag_pair(f32x2r_t h, f32x2r_t w0, f32x2r_t b0, f32x2r_t w1, f32x2r_t b1, f32x2r_t w2,
+                                                   f32x2r_t b2, f32x2r_t w3, f32x2r_t b3, float m0, float m1, float m2, float m3) {
+#pragma clang fp contract(off)
+    const f32x2r_t t0 = (h * w0 + b0) * f32x2r_t{m0, m0};
+    const f32x2r_t t1 = (h * w1 + b1) * f32x2r_t{m1, m1};
+    const f32x2r_t t2 = (h * w2 + b2) * f32x2r_t{m2, m2};
+    const f32x2r_t t3 = (h * w3 + b3) * f32x2r_t{m3, m3};
+    return ((t0 + t1) + t2) + t3;
+}
+
 #define F4_APPLY(dst, expr) do { dst.x = expr(x); dst.y = expr(y); dst.z = expr(z); dst.w = expr(w); } while (0)
 
 // block-wide sum of NV values per thread; result broadcast to all threads.  `red` is [MAX_WAVES][NV].
@@ -261,29 +275,37 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
         // younger than this trip's DMA: the previous trip's 4R stores, the next trip's 4R mask loads and R DMA instructions
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(5 * R) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(9 * R) : "memory");
-        float4 x[R];
+        f32x2r_t xl[R], xh[R];                       // columns (0,1) and (2,3) of this thread's quad
         float sm[R];
         typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
         u32x4_t ov[R];                               // store data: kept live until after the reductions (see below)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            x[r] = *reinterpret_cast<const float4*>(stg + (s * R + r) * row_lds + tid * 16);
-#define FD(e) fddt_diag_elem(x[r].e, w[0].e, b[0].e, w[1].e, b[1].e, w[2].e, b[2].e, w[3].e, b[3].e, m[r][0], m[r][1], m[r][2], m[r][3])
-            F4_APPLY(x[r], FD);
-#undef FD
-            ov[r] = u32x4_t{__float_as_uint(x[r].x), __float_as_uint(x[r].y), __float_as_uint(x[r].z), __float_as_uint(x[r].w)};
+            const float4 xi = *reinterpret_cast<const float4*>(stg + (s * R + r) * row_lds + tid * 16);
+#define FDP(lo, hi, src) fddt_diag_pair(src, f32x2r_t{w[0].lo, w[0].hi}, f32x2r_t{b[0].lo, b[0].hi}, f32x2r_t{w[1].lo, w[1].hi}, \
+                                        f32x2r_t{b[1].lo, b[1].hi}, f32x2r_t{w[2].lo, w[2].hi}, f32x2r_t{b[2].lo, b[2].hi},       \
+                                        f32x2r_t{w[3].lo, w[3].hi}, f32x2r_t{b[3].lo, b[3].hi}, m[r][0], m[r][1], m[r][2], m[r][3])
+            xl[r] = FDP(x, y, (f32x2r_t{xi.x, xi.y}));
+            xh[r] = FDP(z, w, (f32x2r_t{xi.z, xi.w}));
+#undef FDP
+            ov[r] = u32x4_t{__float_as_uint(xl[r].x), __float_as_uint(xl[r].y), __float_as_uint(xh[r].x), __float_as_uint(xh[r].y)};
             __builtin_amdgcn_raw_buffer_store_b128(ov[r], rsO, vo32, (row0 + r) * D * 4, 0);
-            sm[r] = (x[r].x + x[r].y) + (x[r].z + x[r].w);
+            sm[r] = (xl[r].x + xl[r].y) + (xh[r].x + xh[r].y);
         }
         block_sum<R>(sm, red[0], nwaves);
         float mu[R], q[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+#pragma clang fp contract(off)
             mu[r] = sm[r] * inv_d;
-            const float dx = x[r].x - mu[r], dy = x[r].y - mu[r], dz = x[r].z - mu[r], dw = x[r].w - mu[r];
-            q[r] = (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            const f32x2r_t mu2 = {mu[r], mu[r]};
+            const f32x2r_t dl = xl[r] - mu2, dh = xh[r] - mu2;
+            const f32x2r_t ql = dl * dl, qh = dh * dh;
+            q[r] = (ql.x + ql.y) + (qh.x + qh.y);
         }
         block_sum<R>(q, red[1], nwaves);
+        // (one block-wide Chan/Welford reduction instead of these two measured SLOWER here: 108 vs 87 us -- the combination
+        // steps cost more than the second barrier)
         // The registers a 16-byte store reads its data from must not be rewritten while the store may still be queued: with
         // the copy the compiler made for the last row (v_mov into a temporary quad that the DPP reduction right after the
         // store reused) ~1.5 % of h_out came out wrong at D = 1280 -- lanes 12..15 of every 16, second dword -- while the
@@ -293,16 +315,15 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
         for (int r = 0; r < R; ++r) asm volatile("" :: "v"(ov[r]));
 #pragma unroll
         for (int r = 0; r < R; ++r) {
+#pragma clang fp contract(off)
             const float rs = rsqrtf(q[r] * inv_d + a.eps);
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu[r]), rsM, voStat, (row0 + r) * 4, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rs), rsS, voStat, (row0 + r) * 4, 0);
-            float4 y;
-            y.x = (x[r].x - mu[r]) * rs * lnw.x + lnb.x;
-            y.y = (x[r].y - mu[r]) * rs * lnw.y + lnb.y;
-            y.z = (x[r].z - mu[r]) * rs * lnw.z + lnb.z;
-            y.w = (x[r].w - mu[r]) * rs * lnw.w + lnb.w;
-            const u32x2_t yv = {pack_bf16x2(y.x, y.y), pack_bf16x2(y.z, y.w)};
+            const f32x2r_t mu2 = {mu[r], mu[r]}, rs2 = {rs, rs};
+            const f32x2r_t yl = (xl[r] - mu2) * rs2 * f32x2r_t{lnw.x, lnw.y} + f32x2r_t{lnb.x, lnb.y};
+            const f32x2r_t yh = (xh[r] - mu2) * rs2 * f32x2r_t{lnw.z, lnw.w} + f32x2r_t{lnb.z, lnb.w};
+            const u32x2_t yv = {pack_bf16x2(yl.x, yl.y), pack_bf16x2(yh.x, yh.y)};
             __builtin_amdgcn_raw_buffer_store_b64(yv, rsY, vo16, (row0 + r) * D * 2, 0);
         }
     }
@@ -341,9 +362,24 @@ extern "C" int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream) 
                         a->y_bf16 && !a->y_f32 && a->mean && a->rstd && !a->pos && a->w[0] && a->w[1] && a->w[2] && a->w[3] &&
                         a->b[0] && a->b[1] && a->b[2] && a->b[3] && (int64_t)a->rows * a->D * 4 < (1ll << 31);
     if (staged) {
-        static const bool attr = [] { (void)hipFuncSetAttribute((const void*)fddt_ln_fwd_staged_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 4 * 2048); return true; }();
+        static const bool attr = [] {
+            (void)hipFuncSetAttribute((const void*)fddt_ln_fwd_staged_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 4 * 2048);
+#ifdef DICOW_ABLATIONS
+            (void)hipFuncSetAttribute((const void*)fddt_ln_fwd_staged_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 2 * 4 * 2048);
+#endif
+            return true; }();
         (void)attr;
-        const int cap = 256 * 3;                      // three resident workgroups per CU (40 KiB of staging each at D = 1280)
+        int cap = 256 * 2;                            // two resident workgroups per CU (a third one measured SLOWER: 90 vs 82 us)
+#ifdef DICOW_ABLATIONS
+        const int Rv = getenv("DICOW_ROW_R") ? atoi(getenv("DICOW_ROW_R")) : 4;
+        if (getenv("DICOW_ROW_CAP")) cap = 256 * atoi(getenv("DICOW_ROW_CAP"));
+        if (Rv != 4) {
+            grid = dicow_cdiv(a->rows, Rv); if (grid > cap) grid = cap;
+            hipLaunchKernelGGL((fddt_ln_fwd_staged_kernel<2>), dim3(grid), dim3(block), 2 * 2 * 4 * a->D, (hipStream_t)stream, *a);
+            DICOW_CHECK_LAUNCH("fddt_ln_fwd_staged");
+            return DICOW_OK;
+        }
+#endif
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL((fddt_ln_fwd_staged_kernel<4>), dim3(grid), dim3(block), 2 * R * 4 * a->D, (hipStream_t)stream, *a);
         DICOW_CHECK_LAUNCH("fddt_ln_fwd_staged");
