@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--preheat", action="store_true",
                     help="time the recipe's first phase instead (use_fddt_only_n_steps: only FDDT parameters train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (board power / shader clock) during the timed region")
     ap.add_argument("--cpu-sample", default="turbo-b1")
     ap.add_argument("--profile-steps", type=int, default=5,
                     help="instrumented steps run AFTER the timed region (per-launch HIP events of the dominant kernel: roofline)")
@@ -192,6 +193,43 @@ def cpu_config1():
             "sample": f"configs[0]: whisper-tiny + FDDT, B=1, L=64, fp32 oracle forward, best of {len(times)}: {min(times):.3f} s"}
 
 
+class PowerSampler:
+    """Board power and shader clock of this rank's GPU, sampled by rocm-smi from a side thread while the timed region runs
+    (the MFMA-heavy kernels of the step run at the board's power cap: the clock they get is part of the measurement)."""
+    def __init__(self, device):
+        self.device, self.rows, self._stop, self._th = device, [], False, None
+
+    def _run(self):
+        import re, subprocess
+        while not self._stop:
+            try:
+                r = subprocess.run(["rocm-smi", "-d", str(self.device), "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5)
+                card = next(iter(json.loads(r.stdout).values()))
+                w = next((float(v) for k, v in card.items() if "Power" in k and "(W)" in k), None)
+                m = next((re.search(r"(\d+)\s*Mhz", str(v), re.I) for k, v in card.items() if k.lower().startswith("sclk clock speed")), None)
+                if w is not None and m:
+                    self.rows.append((w, float(m.group(1))))
+            except Exception:
+                pass
+            time.sleep(0.25)
+
+    def start(self):
+        import threading
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop = True
+        if self._th is not None:
+            self._th.join(timeout=10)
+        if not self.rows:
+            return None
+        n = len(self.rows)
+        return {"board_w_mean": round(sum(r[0] for r in self.rows) / n, 1), "board_w_max": max(r[0] for r in self.rows),
+                "sclk_mhz_mean": round(sum(r[1] for r in self.rows) / n, 1), "sclk_mhz_min": min(r[1] for r in self.rows), "samples": n,
+                "note": "rocm-smi samples during the timed region (board power cap 1400 W, peak shader clock 2400 MHz)"}
+
+
 PMC_FILES = ("r02_pmc_hbm_traffic.json", "r01g_pmc_hbm_traffic.json")      # newest first
 TRAFFIC_SOURCE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/prof_pmc.sh; fabric-side bytes "
                   "per persistent NT GEMM launch, FETCH_SIZE x2 per the gfx950 correction)")
@@ -296,6 +334,9 @@ def main():
     # ---- the timed region: exactly K steps, no per-launch instrumentation (one event per step boundary for the median)
     ts.reducer.time_exposed = True
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    sampler = PowerSampler(local) if rank == 0 and not a.no_power else None
+    if sampler:
+        sampler.start()
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
@@ -303,6 +344,7 @@ def main():
         marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
+    power = sampler.stop() if sampler else None
     step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
     med_ms = step_ms[len(step_ms) // 2] if a.steps % 2 else 0.5 * (step_ms[a.steps // 2 - 1] + step_ms[a.steps // 2])
     exposed_ms = ts.reducer.exposed_ms()
@@ -335,6 +377,7 @@ def main():
         timer.breakdown("gemm_nt", nprof)
         timer.breakdown("gemm_tn", nprof)
     peak = 2500.0
+    SUSTAINED_MFMA_TF = 1845.0
     TRAFFIC = pmc_traffic()
     # algorithmic TFLOP per utterance of one step: 3 x encoder + 2 x (decoder + head) with the decoder frozen;
     # turbo: 3 x 2.2738 + 2 x 0.0841 = 6.99.  SE-DiCoW: the survey's 10.7 (3.51 encoder) for the headline model only.
@@ -370,7 +413,12 @@ def main():
                      "traffic": TRAFFIC, "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // nprof,
                      "share_of_step": round(prof_ms / nprof / ms, 3),
                      "measured_over": f"{nprof} instrumented steps after the timed region (HIP events around every launch, on the launch stream)",
-                     "traffic_source": TRAFFIC_SOURCE},
+                     "traffic_source": TRAFFIC_SOURCE,
+                     # what the matrix pipe sustains on this board with NO memory traffic at all (tools/power_mfma.sh)
+                     "sustained_mfma_only": {"tflops": SUSTAINED_MFMA_TF, "frac_of_it": round(nt["tflops"] / SUSTAINED_MFMA_TF, 4),
+                                             "what": "register-only v_mfma_f32_32x32x16_bf16 loop on all 256 CUs, random bf16 operands, 5 s: the board "
+                                                     "settles at 1.90 GHz (constant operands: 2.39 GHz, 2453 TF); profiles/r02_power_mfma.txt"}},
+        "power": power,
         "kernels": {"gemm_tn_kernel": {"tflops": round(tn["tflops"], 1), "frac": round(tn["tflops"] / peak, 4),
                                        "share_of_step": round(tn["total_ms"] / nprof / ms, 3)}} if tn else {},
         # preheat phase: forward + dgrad only (2 x encoder + 2 x decoder), no encoder weight gradients

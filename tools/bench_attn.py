@@ -41,7 +41,7 @@ if os.environ.get("ATTN_PROFILE"):
     names = ["stage+wait+barrier", "QK mfma + V tr issue", "softmax", "PV", "lgkm+end barrier"]
     print(f"per k-tile cycles (wave 0, mean over {nblk} workgroups, {nt:.1f} tiles): " +
           ", ".join(f"{n} {pr[:, i].mean() / nt:.0f}" for i, n in enumerate(names)) + f"; loop total {pr[:,5].mean()/nt:.0f}/tile; epilogue {pr[:,7].mean():.0f}")
-if os.environ.get("ATTN_PROFILE"):
+if os.environ.get("ATTN_PROFILE_DKV"):      # only with a build of the stamped dkv kernel (commit 948e096: -DATTN_PROFILE)
     ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=bool(causal), dq_scale=0.125); torch.cuda.synchronize()
     nblk = B * H * ((Lk + 127) // 128)
     rows = (nblk + 39) // 40

@@ -22,9 +22,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)lds_dst, 16, 0, 0);
 }
 
-#ifndef ATTN_ABL
-#define ATTN_ABL 0             // diagnostic builds only (tools/build_attn_variants.sh): bit mask of pieces left out of the dkv loop
-#endif
 #define HD 64
 #define KV_TILE 64
 #define TILE_BYTES (KV_TILE * HD * 2)        // 8 KiB
@@ -183,41 +180,6 @@ __device__ __forceinline__ bf16x8_t pack8(const f32x16_t& s, int r0) {
     return o;
 }
 
-// Packed fp32 helpers (v_pk_fma_f32 / v_pk_add_f32: two lanes-worth of arithmetic per issue slot).  Plain VALU work is paid
-// in matrix-pipe time on this machine (SQ counters of these loops: MFMA-busy cycles + VALU-active cycles ~= SIMD cycles), so
-// the softmax (re)compute is written to the instruction: per 32x32 score block 8 packed scales + 16 exp2 + 8 packed products
-// + 16 packed converts in the backward kernels, 8 packed fma + 16 exp2 + 8 packed adds + 8 max3 in the forward.
-// The products are written as fma(x, y, z) with a zero the optimiser cannot see: a plain vector multiply is split into two
-// v_mul_f32 about half of the time, and inline asm is not an option for values an MFMA has just produced (the compiler
-// pads MFMA -> VALU read hazards with s_nop only for instructions it emitted itself; an asm v_pk_mul_f32 read garbage).
-__device__ __forceinline__ f32x2_t opaque_zero2() {
-    f32x2_t z = {0.f, 0.f};
-    asm volatile("" : "+v"(z));
-    return z;
-}
-typedef __attribute__((ext_vector_type(8))) float f32x8_t;
-// (pairs are taken and put back as SUB-VECTORS -- shufflevector, not element extracts: a pair built from two extracted
-// scalars is what the instruction selector splits again)
-#define PK_PAIR(v, i) __builtin_shufflevector(v, v, 2 * (i), 2 * (i) + 1)
-__device__ __forceinline__ f32x16_t pk_join16(f32x2_t p0, f32x2_t p1, f32x2_t p2, f32x2_t p3, f32x2_t p4, f32x2_t p5, f32x2_t p6,
-                                              f32x2_t p7) {
-    const f32x4_t q0 = __builtin_shufflevector(p0, p1, 0, 1, 2, 3), q1 = __builtin_shufflevector(p2, p3, 0, 1, 2, 3);
-    const f32x4_t q2 = __builtin_shufflevector(p4, p5, 0, 1, 2, 3), q3 = __builtin_shufflevector(p6, p7, 0, 1, 2, 3);
-    const f32x8_t h0 = __builtin_shufflevector(q0, q1, 0, 1, 2, 3, 4, 5, 6, 7), h1 = __builtin_shufflevector(q2, q3, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-}
-__device__ __forceinline__ void pk_scale16(f32x16_t& s, float c, f32x2_t z2) {
-    const f32x2_t c2 = {c, c};
-#define PK_(i) __builtin_elementwise_fma(PK_PAIR(s, i), c2, z2)
-    s = pk_join16(PK_(0), PK_(1), PK_(2), PK_(3), PK_(4), PK_(5), PK_(6), PK_(7));
-#undef PK_
-}
-__device__ __forceinline__ f32x16_t pk_mul16(const f32x16_t& x, const f32x16_t& y, f32x2_t z2) {
-#define PK_(i) __builtin_elementwise_fma(PK_PAIR(x, i), PK_PAIR(y, i), z2)
-    return pk_join16(PK_(0), PK_(1), PK_(2), PK_(3), PK_(4), PK_(5), PK_(6), PK_(7));
-#undef PK_
-}
-
 // XCD-aware workgroup -> (row block, head, batch) map.  Workgroups are dealt round-robin to the 8 XCDs (dispatch id L
 // lands on XCD L % 8), each with a private 4 MiB L2; the natural (x = row block fastest) order therefore scatters the
 // row blocks that share one head's K/V (or Q/dO) over all 8 L2s and every one of them fetches the panels again
@@ -362,21 +324,16 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
             m_ref = m_new;
         }
         const float mL = (m_ref == -INFINITY) ? 0.f : m_ref * LOG2E;
-        {   // packed: 16 v_pk_fma_f32 + 32 v_exp_f32 + 16 v_pk_add_f32 for the 32 scores of a lane
-            const f32x2_t c2 = {LOG2E, LOG2E}, m2 = {-mL, -mL};
-            f32x2_t ps2 = {0.f, 0.f};
+        float psum = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    f32x2_t e = __builtin_elementwise_fma(f32x2_t{s[kb][2 * i], s[kb][2 * i + 1]}, c2, m2);
-                    e.x = __builtin_amdgcn_exp2f(e.x);
-                    e.y = __builtin_amdgcn_exp2f(e.y);
-                    s[kb][2 * i] = e.x; s[kb][2 * i + 1] = e.y;
-                    ps2 = ps2 + e;
-                }
-            l_run += ps2.x + ps2.y;
-        }
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mL));
+                s[kb][r] = p;
+                psum += p;
+            }
+        l_run += psum;
 
         PT(3)
         // ---- O^T += V^T . P^T
@@ -511,14 +468,13 @@ __device__ __forceinline__ void tr_read_block_u(bf16x8_t (&f)[2][2], unsigned a0
 
 // ------------------------------------------------------------------------------------------------ dQ
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bwd_args a) {
-    __shared__ __attribute__((aligned(16))) char smem[6 * TILE_BYTES];      // three (K, V) slots (U images)
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];      // K0 V0 K1 V1 (U images)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
     int qblk, h, b;
     attn_block_coords((a.Lq + 127) / 128, a.H, a.B, qblk, h, b);
     const int q0 = qblk * 128;
-    const f32x2_t z2 = opaque_zero2();
     const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
     const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
     const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
@@ -571,38 +527,27 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
     // lane bases of the transposing reads, once (the stage only adds a scalar)
     const unsigned kb00 = tr_base_u(smem, lane, 0, 0), kb01 = tr_base_u(smem, lane, 0, 1);
     const unsigned kb10 = tr_base_u(smem, lane, 1, 0), kb11 = tr_base_u(smem, lane, 1, 1);
-    // Three-slot ring, ONE barrier per key tile (see attn_fwd_kernel): tile t+1 stays in flight across the barrier that
-    // publishes tile t, tile t+2 is requested into the slot tile t-1 just left.  LDS addresses = eight lane registers
-    // (fragment / transposing-read bases + slot offset) plus immediates.
     stage_tile(srcK, 0, smem, wave);
     stage_tile(srcV, 0, smem + TILE_BYTES, wave);
-    if (nt > 1) {
-        stage_tile(srcK, KV_TILE, smem + 2 * TILE_BYTES, wave);
-        stage_tile(srcV, KV_TILE, smem + 3 * TILE_BYTES, wave);
-    }
-    unsigned fo[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) fo[kk] = (unsigned)uswz(lane & 31, kk * 2 + hh);
-    int slot = 0;
     for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        char* sK = smem + (t & 1) * 2 * TILE_BYTES;
+        char* sV = sK + TILE_BYTES;
+        if (t + 1 < nt) {
+            char* nK = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+            stage_tile(srcK, (t + 1) * KV_TILE, nK, wave);
+            stage_tile(srcV, (t + 1) * KV_TILE, nK + TILE_BYTES, wave);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (t + 2 < nt) {
-            char* nK = smem + (slot == 0 ? 2 : slot - 1) * 2 * TILE_BYTES;
-            stage_tile(srcK, (t + 2) * KV_TILE, nK, wave);
-            stage_tile(srcV, (t + 2) * KV_TILE, nK + TILE_BYTES, wave);
-        }
 
         const int k0 = t * KV_TILE;
         const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
         // K^T fragments for the dQ product: issued now, consumed after S / dP / dS
-        const unsigned stg = (unsigned)(slot * 2 * TILE_BYTES);
+        const unsigned stg = (unsigned)((t & 1) * 2 * TILE_BYTES);
         const unsigned k00 = kb00 + stg, k01 = kb01 + stg, k10 = kb10 + stg, k11 = kb11 + stg;
-        const char* fs[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fs[kk] = smem + fo[kk] + stg;
         tr8_t tk0, tk1;
         tr_issue_u<0>(tk0, k00, k01, k10, k11);
         tr_issue_u<4096>(tk1, k00, k01, k10, k11);
@@ -614,14 +559,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
             f32x16_t s = seed_s, dp = seed_p;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(fs[kk] + kb * 4096);
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(fs[kk] + (TILE_BYTES + kb * 4096));
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(sK + uswz(kb * 32 + (lane & 31), kk * 2 + hh));
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(sV + uswz(kb * 32 + (lane & 31), kk * 2 + hh));
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dp, 0, 0, 0);
             }
-            pk_scale16(s, LOG2E, z2);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r]);
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E);
             if (need_mask) {                          // one branch per block: a test inside the score loop becomes 16
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -629,7 +573,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
                     if (key >= a.Lk || (a.causal && key > qrow)) s[r] = 0.f;
                 }
             }
-            ds[kb] = pk_mul16(s, dp, z2);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ds[kb][r] = s[r] * dp[r];
         }
         // dQ^T[d][q] += K^T[d][key] . dS^T[key][q]
         {
@@ -651,7 +596,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
                 for (int d = 0; d < 2; ++d) dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[x][d], pf, dq[d], 0, 0, 0);
             }
         }
-        slot = slot == 2 ? 0 : slot + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     }
     if (a.dq_colsum) {        // q_proj bias gradient, fused: partial row (b, q block, wave) of the first workspace plane
         const int nqb = (a.Lq + 127) / 128;
@@ -674,80 +621,28 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-// -lse / -delta of a 64-query tile -> LDS (one 4-byte DMA per lane through a buffer descriptor: waves 0/2 fetch the -lse
-// plane, waves 1/3 the -delta plane, so every wave issues the same number of VMEM ops and one counted vmcnt serves all;
-// queries past the end read as zero -- their scores are masked).  No per-tile VALU address arithmetic: the tile only moves
-// the scalar offset.
-__device__ __forceinline__ void stage_stats64(__amdgpu_buffer_rsrc_t rs, int q0, char* dst, int wave, int lane) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_t*)(dst + (wave & 1) * 256), 4, (unsigned)(lane * 4), q0 * 4, 0, 0);
+// lse / delta of a 64-query tile -> LDS (one 4-byte DMA per lane; waves 0/2 fetch lse, waves 1/3 delta, so every wave
+// issues the same number of VMEM ops and one counted vmcnt serves all)
+__device__ __forceinline__ void stage_stats64(const float* lse, const float* delta, int q0, int Lq, char* dst, int wave, int lane) {
+    int q = q0 + lane; q = q < Lq ? q : Lq - 1;
+    const float* src = (wave & 1) ? delta + q : lse + q;
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + (wave & 1) * 256), 4, 0, 0);
 }
 
-#define DKV_SLOT (2 * TILE_BYTES)                 // one ring slot: Q tile | dO tile (U images)
-#define DKV_NSLOT 4
-#define DKV_STATS (DKV_NSLOT * DKV_SLOT)          // (-lse | -delta) slots, 512 B each, behind the ring
-
-// Row fragments (A operands of S = Q K^T and dP = dO V^T: 4 + 4 ds_read_b128) and the seed values (-lse, -delta of the 32
-// queries of a q-block, as the accumulator layout wants them: 4 + 4 broadcast ds_read_b128) of ONE q-block, issued as one
-// asm statement and waited for later (same split issue / wait form as tr8_t above).
-struct dkv_pre_t { bf16x8_t q[4], d[4]; f32x4_t sl[4], sd[4]; };
-template <int OFF_Q>                     // q-block offset inside the slot (dO = +TILE_BYTES)
-__device__ __forceinline__ void dkv_pre_issue_frags(dkv_pre_t& p, const unsigned (&fa)[4]) {
-    asm volatile(
-        "ds_read_b128 %0, %8 offset:%12\n\t"  "ds_read_b128 %4, %8 offset:%13\n\t"
-        "ds_read_b128 %1, %9 offset:%12\n\t"  "ds_read_b128 %5, %9 offset:%13\n\t"
-        "ds_read_b128 %2, %10 offset:%12\n\t" "ds_read_b128 %6, %10 offset:%13\n\t"
-        "ds_read_b128 %3, %11 offset:%12\n\t" "ds_read_b128 %7, %11 offset:%13"
-        : "=&v"(p.q[0]), "=&v"(p.q[1]), "=&v"(p.q[2]), "=&v"(p.q[3]), "=&v"(p.d[0]), "=&v"(p.d[1]), "=&v"(p.d[2]), "=&v"(p.d[3])
-        : "v"(fa[0]), "v"(fa[1]), "v"(fa[2]), "v"(fa[3]), "i"(OFF_Q), "i"(OFF_Q + TILE_BYTES)
-        : "memory");
-}
-template <int OFF_S>                     // q-block offset inside the stats slot
-__device__ __forceinline__ void dkv_pre_issue_stats(dkv_pre_t& p, unsigned sa) {
-    asm volatile(
-        "ds_read_b128 %0, %8 offset:%9\n\t"  "ds_read_b128 %4, %8 offset:%13\n\t"
-        "ds_read_b128 %1, %8 offset:%10\n\t" "ds_read_b128 %5, %8 offset:%14\n\t"
-        "ds_read_b128 %2, %8 offset:%11\n\t" "ds_read_b128 %6, %8 offset:%15\n\t"
-        "ds_read_b128 %3, %8 offset:%12\n\t" "ds_read_b128 %7, %8 offset:%16"
-        : "=&v"(p.sl[0]), "=&v"(p.sl[1]), "=&v"(p.sl[2]), "=&v"(p.sl[3]), "=&v"(p.sd[0]), "=&v"(p.sd[1]), "=&v"(p.sd[2]), "=&v"(p.sd[3])
-        : "v"(sa), "i"(OFF_S), "i"(OFF_S + 32), "i"(OFF_S + 64), "i"(OFF_S + 96),
-          "i"(OFF_S + 256), "i"(OFF_S + 256 + 32), "i"(OFF_S + 256 + 64), "i"(OFF_S + 256 + 96)
-        : "memory");
-}
-template <int N>
-__device__ __forceinline__ void dkv_pre_wait(dkv_pre_t& p) {
-    asm volatile("s_waitcnt lgkmcnt(%16)"
-                 : "+v"(p.q[0]), "+v"(p.q[1]), "+v"(p.q[2]), "+v"(p.q[3]), "+v"(p.d[0]), "+v"(p.d[1]), "+v"(p.d[2]), "+v"(p.d[3]),
-                   "+v"(p.sl[0]), "+v"(p.sl[1]), "+v"(p.sl[2]), "+v"(p.sl[3]), "+v"(p.sd[0]), "+v"(p.sd[1]), "+v"(p.sd[2]), "+v"(p.sd[3])
-                 : "i"(N) : "memory");
-}
-__device__ __forceinline__ f32x16_t join4x4(const f32x4_t (&v)[4]) {
-    const f32x8_t h0 = __builtin_shufflevector(v[0], v[1], 0, 1, 2, 3, 4, 5, 6, 7), h1 = __builtin_shufflevector(v[2], v[3], 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
-}
-
-// Software-pipelined over q-blocks (32 queries): SQ counters and an MFMA-free build showed the two-slot form bound by its
-// own skeleton -- per q-block every wave issued its LDS reads, WAITED for them behind the other seven waves' reads, ran the
-// S / dP MFMAs, waited, did the softmax arithmetic, ran the dV / dK MFMAs; with two waves per SIMD little of that
-// overlapped (3900 cycles per 64-query tile against 2048 of matrix-pipe work per SIMD, and 3700 with no MFMAs at all).
-// Here the row fragments and seeds of q-block n+1 are requested while q-block n's dV / dK MFMAs run, the transposed
-// fragments of q-block n while its S / dP MFMAs run: no LDS round trip is left on a wave's critical path.
 __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_bwd_args a) {
-    __shared__ __attribute__((aligned(16))) char smem[DKV_NSLOT * DKV_SLOT + DKV_NSLOT * 512];
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 1024];   // Q0 dO0 Q1 dO1 (U images) + lse/delta x2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
     int kblk, h, b;
     attn_block_coords((a.Lk + 127) / 128, a.H, a.B, kblk, h, b);
     const int kblk0 = kblk * 128;
-    const f32x2_t z2 = opaque_zero2();
     const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
     const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
     const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
     const unsigned short* dO = reinterpret_cast<const unsigned short*>(a.d_o) + (int64_t)b * a.do_bs + h * HD;
     const float* lse = a.delta + (int64_t)a.B * a.H * a.Lq + ((int64_t)b * a.H + h) * a.Lq;     // -lse plane of the workspace
     const float* delta = a.delta + ((int64_t)b * a.H + h) * a.Lq;                                // -delta plane
-    const __amdgpu_buffer_rsrc_t rsStat = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>((wave & 1) ? delta : lse), 0, (unsigned)(a.Lq * 4), 0x00020000);
 
     // this wave's 32 keys as B operands (column = key, k-slots = d)
     const int key = kblk0 + wave * 32 + (lane & 31);
@@ -767,138 +662,89 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
     const int t0 = a.causal ? (kblk0 / KV_TILE) : 0;                 // query tiles entirely before the key block see none of it
     const int nt = (a.Lq + KV_TILE - 1) / KV_TILE;
     const tile_src_t srcQ = make_tile_src<SWZ_U>(Q, a.q_rs, a.Lq, wave, lane), srcdO = make_tile_src<SWZ_U>(dO, a.do_rs, a.Lq, wave, lane);
-    // Four-slot ring, ONE barrier per 64-query tile, placed between its two q-blocks: the barrier of tile t publishes tile
-    // t+1 (whose first fragments are requested during tile t's second q-block) and proves that every wave has left tile
-    // t-1, whose slot then receives tile t+3.  A tile's DMA therefore has two tile times to land.
-    auto dma_tile = [&](int t) {
-        const int sl = (t - t0) & (DKV_NSLOT - 1);
-        stage_tile(srcQ, t * KV_TILE, smem + sl * DKV_SLOT, wave);
-        stage_tile(srcdO, t * KV_TILE, smem + sl * DKV_SLOT + TILE_BYTES, wave);
-        stage_stats64(rsStat, t * KV_TILE, smem + DKV_STATS + sl * 512, wave, lane);
-    };
-    // lane-derived LDS addresses inside slot 0, once; a tile adds its slot offset (9 v_add_u32 per tile), q-block / operand /
-    // half offsets are immediates
-    unsigned fo[4];
+    if (t0 < nt) {
+        stage_tile(srcQ, t0 * KV_TILE, smem, wave);
+        stage_tile(srcdO, t0 * KV_TILE, smem + TILE_BYTES, wave);
+        stage_stats64(lse, delta, t0 * KV_TILE, a.Lq, smem + 4 * TILE_BYTES, wave, lane);
+    }
+    // lane-derived row-fragment offsets (swizzle XORs) computed once: plain VALU instructions share the SIMD's issue port
+    // with the MFMAs, so per-tile address arithmetic is pure loss
+    int fo[2][4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) fo[kk] = (unsigned)(uintptr_t)(smem + uswz(lane & 31, kk * 2 + hh));
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) fo[qb][kk] = uswz(qb * 32 + (lane & 31), kk * 2 + hh);
     const unsigned qb00 = tr_base_u(smem, lane, 0, 0), qb01 = tr_base_u(smem, lane, 0, 1);
     const unsigned qb10 = tr_base_u(smem, lane, 1, 0), qb11 = tr_base_u(smem, lane, 1, 1);
-    const unsigned statl = (unsigned)(uintptr_t)(smem + DKV_STATS + 16 * hh);
-
-    dkv_pre_t pre;
-    if (t0 < nt) {
-        dma_tile(t0);
-        if (t0 + 1 < nt) dma_tile(t0 + 1);
-        if (t0 + 2 < nt) dma_tile(t0 + 2);
-        if (t0 + 2 < nt) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (t0 + 1 < nt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int t = t0; t < nt; ++t) {
+        char* sQ = smem + ((t - t0) & 1) * 2 * TILE_BYTES;
+        char* sdO = sQ + TILE_BYTES;
+        if (t + 1 < nt) {
+            char* nQ = smem + ((t - t0 + 1) & 1) * 2 * TILE_BYTES;
+            stage_tile(srcQ, (t + 1) * KV_TILE, nQ, wave);
+            stage_tile(srcdO, (t + 1) * KV_TILE, nQ + TILE_BYTES, wave);
+            stage_stats64(lse, delta, (t + 1) * KV_TILE, a.Lq, smem + 4 * TILE_BYTES + ((t - t0 + 1) & 1) * 512, wave, lane);
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        dkv_pre_issue_frags<0>(pre, fo);                             // q-block 0 of tile t0 (slot 0)
-        dkv_pre_issue_stats<0>(pre, statl);
-    }
 
-    // one q-block: QB = 0/1; fs/qs/ss = this tile's addresses; the NEXT q-block's fragments / seeds are requested with NEXT_FRAGS / NEXT_STATS
-#define DKV_QBLOCK(QB, NEXT_FRAGS, NEXT_STATS, MID_WORK)                                                                                      \
+        const int qt0 = t * KV_TILE;
+        const float* sStat = reinterpret_cast<const float*>(smem + 4 * TILE_BYTES + ((t - t0) & 1) * 512);
+        const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + 128 > a.Lk) || (a.causal && (kblk0 + wave * 32 + 31 > qt0));
+        const unsigned stg = (unsigned)(((t - t0) & 1) * 2 * TILE_BYTES);
+        const unsigned q00 = qb00 + stg, q01 = qb01 + stg, q10 = qb10 + stg, q11 = qb11 + stg;
+        const unsigned o00 = q00 + TILE_BYTES, o01 = q01 + TILE_BYTES, o10 = q10 + TILE_BYTES, o11 = q11 + TILE_BYTES;
+#define DKV_QBLOCK(QB)                                                                                                  \
         {                                                                                                               \
-            tr8_t tdo, tq;                        /* (lgkmcnt counts to 15: issue and wait in groups of eight) */       \
-            tr_issue_u<TILE_BYTES + (QB) * 4096>(tdo, q00, q01, q10, q11);                                              \
-            dkv_pre_wait<8>(pre);                 /* LDS returns in order: the 8 transposing reads stay in flight */    \
+            tr8_t tdo, tq;                                                                                              \
+            tr_issue_u<(QB) * 4096>(tdo, o00, o01, o10, o11);                                                           \
             tr_issue_u<(QB) * 4096>(tq, q00, q01, q10, q11);                                                            \
-            /* accumulators seeded with -lse[q], -delta[q]: the first MFMA of a chain takes the seed registers as C */  \
-            f32x16_t s = join4x4(pre.sl), dp = join4x4(pre.sd);                                                         \
-            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pre.q[kk], kf[kk], s, 0, 0, 0);                             \
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pre.d[kk], vf[kk], dp, 0, 0, 0);                           \
+            f32x16_t s, dp;                       /* accumulators seeded with -lse[q], -delta[q] (see attn_bwd_dq_kernel) */ \
+            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                          \
+                const float4 lv = *reinterpret_cast<const float4*>(sStat + (QB) * 32 + 8 * q4 + 4 * hh);                 \
+                const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 64 + (QB) * 32 + 8 * q4 + 4 * hh);          \
+                s[4 * q4] = lv.x; s[4 * q4 + 1] = lv.y; s[4 * q4 + 2] = lv.z; s[4 * q4 + 3] = lv.w;                     \
+                dp[4 * q4] = dv4.x; dp[4 * q4 + 1] = dv4.y; dp[4 * q4 + 2] = dv4.z; dp[4 * q4 + 3] = dv4.w;             \
             }                                                                                                           \
-            MID_WORK                                                                                                    \
-            pk_scale16(s, LOG2E, z2);                                                                                   \
-            f32x16_t pv;                                                                                                \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r]);                        \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(sQ + fo[QB][kk]);                                 \
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(sdO + fo[QB][kk]);                                \
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);                                    \
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
+            }                                                                                                           \
+            f32x16_t pv, dsv;                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E);                \
             if (need_mask) {                      /* ONE branch per block: a test inside the score loop becomes 16 */   \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
                     const int qq = qt0 + (QB) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);                                   \
                     if (qq >= a.Lq || key >= a.Lk || (a.causal && key > qq)) pv[r] = 0.f;                               \
                 }                                                                                                       \
             }                                                                                                           \
-            const f32x16_t dsv = pk_mul16(pv, dp, z2);                                                                  \
-            bf16x8_t pf[2], df[2];                                                                                      \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x) { pf[x] = pack8(pv, 8 * x); df[x] = pack8(dsv, 8 * x); }      \
-            asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(df[0]), "+v"(df[1]));   /* scores are dead from here */   \
-            NEXT_FRAGS                                                                                                  \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) dsv[r] = pv[r] * dp[r];                                      \
             bf16x8_t qtf[2][2], dotf[2][2];                                                                             \
-            tr_wait<8>(tdo);                      /* (8 = the younger fragment reads just issued) */                    \
-            tr_wait<8>(tq);                                                                                             \
-            NEXT_STATS                                                                                                  \
+            tr_wait<0>(tdo);                                                                                            \
+            tr_wait<0>(tq);                                                                                             \
             tr_pack(dotf, tdo);                                                                                         \
             tr_pack(qtf, tq);                                                                                           \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                               \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                             \
+                const bf16x8_t pf = pack8(pv, 8 * x);                                                                   \
+                const bf16x8_t df = pack8(dsv, 8 * x);                                                                  \
                 _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                         \
-                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[x][d], pf[x], dv[d], 0, 0, 0);                 \
-                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[x][d], df[x], dk[d], 0, 0, 0);                  \
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[x][d], pf, dv[d], 0, 0, 0);                    \
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[x][d], df, dk[d], 0, 0, 0);                     \
                 }                                                                                                       \
+            }                                                                                                           \
         }
-#ifdef ATTN_PROFILE
-    long long kacc[4] = {0, 0, 0, 0}, kt_[5], kc0, kr0, kc1, kr1;
-#define KT(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(kt_[i]) :: "memory");
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(kc0), "=s"(kr0) :: "memory");
-#else
-#define KT(i)
-#endif
-    int slot = 0;
-    for (int t = t0; t < nt; ++t) {
-        KT(0)
-        const int qt0 = t * KV_TILE;
-        const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + 128 > a.Lk) || (a.causal && (kblk0 + wave * 32 + 31 > qt0));
-        const unsigned stg = (unsigned)(slot * DKV_SLOT);
-        const unsigned q00 = qb00 + stg, q01 = qb01 + stg, q10 = qb10 + stg, q11 = qb11 + stg;
-        unsigned fs[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fs[kk] = fo[kk] + stg;
-        const unsigned ss = statl + slot * 512;
-        DKV_QBLOCK(0, (dkv_pre_issue_frags<4096>(pre, fs));, (dkv_pre_issue_stats<128>(pre, ss));, )
-        KT(1)
-        // ---- mid-tile: publish tile t+1, recycle the slot of tile t-1
-        if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");          // tile t+2 (5 DMA instructions) may stay in flight
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        DKV_QBLOCK(0)
+        DKV_QBLOCK(1)
+#undef DKV_QBLOCK
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        KT(2)
-#ifdef DKV_DMA_AT_BARRIER
-        if (t + 3 < nt) dma_tile(t + 3);
-#define DKV_DMA_MID
-#else
-        // the DMA instructions of tile t+3 go BEHIND the S / dP MFMAs of the second q-block: issued right after the barrier,
-        // next to the fragment reads, each of them held the wave for ~150 cycles (a fifth of the tile); among MFMAs in flight
-        // the issue costs a third of that and the matrix pipe is busy meanwhile
-#define DKV_DMA_MID if (t + 3 < nt) dma_tile(t + 3);
-#endif
-        const int nslot = (slot + 1) & (DKV_NSLOT - 1);
-        const unsigned nstg = (unsigned)(nslot * DKV_SLOT);
-        unsigned fn[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) fn[kk] = fo[kk] + nstg;
-        const unsigned sn = statl + nslot * 512;
-        // (past the last tile this reads a stale slot; the values are never used -- the counted waits need the 16 reads)
-        DKV_QBLOCK(1, (dkv_pre_issue_frags<0>(pre, fn));, (dkv_pre_issue_stats<0>(pre, sn));, DKV_DMA_MID)
-#undef DKV_DMA_MID
-        KT(3)
-        slot = nslot;
-#ifdef ATTN_PROFILE
-        kacc[0] += kt_[2] - kt_[1]; kacc[1] += kt_[1] - kt_[0]; kacc[2] += kt_[3] - kt_[2];
-#endif
     }
-#ifdef ATTN_PROFILE
-    if (tid == 0) {     // diagnostic build: per-workgroup phase cycles of wave 0 go to the dq columns (this kernel never writes them)
-        const int rec = blockIdx.x;
-        long long* pr = reinterpret_cast<long long*>(reinterpret_cast<char*>(a.dq) + (int64_t)(rec / 40) * a.dq_rs * 2 + (rec % 40) * 64);
-        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(kc1), "=s"(kr1) :: "memory");
-        pr[0] = kacc[0]; pr[1] = kacc[1]; pr[2] = kacc[2]; pr[3] = nt - t0; pr[4] = kc1 - kc0; pr[5] = kr1 - kr0;
-    }
-#endif
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#undef DKV_QBLOCK
     if (a.dv_colsum) {        // v_proj bias gradient, fused: second workspace plane, partial row (b, key block, wave)
         const int nqb = (a.Lq + 127) / 128, nkb = (a.Lk + 127) / 128;
         float* wsr = reinterpret_cast<float*>(a.cs_ws) + (int64_t)a.B * nqb * 4 * a.H * HD +

@@ -56,6 +56,14 @@ def _backward_order(model):
     return groups
 
 
+# reference configs/base.yaml:18 and configs/train/se_dicow.yaml:13 (model.prefixes_to_preheat): the parameters that train in
+# the preheat phase and get lr x fddt_lr_multiplier with weight decay 0 afterwards (containers.py:100-114) -- the FDDT modules,
+# the CTC branch and the SE-DiCoW enrollment cross-attention.  Prefixes a model does not have match nothing.
+REFERENCE_PREHEAT_PREFIXES = ("model.encoder.additional_layer", "model.encoder.additional_self_attention_layer", "model.encoder.lm_head",
+                              "model.encoder.subsample_conv1", "model.encoder.subsample_conv2", "model.encoder.fddts",
+                              "model.encoder.initial_fddt", "model.encoder.ca_enrolls")
+
+
 class FlatStore:
     """Flat fp32 parameter / gradient / Adam-moment buffers for the trainable parameters.
 
@@ -63,7 +71,8 @@ class FlatStore:
     ``p.grad`` (``p._direct_grad``), so autograd performs no extra accumulation pass and the fused optimizer and the
     bucketed all-reduce work on contiguous memory."""
 
-    def __init__(self, model, preheat_prefixes=("model.encoder.fddts", "model.encoder.initial_fddt")):
+    def __init__(self, model, preheat_prefixes=None):
+        preheat_prefixes = REFERENCE_PREHEAT_PREFIXES if preheat_prefixes is None else tuple(preheat_prefixes)
         names = {id(p): n for n, p in model.named_parameters()}
         dev = next(model.parameters()).device
         self.segments = []            # (name, start, end) per backward group
@@ -263,9 +272,17 @@ class TrainStep:
     """model + FlatStore + FusedAdamW (+ GradReducer): ``loss = step(batch)``."""
 
     def __init__(self, model, lr=2e-6, fddt_lr_multiplier=100.0, weight_decay=0.0, max_grad_norm=1.0, warmup_steps=0,
-                 max_steps=0, frozen_keywords=("decoder",), preheat_prefixes=("model.encoder.fddts", "model.encoder.initial_fddt"),
-                 process_group=None, augmenter=None, use_fddt_only_n_steps=0, graph=False):
+                 max_steps=0, frozen_keywords=("decoder",), preheat_prefixes=None,
+                 process_group=None, augmenter=None, use_fddt_only_n_steps=0, graph=False, use_fddt_only_n_epochs=0,
+                 steps_per_epoch=None):
         self.model = model
+        # preheat_prefixes=None: the reference's model.prefixes_to_preheat (REFERENCE_PREHEAT_PREFIXES).
+        # use_fddt_only_n_epochs (base.yaml:59) is the reference's second phase condition (trainers.py:122: epoch >= n_epochs
+        # AND global_step >= n_steps); without a data loader an epoch is `steps_per_epoch` optimizer steps.
+        if use_fddt_only_n_epochs:
+            if not steps_per_epoch:
+                raise ValueError("use_fddt_only_n_epochs needs steps_per_epoch (optimizer steps in one pass over the training set)")
+            use_fddt_only_n_steps = max(int(use_fddt_only_n_steps), int(use_fddt_only_n_epochs) * int(steps_per_epoch))
         # graph=True: after one eager step per phase the whole step (zero-grad, forward, backward, clip, AdamW, bf16 weight
         # refresh) is captured in ONE hipGraph per phase and replayed: small configurations (whisper-base, B = 8: ~1000 launches
         # of a few microseconds each) are bound by the host's launch rate, not by the GPU.  The step has no host-side data
