@@ -37,6 +37,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["avg_launch_ms"] > 0 and "traffic" in rf
     assert d["ms_per_step_median"] > 0 and d["per_rank_ms_per_step"] == [d["ms_per_step"]]
     assert d["loss"] == d["loss"]                                                        # finite
+    sm = rf["sustained_mfma_only"]                                                      # the matrix pipe's ceiling under the power cap
+    assert 1000.0 < sm["tflops"] < rf["peak"] and abs(sm["frac_of_it"] - rf["achieved"] / sm["tflops"]) < 1e-3
+    assert "power" in d                                                                 # rocm-smi samples of the timed region, or None
+    if d["power"] is not None:
+        assert 50.0 < d["power"]["board_w_mean"] < 2000.0 and 100.0 < d["power"]["sclk_mhz_mean"] <= 2500.0 and d["power"]["samples"] >= 1
 
 
 def test_bench_gpus_2_launches_two_ranks_by_itself():
