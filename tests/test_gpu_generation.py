@@ -481,3 +481,55 @@ def test_temperature_fallback_on_the_decoder(pkg):
                                                  no_speech_token_id=3, **kw)
     assert skip == [True, True] and used == [0, 0]
     assert dec.no_speech_prob is not None and dec.no_speech_prob.shape == (2,) and bool((dec.no_speech_prob > 0).all())
+
+
+def test_generate_end_to_end_vs_transformers_whisper_generate(pkg):
+    """Golden F19 (tests/golden/make_golden_generate.py): transformers' own WhisperForConditionalGeneration.generate -- the code the
+    reference's generate() (generation.py:536-564) inherits -- run end to end on a small plain-Whisper model with hashed weights;
+    DiCoW with FDDT off is that model.  The product's generate() must emit the same tokens: forced <|de|> / transcribe prompt,
+    suppress and begin-suppress lists, eos handling, and (case c) the per-row language detection in front of it.  Every recorded
+    best-vs-second score gap of HF's fp32 run is >= 0.39; a row is followed while its gap exceeds 0.15 (bf16 scores: 6e-2)."""
+    import ast
+    from types import SimpleNamespace
+    from tests.util import hashed_init_, hashed_mel, hashed_uniform
+    z = load_golden("f19_hf_generate")
+    c, gen, scale = (ast.literal_eval(str(z[k])) for k in ("cfg", "gen", "scale"))
+    cfg = pkg.DiCoWConfig(use_fddt=False, **c)
+    model = pkg.DiCoWForConditionalGeneration(cfg)
+    hashed_init_(model)                                        # same parameter names as the HF model -> same hashed values
+    d = model.model.decoder
+    with torch.no_grad():                                      # the golden script's apply_scale()
+        from ts_asr_whisper_amd.modeling import sinusoids
+        model.model.encoder.embed_positions.weight.copy_(sinusoids(cfg.max_source_positions, cfg.d_model))
+        d.embed_tokens.weight.mul_(scale["embed_tokens"]); d.embed_positions.weight.mul_(scale["embed_positions"])
+        d.layer_norm.weight.mul_(scale["final_ln"])
+        for l in d.layers:
+            l.encoder_attn.q_proj.weight.mul_(scale["cross_q"]); l.encoder_attn.out_proj.weight.mul_(scale["cross_out"])
+    model = model.cuda().eval()
+    model.tie_weights()
+    model.tokenizer = None
+    B = z["a.seq"].shape[0]
+    x = torch.from_numpy(hashed_mel(B, 80, 3000)).clone() + 0.6 * hashed_uniform(f"f19.x.{int(z['variant'])}", (B, 80, 3000))
+    x[1] = x[1].flip(-1) * 0.7
+    x = x.clamp(-1.5, 1.5).cuda()
+    st = torch.zeros(B, 4, 1500, device="cuda"); st[:, 1] = 1.0
+
+    def follow(ours, ref, gaps, P):
+        n = 0
+        for b in range(B):
+            for i in range(ref.shape[1]):
+                if gaps[b, i] < 0.15:
+                    break
+                assert int(ours[b, P + i]) == int(ref[b, i]), (b, i, ours[b].tolist(), ref[b].tolist())
+                n += 1
+        return n
+
+    gc = SimpleNamespace(language="de", task="transcribe", return_timestamps=False, **gen)
+    out = model.generate(input_features=x, stno_mask=st, generation_config=gc, max_new_tokens=z["a.seq"].shape[1]).cpu()
+    assert out[:, :4].tolist() == [[gen["decoder_start_token_id"], gen["lang_to_id"]["<|de|>"], gen["task_to_id"]["transcribe"], gen["no_timestamps_token_id"]]] * B
+    assert follow(out, z["a.seq"], z["a.gaps"], 4) == z["a.seq"].size
+    gc.language = None                                          # containers.py:58 -> detect per row (reference generation.py:151-221)
+    assert model.detect_language(x, st, gc).cpu().tolist() == z["c.lang"].tolist()
+    out = model.generate(input_features=x, stno_mask=st, generation_config=gc, max_new_tokens=z["c.seq"].shape[1]).cpu()
+    assert out[:, 1].tolist() == z["c.lang"].tolist()
+    assert follow(out, z["c.seq"], z["c.gaps"], 4) == z["c.seq"].size
