@@ -533,3 +533,37 @@ def test_generate_end_to_end_vs_transformers_whisper_generate(pkg):
     out = model.generate(input_features=x, stno_mask=st, generation_config=gc, max_new_tokens=z["c.seq"].shape[1]).cpu()
     assert out[:, 1].tolist() == z["c.lang"].tolist()
     assert follow(out, z["c.seq"], z["c.gaps"], 4) == z["c.seq"].size
+
+
+def test_generate_one_window_with_timestamps_runs_the_seek_loop(pkg):
+    """HF's generate -- which the reference's generate() calls (generation.py:558) -- runs its seek loop on every input: with
+    timestamp prediction on and a tokenizer set, a ONE-window input goes through LongFormDecoder (a second pass over the tail
+    when the window ends in an open timestamp) and comes back as the fix-up matrix, exactly like a long recording; without
+    timestamps it stays a single pass returning prompt + tokens."""
+    from types import SimpleNamespace
+    from ts_asr_whisper_amd.generation import LongFormDecoder, fix_timestamps_from_segmentation
+    z, model, cfg, x, st, prompt = _setup(pkg)
+    W = 2 * cfg.max_source_positions
+    assert x.shape[-1] == W
+    no_ts, eos, pad = 399, 5, 499
+
+    class Tok:
+        prefix_tokens = [int(t) for t in prompt[0]]
+        pad_token_id = pad
+
+        def get_vocab(self):
+            return {"<|0.00|>": no_ts + 1, "Ġ": 7}
+
+    model.set_tokenizer(Tok())
+    gc = SimpleNamespace(eos_token_id=eos, pad_token_id=pad, no_timestamps_token_id=no_ts, max_initial_timestamp_index=50,
+                         decoder_start_token_id=cfg.decoder_start_token_id, return_timestamps=True)
+    xc, sc = x.cuda(), st.cuda()
+    out = model.generate(input_features=xc, stno_mask=sc, generation_config=gc, max_new_tokens=10)
+    segs = LongFormDecoder(model).transcribe(xc, sc, [W] * x.shape[0], prompt[:1], no_ts, eos_token_id=eos, pad_token_id=pad, max_new_tokens=10)
+    want = fix_timestamps_from_segmentation(segs, no_ts + 1, 7, pad, prefix_ids=Tok.prefix_tokens, suffix_ids=[eos])
+    assert torch.equal(out.cpu(), want)
+    assert [[s["tokens"] for s in r] for r in model.last_segments] == [[s["tokens"] for s in r] for r in segs]
+    gc.return_timestamps = False
+    plain = model.generate(input_features=xc, stno_mask=sc, generation_config=gc, decoder_input_ids=prompt, max_new_tokens=3)
+    assert plain.shape == (x.shape[0], prompt.shape[1] + 3) and torch.equal(plain[:, :prompt.shape[1]].cpu(), prompt)
+    model.tokenizer = None

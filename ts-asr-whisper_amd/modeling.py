@@ -661,8 +661,10 @@ class DiCoWForConditionalGeneration(nn.Module):
     def generate(self, input_features=None, stno_mask=None, attention_mask=None, decoder_input_ids=None, max_new_tokens=None,
                  max_length=None, generation_config=None, enrollments=None, num_beams=1, return_timestamps=None, use_graphs=False,
                  **kwargs):
-        """Short-form (one 30 s window) greedy or beam-search decoding with the reference's logits-processor chain
-        (generation.GreedyDecoder.generate / .beam_search).
+        """Greedy or beam-search decoding with the reference's logits-processor chain.  One 30 s window without timestamp
+        prediction (or without a tokenizer): one pass, returns prompt + tokens (generation.GreedyDecoder.generate / .beam_search).
+        Longer recordings, and one window WITH timestamp prediction: the seek loop of HF's / the reference's generate
+        (generation.LongFormDecoder) and the window-relative sequences of _fix_timestamps_from_segmentation.
         ``generation_config``: any object with the HF / reference attribute names (eos_token_id, pad_token_id, suppress_tokens,
         begin_suppress_tokens, return_timestamps, no_timestamps_token_id, max_initial_timestamp_index, ctc_weight, ...).
         The prompt is ``decoder_input_ids`` or [decoder_start_token_id] + the tokenizer's prefix tokens."""
@@ -673,6 +675,17 @@ class DiCoWForConditionalGeneration(nn.Module):
         beams = max(num_beams or 1, get("num_beams", 1) or 1)
         self.stno_mask = stno_mask                            # reference generate() keeps it for detect_language (generation.py:556)
         cfg = self.config
+        ts_on = return_timestamps if return_timestamps is not None else get("return_timestamps", False)
+        one_window = input_features.shape[-1] == 2 * cfg.max_source_positions
+        # HF's generate -- which the reference's calls (generation.py:558) -- runs its seek loop on EVERY input: a single window
+        # that ends in an open timestamp gets a second pass over its tail, and the return value is the segment-derived matrix of
+        # _fix_timestamps_from_segmentation.  With timestamps on and a real tokenizer set (the fix-up needs its ids) a
+        # one-window input therefore takes the same path as a long recording; all of its frames count as valid by default.
+        if one_window and ts_on and hasattr(self.tokenizer, "get_vocab"):
+            if attention_mask is None:
+                attention_mask = torch.ones(input_features.shape[0], input_features.shape[-1], dtype=torch.long, device=input_features.device)
+            return self._generate_long_form(input_features, stno_mask, attention_mask, decoder_input_ids, max_new_tokens, get, beams,
+                                            enrollments, gc)
         if input_features.shape[-1] > 2 * cfg.max_source_positions:
             return self._generate_long_form(input_features, stno_mask, attention_mask, decoder_input_ids, max_new_tokens, get, beams,
                                             enrollments, gc)
