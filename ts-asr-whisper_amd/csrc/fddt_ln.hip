@@ -13,6 +13,19 @@
 #include "common.h"
 
 #define MAX_WAVES 16
+#ifndef ROWS_GATHER
+#define ROWS_GATHER 2      // staged forward: partials read back two waves at a time (78 -> 62 us; all at once: 88 us, register cliff)
+#endif
+#ifndef ROWS_G_FWD
+#define ROWS_G_FWD 2       // LayerNorm-only forward: two at a time (40 -> 30.5 us; all at once 33 us)
+#endif
+#ifndef ROWS_G_BWD
+#define ROWS_G_BWD 0       // LayerNorm-only / generic backward: the plain loop
+#endif
+#ifndef ROWS_G_BWDS
+#define ROWS_G_BWDS 16     // staged backward: all at once
+#endif
+
 
 struct f4 { float x, y, z, w; };
 
@@ -65,7 +78,33 @@ __device__ __forceinline__ f32x2r_t fddt_diag_pair(f32x2r_t h, f32x2r_t w0, f32x
 #define F4_APPLY(dst, expr) do { dst.x = expr(x); dst.y = expr(y); dst.z = expr(z); dst.w = expr(w); } while (0)
 
 // block-wide sum of NV values per thread; result broadcast to all threads.  `red` is [MAX_WAVES][NV].
-template <int NV>
+// The read-back of the per-wave partials is written out per wave count: with the count in a loop variable every partial was
+// a dependent LDS round trip of its own (5 waves x 2 reductions per trip = 30 % of the staged forward's time, ablation builds
+// in profiles/r02_ablations.txt); unrolled, the reads of a reduction are issued together and waited for once.  Same order of
+// additions as the loop.
+template <int NV, int NW, int CHUNK = NW>      // CHUNK partials in flight at a time (registers: CHUNK x NV)
+__device__ __forceinline__ void block_sum_gather(float (&v)[NV], const float* red) {
+    float s[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s[i] = 0.f;
+#pragma unroll
+    for (int w0 = 0; w0 < NW; w0 += CHUNK) {
+        float p[CHUNK][NV];
+#pragma unroll
+        for (int w = 0; w < CHUNK; ++w)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) p[w][i] = (w0 + w < NW) ? red[(w0 + w) * NV + i] : 0.f;
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int w = 0; w < CHUNK; ++w)
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (w0 + w < NW) s[i] += p[w][i];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = s[i];
+}
+template <int NV, bool UNROLLED = false, int CHUNK = 16>   // UNROLLED costs min(NW, CHUNK) x NV registers: only where it measured faster
 __device__ __forceinline__ void block_sum(float (&v)[NV], float* red, int nwaves) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -76,6 +115,15 @@ __device__ __forceinline__ void block_sum(float (&v)[NV], float* red, int nwaves
         for (int i = 0; i < NV; ++i) red[wv * NV + i] = v[i];
     }
     __syncthreads();
+    if (UNROLLED) switch (nwaves) {
+        case 2: block_sum_gather<NV, 2, (CHUNK < 2 ? CHUNK : 2)>(v, red); return;
+        case 3: block_sum_gather<NV, 3, (CHUNK < 3 ? CHUNK : 3)>(v, red); return;
+        case 4: block_sum_gather<NV, 4, (CHUNK < 4 ? CHUNK : 4)>(v, red); return;
+        case 5: block_sum_gather<NV, 5, (CHUNK < 5 ? CHUNK : 5)>(v, red); return;          // D = 1280 (whisper-large-v3-turbo)
+        case 6: block_sum_gather<NV, 6, (CHUNK < 6 ? CHUNK : 6)>(v, red); return;          // D = 1536
+        case 8: block_sum_gather<NV, 8, (CHUNK < 8 ? CHUNK : 8)>(v, red); return;          // D = 2048
+        default: break;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         float s = 0.f;
@@ -124,7 +172,7 @@ __device__ __forceinline__ void block_welford(float (&n)[R], float (&mu)[R], flo
 template <int R, int MAXT, int MODE_T = -1>     // MODE_T: compile-time mode (see fddt_ln_bwd_kernel), -1 = runtime
 __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_fwd_args a) {
     const int mode = MODE_T >= 0 ? MODE_T : a.mode;
-    __shared__ float red[2][MAX_WAVES * R * 3];
+    __shared__ __attribute__((aligned(16))) float red[2][MAX_WAVES * R * 3];
     const int tid = threadIdx.x, col = tid * 4, D = a.D;
     const bool act = col < D;
     const int nwaves = blockDim.x >> 6;
@@ -185,7 +233,8 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
         float sm[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) sm[r] = act ? (x[r].x + x[r].y) + (x[r].z + x[r].w) : 0.f;
-        block_sum<R>(sm, red[0], nwaves);
+        // (unrolled read-back of the partials: LayerNorm-only body 40 -> 32 us; the FDDT bodies lose occupancy to its registers)
+        block_sum<R, (MODE_T == 0 && ROWS_G_FWD != 0), (ROWS_G_FWD ? ROWS_G_FWD : 16)>(sm, red[0], nwaves);
         float mu[R], q[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -193,7 +242,7 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
             const float dx = x[r].x - mu[r], dy = x[r].y - mu[r], dz = x[r].z - mu[r], dw = x[r].w - mu[r];
             q[r] = act ? (dx * dx + dy * dy) + (dz * dz + dw * dw) : 0.f;
         }
-        block_sum<R>(q, red[1], nwaves);
+        block_sum<R, (MODE_T == 0 && ROWS_G_FWD != 0), (ROWS_G_FWD ? ROWS_G_FWD : 16)>(q, red[1], nwaves);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = row0 + r;
@@ -222,10 +271,13 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
 // next trip fetched by LDS-DMA while the current trip is computed -- see fddt_ln_bwd_staged_kernel for the scheme.  The FDDT
 // arithmetic is the reference's evaluation order (fddt_diag_elem), bit-exact like the generic body.
 typedef __attribute__((address_space(3))) void lds_void_f_t;
+#ifndef ROWS_ABL
+#define ROWS_ABL 0     // diagnostic builds (tools/build_rows_variants.sh): 1 no fp32 row store, 2 no bf16 / stats stores, 4 no block reductions, 8 no DMA wait
+#endif
 template <int R>
 __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fddt_ln_fwd_args a) {
     extern __shared__ __attribute__((aligned(16))) char stg[];       // [2 stages][R rows][4*D bytes]
-    __shared__ float red[2][MAX_WAVES * R * 3];
+    __shared__ __attribute__((aligned(16))) float red[2][MAX_WAVES * R * 3];
     const int tid = threadIdx.x, col = tid * 4, D = a.D;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nwaves = blockDim.x >> 6;
@@ -273,7 +325,9 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
         load_masks(row0 + stride);
         stage_rows(row0 + stride, s ^ 1);
         // younger than this trip's DMA: the previous trip's 4R stores, the next trip's 4R mask loads and R DMA instructions
-        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(5 * R) : "memory");
+        if (ROWS_ABL & 8) asm volatile("s_waitcnt vmcnt(60)" ::: "memory");
+        else if (ROWS_ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the store counts changed: wait for everything)
+        else if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(5 * R) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "i"(9 * R) : "memory");
         f32x2r_t xl[R], xh[R];                       // columns (0,1) and (2,3) of this thread's quad
         float sm[R];
@@ -289,10 +343,10 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
             xh[r] = FDP(z, w, (f32x2r_t{xi.z, xi.w}));
 #undef FDP
             ov[r] = u32x4_t{__float_as_uint(xl[r].x), __float_as_uint(xl[r].y), __float_as_uint(xh[r].x), __float_as_uint(xh[r].y)};
-            __builtin_amdgcn_raw_buffer_store_b128(ov[r], rsO, vo32, (row0 + r) * D * 4, 0);
+            if (!(ROWS_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(ov[r], rsO, vo32, (row0 + r) * D * 4, 0);
             sm[r] = (xl[r].x + xl[r].y) + (xh[r].x + xh[r].y);
         }
-        block_sum<R>(sm, red[0], nwaves);
+        if (!(ROWS_ABL & 4)) block_sum<R, ROWS_GATHER != 0, (ROWS_GATHER ? ROWS_GATHER : 16)>(sm, red[0], nwaves);
         float mu[R], q[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -303,7 +357,7 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
             const f32x2r_t ql = dl * dl, qh = dh * dh;
             q[r] = (ql.x + ql.y) + (qh.x + qh.y);
         }
-        block_sum<R>(q, red[1], nwaves);
+        if (!(ROWS_ABL & 4)) block_sum<R, ROWS_GATHER != 0, (ROWS_GATHER ? ROWS_GATHER : 16)>(q, red[1], nwaves);
         // (one block-wide Chan/Welford reduction instead of these two measured SLOWER here: 108 vs 87 us -- the combination
         // steps cost more than the second barrier)
         // The registers a 16-byte store reads its data from must not be rewritten while the store may still be queued: with
@@ -318,13 +372,16 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
 #pragma clang fp contract(off)
             const float rs = rsqrtf(q[r] * inv_d + a.eps);
             typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+            if (!(ROWS_ABL & 2)) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mu[r]), rsM, voStat, (row0 + r) * 4, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(rs), rsS, voStat, (row0 + r) * 4, 0);
+            }
             const f32x2r_t mu2 = {mu[r], mu[r]}, rs2 = {rs, rs};
             const f32x2r_t yl = (xl[r] - mu2) * rs2 * f32x2r_t{lnw.x, lnw.y} + f32x2r_t{lnb.x, lnb.y};
             const f32x2r_t yh = (xh[r] - mu2) * rs2 * f32x2r_t{lnw.z, lnw.w} + f32x2r_t{lnb.z, lnb.w};
             const u32x2_t yv = {pack_bf16x2(yl.x, yl.y), pack_bf16x2(yh.x, yh.y)};
-            __builtin_amdgcn_raw_buffer_store_b64(yv, rsY, vo16, (row0 + r) * D * 2, 0);
+            if (!(ROWS_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b64(yv, rsY, vo16, (row0 + r) * D * 2, 0);
+            else if (yv.x == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b64(yv, rsY, vo16, (row0 + r) * D * 2, 0);
         }
     }
 }
@@ -495,7 +552,7 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
             sums[2 * r] = ok ? (dxh.x + dxh.y) + (dxh.z + dxh.w) : 0.f;
             sums[2 * r + 1] = ok ? (dxh.x * xh[r].x + dxh.y * xh[r].y) + (dxh.z * xh[r].z + dxh.w * xh[r].w) : 0.f;
         }
-        if (do_ln) block_sum<2 * R>(sums, red[it & 1], nwaves);
+        if (do_ln) block_sum<2 * R, ROWS_G_BWD != 0, (ROWS_G_BWD ? ROWS_G_BWD : 16)>(sums, red[it & 1], nwaves);
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int row = row0 + r;
@@ -660,7 +717,7 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
             sums[2 * r] = (dxh.x + dxh.y) + (dxh.z + dxh.w);
             sums[2 * r + 1] = (dxh.x * xh[r].x + dxh.y * xh[r].y) + (dxh.z * xh[r].z + dxh.w * xh[r].w);
         }
-        block_sum<2 * R>(sums, red[it & 1], nwaves);
+        block_sum<2 * R, ROWS_G_BWDS != 0, (ROWS_G_BWDS ? ROWS_G_BWDS : 16)>(sums, red[it & 1], nwaves);    // (160 -> 134 us)
 #pragma unroll
         for (int r = 0; r < R; ++r) { asm volatile("" :: "v"(ov[r])); if (OUT_BF16) asm volatile("" :: "v"(bv[r])); }
 #pragma unroll
@@ -704,10 +761,18 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
     }
 }
 
+#ifndef BWD_R0
 #define BWD_R0 2          // rows per trip and resident workgroups per CU of the LayerNorm-only (mode 0) body
+#endif
+#ifndef BWD_CU0
 #define BWD_CU0 4
+#endif
+#ifndef BWD_RS
 #define BWD_RS 2          // rows per trip / resident workgroups per CU of the LDS-staged FDDT(diag)+LN body
+#endif
+#ifndef BWD_CUS
 #define BWD_CUS 2
+#endif
 static int bwd_grid(int rows, int D, int per_cu) {
     const int block = ((D / 4) + 63) / 64 * 64;
     int grid = (rows + 3) / 4;
@@ -715,7 +780,7 @@ static int bwd_grid(int rows, int D, int per_cu) {
     return grid > cap ? cap : grid;
 }
 
-extern "C" int64_t dicow_fddt_ln_bwd_ws_bytes(int rows, int D) { return (int64_t)bwd_grid(rows, D, BWD_CU0) * 11 * D * 4; }
+extern "C" int64_t dicow_fddt_ln_bwd_ws_bytes(int rows, int D) { return (int64_t)bwd_grid(rows, D, BWD_CU0 > BWD_CUS ? BWD_CU0 : BWD_CUS) * 11 * D * 4; }
 
 extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) {
     DICOW_REQUIRE(a && a->h_in && a->rows > 0 && a->D > 0, "fddt_ln_bwd: null/empty input");
