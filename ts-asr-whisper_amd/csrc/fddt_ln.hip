@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
             sums[2 * r] = (dxh.x + dxh.y) + (dxh.z + dxh.w);
             sums[2 * r + 1] = (dxh.x * xh[r].x + dxh.y * xh[r].y) + (dxh.z * xh[r].z + dxh.w * xh[r].w);
         }
-        block_sum<2 * R, ROWS_G_BWDS != 0, (ROWS_G_BWDS ? ROWS_G_BWDS : 16)>(sums, red[it & 1], nwaves);    // (160 -> 134 us)
+        if (!(ROWS_ABL & 16)) block_sum<2 * R, ROWS_G_BWDS != 0, (ROWS_G_BWDS ? ROWS_G_BWDS : 16)>(sums, red[it & 1], nwaves);    // (160 -> 134 us)
 #pragma unroll
         for (int r = 0; r < R; ++r) { asm volatile("" :: "v"(ov[r])); if (OUT_BF16) asm volatile("" :: "v"(bv[r])); }
 #pragma unroll
@@ -768,10 +768,10 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
 #define BWD_CU0 4
 #endif
 #ifndef BWD_RS
-#define BWD_RS 2          // rows per trip / resident workgroups per CU of the LDS-staged FDDT(diag)+LN body
-#endif
+#define BWD_RS 3          // rows per trip / resident workgroups per CU of the LDS-staged FDDT(diag)+LN body: 3 rows x 1 workgroup
+#endif                    // measured 126 us, 2 x 2: 137, 4 x 1: 128, 3 x 2: 131, 2 x 1: 129 (one block reduction per trip: 32 us of it)
 #ifndef BWD_CUS
-#define BWD_CUS 2
+#define BWD_CUS 1
 #endif
 static int bwd_grid(int rows, int D, int per_cu) {
     const int block = ((D / 4) + 63) / 64 * 64;
