@@ -34,10 +34,44 @@ __global__ void __launch_bounds__(256) mfma_loop(float* out, long long* clk, int
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = w1 - w0; }
 }
 
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+// the 16x16x32 shape (same flops per instruction / 2, twice the instructions): does the board sustain a different rate with it?
+__global__ void __launch_bounds__(256) mfma16_loop(float* out, int iters) {
+    f32x4_t acc[16];
+    for (int i = 0; i < 16; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    bf16x8_t a, b;
+    unsigned x = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
+    for (int r = 0; r < 8; ++r) {
+        x = x * 1664525u + 1013904223u; a[r] = (short)(((x >> 16) & 0x807f) | (0x3e00 + ((x >> 9) & 0x180)));
+        x = x * 1664525u + 1013904223u; b[r] = (short)(((x >> 16) & 0x807f) | (0x3e00 + ((x >> 9) & 0x180)));
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 16; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 int main(int argc, char** argv) {
     const int blocks = 256, iters = 20000;
     if (argc > 1) {   // sustained mode: tools/probe_clock <seconds> [random]   (sample rocm-smi from another shell meanwhile)
         const double secs = atof(argv[1]); const bool rnd = argc > 2;
+        if (argc > 2 && !strcmp(argv[2], "m16")) {        // 16x16x32, random operands: 16 x 16384 flops x 2 per inner trip = the 32x32x16 loop's 8 x 32768 x 2
+            float* o16; hipMalloc(&o16, blocks * 256 * 4);
+            hipEvent_t a0, a1; hipEventCreate(&a0); hipEventCreate(&a1);
+            double tot = 0; int n16 = 0;
+            while (tot < secs * 1e3) {
+                hipEventRecord(a0);
+                for (int k = 0; k < 10; ++k) hipLaunchKernelGGL(mfma16_loop, dim3(blocks), dim3(256), 0, 0, o16, iters);
+                hipEventRecord(a1); hipEventSynchronize(a1);
+                float ms; hipEventElapsedTime(&ms, a0, a1); tot += ms; n16 += 10;
+                if (n16 % 200 == 0) printf("16x16x32 random operands, after %.1f s: %.1f TF sustained\n", tot * 1e-3,
+                                           10.0 * blocks * 4 * iters * 16 * 16384.0 / (ms * 1e-3) * 1e-12);
+            }
+            return 0;
+        }
         float* out; long long* clk; hipMalloc(&out, blocks * 256 * 4); hipMalloc(&clk, blocks * 16);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         double total_ms = 0; int n = 0;
