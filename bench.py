@@ -44,6 +44,11 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=5,
                     help="instrumented steps run AFTER the timed region (per-launch HIP events of the dominant kernel: roofline)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (launch-bound configs)")
+    ap.add_argument("--from-audio", action="store_true",
+                    help="the step starts from 16 kHz waveforms resident in HBM: dicow_logmel -> BatchAugmenter (STNO segment "
+                         "augmentation + joint SpecAug, collators.py:189-214) -> training step (reported beside the headline, never AS it)")
+    ap.add_argument("--gemm-cus", type=int, default=0,
+                    help="limit the persistent GEMM grids to this many CUs (what trainer.GradReducer does for N > 1: CUs left to the RCCL channels)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher self-test: rendezvous + one all-reduce per rank, no training step (runs without a GPU over gloo)")
     return ap.parse_args()
@@ -57,25 +62,52 @@ def _free_port():
 
 
 def launch_ranks(a):
-    """`python bench.py --gpus N` with no rendezvous in the environment: start one process per GPU and relay rank 0's JSON line."""
+    """`python bench.py --gpus N` with no rendezvous in the environment: start one process per GPU and relay rank 0's JSON line.
+    Every child is polled: the first non-zero exit (or the overall timeout) kills the others -- a rank that died before the
+    rendezvous would otherwise leave rank 0 waiting in RCCL forever -- and the stderr tail of the failed ranks is shown."""
     import subprocess
+    import tempfile
     port = _free_port()
-    procs = []
+    procs, errs = [], []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DICOW_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        errs.append(tempfile.TemporaryFile(mode="w+"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None, text=True))
-    out0, _ = procs[0].communicate()
-    rcs = [p.wait() for p in procs]
-    if any(rcs):
-        sys.stderr.write(f"bench.py: rank exit codes {rcs}\n")
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=errs[-1], text=True))
+    deadline = time.time() + float(os.environ.get("DICOW_BENCH_LAUNCH_TIMEOUT", "3600"))
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        if any(rc not in (None, 0) for rc in rcs):
+            failed = f"rank exit codes {rcs}"
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.time() > deadline:
+            failed = f"timeout; rank exit codes so far {rcs}"
+            break
+        time.sleep(0.2)
+    if failed:
         for p in procs:
             if p.poll() is None:
                 p.kill()
+        for p in procs:
+            p.wait()
+        sys.stderr.write(f"bench.py: {failed}\n")
+        for r, f in enumerate(errs):
+            f.seek(0)
+            tail = f.read()[-1500:]
+            if tail.strip() and procs[r].returncode not in (0, -9):
+                sys.stderr.write(f"---- rank {r} stderr (tail)\n{tail}\n")
         sys.exit(1)
-    sys.stdout.write(out0)
+    for f in errs:                                   # warnings of a clean run: relay rank 0's only
+        f.seek(0)
+    sys.stderr.write(errs[0].read())
+    out0.seek(0)
+    sys.stdout.write(out0.read())
     sys.stdout.flush()
 
 
@@ -283,6 +315,9 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and (a.gpus > 1 or world > 1):
         raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} in the environment")
+    if os.environ.get("DICOW_BENCH_FAIL_RANK") == str(rank):     # launcher self-test: this rank dies before the rendezvous
+        sys.stderr.write(f"bench.py: rank {rank} failing on request (DICOW_BENCH_FAIL_RANK)\n")
+        sys.exit(3)
     if a.dry_launch:
         return dry_launch(a, world, rank, local)
     # DICOW_BENCH_SHARE_GPU=1 (tests on a one-GPU box): every rank uses device 0 and the exchange runs over gloo
@@ -319,6 +354,23 @@ def main():
                    **({"graph": True} if a.graph else {}))
     batches = [synthetic_batch(cfg, a.batch, a.labels, seed=1000 + rank * 17 + i, mixed_length=a.se, enrollments=a.se)
                for i in range(2)]
+    if a.gemm_cus:
+        ops.set_gemm_cus(a.gemm_cus)
+    # ---- the batch-preparation front end (reference local_datasets.py:196-214 feature extraction + collators.py:189-214
+    # augmentation: CPU work of the data-loader workers there, kernels here).  Synthetic 30 s waveforms resident in HBM.
+    from ts_asr_whisper_amd.features import log_mel, N_SAMPLES
+    from ts_asr_whisper_amd.augment import BatchAugmenter
+    gw = torch.Generator().manual_seed(77 + rank)
+    waves = [(torch.randn(a.batch, N_SAMPLES, generator=gw) * 0.1).cuda() for _ in range(2)]
+    augmenter = BatchAugmenter(stno_segment_augment_prob=1.0, spec_aug_prob=1.0)      # both augmentations on EVERY step (worst case)
+
+    def front_end(i):
+        b = dict(batches[i % 2])
+        b["input_features"] = log_mel(waves[i % 2], cfg.num_mel_bins)
+        return augmenter(b)
+
+    def run_step(i, **kw):
+        return ts.step(front_end(i) if a.from_audio else batches[i % 2], **kw)
     timer = KernelTimer(ops, ["gemm_nt", "gemm_tn"])
     timer.install()
 
@@ -329,7 +381,7 @@ def main():
             torch.cuda.synchronize()
 
     for i in range(a.warmup):
-        loss = ts.step(batches[i % 2])
+        loss = run_step(i)
     sync()
     # ---- the timed region: exactly K steps, no per-launch instrumentation (one event per step boundary for the median)
     ts.reducer.time_exposed = True
@@ -340,7 +392,7 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(a.steps):
-        loss = ts.step(batches[i % 2])
+        loss = run_step(i)
         marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
@@ -362,9 +414,38 @@ def main():
     nprof = max(1, min(a.profile_steps, a.steps))
     timer.on = True
     for i in range(nprof):
-        ts.step(batches[i % 2], **({"eager": True} if a.graph else {}))
+        run_step(i, **({"eager": True} if a.graph else {}))
     sync()
     timer.on = False
+    # ---- the front end by itself (HIP events on the launch stream, after the timed region): log-mel, augmentation
+    fe = None
+    if rank == 0:
+        try:
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            for i in range(2):
+                front_end(i)
+            t_mel = t_aug = 0.0
+            NFE = 6
+            for i in range(NFE):
+                b = dict(batches[i % 2])
+                evs[0].record()
+                b["input_features"] = log_mel(waves[i % 2], cfg.num_mel_bins)
+                evs[1].record()
+                augmenter(b)
+                evs[2].record()
+                torch.cuda.synchronize()
+                t_mel += evs[0].elapsed_time(evs[1]); t_aug += evs[1].elapsed_time(evs[2])
+            frames = N_SAMPLES // 160
+            mel_flop = a.batch * frames * (2.0 * 400 * 201 * 2 + 2.0 * 201 * cfg.num_mel_bins)
+            mel_bytes = a.batch * (N_SAMPLES * 4 + 2 * cfg.num_mel_bins * frames * 4 * 1.5)   # wave in; mel written, then read + rewritten by the normalisation pass
+            fe = {"logmel_ms": round(t_mel / NFE, 4), "logmel_gflops": round(mel_flop / (t_mel / NFE) / 1e6, 1),
+                  "logmel_algorithmic_mb": round(mel_bytes / 1e6, 1), "logmel_gbps": round(mel_bytes / (t_mel / NFE) / 1e6, 1),
+                  "augment_ms": round(t_aug / NFE, 4),
+                  "what": "dicow_logmel (direct fp32 DFT per frame + slaney mel + log / clamp) on B x 30 s of 16 kHz audio resident in HBM; "
+                          "BatchAugmenter with the STNO segment augmentation and the joint SpecAug forced on (host planner incl.)",
+                  "in_timed_region": bool(a.from_audio)}
+        except Exception as ex:
+            fe = {"logmel_ms": None, "note": f"failed: {ex!r}"}
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -400,14 +481,17 @@ def main():
         "data": "synthetic (random-init weights, N(0,1) mel clamped to [-1.5,1.5], 3-speaker STNO process, random labels)",
         "config": {"workload": f"{a.model} DiCoW fine-tune step, per-GPU batch {a.batch}, L={a.labels}, decoder frozen, "
                                f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}{', CTC 0.3' if a.ctc else ''}{', preheat phase (FDDT-only training)' if a.preheat else ''}"
-                               f"{', step replayed from a hipGraph' if a.graph else ''}",
+                               f"{', step replayed from a hipGraph' if a.graph else ''}{', from 16 kHz audio (log-mel + augmentation inside the step)' if a.from_audio else ''}",
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "trainable_params": sum(n for q, _, n, _ in ts.store.entries if q.requires_grad)},
         "loss": float(loss),
         "per_rank_ms_per_step": rank_ms,
         "allreduce": {"exposed_ms_per_step": rank_exposed,
                       "note": "time the compute stream waits for the side-stream RCCL buckets before the optimizer (0 at one rank)",
                       "backend": dist.get_backend() if dist.is_initialized() else None,
-                      "bytes_per_step": 4 * ts.store.n_trainable if world > 1 else 0},
+                      "forced_on_one_rank": bool(ts.reducer.force and world == 1),
+                      "buckets_per_step": len(ts.reducer.seg) if (world > 1 or ts.reducer.force) else 0,
+                      "gemm_cus": a.gemm_cus or None,
+                      "bytes_per_step": 4 * ts.store.n_trainable if (world > 1 or ts.reducer.force) else 0},
         "roofline": {"bound": "mfma", "kernel": "gemm_ntr_kernel (persistent LDS-ring 256x256 / 192x320) / gemm_nt_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
                      "achieved": round(nt["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(nt["tflops"] / peak, 4),
                      "traffic": TRAFFIC, "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // nprof,
@@ -419,6 +503,7 @@ def main():
                                              "what": "register-only v_mfma_f32_32x32x16_bf16 loop on all 256 CUs, random bf16 operands, 5 s: the board "
                                                      "settles at 1.90 GHz (constant operands: 2.39 GHz, 2453 TF); profiles/r02_power_mfma.txt"}},
         "power": power,
+        "front_end": fe,
         "kernels": {"gemm_tn_kernel": {"tflops": round(tn["tflops"], 1), "frac": round(tn["tflops"] / peak, 4),
                                        "share_of_step": round(tn["total_ms"] / nprof / ms, 3)}} if tn else {},
         # preheat phase: forward + dgrad only (2 x encoder + 2 x decoder), no encoder weight gradients

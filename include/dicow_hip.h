@@ -32,7 +32,7 @@ extern "C" {
 #define DICOW_ERR_INVALID (-1)  /* bad argument / unsupported shape */
 #define DICOW_ERR_LAUNCH (-2)   /* HIP launch failure */
 
-#define DICOW_ABI_VERSION 1
+#define DICOW_ABI_VERSION 2
 
 int dicow_abi_version(void);
 /* Number of CUs the persistent NT GEMM may occupy (0 = all, the default).  Its workgroups own a whole CU each for the
@@ -350,9 +350,10 @@ int dicow_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, flo
  * taken, counters[1 + i] = updates received by run i; torch keeps state['step'] per parameter), advances them and writes
  * hyper[3 i ..] for every active run: HF's LambdaLR indexing (the k-th step uses lambda(k - 1)), linear warm-up, cosine decay
  * to max_steps (configs/train/dicow_v3.yaml:66-68) or constant, x `mult` for preheat runs (containers.py:109-111);
- * preheat_only: the other runs are frozen (trainers.py:122-137) and neither counted nor written. */
-int dicow_adamw_hyper(int* counters, float* hyper, const int* is_pre, int n_runs, int preheat_only, float lr, float mult,
-                      int warmup_steps, int max_steps, int cosine, float beta1, float beta2, void* stream);
+ * preheat_only: the other runs are frozen (trainers.py:122-137) and neither counted nor written.  lr / mult / betas are doubles and
+ * the schedule and 1 - beta^t are evaluated in double on the device, as torch evaluates them on the host. */
+int dicow_adamw_hyper(int* counters, float* hyper, const int* is_pre, int n_runs, int preheat_only, double lr, double mult,
+                      int warmup_steps, int max_steps, int cosine, double beta1, double beta2, void* stream);
 int dicow_adamw_f32_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1, float beta2,
                         float eps, float weight_decay, const float* gnorm_sq, float max_norm, void* stream);
 

@@ -4,7 +4,7 @@ whisper-base and whisper-large-v3-turbo dimensions -- BASELINE.json configs[0], 
 configs[4] -- on integer-hashed weights and inputs (tests/util.py: hashed_init_, hashed_mel, hashed_stno, hashed_labels), so
 that the fixtures hold OUTPUTS only (a few hundred KB each) and the GPU tests regenerate identical weights:
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_realdims.py [rd_tiny rd_base rd_turbo rd_turbo_se]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_realdims.py [rd_tiny rd_base rd_turbo rd_turbo_se rd_turbo_peaked]
 
 Per case: fp32 loss (hard-label and soft-label), encoder output / logits sub-samples and per-frame statistics, every watched
 parameter gradient as (sub-sample, L2 norm, sum), and the deviation of the reference's OWN bf16-autocast run from its fp32 run
@@ -42,7 +42,20 @@ CASES = {
     "rd_base": ("whisper-base", 8, 64, {}, False, True),
     "rd_turbo": ("whisper-large-v3-turbo", 1, 128, {}, False, True),
     "rd_turbo_se": ("whisper-large-v3-turbo", 1, 64, dict(use_enrollments=True, scb_layers=8), True, False),
+    # hashed weights give unit-variance scores, i.e. near-uniform attention: dS = P (dP - delta) is then a difference of
+    # nearly equal numbers and the q / k projection gradients are weakly conditioned.  Same model with every attention's
+    # q_proj / k_proj (weights and the q bias) scaled by QK_SCALE: scores x QK_SCALE^2 -> peaked attention rows.
+    "rd_turbo_peaked": ("whisper-large-v3-turbo", 1, 128, {}, False, False),
 }
+QK_SCALE = {"rd_turbo_peaked": 2.0}
+
+
+def scale_qk_(model, f):
+    """q_proj / k_proj of every attention module x f (in place); the product-side test applies the same function."""
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if ".q_proj." in n or ".k_proj." in n:
+                p.mul_(f)
 TS_N = 1501                                  # <|0.00|> .. <|30.00|>: the last 1501 ids of the multilingual Whisper vocabularies
 
 
@@ -112,6 +125,8 @@ def run_case(name):
     torch.manual_seed(0)
     model = MG.DiCoWForConditionalGeneration(cfg).eval()
     hashed_init_(model)
+    if name in QK_SCALE:
+        scale_qk_(model, QK_SCALE[name])
     with torch.no_grad():                     # Whisper's sinusoidal table, as HF computes it
         model.model.encoder.embed_positions.weight.copy_(MG.mw.sinusoids(1500, cfg.d_model))
     x, st, lab, upp, lens = inputs(preset, B, L, mixed, se, name)
@@ -123,7 +138,7 @@ def run_case(name):
     params = dict(model.named_parameters())
     arrs = {"preset": np.array(preset), "B": np.array(B), "L": np.array(L), "extra": np.array(repr(extra)), "mixed": np.array(mixed),
             "lens": np.array(lens), "stno": st, "labels": lab, "upp_labels": upp, "watched": np.array("\n".join(W)),
-            "ts_start": np.array(ts_start(preset)), "ts_n": np.array(TS_N)}
+            "ts_start": np.array(ts_start(preset)), "ts_n": np.array(TS_N), "qk_scale": np.array(QK_SCALE.get(name, 1.0))}
     print(f"[{name}] model built in {time.time() - t0:.1f} s; {sum(p.numel() for p in model.parameters()) / 1e6:.0f} M parameters", flush=True)
 
     # ---- fp32, hard-label loss, all gradients

@@ -141,3 +141,19 @@ def test_bench_launcher_spawns_the_ranks_itself():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
                        text=True, timeout=120, cwd=root, env=dict(env, RANK="0", WORLD_SIZE="3"))
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_bench_launcher_returns_when_a_rank_dies_before_the_rendezvous():
+    """Rank 1 exits before joining the process group: rank 0 would wait in the rendezvous for its timeout.  The launcher polls
+    every child, kills the survivors on the first non-zero exit and reports the failed rank's stderr."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], capture_output=True,
+                       text=True, timeout=300, cwd=root, env=dict(env, DICOW_BENCH_FAIL_RANK="1"))
+    assert r.returncode == 1 and time.time() - t0 < 120
+    assert "rank exit codes" in r.stderr and "rank 1 failing on request" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

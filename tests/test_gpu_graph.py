@@ -58,3 +58,37 @@ def test_graph_mode_refuses_what_it_cannot_capture():
     ts = TrainStep(model, graph=True)
     with pytest.raises(NotImplementedError):
         ts.step(synthetic_batch(cfg, 1, 8, seed=1))
+
+
+def test_graph_cache_is_bounded_and_evicted_signatures_are_recaptured():
+    """Variable label lengths = one batch signature each.  The cache holds at most max_graphs graphs (LRU, one shared memory
+    pool); a signature that was evicted is captured again, and every step still applies the eager step's update bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    pkg = amd_pkg.load()
+    from ts_asr_whisper_amd.trainer import TrainStep
+    from ts_asr_whisper_amd.data import synthetic_batch
+    cfg = pkg.DiCoWConfig.preset("whisper-tiny", use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True,
+                                 fddt_init="suppressive", non_target_fddt_value=0.5)
+    lengths = [8, 12, 16]
+    order = [0, 0, 1, 1, 2, 2, 0, 0, 1, 2, 2]                          # each signature: eager first, captured on its second visit
+    out = {}
+    for graph in (False, True):
+        torch.manual_seed(0)
+        model = pkg.DiCoWForConditionalGeneration(cfg).cuda()
+        model.tie_weights()
+        ts = TrainStep(model, lr=1e-4, fddt_lr_multiplier=10.0, graph=graph)
+        ts.max_graphs = 2
+        batches = [synthetic_batch(cfg, 2, L, seed=70 + L) for L in lengths]
+        snaps = []
+        for i in order:
+            ts.step(batches[i])
+            snaps.append(ts.store.params.detach().clone())
+            assert len(ts._graphs) <= 2
+        out[graph] = snaps
+        if graph:
+            assert len(ts._graphs) == 2 and ts._graph_pool is not None
+            sigs = [k[1] for k in ts._graphs]
+            assert ts._sig_of(batches[2]) in sigs                      # the most recently replayed signature is resident
+    for k, (a, b) in enumerate(zip(out[False], out[True])):
+        assert torch.equal(a, b), f"parameters differ after step {k + 1}"

@@ -84,3 +84,54 @@ def test_train_step_update_rule_with_staged_freezing():
     assert not any("decoder" in n for n in moved) and "model.encoder.layers.0.fc1.weight" in moved
     # per-run bias correction: the encoder weights were first updated at global step 3
     assert sorted(set(ts.opt.run_t)) == [4, 6]
+
+
+def test_device_schedule_and_bias_corrections_match_torch_over_300_steps(ops):
+    """dicow_adamw_hyper (schedule and 1 - beta^t evaluated in double on the device) + the fused update against
+    torch.optim.AdamW driven by LambdaLR(get_cosine_schedule_with_warmup) -- the reference's optimizer / scheduler pair
+    (containers.py:100-114, dicow_v3.yaml:66-67) -- over 300 steps that cross the warm-up: the applied learning rate equals
+    torch's (as a float) at every step, lr_at() (logging) equals what was applied, parameters stay within 2e-6."""
+    import math
+    from ts_asr_whisper_amd.trainer import FusedAdamW
+
+    class Store:                                            # the slice of FlatStore the optimizer reads
+        pass
+
+    n, steps, warm, total = 4099, 300, 40, 400
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    st = Store()
+    st.params, st.grads = p0.cuda(), torch.zeros(n, device="cuda")
+    st.exp_avg, st.exp_avg_sq = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    st.runs = [(0, 2048, True), (2048, n, False)]
+    opt = FusedAdamW(st, lr=1e-3, fddt_lr_multiplier=10.0, weight_decay=0.01, max_grad_norm=1e9, warmup_steps=warm, max_steps=total)
+    ra, rb = torch.nn.Parameter(p0[:2048].clone()), torch.nn.Parameter(p0[2048:].clone())
+    topt = torch.optim.AdamW([{"params": [ra], "lr": 1e-2, "weight_decay": 0.0}, {"params": [rb], "lr": 1e-3, "weight_decay": 0.01}],
+                             betas=(0.9, 0.999), eps=1e-8)
+
+    def lam(k):                                             # transformers.get_cosine_schedule_with_warmup
+        if k < warm:
+            return float(k) / float(max(1, warm))
+        prog = float(k - warm) / float(max(1, total - warm))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 2.0 * 0.5 * prog)))
+    sched = torch.optim.lr_scheduler.LambdaLR(topt, lam)
+    worst = 0.0
+    for k in range(1, steps + 1):
+        grad = torch.randn(n, generator=g) * 0.1
+        ra.grad, rb.grad = grad[:2048].clone(), grad[2048:].clone()
+        lrs = [gr["lr"] for gr in topt.param_groups]
+        topt.step()
+        sched.step()
+        st.grads.copy_(grad)
+        opt.step()
+        if k in (1, 2, 3, warm, warm + 1, 150, steps):
+            applied = opt.applied_lr()
+            for got, want in zip(applied, lrs):
+                assert got == float(torch.tensor(want, dtype=torch.float32)), (k, got, want)
+            assert float(torch.tensor(opt.lr_at(k) * 10.0, dtype=torch.float32)) == applied[0]
+            hy = opt.hyper.cpu()
+            assert float(hy[1, 2]) == float(torch.tensor(1.0 - 0.999 ** k, dtype=torch.float32)), k
+            assert float(hy[1, 1]) == float(torch.tensor(1.0 - 0.9 ** k, dtype=torch.float32)), k
+            ref = torch.cat([ra.detach(), rb.detach()])
+            worst = max(worst, float((st.params.cpu() - ref).abs().max()))
+    assert worst < 2e-6, worst

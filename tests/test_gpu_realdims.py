@@ -40,6 +40,12 @@ def _build(z):
     torch.manual_seed(0)
     model = pkg.DiCoWForConditionalGeneration(cfg).cuda()
     hashed_init_(model)                                   # identical parameter names -> identical hashed values as the reference run
+    qk = float(z["qk_scale"]) if "qk_scale" in z.files else 1.0
+    if qk != 1.0:                                         # rd_turbo_peaked: q_proj / k_proj x qk_scale (make_golden_realdims.scale_qk_)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if ".q_proj." in n or ".k_proj." in n:
+                    p.mul_(qk)
     with torch.no_grad():
         model.model.encoder.embed_positions.weight.copy_(sinusoids(cfg.max_source_positions, cfg.d_model))
     model.tie_weights()
@@ -90,6 +96,9 @@ def _check_forward(z, out):
 
 def _check_grads(z, model, prefix, names, min_checked):
     named = dict(model.named_parameters())
+    # peaked attention (rd_turbo_peaked): dS is no longer a difference of nearly equal numbers, so the q / k projection
+    # sketches are held to the general bound -- no flash-delta allowance
+    peaked = "qk_scale" in z.files and float(z["qk_scale"]) != 1.0
     worst, n = (0.0, None), 0
     for name in names:
         key = f"{prefix}.g.{name}"
@@ -109,7 +118,7 @@ def _check_grads(z, model, prefix, names, min_checked):
             sk = sketch(named[name].grad.float(), name).cpu()
             # a projection of an N-element tensor is ~ |g| in size: errors are measured against the norm, not the projection
             e_ours, e_ref = float((sk - ref_sk).abs().max()) / max(ref_norm, 1e-30), float((bf_sk - ref_sk).abs().max()) / max(ref_norm, 1e-30)
-            flash_delta = ".q_proj." in name or ".k_proj." in name        # (see the docstring)
+            flash_delta = (".q_proj." in name or ".k_proj." in name) and not peaked        # (see the docstring)
             assert e_ours < (0.16 if flash_delta else max(5e-2, 4 * e_ref)), (name, "sketch", e_ours, e_ref)
         if r_sub > worst[0]:
             worst = (r_sub, name)
@@ -131,7 +140,7 @@ class _Tok:
         return v
 
 
-@pytest.mark.parametrize("case", ["rd_tiny", "rd_base", "rd_turbo", "rd_turbo_se"])
+@pytest.mark.parametrize("case", ["rd_tiny", "rd_base", "rd_turbo", "rd_turbo_se", "rd_turbo_peaked"])
 def test_real_dimension_step_vs_reference_golden(case):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -152,3 +161,53 @@ def test_real_dimension_step_vs_reference_golden(case):
         assert abs(float(out.loss) - float(z["soft.loss"])) < max(2e-2, 3 * dloss), (float(out.loss), float(z["soft.loss"]))
         out.loss.backward()
         _check_grads(z, model, "soft", names, min_checked=8)
+
+
+def test_configs2_batch16_step_row0_vs_reference_golden_and_loss_is_the_mean_of_the_rows():
+    """BASELINE.json configs[2] at ITS OWN batch size: whisper-large-v3-turbo DiCoW, per-GPU batch 16, L = 128, hashed weights.
+    Row 0 of the batch is the sample of golden rd_turbo (the real reference's run), rows 1-15 are further hashed clips:
+      * row 0's encoder output and logits must match the reference within rd_turbo's own tolerances (the B = 16 step takes
+        the 24000-row kernel variants -- persistent 256x256 / 192x320 GEMM tiles, the staged row kernels -- which the B = 1
+        golden run never reaches);
+      * the step's loss is the mean over ALL label positions (modeling_dicow.py:310-323) = the mean of the 16 rows' own
+        losses, each computed by a separate B = 1 forward;
+      * every row's encoder output equals its B = 1 forward (batch invariance of the whole encoder at the bench shape)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tests.util import hashed_stno, hashed_labels
+    z = load_golden("rd_turbo")
+    model, cfg = _build(z)
+    B, L, T = 16, int(z["L"]), cfg.max_source_positions
+    b1 = _batch(z, cfg)
+    x = torch.from_numpy(hashed_mel(B, cfg.num_mel_bins, 2 * T)).clone() * 1.5
+    st = hashed_stno(B, T, "rd_turbo_b16.stno")
+    lab = hashed_labels(B, L, 0, 50257, "rd_turbo_b16.labels", pad_rows=(3, 9))
+    x[0], st[0], lab[0] = b1["input_features"][0].cpu(), b1["stno_mask"][0].cpu(), b1["labels"][0].cpu()
+    upp = lab.clone()
+    upp[0] = b1["upp_labels"][0].cpu()
+    batch = dict(input_features=x.cuda(), stno_mask=st.cuda(), labels=lab.cuda(), upp_labels=upp.cuda())
+    out = model(**batch)
+    enc, logits = out.encoder_last_hidden_state.float(), out.logits.float()
+    assert enc.shape == (B, T, cfg.d_model) and logits.shape[:2] == (B, L)
+
+    import types
+    Row0 = types.SimpleNamespace(encoder_last_hidden_state=enc[:1], logits=logits[:1], loss=None)   # row 0 as a B = 1 output
+    # (the loss line of _check_forward needs row 0's own loss: computed below from the B = 1 forward of row 0)
+    rows_loss, worst_inv = [], 0.0
+    with torch.no_grad():
+        for r in range(B):
+            o1 = model(**{k: v[r:r + 1] for k, v in batch.items()})
+            rows_loss.append(float(o1.loss))
+            d = float((o1.encoder_last_hidden_state.float() - enc[r:r + 1]).abs().max())
+            worst_inv = max(worst_inv, d)
+    Row0.loss = torch.tensor(rows_loss[0])
+    _check_forward(z, Row0)
+    # different tile shapes / split factors at 1500 and 24000 rows: fp32 accumulation order differs, bf16 roundings flip
+    assert worst_inv < 6e-2, worst_inv
+    mean_rows = sum(rows_loss) / B
+    assert abs(float(out.loss) - mean_rows) < 2e-3 * abs(mean_rows), (float(out.loss), mean_rows)
+    out.loss.backward()                                     # the B = 16 backward runs and leaves finite gradients everywhere
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+    print("configs[2] B=16: worst row-vs-B=1 encoder deviation", worst_inv, "loss", float(out.loss), "mean of rows", mean_rows)

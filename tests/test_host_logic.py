@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()                       # raises loudly if the .so has not been built
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dicow_abi_version() == 1
+    assert lib.dicow_abi_version() == 2
 
 
 def test_no_cpu_fallback_and_oracle_not_imported_by_product():
@@ -288,6 +288,51 @@ def test_product_temperature_fallback_matches_transformers_golden():
     _check_fallback(decode_with_fallback, token_compression_ratio, sequence_avg_logprob)
 
 
+def test_fallback_skip_flag_indexing_default_is_transformers_quirk_and_skip_by_row_fixes_it():
+    """Three windows: window 0 fails the log-probability test once and is fine at the next temperature, window 1 decodes
+    fine, window 2 fails it and turns out to be silence when decoded again.  In the second round the sub-batch is [0, 2]:
+    transformers (hence the reference, generation.py:567-611) writes window 2's should_skip at position 1 of `should_skip`
+    -- window 1's slot -- and golden F18 pins that; skip_by_row=True keeps the flag with window 2."""
+    import torch
+    from ts_asr_whisper_amd.generation import decode_with_fallback
+    V, eos, pad = 16, 15, 14
+    def scores_for(tokens, good):
+        sc = torch.full((len(tokens), V), -8.0)
+        for i, t in enumerate(tokens):
+            sc[i, t] = 8.0 if good else -7.9
+        return sc
+    good = {(0, 0): False, (1, 0): True, (2, 0): False, (0, 1): True, (2, 1): False}
+    def decode(rows, temp):
+        k = 0 if temp == 0.0 else 1
+        toks = [[3 + r, 5, 7, eos] for r in rows]
+        return toks, [scores_for(t, good[(r, k)]) for r, t in zip(rows, toks)], [0.99 if (r == 2 and k == 1) else 0.1 for r in rows]
+    kw = dict(compression_ratio_threshold=None, logprob_threshold=-1.0, no_speech_threshold=0.6)
+    final, skip, used = decode_with_fallback(decode, 3, (0.0, 0.2), V, pad, eos, **kw)
+    assert used == [1, 0, 1] and skip == [False, True, False]            # the quirk: flag of window 2 sits in window 1's slot
+    final2, skip2, used2 = decode_with_fallback(decode, 3, (0.0, 0.2), V, pad, eos, skip_by_row=True, **kw)
+    assert used2 == used and final2 == final and skip2 == [False, False, True]
+
+
 def test_graft_entry_exposes_build_and_smoke():
     import __graft_entry__ as g
     assert callable(g.build) and callable(g.smoke)
+
+
+def test_no_environment_knobs_on_the_product_dispatch_path():
+    """Tuning knobs read with getenv() exist only inside `#ifdef DICOW_ABLATIONS` regions of the kernels' host code (diagnostic
+    builds of tools/build_*variants.sh); the shipped library's dispatch depends on its arguments alone."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in sorted(glob.glob(os.path.join(root, "ts-asr-whisper_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "ts-asr-whisper_amd", "csrc", "*.inc"))):
+        depth_abl, stack = 0, []
+        for n, line in enumerate(open(path), 1):
+            t = line.strip()
+            if re.match(r"#\s*if", t):
+                stack.append("DICOW_ABLATIONS" in t and not t.startswith("#ifndef"))
+            elif re.match(r"#\s*else", t) and stack:
+                stack[-1] = False
+            elif re.match(r"#\s*endif", t) and stack:
+                stack.pop()
+            if "getenv(" in t and not t.startswith("//"):
+                assert any(stack), f"{os.path.basename(path)}:{n}: getenv outside DICOW_ABLATIONS: {t}"

@@ -64,5 +64,22 @@ t = timeit(lambda: ops.fddt_ln_bwd(h, M, D, mode=1, stno=st, T=T, w=w, b=b, ln_w
 byt = M * D * (4 + 2 + 4 + 4 + 2)
 res["fddt_ln_bwd"] = {"ms": t, "GBps": byt / t / 1e6}
 print("fddt_ln_bwd", res["fddt_ln_bwd"], flush=True)
+# ---- the log-mel front end (row A1): 16 clips x 30 s of 16 kHz audio -> [16, 128, 3000] fp32
+from ts_asr_whisper_amd.features import log_mel, N_SAMPLES
+from ts_asr_whisper_amd.augment import BatchAugmenter
+wave = torch.randn(B, N_SAMPLES, device="cuda") * 0.1
+for M_ in (80, 128):
+    t = timeit(lambda: log_mel(wave, M_), iters=10)
+    frames = N_SAMPLES // 160
+    fl = B * frames * (2.0 * 400 * 201 * 2 + 2.0 * 201 * M_)
+    byt = B * (N_SAMPLES * 4 + 3 * M_ * frames * 4)          # wave read; mel written, re-read and re-written by the clamp pass
+    res[f"logmel_{M_}"] = {"us": t * 1e3, "GFLOPs_fp32": fl / t / 1e6, "algorithmic_MB": byt / 1e6, "GBps": byt / t / 1e6,
+                           "note": "logmel_kernel (direct DFT, fp32 VALU) + logmel_finalize_kernel"}
+    print(f"logmel_{M_}", res[f"logmel_{M_}"], flush=True)
+mel = torch.randn(B, 128, 3000, device="cuda").clamp_(-1.5, 1.5)
+aug = BatchAugmenter(stno_segment_augment_prob=1.0, spec_aug_prob=1.0)
+t = timeit(lambda: aug({"input_features": mel, "stno_mask": st}), iters=10)
+res["batch_augmenter"] = {"us": t * 1e3, "note": "STNO segment augmentation + joint SpecAug forced on, host planner included"}
+print("batch_augmenter", res["batch_augmenter"], flush=True)
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(res, open("gpurun_out/bench_kernels.json", "w"), indent=1)

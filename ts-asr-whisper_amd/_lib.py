@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DICOW_HIP_LIB") or os.path.join(_HERE, "libdicow_hip.so")   # override: diagnostic builds
 _lib = None
 
-c_vp, c_i, c_i64, c_f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+c_vp, c_i, c_i64, c_f, c_d = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double
 
 
 class FddtLnFwdArgs(C.Structure):
@@ -115,7 +115,7 @@ _SIGS = {
     "dicow_whisper_timestamp_rules": [c_vp, c_i64, c_i, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "dicow_sumsq_f32": [c_vp, c_i64, c_vp, c_vp],
     "dicow_adamw_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_f, c_vp],
-    "dicow_adamw_hyper": [c_vp, c_vp, c_vp, c_i, c_i, c_f, c_f, c_i, c_i, c_i, c_f, c_f, c_vp],
+    "dicow_adamw_hyper": [c_vp, c_vp, c_vp, c_i, c_i, c_d, c_d, c_i, c_i, c_i, c_d, c_d, c_vp],
     "dicow_adamw_f32_dev": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f, c_f, c_f, c_f, c_vp, c_f, c_vp],
 }
 

@@ -329,9 +329,17 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#if defined(DICOW_ABLATIONS) && defined(ATTN_ABL_NOFMA)
+                const float p = __builtin_amdgcn_exp2f(s[kb][r]);
+#elif defined(DICOW_ABLATIONS) && defined(ATTN_ABL_NOEXP)
+                const float p = fmaf(s[kb][r], LOG2E, -mL);
+#else
                 const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mL));
+#endif
                 s[kb][r] = p;
+#if !(defined(DICOW_ABLATIONS) && defined(ATTN_ABL_NOSUM))
                 psum += p;
+#endif
             }
         l_run += psum;
 

@@ -42,13 +42,31 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, b);
 }
 
-// exact (erf) GELU and its derivative (Whisper activation_function="gelu"), evaluated with the Abramowitz-Stegun
-// 7.1.26 form of erfc: 0.5*erfc(|x|/sqrt2) = 0.5 * t*(a1 + t*(a2 + t*(a3 + t*(a4 + t*a5)))) * exp(-x^2/2),
-// t = 1/(1 + p|x|/sqrt2).  |error| < 5e-7 on gelu and gelu' (checked against float64 over [-8, 8]; libm's erff-based
-// fp32 gelu is itself only good to ~1e-6 there) at ~14 full-rate VALU + v_rcp + v_exp per element instead of the
-// ~40 instructions of erff/expf: the GEMM epilogues that apply it run one wave per SIMD, so every VALU cycle in them
-// is a cycle the matrix pipe idles.  The same exponential gives the Gaussian density, so the derivative is ~free.
+// exact (erf) GELU and its derivative (Whisper activation_function="gelu").  Every kernel evaluates the SAME expression (this
+// scalar form and the packed stage-major gelu_cdf_pdf_p below are operation-for-operation identical), so the training
+// forward, the inference forward and the decoder step produce identical activations.
+//   Round 3 form (DICOW_GELU_V 1): Phi(x) = 1 / (1 + 2^(x q(x^2))), q = degree-4 fit of -log2(e) logit(Phi(x)) / x -- see
+//   gelu_cdf_pdf_p.  |d gelu| < 6e-6 over all bf16 inputs.
+//   Round 1/2 form (DICOW_GELU_V 0): Abramowitz-Stegun 7.1.26 erfc, 0.5 erfc(|x|/sqrt2) = t poly4(t) exp(-x^2/2) / 2,
+//   t = 1/(1 + p|x|/sqrt2); |error| < 5e-7.
+#define GELU_Q0 -2.3021653554162658f
+#define GELU_Q1 -0.10500593863530419f
+#define GELU_Q2 0.0002534117686203228f
+#define GELU_Q3 0.00010587535896480078f
+#define GELU_Q4 -4.1117263817008095e-06f
+#ifndef DICOW_GELU_V
+#define DICOW_GELU_V 1
+#endif
 __device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
+#if DICOW_GELU_V == 1
+    const float s = x * x;
+    float q = fmaf(s, GELU_Q4, GELU_Q3);
+    q = fmaf(q, s, GELU_Q2);
+    q = fmaf(q, s, GELU_Q1);
+    q = fmaf(q, s, GELU_Q0);
+    cdf = __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(q * x) + 1.0f);
+    pdf = __builtin_amdgcn_exp2f(s * -0.72134752044448170f) * 0.3989422804014327f;
+#else
     // z = |x| sqrt(log2(e)/2): exp(-x^2/2) = 2^(-z^2) needs no further scaling, t = 1/(1 + p |x|/sqrt2) = 1/(1 + p' z), and the
     // 0.5 of 0.5*erfc is folded into the polynomial coefficients (two multiplies fewer per element than the textbook form)
     const float z = fabsf(x) * 0.84932180028801907f;
@@ -61,6 +79,7 @@ __device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
     const float h = p * t * e;                                                       // Phi(-|x|)
     cdf = x >= 0.f ? 1.0f - h : h;
     pdf = e * 0.3989422804014327f;
+#endif
 }
 __device__ __forceinline__ float gelu_erf(float x) {
     float cdf, pdf;
@@ -96,7 +115,9 @@ __device__ __forceinline__ void stage_fence2(f32x2_t (&a)[NP]) {
 #pragma unroll
     for (int i = 0; i < NP; i += 4) asm volatile("" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
 }
-// x: NP pairs -> cdf = Phi(x), pdf = phi(x)  (same erfc form and coefficients as gelu_cdf_pdf)
+// x: NP pairs -> cdf = Phi(x), pdf = phi(x)
+#if DICOW_GELU_V == 0
+// (round-1/2 form: same erfc expression and coefficients as the scalar A-S 7.1.26 version; kept for A/B builds)
 template <int NP, bool WANT_PDF>
 __device__ __forceinline__ void gelu_cdf_pdf_p(const f32x2_t (&x)[NP], f32x2_t (&cdf)[NP], f32x2_t (&pdf)[NP]) {
     f32x2_t z[NP], t[NP], e[NP], p[NP];
@@ -138,6 +159,103 @@ __device__ __forceinline__ void gelu_cdf_pdf_p(const f32x2_t (&x)[NP], f32x2_t (
         stage_fence2(pdf);
     }
 }
+#elif DICOW_GELU_V == 1
+// Round 3: Phi(x) = 1 / (1 + 2^(x q(x^2))), q = the degree-4 minimax fit (in x^2) of -log2(e) logit(Phi(x)) / x, weighted by
+// Phi (1 - Phi).  The logit of the normal cdf is odd, smooth and nearly cubic, so five coefficients give |dPhi| < 1.5e-6 and
+// |d gelu| < 6e-6 over EVERY bf16 input (tools/gelu_fit.py: exhaustive over the 65280 finite bf16 values in fp32 emulation,
+// bf16-rounded gelu differs from the float64 one for 256 of them against 167 for the erfc form), and the leading coefficient
+// is negative, so the form saturates by itself: x q -> -+inf, 2^. -> 0 / inf, 1/(1 + .) -> 1 / 0 -- no clamp, no sign
+// handling, no NaN for any finite or infinite input.  Per pair: 7 packed full-rate instructions + 2 v_exp + 2 v_rcp
+// (erfc form: ~15 + 4), all of them plain dependency chains that the stage-major order interleaves.
+template <int NP, bool WANT_PDF>
+__device__ __forceinline__ void gelu_cdf_pdf_p(const f32x2_t (&x)[NP], f32x2_t (&cdf)[NP], f32x2_t (&pdf)[NP]) {
+    f32x2_t s[NP], q[NP];
+    const f32x2_t one = {1.0f, 1.0f};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) s[i] = x[i] * x[i];
+    stage_fence2(s);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(s[i], f32x2_t{GELU_Q4, GELU_Q4}, f32x2_t{GELU_Q3, GELU_Q3});
+    stage_fence2(q);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(q[i], s[i], f32x2_t{GELU_Q2, GELU_Q2});
+    stage_fence2(q);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(q[i], s[i], f32x2_t{GELU_Q1, GELU_Q1});
+    stage_fence2(q);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(q[i], s[i], f32x2_t{GELU_Q0, GELU_Q0});
+    stage_fence2(q);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = q[i] * x[i];
+    stage_fence2(q);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { q[i].x = __builtin_amdgcn_exp2f(q[i].x); q[i].y = __builtin_amdgcn_exp2f(q[i].y); }
+    stage_fence2(q);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = q[i] + one;
+    stage_fence2(q);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { cdf[i].x = __builtin_amdgcn_rcpf(q[i].x); cdf[i].y = __builtin_amdgcn_rcpf(q[i].y); }
+    stage_fence2(cdf);
+    if (WANT_PDF) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) s[i] = s[i] * -0.72134752044448170f;             // -x^2/2 * log2(e)
+        stage_fence2(s);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) { s[i].x = __builtin_amdgcn_exp2f(s[i].x); s[i].y = __builtin_amdgcn_exp2f(s[i].y); }
+        stage_fence2(s);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pdf[i] = s[i] * 0.3989422804014327f;
+        stage_fence2(pdf);
+    }
+}
+#elif DICOW_GELU_V == 2
+// A/B candidate without transcendentals: Phi(x) = 0.5 + xc P(xc^2), xc = clamp(x, -4, 4), P of degree 8 through P(16) = 1/8
+template <int NP, bool WANT_PDF>
+__device__ __forceinline__ void gelu_cdf_pdf_p(const f32x2_t (&x)[NP], f32x2_t (&cdf)[NP], f32x2_t (&pdf)[NP]) {
+    f32x2_t s[NP], q[NP], xc[NP];
+    const f32x2_t half = {0.5f, 0.5f};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { xc[i].x = __builtin_amdgcn_fmed3f(x[i].x, -4.0f, 4.0f); xc[i].y = __builtin_amdgcn_fmed3f(x[i].y, -4.0f, 4.0f); }
+    stage_fence2(xc);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) s[i] = xc[i] * xc[i];
+    stage_fence2(s);
+    const float c_[9] = {3.9907026948e-01f, -6.6837845791e-02f, 1.0242059735e-02f, -1.2744738650e-03f, 1.2776073518e-04f,
+                         -9.6645953779e-06f, 4.9620894472e-07f, -1.4959220843e-08f, 1.9681844066e-10f};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(s[i], f32x2_t{c_[8], c_[8]}, f32x2_t{c_[7], c_[7]});
+    stage_fence2(q);
+#pragma unroll
+    for (int k = 6; k >= 0; --k) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(q[i], s[i], f32x2_t{c_[k], c_[k]});
+        stage_fence2(q);
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) cdf[i] = __builtin_elementwise_fma(q[i], xc[i], half);
+    stage_fence2(cdf);
+    if (WANT_PDF) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) s[i] = (x[i] * x[i]) * -0.72134752044448170f;
+        stage_fence2(s);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) { s[i].x = __builtin_amdgcn_exp2f(s[i].x); s[i].y = __builtin_amdgcn_exp2f(s[i].y); }
+        stage_fence2(s);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) pdf[i] = s[i] * 0.3989422804014327f;
+        stage_fence2(pdf);
+    }
+}
+#else
+// ablation: no activation arithmetic at all (cost of everything else in a GELU epilogue)
+template <int NP, bool WANT_PDF>
+__device__ __forceinline__ void gelu_cdf_pdf_p(const f32x2_t (&x)[NP], f32x2_t (&cdf)[NP], f32x2_t (&pdf)[NP]) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) { cdf[i] = f32x2_t{0.5f, 0.5f}; pdf[i] = f32x2_t{0.25f, 0.25f}; }
+}
+#endif
 
 // ---- wave / block reductions (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -502,33 +502,37 @@ extern "C" int dicow_adamw_f32(float* p, const float* g, float* m, float* v, int
 // at max_steps or constant) x the group multiplier for preheat runs.  Both the launch-by-launch step and its captured
 // hipGraph go through this kernel, so they apply bit-identical updates.
 __global__ void adamw_hyper_kernel(int* __restrict__ counters, float* __restrict__ hyper, const int* __restrict__ is_pre, int n_runs,
-                                   int preheat_only, float lr, float mult, int warmup, int max_steps, int cosine, float b1, float b2) {
-    const int i = threadIdx.x;
+                                   int preheat_only, double lr, double mult, int warmup, int max_steps, int cosine, double b1, double b2) {
+    // The schedule and the bias corrections are evaluated in DOUBLE, as torch does (LambdaLR and AdamW's 1 - beta^t are Python
+    // floats): 1 - powf(0.999f, t) is off by ~1e-5 relative for small t -- the float nearest to 0.999 is not 0.999 -- and the
+    // logged learning rate (FusedAdamW.lr_at, Python doubles) then equals the applied one to the last bit of its float value.
+    // One thread per run, any number of runs.
     const int k = counters[0] + 1;
     __syncthreads();
-    if (i == 0) counters[0] = k;
-    if (i >= n_runs) return;
-    const int pre = is_pre[i];
-    if (preheat_only && !pre) return;
-    const int t = counters[1 + i] + 1;
-    counters[1 + i] = t;
+    if (threadIdx.x == 0) counters[0] = k;
     const int ss = k - 1;
-    float l = lr;
-    if (ss < warmup) l = lr * (float)ss / (float)(warmup > 1 ? warmup : 1);
+    double l = lr;
+    if (ss < warmup) l = lr * (double)ss / (double)(warmup > 1 ? warmup : 1);
     else if (cosine && max_steps > 0) {
-        const float prog = (float)(ss - warmup) / (float)((max_steps - warmup) > 1 ? (max_steps - warmup) : 1);
-        const float c = 0.5f * (1.0f + cosf(3.14159265358979323846f * prog));
-        l = lr * (c > 0.f ? c : 0.f);
+        const double prog = (double)(ss - warmup) / (double)((max_steps - warmup) > 1 ? (max_steps - warmup) : 1);
+        const double c = 0.5 * (1.0 + cos(3.14159265358979323846 * prog));
+        l = lr * (c > 0.0 ? c : 0.0);
     }
-    hyper[3 * i] = l * (pre ? mult : 1.0f);
-    hyper[3 * i + 1] = 1.0f - powf(b1, (float)t);
-    hyper[3 * i + 2] = 1.0f - powf(b2, (float)t);
+    for (int i = threadIdx.x; i < n_runs; i += blockDim.x) {
+        const int pre = is_pre[i];
+        if (preheat_only && !pre) continue;
+        const int t = counters[1 + i] + 1;
+        counters[1 + i] = t;
+        hyper[3 * i] = (float)(l * (pre ? mult : 1.0));
+        hyper[3 * i + 1] = (float)(1.0 - pow(b1, (double)t));
+        hyper[3 * i + 2] = (float)(1.0 - pow(b2, (double)t));
+    }
 }
 
-extern "C" int dicow_adamw_hyper(int* counters, float* hyper, const int* is_pre, int n_runs, int preheat_only, float lr, float mult,
-                                 int warmup_steps, int max_steps, int cosine, float beta1, float beta2, void* stream) {
-    DICOW_REQUIRE(counters && hyper && is_pre && n_runs > 0 && n_runs <= 1024, "adamw_hyper: bad args (at most 1024 runs)");
-    const int block = (n_runs + 63) / 64 * 64;
+extern "C" int dicow_adamw_hyper(int* counters, float* hyper, const int* is_pre, int n_runs, int preheat_only, double lr, double mult,
+                                 int warmup_steps, int max_steps, int cosine, double beta1, double beta2, void* stream) {
+    DICOW_REQUIRE(counters && hyper && is_pre && n_runs > 0, "adamw_hyper: bad args");
+    const int block = n_runs >= 1024 ? 1024 : (n_runs + 63) / 64 * 64;
     hipLaunchKernelGGL(adamw_hyper_kernel, dim3(1), dim3(block), 0, (hipStream_t)stream, counters, hyper, is_pre, n_runs, preheat_only,
                        lr, mult, warmup_steps, max_steps, cosine, beta1, beta2);
     DICOW_CHECK_LAUNCH("adamw_hyper");

@@ -414,7 +414,11 @@ extern "C" int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream) 
     const int R = 4;
     const int block = pick_block(a->D);
     int grid = dicow_cdiv(a->rows, R);
-    static const int fwd_env = getenv("DICOW_ROW_FWD") ? atoi(getenv("DICOW_ROW_FWD")) : 0;      // 9: generic body (ablation)
+#ifdef DICOW_ABLATIONS
+    static const int fwd_env = getenv("DICOW_ROW_FWD") ? atoi(getenv("DICOW_ROW_FWD")) : 0;      // 9: generic body (diagnostic builds only)
+#else
+    constexpr int fwd_env = 0;
+#endif
     const bool staged = fwd_env != 9 && block <= 512 && block * 4 == a->D && a->mode == 1 && a->ln_w && !a->in_bf16 && a->h_out &&
                         a->y_bf16 && !a->y_f32 && a->mean && a->rstd && !a->pos && a->w[0] && a->w[1] && a->w[2] && a->w[3] &&
                         a->b[0] && a->b[1] && a->b[2] && a->b[3] && (int64_t)a->rows * a->D * 4 < (1ll << 31);
@@ -790,7 +794,11 @@ extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) 
     DICOW_REQUIRE(a->ln_w == nullptr || (a->mean && a->rstd && a->d_y), "fddt_ln_bwd: LayerNorm needs mean/rstd/d_y");
     DICOW_REQUIRE(a->ln_w || a->g_res, "fddt_ln_bwd: no incoming gradient");
     const int block = pick_block(a->D);
-    static const int r_env = getenv("DICOW_ROW_R") ? atoi(getenv("DICOW_ROW_R")) : 0;       // tuning knob: 0 = auto, 9 = generic body
+#ifdef DICOW_ABLATIONS
+    static const int r_env = getenv("DICOW_ROW_R") ? atoi(getenv("DICOW_ROW_R")) : 0;       // diagnostic builds only: 0 = auto, 9 = generic body
+#else
+    constexpr int r_env = 0;
+#endif
     const bool ln0 = block <= 512 && r_env != 9 && a->mode == 0 && a->ln_w;
     // LDS-staged body: the encoder-layer shape (every FDDT vector present, fp32 in, bf16 d_y, residual gradient, no pos)
     const bool staged = block <= 512 && block * 4 == a->D && a->D % 8 == 0 && r_env != 9 && r_env != 8 && a->mode == 1 && a->ln_w && !a->in_bf16 &&

@@ -46,8 +46,15 @@ __device__ float target_dot(const unsigned short* row, int64_t label, const dico
     return block_reduce_sum(s, red);
 }
 
+// The step's loss is the sum of the row losses IN ROW ORDER: the workgroup that finishes last (ticket) adds row_loss[] up with a
+// fixed assignment of rows to threads and a fixed tree, so the logged loss is bit-reproducible from run to run (a float
+// atomicAdd per row made its last bits depend on the order the workgroups retired in).  One ce_fwd in flight per device.
+__device__ unsigned g_ce_ticket = 0;
+
 __global__ void __launch_bounds__(LOSS_THREADS) ce_fwd_kernel(const dicow_ce_args a) {
     __shared__ float red[LOSS_THREADS / 64];
+    __shared__ float tot[LOSS_THREADS];
+    __shared__ bool last;
     const int r = blockIdx.x;
     const unsigned short* row = reinterpret_cast<const unsigned short*>(a.logits) + (int64_t)r * a.ld;
     // online max / sum-exp, 8 bf16 per load
@@ -101,8 +108,24 @@ __global__ void __launch_bounds__(LOSS_THREADS) ce_fwd_kernel(const dicow_ce_arg
         a.lse[r] = lse;
         a.row_loss[r] = l;
         a.choice[r] = choice;
-        atomicAdd(a.loss_sum, l);
-        if (valid_lo) atomicAdd(a.count, 1.0f);
+        if (valid_lo) atomicAdd(a.count, 1.0f);           // (a count of ones: exact in any order)
+        __threadfence();
+        last = atomicAdd(&g_ce_ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float t = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += LOSS_THREADS) t += __builtin_nontemporal_load(&a.row_loss[i]);
+    tot[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = LOSS_THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) tot[threadIdx.x] += tot[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.loss_sum[0] += tot[0];
+        g_ce_ticket = 0;
     }
 }
 

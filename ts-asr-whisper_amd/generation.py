@@ -407,11 +407,17 @@ def window_needs_fallback(tokens, scores, temperature, vocab_size, compression_r
 
 
 def decode_with_fallback(decode, n_windows, temperatures, vocab_size, pad_token_id, eos_token_id, compression_ratio_threshold=1.35,
-                         logprob_threshold=-1.0, no_speech_threshold=None):
+                         logprob_threshold=-1.0, no_speech_threshold=None, skip_by_row=False):
     """Temperature ladder over a batch of windows.  decode(rows, temperature) -> (token lists of the generated positions,
     [n, V] score tensors, no-speech probabilities or None) for the listed windows.  Every window keeps its latest result;
     those that fail the compression / log-probability test are decoded again at the next temperature.
-    Returns (token lists without the eos, should_skip flags, index of the temperature each window ended with)."""
+    Returns (token lists without the eos, should_skip flags, index of the temperature each window ended with).
+
+    skip_by_row=False reproduces transformers' `generate_with_fallback` (which the reference delegates to, generation.py:567-611)
+    to the letter, INCLUDING its indexing quirk: `should_skip` is written at the window's position in the CURRENT fallback
+    sub-batch, so after the first fallback round a silent window's flag lands on another window of the batch (golden F18 pins
+    that behaviour).  skip_by_row=True is the corrected form: the flag is kept per original window and cleared when the
+    window is decoded again."""
     final, used, skip = [None] * n_windows, [None] * n_windows, [False] * n_windows
     rows = list(range(n_windows))
     for k, temp in enumerate(temperatures):
@@ -425,7 +431,7 @@ def decode_with_fallback(decode, n_windows, temperatures, vocab_size, pad_token_
                     seq = seq[:-npad]
             needs, sk = window_needs_fallback(seq, scores[i], temp, vocab_size, compression_ratio_threshold, logprob_threshold,
                                               no_speech_threshold, None if nsp is None else float(nsp[i]))
-            skip[i] = sk                              # (transformers indexes this list by the position in the CURRENT batch)
+            skip[row if skip_by_row else i] = sk      # (transformers indexes this list by the position in the CURRENT batch)
             final[row], used[row] = (seq[:-1] if seq and seq[-1] == eos_token_id else seq), k
             if needs:
                 again.append(row)

@@ -677,6 +677,22 @@ class DiCoWForConditionalGeneration(nn.Module):
         cfg = self.config
         ts_on = return_timestamps if return_timestamps is not None else get("return_timestamps", False)
         one_window = input_features.shape[-1] == 2 * cfg.max_source_positions
+        # Sampling / fallback arguments that are not honoured on a path raise instead of being ignored (cf. _refuse_unsupported):
+        # HF samples at a scalar temperature > 0 and runs generate_with_fallback inside its seek loop on every input.
+        temps = get("temperature")
+        ladder = isinstance(temps, (tuple, list))
+        takes_seek_loop = (one_window and ts_on and hasattr(self.tokenizer, "get_vocab")) or input_features.shape[-1] > 2 * cfg.max_source_positions
+        if temps is not None and not ladder and float(temps) > 0.0:
+            raise NotImplementedError("generate(temperature=t > 0): plain sampling is not implemented; pass a tuple (0.0, 0.2, ...) for "
+                                      "the temperature-fallback ladder (GreedyDecoder.generate(temperature=...) samples one window)")
+        if ladder and beams > 1:
+            raise NotImplementedError("generate(): the temperature-fallback ladder is implemented for greedy decoding (num_beams == 1)")
+        if ladder and not takes_seek_loop and any(float(t) > 0.0 for t in temps):
+            raise NotImplementedError("generate(): the temperature-fallback ladder runs inside the seek loop (timestamps on and a "
+                                      "tokenizer set, or a recording longer than one window); this call takes the single-pass path")
+        if get("no_speech_threshold") is not None and get("logprob_threshold") is None and ladder:
+            raise ValueError("no_speech_threshold only takes effect together with logprob_threshold (a window is skipped when it is "
+                             "unlikely AND silent)")
         # HF's generate -- which the reference's calls (generation.py:558) -- runs its seek loop on EVERY input: a single window
         # that ends in an open timestamp gets a second pass over its tail, and the return value is the segment-derived matrix of
         # _fix_timestamps_from_segmentation.  With timestamps on and a real tokenizer set (the fix-up needs its ids) a

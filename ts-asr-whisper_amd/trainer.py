@@ -11,6 +11,7 @@ minibatch; trainable gradients live in ONE flat fp32 buffer laid out in backward
 layer's slice is all-reduced (RCCL over xGMI, ``torch.distributed`` backend "nccl") on a side HIP stream as soon as that
 layer's backward has been enqueued, overlapped with the remaining backward.
 """
+import collections
 import math
 import os
 
@@ -158,6 +159,11 @@ class FusedAdamW:
             return self.lr * max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
         return self.lr
 
+    def applied_lr(self):
+        """Learning rates the LAST optimizer step applied, one per run, read back from the device (hyper[:, 0]: the scheduled
+        rate x the group multiplier; what the reference's trainer logs per parameter group).  Synchronises: logging only."""
+        return self.hyper[:, 0].detach().cpu().tolist()
+
     def advance(self, preheat_only=False):
         """Host mirrors of the device counters, one optimizer step on (the device side is launch())."""
         self.t += 1
@@ -171,8 +177,8 @@ class FusedAdamW:
         s = self.s
         L_ = ops.L
         L_.call("dicow_adamw_hyper", self.counters.data_ptr(), self.hyper.data_ptr(), self.is_pre.data_ptr(), len(s.runs),
-                int(preheat_only), self.lr, self.mult, int(self.warmup), int(self.max_steps), int(self.schedule == "cosine"),
-                self.betas[0], self.betas[1], L_.stream())
+                int(preheat_only), float(self.lr), float(self.mult), int(self.warmup), int(self.max_steps),
+                int(self.schedule == "cosine"), float(self.betas[0]), float(self.betas[1]), L_.stream())
         self.gnorm_sq.zero_()
         ops.sumsq(s.grads, self.gnorm_sq)                 # frozen runs hold zeros
         for i, (a, b, pre) in enumerate(s.runs):
@@ -289,7 +295,14 @@ class TrainStep:
         # dependence: the clip coefficient stays on the device, the schedule's scalars are rewritten in device memory
         # before each replay (FusedAdamW.advance).
         self.graph = bool(graph)
-        self._graphs = {}             # (phase, batch signature) -> (CUDAGraph, static batch, static loss)
+        # (phase, batch signature) -> (CUDAGraph, static batch, static loss), least recently used first.  Real batches vary in
+        # label length (and SE-DiCoW enrollment length), and the hard loss is a mean over ALL label positions
+        # (modeling_dicow.py:310-323), so labels cannot be padded to length buckets without changing the loss: instead the cache
+        # is bounded (max_graphs, LRU eviction), every capture allocates from ONE shared pool (the footprint is the largest
+        # graph's, not the sum), and a signature is only captured the second time it is seen.
+        self._graphs = collections.OrderedDict()
+        self.max_graphs = 8
+        self._graph_pool = None
         self._eager_done = set()
         self.augmenter = augmenter          # augment.BatchAugmenter: the collator's training-time block, on the GPU
         freeze_by_keyword(model, frozen_keywords)
@@ -376,7 +389,7 @@ class TrainStep:
             self.model._sig = None
 
     def _graph_step(self, batch):
-        if self.reducer.world > 1:
+        if self.reducer.world > 1 or self.reducer.force:
             raise NotImplementedError("TrainStep(graph=True) captures the single-GPU step; the bucketed side-stream exchange is not captured")
         if self.model.config.ctc_weight > 0.0 or self.augmenter is not None:
             raise NotImplementedError("TrainStep(graph=True): the CTC label preparation / the augmentation planner read device data on "
@@ -389,11 +402,15 @@ class TrainStep:
             self._eager_done.add(key)
             return self._eager_step([batch])
         if key not in self._graphs:
+            while len(self._graphs) >= max(1, self.max_graphs):     # bounded cache: drop the least recently replayed graph
+                self._graphs.popitem(last=False)
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
             static = self._clone(batch)
             self._invalidate_weight_copies()            # the capture must contain the bf16 weight refresh
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, pool=self._graph_pool):
                 self.store.zero_grad()
                 out = self.model(**static)
                 out.loss.backward()
@@ -401,6 +418,7 @@ class TrainStep:
                 loss = out.loss.detach()
             self._graphs[key] = (g, static, loss)
             # (capturing does not execute: the replay below is this step)
+        self._graphs.move_to_end(key)
         g, static, loss = self._graphs[key]
         self._copy_into(static, batch)
         self.opt.advance(preheat_only=self.warmup_phase)
