@@ -178,6 +178,20 @@ typedef struct {
 int64_t dicow_gemm_tn_ws_bytes(const dicow_gemm_tn_args* a);
 int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream);
 
+/* Several weight gradients with the same contraction length as ONE persistent launch (the four dW of an encoder layer:
+ * autograd's wgrad of q/k/v, out_proj, fc1, fc2 reached from encoder.py:216-221).  Pooled, the output tiles cover the chip
+ * with whole contractions and only the remainder is split; one fix-up launch adds those partials in a fixed order.  Same
+ * results as calling dicow_gemm_tn on p[0..n) in turn up to fp32 summation order (deterministic); problems that cannot be
+ * pooled (N < 256, batches, different Mk) are run one by one.  ws: dicow_gemm_tn_group_ws_bytes. */
+#define DICOW_TN_GROUP_MAX 6
+typedef struct {
+    int n;
+    dicow_gemm_tn_args p[DICOW_TN_GROUP_MAX];       /* (their own ws / ws_bytes fields are ignored) */
+    void* ws; int64_t ws_bytes;
+} dicow_gemm_tn_group_args;
+int64_t dicow_gemm_tn_group_ws_bytes(const dicow_gemm_tn_group_args* a);
+int dicow_gemm_tn_group(const dicow_gemm_tn_group_args* a, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ attention
  * Flash-style softmax(Q K^T) V with head_dim 64, scaling 1.0 (q is pre-scaled by the projection epilogue,
  * HF:modeling_whisper.py:309,337-351).  Dense (encoder 1500x1500, SE enrollment cross-attention

@@ -403,6 +403,70 @@ def test_gemm_tn_at_bench_shapes_vs_torch(ops, N1, N2):
     assert float((C - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("gemm_cus", [0, 240])
+def test_gemm_tn_group_layer_wgrads_at_bench_shape_vs_torch(ops, gemm_cus):
+    """The four weight gradients of a large-v3-turbo encoder layer at B = 16 (M = 24000) as ONE pooled launch
+    (dicow_gemm_tn_group): fused q/k/v with its three row segments, out-proj, fc1, fc2 -- 300 output tiles, whole contractions
+    on the first 256 (240 with CUs reserved for the RCCL channels), a split remainder added by the fix-up launch.  Element-wise
+    against fp32 torch matmuls, accumulate semantics, operands as strided column slices where the engine passes slices; a
+    second run must reproduce the first bit for bit (fixed summation order)."""
+    Mk, D, F_ = 24000, 1280, 5120
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rnd = lambda *s: _bf(torch.randn(*s, device="cuda", generator=g) * 0.1)
+    gb, a_act, d_u, xln2, g2b, o_act, d_qkv, xln = rnd(Mk, D), rnd(Mk, F_), rnd(Mk, F_), rnd(Mk, D), rnd(Mk, D), rnd(Mk, D), rnd(Mk, 3 * D), rnd(Mk, D)
+    outs0 = [torch.randn(D, F_, device="cuda", generator=g), torch.randn(F_, D, device="cuda", generator=g),
+             torch.randn(D, D, device="cuda", generator=g), torch.randn(D, D, device="cuda", generator=g),
+             torch.randn(D, D, device="cuda", generator=g), torch.randn(D, D, device="cuda", generator=g)]
+    refs = [outs0[0] + gb.float().t() @ a_act.float(), outs0[1] + d_u.float().t() @ xln2.float(), outs0[2] + g2b.float().t() @ o_act.float()]
+    qkv_ref = d_qkv.float().t() @ xln.float()
+    refs += [outs0[3] + qkv_ref[:D], outs0[4] + qkv_ref[D:2 * D], outs0[5] + qkv_ref[2 * D:]]
+
+    def run():
+        outs = [t.clone() for t in outs0]
+        grp = ops.TnGroup()
+        grp.add(gb, a_act, outs[0], Mk, D, F_)
+        grp.add(d_u, xln2, outs[1], Mk, F_, D)
+        grp.add(g2b, o_act, outs[2], Mk, D, D)
+        grp.add(d_qkv, xln, outs[3], Mk, 3 * D, D, ldc=D, C_seg=(outs[4], outs[5]), seg_rows=D)
+        grp.run()
+        torch.cuda.synchronize()
+        return outs
+    prev = ops.set_gemm_cus(gemm_cus)
+    try:
+        outs = run()
+        again = run()
+    finally:
+        ops.set_gemm_cus(prev)
+    for i, (got, ref) in enumerate(zip(outs, refs)):
+        assert float((got - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max())), i
+    for a_, b_ in zip(outs, again):
+        assert torch.equal(a_, b_)
+
+
+def test_gemm_tn_group_falls_back_and_handles_odd_pools(ops):
+    """Pools the grouped kernel cannot take (too few tiles, N < 256, different contraction lengths) run problem by problem;
+    a pool with more than one full round plus a ragged remainder goes through the grouped kernel.  All against torch."""
+    g = torch.Generator(device="cuda").manual_seed(6)
+    rnd = lambda *s: _bf(torch.randn(*s, device="cuda", generator=g) * 0.1)
+    cases = [
+        [(1000, 256, 512), (1000, 512, 256)],                               # 4 tiles: fall-back
+        [(3000, 128, 512), (3000, 512, 384)],                               # N1 < 256: fall-back
+        [(2000, 512, 512), (3000, 512, 512)],                               # different Mk: fall-back
+        [(1100, 2560, 3072), (1100, 1280, 3840), (1100, 3840, 2568), (1100, 2304, 2048)],   # 120 + 75 + 165 + 72 tiles, ragged N2
+    ]
+    for pool in cases:
+        grp, want, outs = ops.TnGroup(), [], []
+        for Mk, N1, N2 in pool:
+            A, Bm = rnd(Mk, N1), rnd(Mk, N2)
+            Cc = torch.randn(N1, N2, device="cuda", generator=g)
+            want.append(Cc + A.float().t() @ Bm.float())
+            outs.append(Cc)
+            grp.add(A, Bm, Cc, Mk, N1, N2)
+        grp.run()
+        for got, ref in zip(outs, want):
+            assert float((got - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max())), pool
+
+
 def test_attention_at_bench_shape_vs_torch(ops):
     """B = 16, H = 20, T = 1500 (one encoder layer's attention of the bench batch): forward and backward vs torch fp32 math."""
     B, H, Tq = 16, 20, 1500

@@ -133,5 +133,9 @@ def test_device_schedule_and_bias_corrections_match_torch_over_300_steps(ops):
             assert float(hy[1, 2]) == float(torch.tensor(1.0 - 0.999 ** k, dtype=torch.float32)), k
             assert float(hy[1, 1]) == float(torch.tensor(1.0 - 0.9 ** k, dtype=torch.float32)), k
             ref = torch.cat([ra.detach(), rb.detach()])
-            worst = max(worst, float((st.params.cpu() - ref).abs().max()))
-    assert worst < 2e-6, worst
+            dev = float((st.params.cpu() - ref).abs().max())
+            if k <= 3:
+                assert dev < 5e-7, (k, dev)                  # step by step: last-bit agreement
+            worst = max(worst, dev)
+    # 300 updates of up to 1e-2 on values of a few units: fp32 rounding differences of the two update expressions random-walk
+    assert worst < 3e-5, worst

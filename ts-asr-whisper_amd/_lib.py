@@ -40,6 +40,13 @@ class GemmTnArgs(C.Structure):
                 ("C_seg", c_vp * 2), ("seg_rows", c_i), ("ws", c_vp), ("ws_bytes", c_i64)]
 
 
+TN_GROUP_MAX = 6
+
+
+class GemmTnGroupArgs(C.Structure):
+    _fields_ = [("n", c_i), ("p", GemmTnArgs * TN_GROUP_MAX), ("ws", c_vp), ("ws_bytes", c_i64)]
+
+
 class AttnFwdArgs(C.Structure):
     _fields_ = [("q", c_vp), ("k", c_vp), ("v", c_vp), ("o", c_vp), ("lse", c_vp),
                 ("q_bs", c_i64), ("q_rs", c_i64), ("k_bs", c_i64), ("k_rs", c_i64),
@@ -95,6 +102,7 @@ _SIGS = {
     "dicow_fddt_full_combine_bwd": [c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_gemm_nt": [C.POINTER(GemmArgs), c_vp],
     "dicow_gemm_tn": [C.POINTER(GemmTnArgs), c_vp],
+    "dicow_gemm_tn_group": [C.POINTER(GemmTnGroupArgs), c_vp],
     "dicow_attn_fwd": [C.POINTER(AttnFwdArgs), c_vp],
     "dicow_attn_bwd": [C.POINTER(AttnBwdArgs), c_vp],
     "dicow_ce_loss_fwd": [C.POINTER(CeArgs), c_vp],
@@ -152,6 +160,7 @@ _SIGS64 = {   # functions returning int64_t (workspace sizes)
     "dicow_attn_bwd_colsum_ws_bytes": [c_i, c_i, c_i, c_i],
     "dicow_fddt_ln_bwd_ws_bytes": [c_i, c_i],
     "dicow_gemm_tn_ws_bytes": [C.POINTER(GemmTnArgs)],
+    "dicow_gemm_tn_group_ws_bytes": [C.POINTER(GemmTnGroupArgs)],
     "dicow_logmel_ws_bytes": [c_i, c_i],
     "dicow_ctc_ws_bytes": [c_i, c_i, c_i],
 }

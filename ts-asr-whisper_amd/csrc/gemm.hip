@@ -1383,36 +1383,14 @@ __device__ __forceinline__ void tn256_mfma(f32x16_t (&acc)[2][4], const tn256_fr
 // (Tried and dropped: the 4-wave / 128x128-wave-tile / AGPR form that pays off for the NT kernel.  Here every MFMA operand
 // comes from ds_read_b64_tr_b16 -- 16 LDS instructions per 16 MFMAs instead of 8 -- and a single wave per SIMD cannot hide
 // their issue: 0.78 PF with batched reads, 0.73 PF with reads threaded between groups of 4 MFMAs, against 0.82 PF here.)
-__global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_args a, int tiles_per_batch, int total_tiles,
-                                                            int tiles_per_split) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// One (output tile, contraction range) unit of the 256 x 256 TN kernel: contraction tiles [kt0, kt1) of the 256 x 256 output
+// tile at (n1_0, n2_0).  wpart == nullptr: the result goes (accumulates) into C; otherwise it is a PARTIAL sum and is
+// written to wpart with element (n1, n2) at wpart[(n1 - wr0) * wld + (n2 - wc0)].  Shared by the split-K kernel
+// (gemm_tn256_kernel) and the grouped kernel (gemm_tn256g_kernel); the caller has made sure no LDS traffic is in flight.
+__device__ __forceinline__ void tn256_unit(const dicow_gemm_tn_args& a, char* smem, int tiles_per_batch, int n1_0, int n2_0, int kt0,
+                                           int kt1, float* wpart, int wr0, int wc0, int64_t wld) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt1 = (a.N1 + 255) / 256, nt2 = (a.N2 + 255) / 256;
-    // (split, tile) pairs in split-major order, dealt to the XCDs in contiguous chunks (flat 1-D grid, block L lands on XCD
-    // L % 8): the ~32 workgroups an XCD runs at a time then belong to ONE split -- the same rows of A and B -- and cover a
-    // compact block of output tiles, so every 64-row slice of an operand panel is fetched into that L2 once and hit by the
-    // other tiles of its row / column.  (With the split on gridDim.z an XCD held 3 tiles of each of 10 splits: a third of the
-    // reuse, 3.5x the algorithmic bytes on the fabric side of L2.)
-    const int ntile = nt1 * nt2;
-    int split, t1, t2;
-    {
-        const int nwg = (int)gridDim.x, L = (int)blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, loc = L >> 3;
-        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-        split = id / ntile;
-        const int tid_ = id - split * ntile;
-        const int GM = 8, per_group = GM * nt2;
-        const int group = tid_ / per_group, rem = tid_ - group * per_group;
-        const int first = group * GM;
-        const int gsize = (nt1 - first) < GM ? (nt1 - first) : GM;
-        t1 = first + rem % gsize;
-        t2 = rem / gsize;
-    }
-    const int n1_0 = t1 * 256, n2_0 = t2 * 256;
-    const int kt0 = split * tiles_per_split;
-    int kt1 = kt0 + tiles_per_split; kt1 = kt1 < total_tiles ? kt1 : total_tiles;
-    if (kt0 >= kt1) return;
     const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A);
     const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B);
     const int w1 = wave >> 2, w2 = wave & 3;          // wave tile: n1 [w1*128, +128), n2 [w2*64, +64)
@@ -1534,8 +1512,6 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_
     tn256_mfma(acc, f1);
 
     const int hh = lane >> 5;
-    const bool to_ws = (int)gridDim.x > ntile;
-    float* wsz = reinterpret_cast<float*>(a.ws) + (int64_t)split * a.N1 * a.N2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n1 = n1_0 + w1 * 128 + j * 32 + (lane & 31);
@@ -1547,8 +1523,8 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_
                 const int n2 = n2_0 + w2 * 64 + i * 32 + 8 * q + 4 * hh;
                 if (n2 >= a.N2) continue;
                 float4 v = make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                if (to_ws) {
-                    *reinterpret_cast<float4*>(wsz + (int64_t)n1 * a.N2 + n2) = v;
+                if (wpart) {                          // a partial sum: element (n1, n2) at wpart[(n1 - wr0) * wld + (n2 - wc0)]
+                    *reinterpret_cast<float4*>(wpart + (int64_t)(n1 - wr0) * wld + (n2 - wc0)) = v;
                     continue;
                 }
                 float* cp;
@@ -1566,6 +1542,134 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_
             }
         }
     }
+}
+
+__global__ void __launch_bounds__(512, 2) gemm_tn256_kernel(const dicow_gemm_tn_args a, int tiles_per_batch, int total_tiles,
+                                                            int tiles_per_split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nt1 = (a.N1 + 255) / 256, nt2 = (a.N2 + 255) / 256;
+    // (split, tile) pairs in split-major order, dealt to the XCDs in contiguous chunks (flat 1-D grid, block L lands on XCD
+    // L % 8): the ~32 workgroups an XCD runs at a time then belong to ONE split -- the same rows of A and B -- and cover a
+    // compact block of output tiles, so every 64-row slice of an operand panel is fetched into that L2 once and hit by the
+    // other tiles of its row / column.  (With the split on gridDim.z an XCD held 3 tiles of each of 10 splits: a third of the
+    // reuse, 3.5x the algorithmic bytes on the fabric side of L2.)
+    const int ntile = nt1 * nt2;
+    int split, t1, t2;
+    {
+        const int nwg = (int)gridDim.x, L = (int)blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, loc = L >> 3;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        split = id / ntile;
+        const int tid_ = id - split * ntile;
+        const int GM = 8, per_group = GM * nt2;
+        const int group = tid_ / per_group, rem = tid_ - group * per_group;
+        const int first = group * GM;
+        const int gsize = (nt1 - first) < GM ? (nt1 - first) : GM;
+        t1 = first + rem % gsize;
+        t2 = rem / gsize;
+    }
+    const int n1_0 = t1 * 256, n2_0 = t2 * 256;
+    const int kt0 = split * tiles_per_split;
+    int kt1 = kt0 + tiles_per_split; kt1 = kt1 < total_tiles ? kt1 : total_tiles;
+    if (kt0 >= kt1) return;
+    const bool to_ws = (int)gridDim.x > ntile;
+    tn256_unit(a, smem, tiles_per_batch, n1_0, n2_0, kt0, kt1,
+               to_ws ? reinterpret_cast<float*>(a.ws) + (int64_t)split * a.N1 * a.N2 : nullptr, 0, 0, a.N2);
+}
+
+// ------------------------------------------------------------------------------------------------ TN, grouped ("stream-K" over a layer)
+// The four weight gradients of an encoder layer (q/k/v fused, out-proj, fc1, fc2: 75 + 25 + 100 + 100 output tiles of 256 x 256
+// at large-v3-turbo dimensions, each contracted over the same M = B T rows) as ONE persistent launch.  Alone, each of them has
+// fewer tiles than the chip has CUs and needs a 4...10-way split of the contraction to fill it: 400 MB of fp32 partials per
+// layer written, re-read and added by six reduce launches (2.4 % of the step, round 2).  Pooled, the 300 tiles cover the 256
+// CUs once with WHOLE contractions -- those tiles accumulate straight into the gradient, no partials at all -- and only the
+// remaining T mod G tiles are split, s = floor(G / rem) ways, so that the last round is as full as the first: the work per
+// CU is balanced like a stream-K schedule, but every workgroup of a round runs the same contraction range at the same time
+// (operand panels are shared through the XCD's L2; a free-running stream-K walk offsets every CU's k position and would
+// stream each operand once per TILE: ~7 GB per layer).  Partials: rem x s tiles of 256 KB (<= 64 MB), added to the
+// gradients in split order by ONE fix-up launch (tn_group_fixup_kernel) -- deterministic, no atomics, no flags.
+#define TN_GROUP_MAX DICOW_TN_GROUP_MAX
+struct tn_group_plan_t {
+    int n, G, T, R, rem, s, chunk, kiters;          // problems, workgroups, tiles, full rounds, remainder tiles, splits, tiles per split
+    int tile0[TN_GROUP_MAX + 1];                    // first pooled tile id of problem p
+    int nt1[TN_GROUP_MAX], nt2[TN_GROUP_MAX];
+};
+struct tn_group_kargs_t { dicow_gemm_tn_args p[TN_GROUP_MAX]; tn_group_plan_t plan; float* ws; };
+
+// pooled tile id -> (problem, 256-row block t1, 256-column block t2); tiles of a problem in the grouped (8 row blocks) order
+__device__ __forceinline__ void tn_group_tile(const tn_group_plan_t& pl, int id, int& p, int& t1, int& t2) {
+    p = 0;
+#pragma unroll
+    for (int i = 1; i < TN_GROUP_MAX; ++i) if (i < pl.n && id >= pl.tile0[i]) p = i;
+    const int tid_ = id - pl.tile0[p];
+    const int nt1 = pl.nt1[p], nt2 = pl.nt2[p];
+    const int GM = 8, per_group = GM * nt2;
+    const int group = tid_ / per_group, rem = tid_ - group * per_group;
+    const int first = group * GM;
+    const int gsize = (nt1 - first) < GM ? (nt1 - first) : GM;
+    t1 = first + rem % gsize;
+    t2 = rem / gsize;
+}
+
+__global__ void __launch_bounds__(512, 2) gemm_tn256g_kernel(const tn_group_kargs_t g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const tn_group_plan_t& pl = g.plan;
+    // workgroup L runs on XCD L % 8: give every XCD a contiguous chunk of each round's ids (adjacent tiles share panels)
+    const int nwg = (int)gridDim.x, L = (int)blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7, loc = L >> 3;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    bool first = true;
+    for (int rd = 0; rd <= pl.R; ++rd) {
+        int id, kt0 = 0, kt1 = pl.kiters, split = -1;
+        if (rd < pl.R) {
+            id = rd * pl.G + w;
+        } else {                                      // the split round: items split-major (one k range = one run of workgroups)
+            if (pl.rem == 0 || w >= pl.rem * pl.s) break;
+            split = w / pl.rem;
+            id = pl.R * pl.G + (w - split * pl.rem);
+            kt0 = split * pl.chunk;
+            kt1 = kt0 + pl.chunk < pl.kiters ? kt0 + pl.chunk : pl.kiters;
+        }
+        int p, t1, t2;
+        tn_group_tile(pl, id, p, t1, t2);
+        if (!first) {                                 // the previous unit's trailing (empty) DMA and fragment reads are done
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        first = false;
+        float* wpart = split < 0 ? nullptr : g.ws + ((int64_t)(id - pl.R * pl.G) * pl.s + split) * 65536;
+        if (kt0 < kt1)
+            tn256_unit(g.p[p], smem, pl.kiters, t1 * 256, t2 * 256, kt0, kt1, wpart, t1 * 256, t2 * 256, 256);
+    }
+}
+
+// C tile (+)= sum_{split} partial[tile][split]  in split order; one workgroup = 4 rows of a 256 x 256 tile
+__global__ void __launch_bounds__(256) tn_group_fixup_kernel(const tn_group_kargs_t g) {
+    const tn_group_plan_t& pl = g.plan;
+    const int lt = blockIdx.x >> 6, rb = blockIdx.x & 63;          // remainder tile, block of 4 rows
+    int p, t1, t2;
+    tn_group_tile(pl, pl.R * pl.G + lt, p, t1, t2);
+    const dicow_gemm_tn_args& a = g.p[p];
+    const int row = rb * 4 + (threadIdx.x >> 6), c4 = (threadIdx.x & 63) * 4;
+    const int n1 = t1 * 256 + row, n2 = t2 * 256 + c4;
+    if (n1 >= a.N1 || n2 >= a.N2) return;
+    // (a split whose range is empty -- chunk * split >= kiters -- wrote nothing: skip it)
+    const float* wp = g.ws + (int64_t)lt * pl.s * 65536 + row * 256 + c4;
+    float* cp;
+    if (a.seg_rows > 0 && n1 >= a.seg_rows) {
+        const int sg = n1 / a.seg_rows;
+        cp = a.C_seg[sg - 1] + (int64_t)(n1 - sg * a.seg_rows) * a.ldc + n2;
+    } else {
+        cp = a.C + (int64_t)n1 * a.ldc + n2;
+    }
+    float4 sacc = a.accumulate ? *reinterpret_cast<const float4*>(cp) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < pl.s; ++z) {
+        if (z * pl.chunk >= pl.kiters) break;
+        const float4 v = *reinterpret_cast<const float4*>(wp + (int64_t)z * 65536);
+        sacc.x += v.x; sacc.y += v.y; sacc.z += v.z; sacc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(cp) = sacc;
 }
 
 // C[r][:] (+)= sum_z ws[z][row0 + r][:]   for r < nrows   (ldc may exceed N2)
@@ -1586,6 +1690,8 @@ __global__ void tn_reduce_kernel(const float* __restrict__ ws, int splits, int64
     }
 }
 
+static std::once_flag g_tn_once;
+static int g_tn_ncu = 256;
 // Tile size + contraction split: minimise  flops / (rate * grid-quantisation efficiency) + split-reduction traffic.
 static void tn_plan(const dicow_gemm_tn_args* a, int& tpb, int& total, int& nt, int& splits, int& tps, int& tile) {
     const int batch = a->batch > 0 ? a->batch : 1;
@@ -1658,6 +1764,89 @@ extern "C" int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream) {
                                (int64_t)a->N1 * a->N2, row0, nrows, a->N2, C, a->ldc, a->accumulate);
             DICOW_CHECK_LAUNCH("tn_reduce");
         }
+    }
+    return DICOW_OK;
+}
+
+// ---- grouped launch (see gemm_tn256g_kernel).  Eligible: every problem has N1, N2 >= 256, batch == 1, the same Mk, 32-bit
+// operand offsets; anything else runs problem by problem through dicow_gemm_tn (same results as separate calls).
+static bool tn_group_plan(const dicow_gemm_tn_group_args* ga, tn_group_plan_t& pl) {
+    if (ga->n < 2 || ga->n > TN_GROUP_MAX) return false;
+    const int Mk = ga->p[0].Mk;
+    int T = 0;
+    for (int i = 0; i < ga->n; ++i) {
+        const dicow_gemm_tn_args& a = ga->p[i];
+        if (a.Mk != Mk || (a.batch > 1) || a.N1 < 256 || a.N2 < 256) return false;
+        if ((int64_t)a.Mk * a.lda * 2 >= (1ll << 32) || (int64_t)a.Mk * a.ldb * 2 >= (1ll << 32)) return false;
+        pl.tile0[i] = T;
+        pl.nt1[i] = dicow_cdiv(a.N1, 256); pl.nt2[i] = dicow_cdiv(a.N2, 256);
+        T += pl.nt1[i] * pl.nt2[i];
+    }
+    for (int i = ga->n; i <= TN_GROUP_MAX; ++i) pl.tile0[i] = T;
+    for (int i = ga->n; i < TN_GROUP_MAX; ++i) { pl.nt1[i] = pl.nt2[i] = 1; }
+    std::call_once(g_tn_once, [] { int dev = 0; hipDeviceProp_t pr; if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) g_tn_ncu = pr.multiProcessorCount; });
+    const int lim = g_gemm_cus.load();
+    const int G = (lim > 0 && lim < g_tn_ncu) ? lim : g_tn_ncu;
+    pl.n = ga->n; pl.G = G; pl.T = T; pl.kiters = dicow_cdiv(Mk, TK);
+    if (T < G) return false;                        // fewer pooled tiles than CUs: the per-problem split-K plans do better
+    pl.R = T / G; pl.rem = T - pl.R * G;
+    pl.s = pl.rem > 0 ? G / pl.rem : 1;
+    if (pl.s > pl.kiters) pl.s = pl.kiters;
+    if (pl.s > 64) pl.s = 64;
+    pl.chunk = dicow_cdiv(pl.kiters, pl.s);
+    return true;
+}
+
+extern "C" int64_t dicow_gemm_tn_group_ws_bytes(const dicow_gemm_tn_group_args* ga) {
+    if (!ga) return 0;
+    tn_group_plan_t pl;
+    int64_t need = 0;
+    if (tn_group_plan(ga, pl)) need = (int64_t)pl.rem * pl.s * 65536 * 4;
+    for (int i = 0; i < ga->n && i < TN_GROUP_MAX; ++i) {          // (the fall-back path's needs, so that one query covers both)
+        const int64_t w = dicow_gemm_tn_ws_bytes(&ga->p[i]);
+        need = w > need ? w : need;
+    }
+    return need;
+}
+
+extern "C" int dicow_gemm_tn_group(const dicow_gemm_tn_group_args* ga, void* stream) {
+    DICOW_REQUIRE(ga && ga->n >= 1 && ga->n <= TN_GROUP_MAX, "gemm_tn_group: 1..%d problems", TN_GROUP_MAX);
+    tn_group_plan_t pl;
+    bool ok = true;
+    for (int i = 0; i < ga->n; ++i) {
+        const dicow_gemm_tn_args* a = &ga->p[i];
+        DICOW_REQUIRE(a->A && a->B && a->C, "gemm_tn_group: null operand in problem %d", i);
+        DICOW_REQUIRE(a->Mk > 0 && a->N1 >= 8 && a->N2 >= 8 && a->N1 % 8 == 0 && a->N2 % 8 == 0, "gemm_tn_group: bad shape in problem %d", i);
+        DICOW_REQUIRE(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->ldc % 4 == 0, "gemm_tn_group: lda/ldb %% 8, ldc %% 4 required");
+        DICOW_REQUIRE(a->seg_rows == 0 || (a->seg_rows % 128 == 0 && a->N1 <= 3 * a->seg_rows && a->C_seg[0] &&
+                                            (a->N1 <= 2 * a->seg_rows || a->C_seg[1])), "gemm_tn_group: bad C segments");
+    }
+    ok = tn_group_plan(ga, pl);
+    if (!ok) {                                      // not poolable: problem by problem
+        for (int i = 0; i < ga->n; ++i) {
+            dicow_gemm_tn_args a = ga->p[i];
+            a.ws = ga->ws; a.ws_bytes = ga->ws_bytes;
+            const int rc = dicow_gemm_tn(&a, stream);
+            if (rc != DICOW_OK) return rc;
+        }
+        return DICOW_OK;
+    }
+    const int64_t need = (int64_t)pl.rem * pl.s * 65536 * 4;
+    DICOW_REQUIRE(need == 0 || (ga->ws && ga->ws_bytes >= need), "gemm_tn_group: workspace too small (need %ld bytes)", (long)need);
+    static const bool attr_set = [] {
+        (void)hipFuncSetAttribute((const void*)gemm_tn256g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
+        return true;
+    }();
+    (void)attr_set;
+    tn_group_kargs_t k;
+    memset(&k, 0, sizeof(k));
+    for (int i = 0; i < ga->n; ++i) k.p[i] = ga->p[i];
+    k.plan = pl; k.ws = reinterpret_cast<float*>(ga->ws);
+    hipLaunchKernelGGL(gemm_tn256g_kernel, dim3(pl.G), dim3(512), TN256_LDS, (hipStream_t)stream, k);
+    DICOW_CHECK_LAUNCH("gemm_tn_group");
+    if (pl.rem > 0) {
+        hipLaunchKernelGGL(tn_group_fixup_kernel, dim3(pl.rem * 64), dim3(256), 0, (hipStream_t)stream, k);
+        DICOW_CHECK_LAUNCH("tn_group_fixup");
     }
     return DICOW_OK;
 }

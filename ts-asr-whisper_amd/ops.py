@@ -201,6 +201,46 @@ def gemm_tn(A, B, C_out, Mk, N1, N2, *, lda=None, ldb=None, ldc=None, batch=1, s
     L.call_struct("dicow_gemm_tn", a)
 
 
+def _tn_fill(a, A, B, C_out, Mk, N1, N2, lda, ldb, ldc, accumulate, C_seg, seg_rows):
+    a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
+    a.Mk, a.N1, a.N2 = Mk, N1, N2
+    a.lda = N1 if lda is None else lda
+    a.ldb = N2 if ldb is None else ldb
+    a.ldc = N2 if ldc is None else ldc
+    a.batch, a.strideA, a.strideB, a.accumulate = 1, 0, 0, int(accumulate)
+    if C_seg is not None:
+        for i, t in enumerate(C_seg):
+            a.C_seg[i] = t.data_ptr()
+        a.seg_rows = seg_rows
+
+
+class TnGroup:
+    """Weight gradients C_i (+)= A_i^T B_i collected over a layer's backward and run as ONE pooled launch
+    (dicow_gemm_tn_group): ``add`` records a problem (and keeps its operands alive), ``run`` launches what was recorded."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, A, B, C_out, Mk, N1, N2, *, lda=None, ldb=None, ldc=None, accumulate=True, C_seg=None, seg_rows=0):
+        self.items.append((A, B, C_out, Mk, N1, N2, lda, ldb, ldc, accumulate, C_seg, seg_rows))
+        if len(self.items) == L.TN_GROUP_MAX:
+            self.run()
+
+    def run(self):
+        if not self.items:
+            return
+        g = L.GemmTnGroupArgs()
+        g.n = len(self.items)
+        for i, it in enumerate(self.items):
+            _tn_fill(g.p[i], *it)
+        need = L.lib().dicow_gemm_tn_group_ws_bytes(C.byref(g))
+        if need:
+            ws = workspace(need, self.items[0][2].device)
+            g.ws, g.ws_bytes = ws.data_ptr(), ws.numel()
+        L.call_struct("dicow_gemm_tn_group", g)
+        self.items = []
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _bs_rs(t, name):
     # t: [B, L, H, 64] view (any batch/row stride)
