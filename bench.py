@@ -134,6 +134,23 @@ class KernelTimer:
             setattr(self.ops, n, wrapped)
         import ts_asr_whisper_amd.engine as eng      # engine calls through the module attribute `ops.<name>`
         assert eng.ops is self.ops
+        # the pooled weight-gradient launch of an encoder layer (ops.TnGroup.run -> dicow_gemm_tn_group) counts as gemm_tn
+        if "gemm_tn" in self.names:
+            run0 = self.ops.TnGroup.run
+            timer = self
+
+            def run(grp):
+                if not timer.on or not grp.items:
+                    return run0(grp)
+                work = sum(2.0 * it[3] * it[4] * it[5] for it in grp.items)
+                key = (grp.items[0][3], sum(it[4] * it[5] for it in grp.items), len(grp.items), 1, 0, "pooled", "float32")
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = run0(grp)
+                e.record()
+                timer.rec["gemm_tn"].append((s, e, work, key))
+                return r
+            self.ops.TnGroup.run = run
 
     @staticmethod
     def work(name, a, kw):
@@ -262,28 +279,37 @@ class PowerSampler:
                 "note": "rocm-smi samples during the timed region (board power cap 1400 W, peak shader clock 2400 MHz)"}
 
 
-PMC_FILES = ("r02_pmc_hbm_traffic.json", "r01g_pmc_hbm_traffic.json")      # newest first
+PMC_FILES = ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01g_pmc_hbm_traffic.json")      # newest first
 TRAFFIC_SOURCE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/prof_pmc.sh; fabric-side bytes "
                   "per persistent NT GEMM launch, FETCH_SIZE x2 per the gfx950 correction)")
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC summary (counters cannot be read live)."""
+def pmc_traffic(live):
+    """HBM-side bytes per launch of the dominant kernel class from the committed PMC summary (counters cannot be read live).
+    `live`: {kernel instantiation: launches} of THIS run (ops.gemm_dispatch_log()).  The summary is only quoted when it was
+    taken on the kernels that ran here: every gemm_ntr instantiation of the live run must be in the file and vice versa,
+    and the per-instantiation launch mix must agree (the file's numbers are weighted with the LIVE launch counts)."""
     global TRAFFIC_SOURCE
     try:
         name = next(n for n in PMC_FILES if os.path.exists(os.path.join(ROOT, "profiles", n)))
-        TRAFFIC_SOURCE = TRAFFIC_SOURCE % name
         with open(os.path.join(ROOT, "profiles", name)) as f:
             d = json.load(f)
+        filed = {k for k, v in d.items() if k.startswith("gemm_ntr") and v.get("hbm_read_bytes_per_launch_corrected") is not None}
+        ran = {k for k in live if k.startswith("gemm_ntr")}
+        if not ran or filed != ran:
+            TRAFFIC_SOURCE = (f"REFUSED profiles/{name}: its persistent-GEMM kernels {sorted(filed)} are not the ones of this run "
+                              f"{sorted(ran)} -- re-take the counter passes (tools/prof_pmc.sh)")
+            return None
+        TRAFFIC_SOURCE = TRAFFIC_SOURCE % name
         tot = n = 0
-        for k, v in d.items():
-            if k.startswith(("gemm_ntr", "gemm_nt256w", "gemm_ntw")) and v.get("hbm_read_bytes_per_launch_corrected") is not None:
-                tot += (v["hbm_read_bytes_per_launch_corrected"] + (v.get("hbm_write_bytes_per_launch") or 0)) * v["launches"]
-                n += v["launches"]
+        for k in ran:
+            v = d[k]
+            tot += (v["hbm_read_bytes_per_launch_corrected"] + (v.get("hbm_write_bytes_per_launch") or 0)) * live[k]
+            n += live[k]
         return round(tot / n) if n else None
-    except Exception:
+    except Exception as ex:
+        TRAFFIC_SOURCE = f"no usable PMC summary: {ex!r}"
         return None
-
 
 
 def dry_launch(a, world, rank, local):
@@ -459,7 +485,7 @@ def main():
         timer.breakdown("gemm_tn", nprof)
     peak = 2500.0
     SUSTAINED_MFMA_TF = 1845.0
-    TRAFFIC = pmc_traffic()
+    TRAFFIC = None                                   # filled in after the encoder-forward leg (the committed counter passes cover the whole command)
     # algorithmic TFLOP per utterance of one step: 3 x encoder + 2 x (decoder + head) with the decoder frozen;
     # turbo: 3 x 2.2738 + 2 x 0.0841 = 6.99.  SE-DiCoW: the survey's 10.7 (3.51 encoder) for the headline model only.
     T_, D_, F_, Le, Ld = cfg.max_source_positions, cfg.d_model, cfg.encoder_ffn_dim, cfg.encoder_layers, cfg.decoder_layers
@@ -505,7 +531,10 @@ def main():
         "power": power,
         "front_end": fe,
         "kernels": {"gemm_tn_kernel": {"tflops": round(tn["tflops"], 1), "frac": round(tn["tflops"] / peak, 4),
-                                       "share_of_step": round(tn["total_ms"] / nprof / ms, 3)}} if tn else {},
+                                       "share_of_step": round(tn["total_ms"] / nprof / ms, 3),
+                                       "what": "every weight gradient incl. its split fix-up / reduce launches: gemm_tn256g_kernel (an encoder "
+                                               "layer's four dW pooled in one persistent launch) + tn_group_fixup_kernel, gemm_tn256_kernel / "
+                                               "gemm_tn_kernel + tn_reduce_kernel for the rest"}} if tn else {},
         # preheat phase: forward + dgrad only (2 x encoder + 2 x decoder), no encoder weight gradients
         "step_tflops": None if tf_utt is None else round(tf_utt * utts, 1),
     }
@@ -536,6 +565,8 @@ def main():
                                   "note": "encoder forward only, torch.no_grad(), algorithmic FLOPs of SURVEY 8d / dense bf16 peak 2.5 PF"}
     except Exception as ex:
         out["encoder_forward"] = {"ms": None, "note": f"failed: {ex!r}"}
+    out["roofline"]["traffic"] = pmc_traffic(ops.gemm_dispatch_log())
+    out["roofline"]["traffic_source"] = TRAFFIC_SOURCE
     if not a.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(a.model, a.labels)

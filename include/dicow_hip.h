@@ -40,6 +40,10 @@ int dicow_abi_version(void);
  * that many CUs -- otherwise the GEMM workgroups that find their CU taken start only when another one has finished its
  * whole tile list.  Returns the previous value. */
 int dicow_set_gemm_cus(int n);
+/* Names (as a profiler prints them) and launch counts of the GEMM kernel instantiations this process has dispatched,
+ * "name\tcount\n" per line; returns the number of bytes written (call with buf = NULL to size it).  Measurement support:
+ * bench.py quotes a committed rocprofv3 counter summary only for kernels that occur in this list. */
+int dicow_gemm_dispatch_log(char* buf, int cap);
 const char* dicow_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------ casts

@@ -89,6 +89,7 @@ EPI_GELU_DAUX, EPI_MUL_AUX, EPI_COLSUM = 128, 256, 512
 # name -> argtypes ; every function returns int
 _SIGS = {
     "dicow_set_gemm_cus": [c_i],
+    "dicow_gemm_dispatch_log": [c_vp, c_i],
     "dicow_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
     "dicow_cast_transpose_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp],
     "dicow_conv_weight_pack": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],

@@ -40,6 +40,18 @@ def workspace(nbytes: int, device) -> torch.Tensor:
     return t
 
 
+def gemm_dispatch_log() -> dict:
+    """{kernel instantiation name (as rocprofv3 prints it): launches so far in this process} (dicow_gemm_dispatch_log)."""
+    n = L.lib().dicow_gemm_dispatch_log(None, 0)
+    buf = C.create_string_buffer(n + 64)
+    L.lib().dicow_gemm_dispatch_log(buf, n + 64)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        k, _, c = line.partition("\t")
+        out[k] = int(c)
+    return out
+
+
 def set_gemm_cus(n: int) -> int:
     """CUs the persistent NT GEMM may occupy (0 = all); returns the previous setting (dicow_set_gemm_cus)."""
     return L.lib().dicow_set_gemm_cus(int(n))
