@@ -206,6 +206,9 @@ typedef struct {
     float* lse;                                     /* [B,H,Lq] natural-log-sum-exp, saved for backward */
     int64_t q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;
     int B, H, Lq, Lk; int causal;
+    int q_log2;                                     /* 1: q carries a factor log2(e) (folded into the projection's q-scale, which the
+                                                       caller then sets to head_dim^-0.5 * log2 e): the scores are base-2 exponents.
+                                                       Same softmax, same lse (natural log) -- the kernel saves a multiply-add per score */
 } dicow_attn_fwd_args;
 int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream);
 
@@ -220,6 +223,8 @@ typedef struct {
     /* optional fused bias gradients: dq_colsum[h*64+d] += sum_{b,q} dq (as stored), dv_colsum likewise; NULL = off.
        cs_ws: dicow_attn_bwd_colsum_ws_bytes(B, H, Lq, Lk) bytes of scratch (per-wave partial rows, reduced afterwards) */
     float* dq_colsum; float* dv_colsum; void* cs_ws; int64_t cs_ws_bytes;
+    int q_log2;                                     /* as in dicow_attn_fwd_args; dq keeps its meaning (gradient of the projection
+                                                       output before ANY scaling when dq_scale = head_dim^-0.5), dk = ln 2 dS^T q */
 } dicow_attn_bwd_args;
 int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream);
 int64_t dicow_attn_bwd_colsum_ws_bytes(int B, int H, int Lq, int Lk);

@@ -467,26 +467,31 @@ def test_gemm_tn_group_falls_back_and_handles_odd_pools(ops):
             assert float((got - ref).abs().max()) < 2e-3 * max(1.0, float(ref.abs().max())), pool
 
 
-def test_attention_at_bench_shape_vs_torch(ops):
-    """B = 16, H = 20, T = 1500 (one encoder layer's attention of the bench batch): forward and backward vs torch fp32 math."""
+@pytest.mark.parametrize("q_log2", [False, True])
+def test_attention_at_bench_shape_vs_torch(ops, q_log2):
+    """B = 16, H = 20, T = 1500 (one encoder layer's attention of the bench batch): forward and backward vs torch fp32 math.
+    q_log2: the encoder's mode -- q carries log2(e), scores are base-2 exponents (reference scores = (q . k) ln 2)."""
     B, H, Tq = 16, 20, 1500
+    ln2 = 0.6931471805599453 if q_log2 else 1.0
     g = torch.Generator(device="cuda").manual_seed(5)
     mk = lambda s: _bf(torch.randn(B, Tq, H, 64, device="cuda", generator=g) * s)
     q, k, v, do = mk(0.35), mk(1.0), mk(1.0), mk(0.5)
     o = torch.empty_like(q)
     lse = torch.empty(B, H, Tq, device="cuda")
-    ops.attn_fwd(q, k, v, o, lse)
+    ops.attn_fwd(q, k, v, o, lse, q_log2=q_log2)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     delta = torch.empty(2, B, H, Tq, device="cuda")
-    ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv)
+    ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, q_log2=q_log2)
     worst = 0.0
     for b in (0, 7, 15):                                      # fp32 reference per batch row (2.9 GB of scores otherwise)
         qf, kf, vf = (t[b].float().permute(1, 0, 2).requires_grad_(True) for t in (q, k, v))
-        s = qf @ kf.transpose(1, 2)
+        s = (qf @ kf.transpose(1, 2)) * ln2
         of = torch.softmax(s, -1) @ vf
         of.backward(do[b].float().permute(1, 0, 2))
         assert float((o[b].float().permute(1, 0, 2) - of.detach()).abs().max()) < 2e-2
-        for got, ref in ((dq, qf.grad), (dk, kf.grad), (dv, vf.grad)):
+        lse_ref = torch.logsumexp(s.detach(), -1)
+        assert float((lse[b] - lse_ref).abs().max()) < 3e-3
+        for got, ref in ((dq, qf.grad / ln2), (dk, kf.grad), (dv, vf.grad)):
             err = float((got[b].float().permute(1, 0, 2) - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
             worst = max(worst, err)
             assert err < 3e-2, err

@@ -29,9 +29,10 @@ def timeit(fn, iters=10):
     torch.cuda.synchronize()
     return sum(s.elapsed_time(e) for s, e in evs) / iters
 fl = 4.0 * B * H * Lq * Lk * 64 * (0.5 if causal else 1.0)
-t = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, causal=bool(causal)))
+LOG2 = os.environ.get("ATTN_LOG2") == "1"          # the encoder's mode: q carries log2(e)
+t = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, causal=bool(causal), q_log2=LOG2))
 print(f"attn_fwd B{B} H{H} Lq{Lq} Lk{Lk} causal{causal}: {t*1e3:.1f} us  {fl/t/1e9:.0f} TF")
-t = timeit(lambda: ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=bool(causal), dq_scale=0.125))
+t = timeit(lambda: ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=bool(causal), dq_scale=0.125, q_log2=LOG2))
 print(f"attn_bwd (dq+dkv): {t*1e3:.1f} us  {3.5*fl/t/1e9:.0f} TF (7 matmul passes)")
 if os.environ.get("ATTN_PROFILE"):
     ops.attn_fwd(q, k, v, o, lse, causal=bool(causal)); torch.cuda.synchronize()

@@ -51,7 +51,7 @@ class AttnFwdArgs(C.Structure):
     _fields_ = [("q", c_vp), ("k", c_vp), ("v", c_vp), ("o", c_vp), ("lse", c_vp),
                 ("q_bs", c_i64), ("q_rs", c_i64), ("k_bs", c_i64), ("k_rs", c_i64),
                 ("v_bs", c_i64), ("v_rs", c_i64), ("o_bs", c_i64), ("o_rs", c_i64),
-                ("B", c_i), ("H", c_i), ("Lq", c_i), ("Lk", c_i), ("causal", c_i)]
+                ("B", c_i), ("H", c_i), ("Lq", c_i), ("Lk", c_i), ("causal", c_i), ("q_log2", c_i)]
 
 
 class AttnBwdArgs(C.Structure):
@@ -61,7 +61,7 @@ class AttnBwdArgs(C.Structure):
                 ("o_bs", c_i64), ("o_rs", c_i64), ("do_bs", c_i64), ("do_rs", c_i64),
                 ("dq_bs", c_i64), ("dq_rs", c_i64), ("dk_bs", c_i64), ("dk_rs", c_i64), ("dv_bs", c_i64), ("dv_rs", c_i64),
                 ("B", c_i), ("H", c_i), ("Lq", c_i), ("Lk", c_i), ("causal", c_i), ("dq_scale", c_f),
-                ("dq_colsum", c_vp), ("dv_colsum", c_vp), ("cs_ws", c_vp), ("cs_ws_bytes", c_i64)]
+                ("dq_colsum", c_vp), ("dv_colsum", c_vp), ("cs_ws", c_vp), ("cs_ws_bytes", c_i64), ("q_log2", c_i)]
 
 
 class CeArgs(C.Structure):

@@ -198,7 +198,26 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
     h = bh % H; b = bh / H;
 }
 
-__global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_args a) {
+#ifndef ATTN_FWD_WGS
+#define ATTN_FWD_WGS 2
+#endif
+#ifndef ATTN_FWD_ILP
+#define ATTN_FWD_ILP 0
+#endif
+#ifndef ATTN_FWD_MSUM
+#define ATTN_FWD_MSUM 0
+#endif
+#ifndef ATTN_FWD_ASMSEED
+#define ATTN_FWD_ASMSEED 0
+#endif
+// LOG2: q carries a factor log2(e) (folded into the q-scale of the projection epilogue), i.e. the scores ARE base-2
+// exponents.  The forward loop is bound by its VALU instruction count (removing the 32 fma of a tile: -6 %, measured), so
+//   * the S accumulators are SEEDED with -m_ref (a 16-register tuple that only changes when the reference moves): the MFMA
+//     chain delivers s - m_ref and the per-score fma disappears -- p = 2^s' straight away;
+//   * the row sum l += sum p runs on the matrix pipe: one more MFMA per P fragment against a constant all-ones operand
+//     (D[i][q] = sum_k P^T[k][q] for every i; 4 MFMAs per tile instead of 32 v_add and the final half-wave exchange).
+template <bool LOG2>
+__global__ void __launch_bounds__(256, ATTN_FWD_WGS) attn_fwd_kernel(const dicow_attn_fwd_args a) {
     __shared__ __attribute__((aligned(16))) char smem[6 * TILE_BYTES];      // three (K, V) slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -223,7 +242,13 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_ref = -INFINITY, l_run = 0.f;     // reference maximum (raw score units) and running sum of 2^((s - m_ref) log2 e)
+    float m_ref = -INFINITY, l_run = 0.f;     // reference maximum (raw score units; LOG2: base-2 units) and running sum of 2^((s - m_ref) log2 e)
+    f32x16_t seed, lacc;                      // LOG2: -m_ref in every entry (0 while no score has been seen); row sums on the matrix pipe
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { seed[r] = 0.f; lacc[r] = 0.f; }
+    bf16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
     int kv_end = a.Lk;
     if (a.causal) { const int lim = q0 + 128 < a.Lk ? q0 + 128 : a.Lk; kv_end = lim; }   // keys <= last q row of the block
@@ -279,11 +304,24 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
         f32x16_t s[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            if constexpr (LOG2) {
+#if ATTN_FWD_ASMSEED
+                // vdst != srcC spelled out: left to the register allocator, the seed tuple is COPIED into one of the two S
+                // blocks every tile (16 v_mov in front of the MFMA chain)
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[kb]) : "v"(kfr[kb][0]), "v"(qf[0]), "v"(seed));
+#else
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][0], qf[0], seed, 0, 0, 0);
+#endif
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+                for (int kk = 1; kk < 4; ++kk)
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
+            } else {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
+            }
         }
         // V^T fragments for both 32-key blocks: issued now, consumed after the softmax
         const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
@@ -308,10 +346,67 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
                     if (key >= a.Lk || (a.causal && key > qrow)) s[kb][r] = -INFINITY;
                 }
         }
+#if ATTN_FWD_ILP
+        // four independent max3 chains (a single chain of 16 dependent v_max3 stalls a wave that has one partner on its SIMD),
+        // and the half-wave exchange through v_permlane32_swap (VALU) instead of ds_bpermute + lgkmcnt(0)
+        float mq[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) mq[c] = fmaxf(s[0][c], s[1][c]);
+#pragma unroll
+        for (int r = 4; r < 16; r += 4)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) mq[c] = fmaxf(fmaxf(mq[c], s[0][r + c]), s[1][r + c]);
+        float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+#else
         float mx = fmaxf(s[0][0], s[1][0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);        // -> v_max3_f32
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+#endif
+        float psum = 0.f;
+        if constexpr (LOG2) {
+            // s holds s - m_ref (0 subtracted while the row has no reference yet).  The reference moves when a row maximum has
+            // grown by more than 2^8 -- or when the row sees its first finite score.
+            const bool unset = m_ref == -INFINITY;
+            if (__builtin_amdgcn_ballot_w64(mx > 8.0f || (unset && mx > -INFINITY)) != 0) {
+                float d = unset ? mx : fmaxf(mx, 0.f);
+                const bool none = d == -INFINITY;              // still nothing visible for this row
+                d = none ? 0.f : d;
+                const float alpha = unset ? 1.0f : __builtin_amdgcn_exp2f(-d);
+#if ATTN_FWD_MSUM
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
+#else
+                l_run *= alpha;
+#endif
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kb][r] -= d;
+                m_ref = none ? m_ref : (unset ? d : m_ref + d);
+                const float ns = none ? 0.f : -m_ref;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) seed[r] = ns;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[kb][r]);
+                    s[kb][r] = p;
+#if !ATTN_FWD_MSUM
+                    psum += p;               // (one chain of scalar adds: packed f32 adds beside MFMAs cost more than they save)
+#endif
+                }
+        } else {
         if (__builtin_amdgcn_ballot_w64(mx > m_ref + 8.0f * LN2) != 0) {       // also taken on the first tile (m_ref = -inf)
             const float m_new = fmaxf(m_ref, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at 0
@@ -324,7 +419,9 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
             m_ref = m_new;
         }
         const float mL = (m_ref == -INFINITY) ? 0.f : m_ref * LOG2E;
-        float psum = 0.f;
+#if ATTN_FWD_ILP
+        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
+#endif
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -338,11 +435,18 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
 #endif
                 s[kb][r] = p;
 #if !(defined(DICOW_ABLATIONS) && defined(ATTN_ABL_NOSUM))
+#if ATTN_FWD_ILP
+                ps4[r & 3] += p;
+#else
                 psum += p;
 #endif
+#endif
             }
+#if ATTN_FWD_ILP
+        psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
+#endif
+        }
         l_run += psum;
-
         PT(3)
         // ---- O^T += V^T . P^T
         {
@@ -354,6 +458,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
                 const bf16x8_t pf = pack8(s[0], 8 * x);
 #pragma unroll
                 for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+                if (LOG2 && ATTN_FWD_MSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
             }
             {   // next tile's K fragments (unconditional: the counted LDS waits below rely on exactly 8 reads here; past the
                 // last tile this reads a stale slot and the values are never used)
@@ -373,6 +478,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
                 const bf16x8_t pf = pack8(s[1], 8 * x);
 #pragma unroll
                 for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+                if (LOG2 && ATTN_FWD_MSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
             }
         }
         PT(4)
@@ -387,7 +493,7 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
 #endif
 
     // ---- epilogue
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = (LOG2 && ATTN_FWD_MSUM) ? lacc[0] : l_run + __shfl_xor(l_run, 32, 64);
     const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     if (qrow < a.Lq) {
         unsigned short* O = reinterpret_cast<unsigned short*>(a.o) + (int64_t)b * a.o_bs + (int64_t)qrow * a.o_rs + h * HD;
@@ -402,7 +508,8 @@ __global__ void __launch_bounds__(256, 2) attn_fwd_kernel(const dicow_attn_fwd_a
             }
 #ifndef ATTN_PROFILE
         if (a.lse && hh == 0)
-            a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = m_ref + __builtin_amdgcn_logf(l_tot) * LN2;
+            a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = LOG2 ? (m_ref + __builtin_amdgcn_logf(l_tot)) * LN2      // (v_log_f32 is log2)
+                                                                : m_ref + __builtin_amdgcn_logf(l_tot) * LN2;
 #endif
     }
 #ifdef ATTN_PROFILE
@@ -427,7 +534,8 @@ extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
         !check_strides(a->o_rs, "o")) return DICOW_ERR_INVALID;
     DICOW_REQUIRE(a->q_bs % 8 == 0 && a->k_bs % 8 == 0 && a->v_bs % 8 == 0 && a->o_bs % 4 == 0, "attn_fwd: batch strides must keep 16-byte alignment");
     dim3 grid(dicow_cdiv(a->Lq, 128) * a->H * a->B);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    if (a->q_log2) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("attn_fwd");
     return DICOW_OK;
 }
@@ -512,7 +620,9 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
             dsum = fmaf(bfbits2f((unsigned short)of[e]), bfbits2f((unsigned short)dof[kk][e]), dsum);
     }
     dsum += __shfl_xor(dsum, 32, 64);
-    const float nlse = -a.lse[stat];
+    // q_log2: the scores are base-2 exponents already (q carries log2 e): seed with -lse in base-2 units, exponent scale 1
+    const float emul = a.q_log2 ? 1.0f : LOG2E;
+    const float nlse = a.q_log2 ? -a.lse[stat] * LOG2E : -a.lse[stat];
     const float ndlt = -dsum;
     if (hh == 0 && qrow < a.Lq) {
         a.delta[stat] = ndlt;
@@ -573,7 +683,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dp, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E);
+            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * emul);
             if (need_mask) {                          // one branch per block: a test inside the score loop becomes 16
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -666,6 +776,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+    // q_log2: q = log2(e) q_true and the -lse plane was published in base-2 units by the dq kernel: exponent scale 1, and
+    // dK = dS^T q_true = ln 2 * dS^T q
+    const float emul = a.q_log2 ? 1.0f : LOG2E;
+    const float dk_mul = a.q_log2 ? LN2 : 1.0f;
 
     const int t0 = a.causal ? (kblk0 / KV_TILE) : 0;                 // query tiles entirely before the key block see none of it
     const int nt = (a.Lq + KV_TILE - 1) / KV_TILE;
@@ -724,7 +838,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
             }                                                                                                           \
             f32x16_t pv, dsv;                                                                                           \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * LOG2E);                \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * emul);                 \
             if (need_mask) {                      /* ONE branch per block: a test inside the score loop becomes 16 */   \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
                     const int qq = qt0 + (QB) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);                                   \
@@ -767,8 +881,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int col = d * 32 + 8 * q4 + 4 * hh;
-                *reinterpret_cast<uint2*>(DK + col) = make_uint2(pack_bf16x2(dk[d][4 * q4], dk[d][4 * q4 + 1]),
-                                                                 pack_bf16x2(dk[d][4 * q4 + 2], dk[d][4 * q4 + 3]));
+                *reinterpret_cast<uint2*>(DK + col) = make_uint2(pack_bf16x2(dk[d][4 * q4] * dk_mul, dk[d][4 * q4 + 1] * dk_mul),
+                                                                 pack_bf16x2(dk[d][4 * q4 + 2] * dk_mul, dk[d][4 * q4 + 3] * dk_mul));
                 *reinterpret_cast<uint2*>(DV + col) = make_uint2(pack_bf16x2(dv[d][4 * q4], dv[d][4 * q4 + 1]),
                                                                  pack_bf16x2(dv[d][4 * q4 + 2], dv[d][4 * q4 + 3]));
             }
@@ -800,6 +914,10 @@ extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
         const int rq = a->B * dicow_cdiv(a->Lq, 128) * 4, rk = a->B * dicow_cdiv(a->Lk, 128) * 4;
         const float* ws = reinterpret_cast<const float*>(a->cs_ws);
         int rc = DICOW_OK;
+        if (a->dq_colsum && a->dv_colsum && rq == rk) {       // self-attention: both column sums in ONE reduce launch
+            float* outs[2] = {a->dq_colsum, a->dv_colsum};
+            return dicow_launch_reduce_multi(ws, rq, D, (int64_t)rq * D, outs, 2, D, st);
+        }
         if (a->dq_colsum) rc = dicow_launch_reduce_parts(ws, rq, D, a->dq_colsum, D, st);
         if (rc == DICOW_OK && a->dv_colsum) rc = dicow_launch_reduce_parts(ws + (int64_t)rq * D, rk, D, a->dv_colsum, D, st);
         return rc;

@@ -45,22 +45,26 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 // exact (erf) GELU and its derivative (Whisper activation_function="gelu").  Every kernel evaluates the SAME expression (this
 // scalar form and the packed stage-major gelu_cdf_pdf_p below are operation-for-operation identical), so the training
 // forward, the inference forward and the decoder step produce identical activations.
-//   Round 3 form (DICOW_GELU_V 1): Phi(x) = 1 / (1 + 2^(x q(x^2))), q = degree-4 fit of -log2(e) logit(Phi(x)) / x -- see
-//   gelu_cdf_pdf_p.  |d gelu| < 6e-6 over all bf16 inputs.
+//   Round 3 form (DICOW_GELU_V 1): Phi(x) = 1 / (1 + 2^(x q(x^2))), q = degree-6 fit of -log2(e) logit(Phi(x)) / x -- see
+//   gelu_cdf_pdf_p.  |d gelu| < 5e-7 over all bf16 inputs.
 //   Round 1/2 form (DICOW_GELU_V 0): Abramowitz-Stegun 7.1.26 erfc, 0.5 erfc(|x|/sqrt2) = t poly4(t) exp(-x^2/2) / 2,
 //   t = 1/(1 + p|x|/sqrt2); |error| < 5e-7.
-#define GELU_Q0 -2.3021653554162658f
-#define GELU_Q1 -0.10500593863530419f
-#define GELU_Q2 0.0002534117686203228f
-#define GELU_Q3 0.00010587535896480078f
-#define GELU_Q4 -4.1117263817008095e-06f
+#define GELU_Q0 -2.30220720357529451e+00f
+#define GELU_Q1 -1.04838581318361504e-01f
+#define GELU_Q2 9.55929831375757871e-05f
+#define GELU_Q3 1.59389397366708184e-04f
+#define GELU_Q4 -1.14524280114105203e-05f
+#define GELU_Q5 3.85044882878601587e-07f
+#define GELU_Q6 -5.20990630162781774e-09f
 #ifndef DICOW_GELU_V
 #define DICOW_GELU_V 1
 #endif
 __device__ __forceinline__ void gelu_cdf_pdf(float x, float& cdf, float& pdf) {
 #if DICOW_GELU_V == 1
     const float s = x * x;
-    float q = fmaf(s, GELU_Q4, GELU_Q3);
+    float q = fmaf(s, GELU_Q6, GELU_Q5);
+    q = fmaf(q, s, GELU_Q4);
+    q = fmaf(q, s, GELU_Q3);
     q = fmaf(q, s, GELU_Q2);
     q = fmaf(q, s, GELU_Q1);
     q = fmaf(q, s, GELU_Q0);
@@ -160,13 +164,14 @@ __device__ __forceinline__ void gelu_cdf_pdf_p(const f32x2_t (&x)[NP], f32x2_t (
     }
 }
 #elif DICOW_GELU_V == 1
-// Round 3: Phi(x) = 1 / (1 + 2^(x q(x^2))), q = the degree-4 minimax fit (in x^2) of -log2(e) logit(Phi(x)) / x, weighted by
-// Phi (1 - Phi).  The logit of the normal cdf is odd, smooth and nearly cubic, so five coefficients give |dPhi| < 1.5e-6 and
-// |d gelu| < 6e-6 over EVERY bf16 input (tools/gelu_fit.py: exhaustive over the 65280 finite bf16 values in fp32 emulation,
-// bf16-rounded gelu differs from the float64 one for 256 of them against 167 for the erfc form), and the leading coefficient
-// is negative, so the form saturates by itself: x q -> -+inf, 2^. -> 0 / inf, 1/(1 + .) -> 1 / 0 -- no clamp, no sign
-// handling, no NaN for any finite or infinite input.  Per pair: 7 packed full-rate instructions + 2 v_exp + 2 v_rcp
-// (erfc form: ~15 + 4), all of them plain dependency chains that the stage-major order interleaves.
+// Round 3: Phi(x) = 1 / (1 + 2^(x q(x^2))), q = the degree-6 minimax fit (in x^2, over |x| <= 6) of -log2(e) logit(Phi(x)) / x,
+// weighted by the gelu error it causes.  The logit of the normal cdf is odd, smooth and nearly cubic, so seven coefficients give
+// |d gelu| < 5e-7 over EVERY bf16 input and a RELATIVE error below 3e-4 down to gelu(-4) = -1.3e-4 (tools/gelu_fit.py:
+// exhaustive over the 65280 finite bf16 values in fp32 emulation; the bf16-rounded activation equals the rounded float64 one
+// wherever |gelu| > 1e-4), and the leading coefficient is negative, so the form saturates by itself: x q -> -+inf,
+// 2^. -> 0 / inf, 1/(1 + .) -> 1 / 0 -- no clamp, no sign handling, no NaN for any finite or infinite input.  Per pair:
+// 9 packed full-rate instructions + 2 v_exp + 2 v_rcp (erfc form: ~15 + 4), all plain dependency chains that the
+// stage-major order interleaves.
 template <int NP, bool WANT_PDF>
 __device__ __forceinline__ void gelu_cdf_pdf_p(const f32x2_t (&x)[NP], f32x2_t (&cdf)[NP], f32x2_t (&pdf)[NP]) {
     f32x2_t s[NP], q[NP];
@@ -175,7 +180,13 @@ __device__ __forceinline__ void gelu_cdf_pdf_p(const f32x2_t (&x)[NP], f32x2_t (
     for (int i = 0; i < NP; ++i) s[i] = x[i] * x[i];
     stage_fence2(s);
 #pragma unroll
-    for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(s[i], f32x2_t{GELU_Q4, GELU_Q4}, f32x2_t{GELU_Q3, GELU_Q3});
+    for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(s[i], f32x2_t{GELU_Q6, GELU_Q6}, f32x2_t{GELU_Q5, GELU_Q5});
+    stage_fence2(q);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(q[i], s[i], f32x2_t{GELU_Q4, GELU_Q4});
+    stage_fence2(q);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(q[i], s[i], f32x2_t{GELU_Q3, GELU_Q3});
     stage_fence2(q);
 #pragma unroll
     for (int i = 0; i < NP; ++i) q[i] = __builtin_elementwise_fma(q[i], s[i], f32x2_t{GELU_Q2, GELU_Q2});

@@ -412,7 +412,9 @@ class EncoderEngine:
                 ops.fddt_ln_fwd(hs, rows, D, mode=ops.MODE_NONE, ln_w=ln.weight.detach(), ln_b=ln.bias.detach(),
                                 y_bf16=xln, mean=mean, rstd=rstd)
             Ls.rows, Ls.B_after, Ls.hp, Ls.xln, Ls.mean, Ls.rstd = rows, Bc, hp, xln, mean, rstd
-            # ---- self-attention (HF WhisperAttention; q pre-scaled in the projection epilogue)
+            # ---- self-attention (HF WhisperAttention; q pre-scaled in the projection epilogue).  (The kernels also have a
+            # q_log2 mode -- log2(e) folded into this scale, S accumulators seeded with -m_ref -- which measured no faster:
+            # profiles/r03_attn_fwd_variants.txt; the encoder keeps the reference's rounding point of q.)
             qkv = linear_fwd(xln, w.att.qkv, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
             o = _e((rows, D), BF16, dev)
             lse = _e((Bc, H, T), F32, dev)

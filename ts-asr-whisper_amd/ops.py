@@ -260,8 +260,11 @@ def _bs_rs(t, name):
     return t.stride(0), t.stride(1)
 
 
-def attn_fwd(q, k, v, o, lse=None, causal=False):
-    """q [B,Lq,H,64], k/v [B,Lk,H,64] bf16 views; o like q; lse [B,H,Lq] fp32."""
+LOG2E = 1.4426950408889634          # q-scale factor of the q_log2 attention mode: head_dim^-0.5 * LOG2E in the projection epilogue
+
+
+def attn_fwd(q, k, v, o, lse=None, causal=False, q_log2=False):
+    """q [B,Lq,H,64], k/v [B,Lk,H,64] bf16 views; o like q; lse [B,H,Lq] fp32.  q_log2: q carries a factor log2(e)."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (o, "o")):
         _req(t, BF16, "attn_fwd." + n)
     a = L.AttnFwdArgs()
@@ -271,11 +274,11 @@ def attn_fwd(q, k, v, o, lse=None, causal=False):
     a.v_bs, a.v_rs = _bs_rs(v, "v")
     a.o_bs, a.o_rs = _bs_rs(o, "o")
     a.B, a.Lq, a.H = q.shape[0], q.shape[1], q.shape[2]
-    a.Lk, a.causal = k.shape[1], int(causal)
+    a.Lk, a.causal, a.q_log2 = k.shape[1], int(causal), int(q_log2)
     L.call_struct("dicow_attn_fwd", a)
 
 
-def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0, dq_colsum=None, dv_colsum=None):
+def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0, dq_colsum=None, dv_colsum=None, q_log2=False):
     """Backward of attn_fwd.  All [B,L,H,64] bf16 views; lse [B,H,Lq] fp32; delta = workspace [2,B,H,Lq] fp32."""
     assert delta.numel() >= 2 * lse.numel(), "attn_bwd: delta workspace must hold 2*B*H*Lq floats"
     a = L.AttnBwdArgs()
@@ -291,7 +294,7 @@ def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0
     a.dk_bs, a.dk_rs = _bs_rs(dk, "dk")
     a.dv_bs, a.dv_rs = _bs_rs(dv, "dv")
     a.B, a.Lq, a.H = q.shape[0], q.shape[1], q.shape[2]
-    a.Lk, a.causal, a.dq_scale = k.shape[1], int(causal), dq_scale
+    a.Lk, a.causal, a.dq_scale, a.q_log2 = k.shape[1], int(causal), dq_scale, int(q_log2)
     if dq_colsum is not None or dv_colsum is not None:       # fused q / v bias gradients ([H*64] fp32, accumulated)
         ws = workspace(L.lib().dicow_attn_bwd_colsum_ws_bytes(a.B, a.H, a.Lq, a.Lk), q.device)
         a.dq_colsum, a.dv_colsum, a.cs_ws, a.cs_ws_bytes = _p(dq_colsum), _p(dv_colsum), ws.data_ptr(), ws.numel()
