@@ -326,16 +326,37 @@ def dry_launch(a, world, rank, local):
     dist.all_reduce(t)
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_gpus": dist.get_world_size(), "backend": dist.get_backend(),
+        emit(json.dumps({"dry_launch": True, "n_gpus": dist.get_world_size(), "backend": dist.get_backend(),
                           "allreduce_sum": float(t), "expected_sum": a.gpus * (a.gpus + 1) / 2,
                           "config": {"global_batch": a.batch * a.gpus, "parallelism": f"dp{a.gpus}"}}))
     dist.destroy_process_group()
+
+
+_REAL_STDOUT = None
+
+
+def _claim_stdout():
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner ("RCCL version : ...", five lines) to file
+    descriptor 1 when a communicator is created / destroyed, rocm-smi helpers may chat too: point fd 1 at stderr for the
+    whole run and keep the real stdout for the JSON line."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def emit(line):
+    out = _REAL_STDOUT if _REAL_STDOUT is not None else sys.stdout
+    out.write(line + "\n")
+    out.flush()
 
 
 def main():
     a = parse()
     if a.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(a)                       # self-launch: one process per GPU
+    _claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -576,9 +597,9 @@ def main():
             out["cpu_baseline"]["config1"] = cpu_config1()
         except Exception as ex:
             out["cpu_baseline"]["config1"] = {"value": None, "sample": f"failed: {ex!r}"}
-    print(json.dumps(out))
     if dist.is_initialized():
         dist.destroy_process_group()
+    emit(json.dumps(out))
 
 
 if __name__ == "__main__":

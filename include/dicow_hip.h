@@ -186,8 +186,9 @@ int dicow_gemm_tn(const dicow_gemm_tn_args* a, void* stream);
  * autograd's wgrad of q/k/v, out_proj, fc1, fc2 reached from encoder.py:216-221).  Pooled, the output tiles cover the chip
  * with whole contractions and only the remainder is split; one fix-up launch adds those partials in a fixed order.  Same
  * results as calling dicow_gemm_tn on p[0..n) in turn up to fp32 summation order (deterministic); problems that cannot be
- * pooled (N < 256, batches, different Mk) are run one by one.  ws: dicow_gemm_tn_group_ws_bytes. */
-#define DICOW_TN_GROUP_MAX 6
+ * pooled (N < 256, batches, different Mk, fewer pooled tiles than CUs) are run one by one.  ws: dicow_gemm_tn_group_ws_bytes.
+ * Up to 24 problems: a small model (whisper-base: 48 tiles per layer) pools the weight gradients of ALL its layers. */
+#define DICOW_TN_GROUP_MAX 24
 typedef struct {
     int n;
     dicow_gemm_tn_args p[DICOW_TN_GROUP_MAX];       /* (their own ws / ws_bytes fields are ignored) */

@@ -43,8 +43,8 @@ def _bench(env, *extra):
                         "--profile-steps", "1", "--no-cpu-baseline", "--no-power", *extra],
                        capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout      # ONE JSON line: RCCL's version banner must not reach stdout
     return json.loads(lines[0])
 
 

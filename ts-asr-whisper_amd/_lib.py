@@ -40,7 +40,7 @@ class GemmTnArgs(C.Structure):
                 ("C_seg", c_vp * 2), ("seg_rows", c_i), ("ws", c_vp), ("ws_bytes", c_i64)]
 
 
-TN_GROUP_MAX = 6
+TN_GROUP_MAX = 24
 
 
 class GemmTnGroupArgs(C.Structure):

@@ -541,12 +541,14 @@ class EncoderEngine:
                         dln_b=G.get(enc.layer_norm.bias), colsum_out=G.get(last.fc2.bias))
         hook = getattr(enc, "_segment_hook", None) or (lambda name: None)
         hook("final_ln")
+        # Weight gradients are recorded per layer and run as ONE pooled launch (ops.TnGroup / dicow_gemm_tn_group) as soon as
+        # the pool holds a tile for every CU: large-v3-turbo has 300 tiles per layer (one launch per layer), whisper-base 48
+        # (all six layers in one launch at the end).  A layer's DP bucket is only handed over once its gradients have run.
+        tng, pend, ncu = ops.TnGroup(), [], ops.num_cus(dev)
         for i in range(nl - 1, -1, -1):
             lyr, w, Ls = enc.layers[i], W.layers[i], S.layers[i]
             rows, Bc = Ls.rows, Ls.B_after
-            # ---- FFN backward.  The layer's four weight gradients are recorded and run as ONE pooled launch at the end of the
-            # layer (ops.TnGroup / dicow_gemm_tn_group): their operands (gb, d_u, g2b, d_qkv and the saved activations) live on
-            tng = ops.TnGroup()
+            # ---- FFN backward (the weight-gradient operands gb, d_u, g2b, d_qkv and the saved activations live on until tng.run())
             linear_wgrad(gb, Ls.a, G.get(lyr.fc2.weight), rows, group=tng)
             d_u = linear_dgrad(gb, w.fc2, rows, aux=Ls.u, colsum_out=G.get(lyr.fc1.bias))     # fc1 bias grad = colsum(d_u), fused
             linear_wgrad(d_u, Ls.xln2, G.get(lyr.fc1.weight), rows, group=tng)
@@ -570,7 +572,6 @@ class EncoderEngine:
                          dq_colsum=G.get(att.q_proj.bias), dv_colsum=G.get(att.v_proj.bias))   # q / v bias grads, fused
             qkv_wgrad(d_qkv, Ls.xln, G.get(att.q_proj.weight), G.get(att.k_proj.weight), G.get(att.v_proj.weight), rows, D, group=tng)
             d_xln = linear_dgrad(d_qkv, w.att.qkv, rows)
-            tng.run()
             # ---- LayerNorm1 (+ SCB) + FDDT backward; the column sum of the result is the previous fc2's bias grad
             fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None
             mode, fw, fb = fddt_ptrs(fd, cfg)
@@ -614,7 +615,12 @@ class EncoderEngine:
                 ops.fddt_ln_bwd(Ls.h_in, rows_in, D, mode=mode, stno=S.stno, stno_bstride=Ls.bstride, T=T, w=fw, b=fb,
                                 g_res=gin, g_out=g0, g_out_bf16=g0b, dw=dw, db=db, colsum_out=prev_b2)
             g, gb = g0, g0b
-            hook(f"layer{i}")
+            pend.append(f"layer{i}")
+            if i == 0 or tng.tiles() >= ncu or len(tng.items) + 6 > L.TN_GROUP_MAX:
+                tng.run()
+                for name in pend:
+                    hook(name)
+                pend = []
         self._stem_backward(S, g, G)
         hook("stem")
 

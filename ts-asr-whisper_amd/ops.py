@@ -52,6 +52,19 @@ def gemm_dispatch_log() -> dict:
     return out
 
 
+_NCU = {}
+
+
+def num_cus(device=None) -> int:
+    """CUs the persistent GEMM grids may use on this device (all of them unless set_gemm_cus limited it)."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev not in _NCU:
+        _NCU[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    lim = L.lib().dicow_set_gemm_cus(0)
+    L.lib().dicow_set_gemm_cus(lim)
+    return lim if 0 < lim < _NCU[dev] else _NCU[dev]
+
+
 def set_gemm_cus(n: int) -> int:
     """CUs the persistent NT GEMM may occupy (0 = all); returns the previous setting (dicow_set_gemm_cus)."""
     return L.lib().dicow_set_gemm_cus(int(n))
@@ -237,6 +250,10 @@ class TnGroup:
         self.items.append((A, B, C_out, Mk, N1, N2, lda, ldb, ldc, accumulate, C_seg, seg_rows))
         if len(self.items) == L.TN_GROUP_MAX:
             self.run()
+
+    def tiles(self):
+        """256 x 256 output tiles recorded so far (the pooled launch wants at least one per CU)."""
+        return sum(((it[4] + 255) // 256) * ((it[5] + 255) // 256) for it in self.items)
 
     def run(self):
         if not self.items:
