@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 out=gpurun_out/dp_single_rank.txt; : > $out
 line() { python -c "
 import json,sys
-d=json.loads(open('$1').read().strip().splitlines()[-1]); a=d['allreduce']
+d=json.loads([l for l in open("$1").read().splitlines() if l.startswith("{")][-1]); a=d['allreduce']
 print('%-44s %8.3f ms/step (median %8.3f)  %7.2f utt/s  backend=%s bytes/step=%d buckets=%d exposed=%s gemm_cus=%s loss=%.6f' % ('$2', d['ms_per_step'], d['ms_per_step_median'], d['value'], a['backend'], a['bytes_per_step'], a['buckets_per_step'], a['exposed_ms_per_step'], a['gemm_cus'], d['loss']))" >> $out; }
 for rep in 1 2; do
 python bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-power > gpurun_out/_dp_a.json 2>/dev/null; line gpurun_out/_dp_a.json "plain (no process group)"

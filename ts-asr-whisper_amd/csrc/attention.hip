@@ -199,7 +199,7 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
 }
 
 #ifndef ATTN_FWD_WGS
-#define ATTN_FWD_WGS 2
+#define ATTN_FWD_WGS 3          // workgroups per CU: 154 VGPRs fit three; equal time at large-v3-turbo (3840 workgroups), one round instead of 1.5 at whisper-base B = 8 (768)
 #endif
 #ifndef ATTN_FWD_ILP
 #define ATTN_FWD_ILP 0
@@ -217,7 +217,7 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
 //   * the row sum l += sum p runs on the matrix pipe: one more MFMA per P fragment against a constant all-ones operand
 //     (D[i][q] = sum_k P^T[k][q] for every i; 4 MFMAs per tile instead of 32 v_add and the final half-wave exchange).
 template <bool LOG2>
-__global__ void __launch_bounds__(256, ATTN_FWD_WGS) attn_fwd_kernel(const dicow_attn_fwd_args a) {
+__global__ void __launch_bounds__(256, LOG2 ? 2 : ATTN_FWD_WGS) attn_fwd_kernel(const dicow_attn_fwd_args a) {
     __shared__ __attribute__((aligned(16))) char smem[6 * TILE_BYTES];      // three (K, V) slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
 typedef __attribute__((address_space(3))) void lds_void_t;
 template <int R, bool OUT_BF16>
 __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fddt_ln_bwd_args a) {
-    extern __shared__ __attribute__((aligned(16))) char stg[];       // [2 stages][R rows][10*D bytes]: h_in | g_res | d_y
+    extern __shared__ __attribute__((aligned(16))) char stg[];       // [2 or 3 stages][R rows][10*D bytes]: h_in | g_res | d_y
     __shared__ float red[2][MAX_WAVES * 2 * R];
     const int tid = threadIdx.x, lane = tid & 63, col = tid * 4, D = a.D;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -670,7 +670,14 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
     };
     const int stride = gridDim.x * R;
     int row0 = blockIdx.x * R, it = 0;
+#if BWD_DEPTH == 2
+    // Three LDS stages, the row DMA runs TWO trips ahead (the per-row scalars one): with one trip in flight a CU holds 38 KB
+    // of requests, ~19 GB/s per CU at the loaded HBM latency -- 4.9 TB/s chip-wide at best, 3.9 measured; two trips hold 77 KB.
+    if (row0 < a.rows) { load_scalars(row0); stage_rows(row0, 0); stage_rows(row0 + stride, 1); }
+    int sg = 0;                                                      // LDS stage of the trip being computed
+#else
     if (row0 < a.rows) { load_scalars(row0); stage_rows(row0, 0); }
+#endif
     // Store data lives in these quads until the NEXT trip's reduction is over: rewriting the registers of a queued 16-byte store
     // (the compiler reused its temporaries at once) corrupted ~1 % of g_out at D = 1280, exactly as in the staged forward.
     typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -680,17 +687,31 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
 #pragma unroll
     for (int r = 0; r < R; ++r) { ov[r] = u32x4_t{0, 0, 0, 0}; bv[r] = u32x2_t{0, 0}; }
     for (; row0 < a.rows; row0 += stride, ++it) {
+#if BWD_DEPTH == 2
+        const int s = sg;
+        const int s2 = sg == 0 ? 2 : sg - 1;                         // (sg + 2) % 3: the stage trip t-1 has finished reading
+        sg = sg == 2 ? 0 : sg + 1;
+#else
         const int s = it & 1;
+#endif
         float sc[R][6];
 #pragma unroll
         for (int r = 0; r < R; ++r)
 #pragma unroll
             for (int c = 0; c < 6; ++c) sc[r][c] = sc_n[r][c];
         load_scalars(row0 + stride);
+#if BWD_DEPTH == 2
+        stage_rows(row0 + 2 * stride, s2);                           // (past the end: out-of-range rows read as zero)
+        // issue order: ... S(t) D(t+1) | stores(t-1) | S(t+1) D(t+2) | this wait.  Needed: D(t) (older) and S(t); younger than
+        // S(t): D(t+1) 3R, the previous trip's stores, S(t+1) 6R, D(t+2) 3R.  First trip: S(0) D(0) D(1) | S(1) D(2).
+        if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(12 * R) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((OUT_BF16 ? 14 : 13) * R) : "memory");
+#else
         stage_rows(row0 + stride, s ^ 1);                            // (past the end: out-of-range rows read as zero)
         // younger than this trip's DMA: the previous trip's stores, the scalars and the DMA just issued -- fixed counts
         if (it == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(9 * R) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" :: "i"((OUT_BF16 ? 11 : 10) * R) : "memory");
+#endif
         float4 hin[R], xh[R], dy[R], scw[R];
         float m[R][4], rs[R], sums[2 * R];
 #pragma unroll
@@ -765,6 +786,10 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
     }
 }
 
+#ifndef BWD_DEPTH
+#define BWD_DEPTH 1       // row DMA trips in flight in the staged backward (1: two LDS stages, 2: three -- measured equal: 124-126 us
+                          // either way, profiles/r03_rows_depth.txt; the barrier of the per-trip block reduction is the limit, not the DMA latency)
+#endif
 #ifndef BWD_R0
 #define BWD_R0 2          // rows per trip and resident workgroups per CU of the LayerNorm-only (mode 0) body
 #endif
@@ -803,7 +828,13 @@ extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) 
     // LDS-staged body: the encoder-layer shape (every FDDT vector present, fp32 in, bf16 d_y, residual gradient, no pos)
     const bool staged = block <= 512 && block * 4 == a->D && a->D % 8 == 0 && r_env != 9 && r_env != 8 && a->mode == 1 && a->ln_w && !a->in_bf16 &&
                         !a->dy_f32 && a->g_res && a->g_out && !a->pos && a->w[0] && a->w[1] && a->w[2] && a->w[3] &&
-                        a->b[0] && a->b[1] && a->b[2] && a->b[3] && (int64_t)a->rows * a->D * 4 < (1ll << 31);
+                        a->b[0] && a->b[1] && a->b[2] && a->b[3] && (int64_t)a->rows * a->D * 4 < (1ll << 31) &&
+                        (BWD_DEPTH + 1) * BWD_RS * 10 * a->D <= 150 * 1024;       // the row stages must fit the CU's 160 KiB of LDS
+    static const bool attr_set = [] {
+        (void)hipFuncSetAttribute((const void*)fddt_ln_bwd_staged_kernel<BWD_RS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)fddt_ln_bwd_staged_kernel<BWD_RS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        return true; }();
+    (void)attr_set;
     const int grid = bwd_grid(a->rows, a->D, ln0 ? BWD_CU0 : staged ? BWD_CUS : 2);
     const int D = a->D;
     float* outs[11] = {a->ln_w ? a->dln_w : nullptr, a->ln_w ? a->dln_b : nullptr, a->colsum_out,
@@ -820,9 +851,9 @@ extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) 
     else if (r_env == 9)                                                                    // generic body (ablation)
         hipLaunchKernelGGL((fddt_ln_bwd_kernel<2, 512>), dim3(grid), dim3(block), 0, st, *a);
     else if (staged && a->g_out_bf16)
-        hipLaunchKernelGGL((fddt_ln_bwd_staged_kernel<BWD_RS, true>), dim3(grid), dim3(block), 2 * BWD_RS * 10 * a->D, st, *a);
+        hipLaunchKernelGGL((fddt_ln_bwd_staged_kernel<BWD_RS, true>), dim3(grid), dim3(block), (BWD_DEPTH + 1) * BWD_RS * 10 * a->D, st, *a);
     else if (staged)
-        hipLaunchKernelGGL((fddt_ln_bwd_staged_kernel<BWD_RS, false>), dim3(grid), dim3(block), 2 * BWD_RS * 10 * a->D, st, *a);
+        hipLaunchKernelGGL((fddt_ln_bwd_staged_kernel<BWD_RS, false>), dim3(grid), dim3(block), (BWD_DEPTH + 1) * BWD_RS * 10 * a->D, st, *a);
     else if (ln0)
         hipLaunchKernelGGL((fddt_ln_bwd_kernel<BWD_R0, 512, 0, 1>), dim3(grid), dim3(block), 0, st, *a);
     else
