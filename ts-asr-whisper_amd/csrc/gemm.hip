@@ -1823,7 +1823,8 @@ static bool tn_group_plan(const dicow_gemm_tn_group_args* ga, tn_group_plan_t& p
     const int lim = g_gemm_cus.load();
     const int G = (lim > 0 && lim < g_tn_ncu) ? lim : g_tn_ncu;
     pl.n = ga->n; pl.G = G; pl.T = T; pl.kiters = dicow_cdiv(Mk, TK);
-    if (T < G) return false;                        // fewer pooled tiles than CUs: the per-problem split-K plans do better
+    if (4 * T < 3 * G) return false;                // far fewer pooled tiles than CUs: the per-problem split-K plans do better
+                                                    // (from 3/4 G on, one whole contraction per workgroup still beats them)
     pl.R = T / G; pl.rem = T - pl.R * G;
     pl.s = pl.rem > 0 ? G / pl.rem : 1;
     if (pl.s > pl.kiters) pl.s = pl.kiters;

@@ -544,8 +544,9 @@ class EncoderEngine:
         # Weight gradients are recorded per layer and run as ONE pooled launch (ops.TnGroup / dicow_gemm_tn_group) as soon as
         # the pool holds a tile for every CU: large-v3-turbo has 300 tiles per layer (one launch per layer), whisper-base 48
         # (all six layers in one launch at the end).  A layer's DP bucket is only handed over once its gradients have run.
-        tng, pend, ncu = ops.TnGroup(), [], ops.num_cus(dev)
+        tng, pend, ncu, per_layer = ops.TnGroup(), [], ops.num_cus(dev), 0
         for i in range(nl - 1, -1, -1):
+            n_before = len(tng.items)
             lyr, w, Ls = enc.layers[i], W.layers[i], S.layers[i]
             rows, Bc = Ls.rows, Ls.B_after
             # ---- FFN backward (the weight-gradient operands gb, d_u, g2b, d_qkv and the saved activations live on until tng.run())
@@ -616,7 +617,8 @@ class EncoderEngine:
                                 g_res=gin, g_out=g0, g_out_bf16=g0b, dw=dw, db=db, colsum_out=prev_b2)
             g, gb = g0, g0b
             pend.append(f"layer{i}")
-            if i == 0 or tng.tiles() >= ncu or len(tng.items) + 6 > L.TN_GROUP_MAX:
+            per_layer = max(per_layer, len(tng.items) - n_before)      # problems a layer records (4 with fused q/k/v, else 6)
+            if i == 0 or tng.tiles() >= ncu or len(tng.items) + per_layer > L.TN_GROUP_MAX:
                 tng.run()
                 for name in pend:
                     hook(name)
