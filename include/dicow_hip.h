@@ -163,6 +163,10 @@ typedef struct {
 } dicow_gemm_args;
 int dicow_gemm_nt(const dicow_gemm_args* a, void* stream);
 int64_t dicow_gemm_nt_colsum_ws_bytes(int M, int N);
+/* Deep contraction, small output (K >= 8192, fewer 128 x 128 tiles than workgroup slots, no epilogue: the tied LM head's dgrad,
+ * modeling_dicow.py:302): when the caller passes this many bytes in colsum_ws / colsum_ws_bytes, the contraction is cut into
+ * equal ranges that run as one batched launch and are added up in a fixed order.  0 = the problem is not split. */
+int64_t dicow_gemm_nt_splitk_ws_bytes(const dicow_gemm_args* a);
 
 /* C[N1,N2] (+)= sum_m A[m,N1] * B[m,N2]  (fp32 C): every weight gradient dW = dY^T X.  When the output has too few
  * tiles to fill the chip the contraction is split over grid.z; the splits write fp32 partials to the caller's

@@ -242,6 +242,30 @@ def test_gemm_nt_cu_limit(ops):
     assert maxdiff(C0.float().cpu(), A @ B.t()) < 3e-2
 
 
+@pytest.mark.parametrize("M,N,K,f32", [(1024, 512, 51968, False), (2048, 1280, 51968, False), (200, 384, 8192, True), (1024, 512, 51968 + 64, False)])
+def test_gemm_nt_deep_contraction_split(ops, M, N, K, f32):
+    """The tied LM head's dgrad shape (modeling_dicow.py:302: d_x = d_logits [B L, Vpad] . E): few output tiles, 812 k-steps.
+    ops.gemm_nt hands the library a workspace and the contraction runs as equal ranges of one batched launch, summed in range
+    order (dicow_gemm_nt_splitk_ws_bytes); K = 51968 + 64 has 813 = 3 x 271 k-steps (three ranges).  Against fp32 torch."""
+    from ts_asr_whisper_amd import _lib as L
+    import ctypes as C
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    B = (torch.randn(N, K, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    out = torch.empty(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device="cuda")
+    a = L.GemmArgs()
+    a.A, a.B, a.C, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.batch = A.data_ptr(), B.data_ptr(), out.data_ptr(), M, N, K, K, K, N, 1
+    a.flags = L.EPI_OUT_F32 if f32 else 0
+    assert L.lib().dicow_gemm_nt_splitk_ws_bytes(C.byref(a)) > 0           # this shape IS split
+    ops.gemm_nt(A, B, out, M, N, K)
+    ref = A.float() @ B.float().t()
+    err = float((out.float() - ref).abs().max())
+    assert err < (2e-3 if f32 else 2e-2) * max(1.0, float(ref.abs().max())), err
+    again = torch.empty_like(out)
+    ops.gemm_nt(A, B, again, M, N, K)
+    assert torch.equal(out, again)                                         # fixed summation order
+
+
 def test_gelu_device_accuracy(ops):
     """The GELU of the epilogues -- x / (1 + 2^(x q(x^2))), q a degree-6 fit of the normal cdf's logit (common.h) -- against
     float64 erf on a dense grid of bf16 inputs in [-9, 9]: |err| < 1e-6 before the bf16 rounding, and the ROUNDED activation

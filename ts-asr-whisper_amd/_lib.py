@@ -161,6 +161,7 @@ _SIGS64 = {   # functions returning int64_t (workspace sizes)
     "dicow_attn_bwd_colsum_ws_bytes": [c_i, c_i, c_i, c_i],
     "dicow_fddt_ln_bwd_ws_bytes": [c_i, c_i],
     "dicow_gemm_tn_ws_bytes": [C.POINTER(GemmTnArgs)],
+    "dicow_gemm_nt_splitk_ws_bytes": [C.POINTER(GemmArgs)],
     "dicow_gemm_tn_group_ws_bytes": [C.POINTER(GemmTnGroupArgs)],
     "dicow_logmel_ws_bytes": [c_i, c_i],
     "dicow_ctc_ws_bytes": [c_i, c_i, c_i],

@@ -1002,9 +1002,64 @@ extern "C" int64_t dicow_gemm_nt_colsum_ws_bytes(int M, int N) {
 
 static int gemm_nt_impl(const dicow_gemm_args* a, void* stream, bool* fused_colsum, int* colsum_rows);
 
+// ---- deep contractions with a small output (the tied LM head's dgrad: [B L, D] = d_logits [B L, 51968] . E: 32 output tiles at
+// whisper-base, 160 at large-v3-turbo, 812 k-steps each): the contraction is cut into S equal ranges that run as the S
+// "batches" of one launch (operand stride = the range's k offset) writing fp32 partials to the caller's workspace; one small
+// kernel adds them in range order and rounds once.  Deterministic; only taken when the caller provides the workspace.
+static int g_ncu_all = 256;
+static int nt_splitk_plan(const dicow_gemm_args* a) {
+    if (a->batch > 1 || (a->flags & ~DICOW_EPI_OUT_F32) != 0 || a->bias || a->residual || a->aux) return 1;
+    if (a->K % BK != 0 || a->K < 8192 || a->M <= 16) return 1;
+    const int64_t tiles = (int64_t)dicow_cdiv(a->M, BM) * dicow_cdiv(a->N, BN);
+    if (tiles >= 2 * g_ncu_all) return 1;                      // enough tiles already (two 128 x 128 workgroups per CU)
+    const int nk = a->K / BK;
+    int best = 1;
+    for (int sp = 2; sp <= 64; ++sp) {
+        if (nk % sp != 0 || nk / sp < 16) continue;            // equal ranges of at least 1024 columns
+        best = sp;
+        if (tiles * sp >= 2 * g_ncu_all) break;                // the first divisor that fills every workgroup slot
+    }
+    return best;
+}
+extern "C" int64_t dicow_gemm_nt_splitk_ws_bytes(const dicow_gemm_args* a) {
+    if (!a) return 0;
+    const int sp = nt_splitk_plan(a);
+    return sp > 1 ? (int64_t)sp * a->M * a->N * 4 : 0;
+}
+__global__ void nt_splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t mn, int N, void* __restrict__ C, int64_t ldc,
+                                        int out_f32) {
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < mn; i += (int64_t)gridDim.x * blockDim.x * 4) {
+        float4 t = *reinterpret_cast<const float4*>(ws + i);
+        for (int z = 1; z < splits; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)z * mn + i);
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+        }
+        const int64_t m = i / N; const int n = (int)(i - m * N);
+        if (out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + m * ldc + n) = t;
+        else *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(C) + m * ldc + n) = make_uint2(pack_bf16x2(t.x, t.y), pack_bf16x2(t.z, t.w));
+    }
+}
+
 extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     DICOW_REQUIRE(a && a->A && a->B && a->C, "gemm_nt: null operand");
-    if (!(a->flags & DICOW_EPI_COLSUM)) return gemm_nt_impl(a, stream, nullptr, nullptr);
+    if (!(a->flags & DICOW_EPI_COLSUM)) {
+        const int sp = (a->colsum_ws && a->N % 4 == 0 && a->ldc % 4 == 0) ? nt_splitk_plan(a) : 1;
+        if (sp > 1 && a->colsum_ws_bytes >= (int64_t)sp * a->M * a->N * 4) {
+            dicow_gemm_args b = *a;
+            b.K = a->K / sp; b.batch = sp; b.strideA = b.K; b.strideB = b.K;
+            b.C = a->colsum_ws; b.ldc = a->N; b.strideC = (int64_t)a->M * a->N; b.flags = DICOW_EPI_OUT_F32;
+            b.colsum_ws = nullptr; b.colsum_ws_bytes = 0; b.colsum_out = nullptr;
+            const int rc = gemm_nt_impl(&b, stream, nullptr, nullptr);
+            if (rc != DICOW_OK) return rc;
+            const int64_t mn = (int64_t)a->M * a->N;
+            int grid = (int)((mn / 4 + 255) / 256); if (grid > 2048) grid = 2048;
+            hipLaunchKernelGGL(nt_splitk_reduce_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)a->colsum_ws, sp, mn,
+                               a->N, a->C, a->ldc, (a->flags & DICOW_EPI_OUT_F32) ? 1 : 0);
+            DICOW_CHECK_LAUNCH("nt_splitk_reduce");
+            return DICOW_OK;
+        }
+        return gemm_nt_impl(a, stream, nullptr, nullptr);
+    }
     DICOW_REQUIRE(a->colsum_out && a->colsum_ws && a->colsum_ws_bytes >= dicow_gemm_nt_colsum_ws_bytes(a->M, a->N),
                   "gemm_nt: COLSUM needs colsum_out and colsum_ws of dicow_gemm_nt_colsum_ws_bytes() bytes");
     DICOW_REQUIRE(!(a->flags & DICOW_EPI_OUT_F32) && a->batch <= 1, "gemm_nt: COLSUM supports a single bf16 result");
@@ -1020,7 +1075,6 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
 
 // one-time kernel attributes (dynamic LDS sizes) and device properties; the C ABI may be entered from any host thread -- the
 // forward thread and autograd's backward thread both launch GEMMs -- so this runs under std::call_once
-static int g_ncu_all = 256;
 static void gemm_nt_setup() {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);

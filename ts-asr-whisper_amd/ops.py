@@ -202,6 +202,11 @@ def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, re
         ws = workspace(L.lib().dicow_gemm_nt_colsum_ws_bytes(M, N), C_out.device)
         a.colsum_out, a.colsum_ws, a.colsum_ws_bytes = colsum_out.data_ptr(), ws.data_ptr(), ws.numel()
     a.flags, a.scale, a.scale_ncols = flags, scale, scale_ncols
+    if K >= 8192 and colsum_out is None:             # deep contraction, small output: split ranges + ordered sum (LM-head dgrad)
+        need = L.lib().dicow_gemm_nt_splitk_ws_bytes(C.byref(a))
+        if need:
+            ws = workspace(need, C_out.device)
+            a.colsum_ws, a.colsum_ws_bytes = ws.data_ptr(), ws.numel()
     L.call_struct("dicow_gemm_nt", a)
 
 
