@@ -1167,7 +1167,10 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             const int64_t t44 = (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch;
             const int64_t t35 = (int64_t)dicow_cdiv(a->M, 192) * dicow_cdiv(a->N, 320) * batch;
             const int64_t w44 = dicow_cdiv(t44, ncu) * 256 * 256, w35 = dicow_cdiv(t35, ncu) * 192 * 320;
-            const bool use35 = variant == 13 || variant == 22 || (variant != 12 && variant != 21 && a->N >= 320 && a->N <= 2048 && w35 < w44);
+            // (round 3: with the cheaper GELU the inference fc1 -- bias + GELU, no saved derivative -- gains 8 us per launch from
+            // the smaller tiles at N = 5120 too: encoder forward 38.86 -> 38.60 ms in-situ; the training epilogues still lose)
+            const bool wide_ok = a->N <= 2048 || a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU);
+            const bool use35 = variant == 13 || variant == 22 || (variant != 12 && variant != 21 && a->N >= 320 && wide_ok && w35 < w44);
             const int total = (int)(use35 ? t35 : t44);
             // balanced grid: with r = ceil(total / ncu) rounds needed anyway, ceil(total / r) workgroups each take r (or
             // r - 1) tiles -- e.g. 470 tiles run on 235 workgroups x 2 instead of 214 x 2 + 42 x 1: same makespan, fewer
