@@ -494,16 +494,17 @@ class EncoderEngine:
         if ggate is not None:
             ggate.add_(((gq * s.upd.view(Bp, T, D).float()).sum() * (1 - tg * tg)).reshape(-1))
         d_upd = (gq * tg).to(BF16).contiguous().view(rp, D)
+        tng = ops.TnGroup()                      # the block's six weight gradients: one pooled launch (400 tiles at large-v3-turbo)
         bias_grad(d_upd, G.get(blk.ffn[3].bias))
-        linear_wgrad(d_upd, s.a, G.get(blk.ffn[3].weight), rp)
+        linear_wgrad(d_upd, s.a, G.get(blk.ffn[3].weight), rp, group=tng)
         d_u = linear_dgrad(d_upd, w.f3, rp, aux=s.u)
         bias_grad(d_u, G.get(blk.ffn[0].bias))
-        linear_wgrad(d_u, s.cat, G.get(blk.ffn[0].weight), rp)
+        linear_wgrad(d_u, s.cat, G.get(blk.ffn[0].weight), rp, group=tng)
         d_cat = linear_dgrad(d_u, w.f0, rp)                                  # [rp, 2D]
         d_attn = d_cat[:, :D]
         att = blk.cross_attn
         bias_grad(d_attn, G.get(att.out_proj.bias))
-        linear_wgrad(d_attn, s.o, G.get(att.out_proj.weight), rp)
+        linear_wgrad(d_attn, s.o, G.get(att.out_proj.weight), rp, group=tng)
         d_o = _e((rp, D), BF16, dev)
         ops.gemm_nt(d_attn, w.att.o.wt, d_o, rp, D, D, lda=2 * D)
         dq = _e((rp, D), BF16, dev)
@@ -514,9 +515,10 @@ class EncoderEngine:
                      heads(dkv[:, D:], Bp, T, H), dq_scale=0.125)
         bias_grad(dq, G.get(att.q_proj.bias))
         bias_grad(dkv[:, D:], G.get(att.v_proj.bias))
-        linear_wgrad(dq, s.q_in, G.get(att.q_proj.weight), rp)
-        linear_wgrad(dkv[:, :D], s.kv_in, G.get(att.k_proj.weight), rp)
-        linear_wgrad(dkv[:, D:], s.kv_in, G.get(att.v_proj.weight), rp)
+        linear_wgrad(dq, s.q_in, G.get(att.q_proj.weight), rp, group=tng)
+        linear_wgrad(dkv[:, :D], s.kv_in, G.get(att.k_proj.weight), rp, group=tng)
+        linear_wgrad(dkv[:, D:], s.kv_in, G.get(att.v_proj.weight), rp, group=tng)
+        tng.run()
         d_qin = linear_dgrad(dq, w.att.q, rp, out_dtype=F32)
         d_kvin = linear_dgrad(dkv, w.att.kv, rp, out_dtype=F32)
         gin = g.clone()
