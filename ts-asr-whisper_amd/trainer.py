@@ -212,6 +212,8 @@ class GradReducer:
             reserve = int(os.environ.get("DICOW_RCCL_CUS", "16"))
             ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
             ops.set_gemm_cus(max(ncu - reserve, ncu // 2))
+        # the mean of the ranks' gradients: ncclAvg where the backend has it (RCCL), sum + one division pass otherwise (gloo)
+        self._avg_in_collective = bool(dist.is_initialized() and dist.get_backend(process_group) == "nccl")
         self.seg = {name: (a, b) for name, a, b in store.segments}
         self.pending = []
         self.time_exposed = False     # bench: record how long the compute stream waits for the side-stream buckets
@@ -234,8 +236,11 @@ class GradReducer:
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
             buf = self.s.grads[a:b]
-            dist.all_reduce(buf, group=self.pg)
-            buf.div_(self.world)
+            if self._avg_in_collective:               # RCCL averages inside the collective: no second pass over the 2.5 GB
+                dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg)
+            else:
+                dist.all_reduce(buf, group=self.pg)
+                buf.div_(self.world)
 
     def _reduce_preheat_runs(self):
         """Phase 1 of the staged freezing: the frozen runs hold zeros, so only the (small) preheat runs are exchanged,
