@@ -139,3 +139,41 @@ def test_device_schedule_and_bias_corrections_match_torch_over_300_steps(ops):
             worst = max(worst, dev)
     # 300 updates of up to 1e-2 on values of a few units: fp32 rounding differences of the two update expressions random-walk
     assert worst < 3e-5, worst
+
+
+def test_first_writer_gradients_equal_zero_fill_plus_accumulate():
+    """FlatStore.zero_grad(first_writer=True): the encoder layers' weight-matrix gradients are WRITTEN by the first micro-batch's
+    weight-gradient GEMM (no zero fill, no read of the old value) and accumulated by later micro-batches.  The flat gradient
+    buffer must equal the zero-fill + accumulate path bit for bit -- after one micro-batch, after two (accumulation), and on a
+    second step that starts from a buffer full of the previous step's gradients."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ts_asr_whisper_amd.trainer import TrainStep
+    from ts_asr_whisper_amd.data import synthetic_batch
+    cfg = pkg.DiCoWConfig.preset("whisper-tiny", use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True,
+                                 fddt_init="suppressive", non_target_fddt_value=0.5)
+    batches = [synthetic_batch(cfg, 2, 12, seed=60 + i) for i in range(3)]
+    grads = {}
+    for fw in (False, True):
+        torch.manual_seed(0)
+        model = pkg.DiCoWForConditionalGeneration(cfg).cuda()
+        model.tie_weights()
+        ts = TrainStep(model, lr=1e-4, fddt_lr_multiplier=10.0)
+        ts.first_writer = fw
+        snaps = []
+        ts.begin_step()
+        ts._micro(batches[0], 0.5)
+        snaps.append(ts.store.grads.clone())
+        ts._micro(batches[1], 0.5)                                   # second micro-batch: accumulates
+        snaps.append(ts.store.grads.clone())
+        ts.finish_step()
+        ts.begin_step()                                              # the matrices still hold the previous step's gradients
+        ts._micro(batches[2], 1.0)
+        snaps.append(ts.store.grads.clone())
+        if fw:
+            assert ts.store._over and len(ts.store._zero_ranges) <= len(model.model.encoder.layers) + 2
+            assert not any(getattr(p, "_grad_overwrite", False) for p, _, _ in ts.store._over)      # every flag was consumed
+        grads[fw] = snaps
+    for k, (a, b) in enumerate(zip(grads[False], grads[True])):
+        assert torch.equal(a, b), f"snapshot {k}: first-writer gradients differ from zero-fill + accumulate"
+    assert float(grads[True][0].abs().sum()) > 0

@@ -206,30 +206,44 @@ def linear_dgrad(dy, lw, M, aux=None, out=None, out_dtype=BF16, accumulate=False
     return out
 
 
-def linear_wgrad(dy, x, gw, M, n_rows=None, group=None):
+def _first_writer(*params):
+    """True when every listed parameter's gradient is flagged "write, do not accumulate" for this micro-batch
+    (trainer.FlatStore.zero_grad(first_writer=True)); the flags are consumed: the next micro-batch accumulates."""
+    if not params or not all(getattr(p, "_grad_overwrite", False) for p in params):
+        return False
+    for p in params:
+        p._grad_overwrite = False
+    return True
+
+
+def linear_wgrad(dy, x, gw, M, n_rows=None, group=None, param=None):
     """dW[N,K] += dy[M,N]^T @ x[M,K]; dy/x may be column slices (strided).  group: an ops.TnGroup that collects the layer's
-    weight gradients for one pooled launch (the operands must stay untouched until group.run())."""
+    weight gradients for one pooled launch (the operands must stay untouched until group.run()).  param: the parameter gw
+    belongs to -- when its gradient is flagged first-writer the GEMM overwrites (dW = ...) instead of accumulating."""
     if gw is None:
         return
     N = dy.shape[1] if n_rows is None else n_rows
+    acc = not (param is not None and _first_writer(param))
     if group is not None:
-        group.add(dy, x, gw, M, N, x.shape[1], lda=dy.stride(0), ldb=x.stride(0), ldc=gw.stride(0))
+        group.add(dy, x, gw, M, N, x.shape[1], lda=dy.stride(0), ldb=x.stride(0), ldc=gw.stride(0), accumulate=acc)
         return
-    ops.gemm_tn(dy, x, gw, M, N, x.shape[1], lda=dy.stride(0), ldb=x.stride(0), ldc=gw.stride(0))
+    ops.gemm_tn(dy, x, gw, M, N, x.shape[1], lda=dy.stride(0), ldb=x.stride(0), ldc=gw.stride(0), accumulate=acc)
 
 
-def qkv_wgrad(d_qkv, x, gq, gk, gv, M, D, group=None):
+def qkv_wgrad(d_qkv, x, gq, gk, gv, M, D, group=None, params=None):
     """Weight gradients of the fused q/k/v projection from ONE TN GEMM (C rows segmented over the three tensors)."""
     if gq is not None and gk is not None and gv is not None and D % 128 == 0:
-        kw = dict(lda=d_qkv.stride(0), ldb=x.stride(0), ldc=D, C_seg=(gk, gv), seg_rows=D)
+        acc = not (params is not None and _first_writer(*params))
+        kw = dict(lda=d_qkv.stride(0), ldb=x.stride(0), ldc=D, C_seg=(gk, gv), seg_rows=D, accumulate=acc)
         if group is not None:
             group.add(d_qkv, x, gq, M, 3 * D, D, **kw)
         else:
             ops.gemm_tn(d_qkv, x, gq, M, 3 * D, D, **kw)
         return
-    linear_wgrad(d_qkv[:, :D], x, gq, M, group=group)
-    linear_wgrad(d_qkv[:, D:2 * D], x, gk, M, group=group)
-    linear_wgrad(d_qkv[:, 2 * D:], x, gv, M, group=group)
+    pq, pk, pv = params if params is not None else (None, None, None)
+    linear_wgrad(d_qkv[:, :D], x, gq, M, group=group, param=pq)
+    linear_wgrad(d_qkv[:, D:2 * D], x, gk, M, group=group, param=pk)
+    linear_wgrad(d_qkv[:, 2 * D:], x, gv, M, group=group, param=pv)
 
 
 def bias_grad(dy, gb):
@@ -552,9 +566,9 @@ class EncoderEngine:
             lyr, w, Ls = enc.layers[i], W.layers[i], S.layers[i]
             rows, Bc = Ls.rows, Ls.B_after
             # ---- FFN backward (the weight-gradient operands gb, d_u, g2b, d_qkv and the saved activations live on until tng.run())
-            linear_wgrad(gb, Ls.a, G.get(lyr.fc2.weight), rows, group=tng)
+            linear_wgrad(gb, Ls.a, G.get(lyr.fc2.weight), rows, group=tng, param=lyr.fc2.weight)
             d_u = linear_dgrad(gb, w.fc2, rows, aux=Ls.u, colsum_out=G.get(lyr.fc1.bias))     # fc1 bias grad = colsum(d_u), fused
-            linear_wgrad(d_u, Ls.xln2, G.get(lyr.fc1.weight), rows, group=tng)
+            linear_wgrad(d_u, Ls.xln2, G.get(lyr.fc1.weight), rows, group=tng, param=lyr.fc1.weight)
             d_xln2 = linear_dgrad(d_u, w.fc1, rows)
             g2 = _e((rows, D), F32, dev)
             g2b = _e((rows, D), BF16, dev)
@@ -564,7 +578,7 @@ class EncoderEngine:
                             colsum_out=G.get(lyr.self_attn.out_proj.bias))
             # ---- attention backward
             att = lyr.self_attn
-            linear_wgrad(g2b, Ls.o, G.get(att.out_proj.weight), rows, group=tng)
+            linear_wgrad(g2b, Ls.o, G.get(att.out_proj.weight), rows, group=tng, param=att.out_proj.weight)
             d_o = linear_dgrad(g2b, w.att.o, rows)
             d_qkv = _e((rows, 3 * D), BF16, dev)
             delta = _e((2, Bc, H, T), F32, dev)
@@ -573,7 +587,8 @@ class EncoderEngine:
                          heads(Ls.o, Bc, T, H), heads(d_o, Bc, T, H), Ls.lse, delta, heads(d_qkv[:, :D], Bc, T, H),
                          heads(d_qkv[:, D:2 * D], Bc, T, H), heads(d_qkv[:, 2 * D:], Bc, T, H), dq_scale=0.125,
                          dq_colsum=G.get(att.q_proj.bias), dv_colsum=G.get(att.v_proj.bias))   # q / v bias grads, fused
-            qkv_wgrad(d_qkv, Ls.xln, G.get(att.q_proj.weight), G.get(att.k_proj.weight), G.get(att.v_proj.weight), rows, D, group=tng)
+            qkv_wgrad(d_qkv, Ls.xln, G.get(att.q_proj.weight), G.get(att.k_proj.weight), G.get(att.v_proj.weight), rows, D, group=tng,
+                      params=(att.q_proj.weight, att.k_proj.weight, att.v_proj.weight))
             d_xln = linear_dgrad(d_qkv, w.att.qkv, rows)
             # ---- LayerNorm1 (+ SCB) + FDDT backward; the column sum of the result is the previous fc2's bias grad
             fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None

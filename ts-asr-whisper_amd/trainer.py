@@ -44,6 +44,7 @@ def _backward_order(model):
     nl = len(enc.layers)
     for i in range(nl - 1, -1, -1):
         ps = list(enc.layers[i].parameters())
+        ps = [p for p in ps if p.dim() == 2] + [p for p in ps if p.dim() != 2]     # weight matrices first (FlatStore.zero_grad)
         if hasattr(enc, "fddts") and i < len(enc.fddts):
             ps += list(enc.fddts[i].parameters())
         if hasattr(enc, "ca_enrolls") and i < len(enc.ca_enrolls):
@@ -113,9 +114,35 @@ class FlatStore:
             else:
                 self.runs.append((o, pad_end, pre))
         self.n_trainable = sum(n for _, _, n, _ in entries)
+        # Gradients the backward pass WRITES instead of accumulating into zeros: the encoder layers' weight matrices (628 M of
+        # the 637 M trainable values of large-v3-turbo), each produced by exactly one weight-gradient GEMM per micro-batch
+        # (engine.EncoderEngine.backward -> ops.TnGroup).  zero_grad(first_writer=True) skips their 2.5 GB fill and flags them;
+        # the engine then runs the first micro-batch's GEMM with accumulate = 0 (no read of the old value either) and clears
+        # the flag, so later micro-batches accumulate.  Everything else (vectors, FDDT, stem, decoder) is zeroed as before.
+        enc = model.model.encoder
+        over = {id(p) for lyr in enc.layers for p in lyr.parameters() if p.dim() == 2}
+        self._over = [(p, o, n) for p, o, n, _ in entries if id(p) in over]
+        keep, cur = [], 0
+        for p, o, n in sorted(self._over, key=lambda t: t[1]):
+            if o > cur:
+                keep.append((cur, o))
+            cur = max(cur, o + n)
+        if cur < self.numel:
+            keep.append((cur, self.numel))
+        self._zero_ranges = keep                     # the complement of the overwritable matrices: ~one range per layer
 
-    def zero_grad(self):
-        self.grads.zero_()
+    def zero_grad(self, first_writer=False):
+        """first_writer: only valid when every flagged matrix is certain to receive its gradient in the coming backward pass
+        (the full training phase; TrainStep decides)."""
+        if not first_writer or not self._over:
+            self.grads.zero_()
+            for p, _, _ in self._over:
+                p._grad_overwrite = False
+            return
+        for a, b in self._zero_ranges:
+            self.grads[a:b].zero_()
+        for p, _, _ in self._over:
+            p._grad_overwrite = bool(p.requires_grad)
 
 
 class FusedAdamW:
@@ -299,6 +326,7 @@ class TrainStep:
         # of a few microseconds each) are bound by the host's launch rate, not by the GPU.  The step has no host-side data
         # dependence: the clip coefficient stays on the device, the schedule's scalars are rewritten in device memory
         # before each replay (FusedAdamW.advance).
+        self.first_writer = True      # encoder weight-matrix gradients are written, not accumulated into a zero fill (FlatStore.zero_grad)
         self.graph = bool(graph)
         # (phase, batch signature) -> (CUDAGraph, static batch, static loss), least recently used first.  Real batches vary in
         # label length (and SE-DiCoW enrollment length), and the hard loss is a mean over ALL label positions
@@ -343,7 +371,7 @@ class TrainStep:
         if self.warmup_phase and self.global_step >= self.use_fddt_only_n_steps:
             self._set_phase(preheat_only=False)
             self.warmup_phase = False
-        self.store.zero_grad()
+        self.store.zero_grad(first_writer=self.first_writer and not self.warmup_phase)
 
     def finish_step(self):
         """Gradients are in the flat store: exchange (DP), clip, AdamW, invalidate the bf16 compute copies."""
@@ -416,7 +444,7 @@ class TrainStep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._graph_pool):
-                self.store.zero_grad()
+                self.store.zero_grad(first_writer=self.first_writer and not self.warmup_phase)
                 out = self.model(**static)
                 out.loss.backward()
                 self.opt.launch(preheat_only=self.warmup_phase)
