@@ -338,7 +338,7 @@ class GreedyDecoder:
     @torch.no_grad()
     def generate_with_fallback(self, input_features, stno_mask, decoder_input_ids, max_new_tokens, temperatures=(0.0, 0.2, 0.4, 0.6, 0.8, 1.0),
                                compression_ratio_threshold=1.35, logprob_threshold=-1.0, no_speech_threshold=None,
-                               no_speech_token_id=None, generator=None, enrollments=None, **gen_kw):
+                               no_speech_token_id=None, generator=None, enrollments=None, skip_by_row=False, **gen_kw):
         """Whisper's temperature fallback over one batch of windows (reference generation.py:567-611 -> transformers'
         generate_with_fallback): greedy first; windows whose output is too repetitive (zlib compression ratio) or too unlikely
         (average log-probability) are decoded again -- encoder included, as in HF -- with sampling at the next temperature; a
@@ -364,7 +364,7 @@ class GreedyDecoder:
             return toks, [scores[:, i] for i in range(len(rows))], self.no_speech_prob
 
         return decode_with_fallback(decode, B, tuple(temperatures), cfg.vocab_size, pad, eos, compression_ratio_threshold,
-                                    logprob_threshold, no_speech_threshold)
+                                    logprob_threshold, no_speech_threshold, skip_by_row=skip_by_row)
 
 
 # ------------------------------------------------------------------------------------------------ temperature fallback
@@ -620,8 +620,10 @@ class LongFormDecoder:
             skip = [False] * len(active)
             if gen_kw.get("temperatures") is not None and self.num_beams == 1:
                 # temperature fallback (reference generation.py:567-611): per-window ladder, silent windows skipped
+                # (skip_by_row=True: keep a silent window's skip flag with ITS recording instead of transformers' position in
+                # the fallback sub-batch -- see decode_with_fallback; default = the reference's behaviour)
                 fb = {k: gen_kw[k] for k in ("compression_ratio_threshold", "logprob_threshold", "no_speech_threshold",
-                                             "no_speech_token_id", "generator") if k in gen_kw}
+                                             "no_speech_token_id", "generator", "skip_by_row") if k in gen_kw}
                 tok_lists, skip, _ = self.decoder.generate_with_fallback(feats, stno, prompt[active], n_new,
                                                                          temperatures=gen_kw["temperatures"], **fb, **kw)
             elif self.num_beams > 1:
