@@ -67,6 +67,20 @@ int dicow_colsum_bf16(const void* x, int64_t ld, float* out, int rows, int N, vo
 /* out[t,:] += sum_b g[b,t,:]   (gradient of encoder.embed_positions, encoder.py:177-179) */
 int dicow_sum_over_batch(const float* g, float* out, int B, int64_t TD, void* stream);
 
+/* Element-wise glue of the SE-DiCoW speaker-communication block (reference src/models/dicow/layers.py:145-193) on the interleaved
+ * row layout [Bp][2][T][D] (slot 0 = mixture, slot 1 = enrollment; encoder.py:152-154):
+ *   split      hf fp32 -> q_in / kv_in bf16 [Bp*T, D] and the right half of cat bf16 [Bp*T, ldcat] (= q_in, layers.py:161)
+ *   merge_fwd  out = hf; out[mixture] += tanh(gate[0]) * upd                                            (layers.py:186-191)
+ *   gate_bwd   d_upd = bf16(g[mixture] * tanh(gate));  d_gate[0] += (1 - tanh^2) * sum(g[mixture] * upd)  (d_gate may be NULL)
+ *   merge_bwd  gin = g; gin[mixture] += d_qin + d_cat[:, D:2D]; gin[enrollment] += d_kvin */
+int dicow_scb_split(const float* hf, void* q_in, void* kv_in, void* cat, int64_t ldcat, int Bp, int T, int D, void* stream);
+int dicow_scb_merge_fwd(const float* hf, const void* upd, const float* gate, float* out, int Bp, int T, int D, void* stream);
+int64_t dicow_scb_gate_bwd_ws_bytes(void);
+int dicow_scb_gate_bwd(const float* g, const void* upd, const float* gate, void* d_upd, float* d_gate, int Bp, int T, int D,
+                       void* ws, int64_t ws_bytes, void* stream);
+int dicow_scb_merge_bwd(const float* g, const float* d_qin, const void* d_cat, int64_t ldcat, const float* d_kvin, float* gin,
+                        int Bp, int T, int D, void* stream);
+
 /* ------------------------------------------------------------------------------------------------ FDDT + LayerNorm
  * Fused row kernel.  Replaces FDDT.forward (src/models/dicow/FDDT.py:41-63) with CustomDiagonalLinear
  * (layers.py:73-77), the optional position-embedding add (encoder.py:177-179) and the LayerNorm that follows

@@ -97,6 +97,10 @@ _SIGS = {
     "dicow_mel_to_timemajor": [c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_colsum_bf16": [c_vp, c_i64, c_vp, c_i, c_i, c_vp, c_i64, c_vp],
     "dicow_sum_over_batch": [c_vp, c_vp, c_i, c_i64, c_vp],
+    "dicow_scb_split": [c_vp, c_vp, c_vp, c_vp, c_i64, c_i, c_i, c_i, c_vp],
+    "dicow_scb_merge_fwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
+    "dicow_scb_gate_bwd": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp, c_i64, c_vp],
+    "dicow_scb_merge_bwd": [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_fddt_ln_fwd": [C.POINTER(FddtLnFwdArgs), c_vp],
     "dicow_fddt_ln_bwd": [C.POINTER(FddtLnBwdArgs), c_vp],
     "dicow_fddt_full_combine_fwd": [c_vp, c_vp, c_i, c_vp, c_i64, c_i, c_vp, c_i, c_i, c_i, c_vp],
@@ -164,6 +168,7 @@ _SIGS64 = {   # functions returning int64_t (workspace sizes)
     "dicow_gemm_nt_splitk_ws_bytes": [C.POINTER(GemmArgs)],
     "dicow_gemm_tn_group_ws_bytes": [C.POINTER(GemmTnGroupArgs)],
     "dicow_logmel_ws_bytes": [c_i, c_i],
+    "dicow_scb_gate_bwd_ws_bytes": [],
     "dicow_ctc_ws_bytes": [c_i, c_i, c_i],
 }
 

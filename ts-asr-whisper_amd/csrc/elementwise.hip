@@ -551,3 +551,134 @@ extern "C" int dicow_adamw_f32_dev(float* p, const float* g, float* m, float* v,
     DICOW_CHECK_LAUNCH("adamw_f32_dev");
     return DICOW_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ speaker-communication block glue
+// The element-wise steps around the SE-DiCoW enrollment cross-attention (reference layers.py:145-193) on the interleaved row
+// layout [Bp][2][T][D] (slot 0 = mixture, slot 1 = enrollment), one pass each instead of cast + strided copies + torch ops:
+//   split      hf fp32 -> q_in bf16 (mixture rows), kv_in bf16 (enrollment rows), right half of `cat` = q_in   (layers.py:161)
+//   merge_fwd  out = hf;  out[mixture] += tanh(gate) * upd
+//   gate_bwd   d_upd = bf16(g[mixture] * tanh(gate));  d gate += (1 - tanh^2) * sum(g[mixture] * upd)   (fixed-order sum)
+//   merge_bwd  gin = g;  gin[mixture] += d_qin + d_cat[:, D:];  gin[enrollment] += d_kvin
+__device__ __forceinline__ float4 bf4_to_f4(uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__global__ void scb_split_kernel(const float* __restrict__ hf, unsigned short* __restrict__ q_in, unsigned short* __restrict__ kv_in,
+                                 unsigned short* __restrict__ cat, int64_t td, int D, int64_t ldcat, int Bp) {
+    const int64_t n4 = (int64_t)Bp * td / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i * 4, b = e / td, off = e - b * td;
+        const float4 m = *reinterpret_cast<const float4*>(hf + (2 * b) * td + off);
+        const float4 r = *reinterpret_cast<const float4*>(hf + (2 * b + 1) * td + off);
+        const uint2 mb = make_uint2(pack_bf16x2(m.x, m.y), pack_bf16x2(m.z, m.w));
+        *reinterpret_cast<uint2*>(q_in + e) = mb;
+        *reinterpret_cast<uint2*>(kv_in + e) = make_uint2(pack_bf16x2(r.x, r.y), pack_bf16x2(r.z, r.w));
+        const int64_t row = e / D; const int col = (int)(e - row * D);
+        *reinterpret_cast<uint2*>(cat + row * ldcat + D + col) = mb;
+    }
+}
+__global__ void scb_merge_fwd_kernel(const float* __restrict__ hf, const unsigned short* __restrict__ upd, const float* __restrict__ gate,
+                                     float* __restrict__ out, int64_t td, int Bp) {
+    const float tg = tanhf(gate[0]);
+    const int64_t n4 = (int64_t)2 * Bp * td / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i * 4, slot = e / td, off = e - slot * td;
+        float4 v = *reinterpret_cast<const float4*>(hf + e);
+        if ((slot & 1) == 0) {
+            const float4 u = bf4_to_f4(*reinterpret_cast<const uint2*>(upd + (slot >> 1) * td + off));
+            v.x += u.x * tg; v.y += u.y * tg; v.z += u.z * tg; v.w += u.w * tg;
+        }
+        *reinterpret_cast<float4*>(out + e) = v;
+    }
+}
+__global__ void __launch_bounds__(256) scb_gate_bwd_kernel(const float* __restrict__ g, const unsigned short* __restrict__ upd,
+                                                           const float* __restrict__ gate, unsigned short* __restrict__ d_upd,
+                                                           float* __restrict__ partial, int64_t td, int Bp) {
+    __shared__ float red[4];
+    const float tg = tanhf(gate[0]);
+    const int64_t n4 = (int64_t)Bp * td / 4;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i * 4, b = e / td, off = e - b * td;
+        const float4 gq = *reinterpret_cast<const float4*>(g + (2 * b) * td + off);
+        const float4 u = bf4_to_f4(*reinterpret_cast<const uint2*>(upd + e));
+        acc += (gq.x * u.x + gq.y * u.y) + (gq.z * u.z + gq.w * u.w);
+        *reinterpret_cast<uint2*>(d_upd + e) = make_uint2(pack_bf16x2(gq.x * tg, gq.y * tg), pack_bf16x2(gq.z * tg, gq.w * tg));
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void scb_gate_finish_kernel(const float* __restrict__ partial, int n, const float* __restrict__ gate, float* __restrict__ d_gate) {
+    __shared__ float red[256];
+    float t = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) t += partial[i];
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) { const float tg = tanhf(gate[0]); d_gate[0] += red[0] * (1.f - tg * tg); }
+}
+__global__ void scb_merge_bwd_kernel(const float* __restrict__ g, const float* __restrict__ d_qin, const unsigned short* __restrict__ d_cat,
+                                     int64_t ldcat, const float* __restrict__ d_kvin, float* __restrict__ gin, int64_t td, int D, int Bp) {
+    const int64_t n4 = (int64_t)2 * Bp * td / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = i * 4, slot = e / td, off = e - slot * td, b = slot >> 1, pe = b * td + off;
+        float4 v = *reinterpret_cast<const float4*>(g + e);
+        if ((slot & 1) == 0) {
+            const float4 a = *reinterpret_cast<const float4*>(d_qin + pe);
+            const int64_t row = pe / D; const int col = (int)(pe - row * D);
+            const float4 c = bf4_to_f4(*reinterpret_cast<const uint2*>(d_cat + row * ldcat + D + col));
+            v.x += a.x + c.x; v.y += a.y + c.y; v.z += a.z + c.z; v.w += a.w + c.w;
+        } else {
+            const float4 a = *reinterpret_cast<const float4*>(d_kvin + pe);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        *reinterpret_cast<float4*>(gin + e) = v;
+    }
+}
+static int scb_grid(int64_t n4) { int64_t g = (n4 + 255) / 256; return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); }
+#define SCB_CHECK(name) DICOW_REQUIRE(Bp > 0 && T > 0 && D > 0 && D % 4 == 0, name ": bad shape")
+extern "C" int dicow_scb_split(const float* hf, void* q_in, void* kv_in, void* cat, int64_t ldcat, int Bp, int T, int D, void* stream) {
+    DICOW_REQUIRE(hf && q_in && kv_in && cat && ldcat >= 2 * D && ldcat % 4 == 0, "scb_split: bad args");
+    SCB_CHECK("scb_split");
+    const int64_t td = (int64_t)T * D;
+    hipLaunchKernelGGL(scb_split_kernel, dim3(scb_grid(Bp * td / 4)), dim3(256), 0, (hipStream_t)stream, hf, (unsigned short*)q_in,
+                       (unsigned short*)kv_in, (unsigned short*)cat, td, D, ldcat, Bp);
+    DICOW_CHECK_LAUNCH("scb_split");
+    return DICOW_OK;
+}
+extern "C" int dicow_scb_merge_fwd(const float* hf, const void* upd, const float* gate, float* out, int Bp, int T, int D, void* stream) {
+    DICOW_REQUIRE(hf && upd && gate && out, "scb_merge_fwd: null operand");
+    SCB_CHECK("scb_merge_fwd");
+    const int64_t td = (int64_t)T * D;
+    hipLaunchKernelGGL(scb_merge_fwd_kernel, dim3(scb_grid(2 * Bp * td / 4)), dim3(256), 0, (hipStream_t)stream, hf,
+                       (const unsigned short*)upd, gate, out, td, Bp);
+    DICOW_CHECK_LAUNCH("scb_merge_fwd");
+    return DICOW_OK;
+}
+extern "C" int64_t dicow_scb_gate_bwd_ws_bytes(void) { return 1024 * 4; }
+extern "C" int dicow_scb_gate_bwd(const float* g, const void* upd, const float* gate, void* d_upd, float* d_gate, int Bp, int T, int D,
+                                  void* ws, int64_t ws_bytes, void* stream) {
+    DICOW_REQUIRE(g && upd && gate && d_upd && ws && ws_bytes >= 1024 * 4, "scb_gate_bwd: bad args (ws: dicow_scb_gate_bwd_ws_bytes)");
+    SCB_CHECK("scb_gate_bwd");
+    const int64_t td = (int64_t)T * D;
+    int grid = scb_grid(Bp * td / 4); if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(scb_gate_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, (const unsigned short*)upd, gate,
+                       (unsigned short*)d_upd, (float*)ws, td, Bp);
+    DICOW_CHECK_LAUNCH("scb_gate_bwd");
+    if (d_gate) {
+        hipLaunchKernelGGL(scb_gate_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, grid, gate, d_gate);
+        DICOW_CHECK_LAUNCH("scb_gate_finish");
+    }
+    return DICOW_OK;
+}
+extern "C" int dicow_scb_merge_bwd(const float* g, const float* d_qin, const void* d_cat, int64_t ldcat, const float* d_kvin, float* gin,
+                                   int Bp, int T, int D, void* stream) {
+    DICOW_REQUIRE(g && d_qin && d_cat && d_kvin && gin && ldcat >= 2 * D && ldcat % 4 == 0, "scb_merge_bwd: bad args");
+    SCB_CHECK("scb_merge_bwd");
+    const int64_t td = (int64_t)T * D;
+    hipLaunchKernelGGL(scb_merge_bwd_kernel, dim3(scb_grid(2 * Bp * td / 4)), dim3(256), 0, (hipStream_t)stream, g, d_qin,
+                       (const unsigned short*)d_cat, ldcat, d_kvin, gin, td, D, Bp);
+    DICOW_CHECK_LAUNCH("scb_merge_bwd");
+    return DICOW_OK;
+}

@@ -470,25 +470,22 @@ class EncoderEngine:
         rows = Bc * T
         Bp = Bc // 2
         rp = Bp * T
-        hb = ops.cast_bf16(hf)                                              # [rows, D] bf16 (GEMM operand)
-        h4 = hb.view(Bp, 2, T, D)
-        q_in = h4[:, 0].contiguous().view(rp, D)                            # mixture rows
-        kv_in = h4[:, 1].contiguous().view(rp, D)                           # enrollment rows
+        # de-interleave + cast in one pass (ops.scb_split): mixture rows -> q_in, enrollment rows -> kv_in, and the right half of
+        # `cat` = q_in ([attn_output | q], layers.py:161)
+        q_in, kv_in = _e((rp, D), BF16, dev), _e((rp, D), BF16, dev)
+        cat = _e((rp, 2 * D), BF16, dev)
+        ops.scb_split(hf, q_in, kv_in, cat, Bp, T, D)
         q = linear_fwd(q_in, w.att.q, rp, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
         kv = linear_fwd(kv_in, w.att.kv, rp)
         o = _e((rp, D), BF16, dev)
         lse = _e((Bp, H, T), F32, dev)
         ops.attn_fwd(heads(q, Bp, T, H), heads(kv[:, :D], Bp, T, H), heads(kv[:, D:], Bp, T, H), heads(o, Bp, T, H), lse)
-        cat = _e((rp, 2 * D), BF16, dev)                                    # [attn_output | q]  (layers.py:161)
         ops.gemm_nt(o, w.att.o.w, cat, rp, D, D, ldc=2 * D, bias=w.att.o.b)
-        cat[:, D:].copy_(q_in)
         u = _e((rp, F_), BF16, dev)
         a = linear_fwd(cat, w.f0, rp, gelu_aux=u)
         upd = linear_fwd(a, w.f3, rp)                                       # bf16 [rp, D]
-        gate = torch.tanh(blk.cross_gate.gate.detach())
-        out = hf.clone()
-        o4 = out.view(Bp, 2, T, D)
-        o4[:, 0].add_(upd.view(Bp, T, D).float() * gate)
+        out = _e((rows, D), F32, dev)
+        ops.scb_merge_fwd(hf, upd, blk.cross_gate.gate.detach(), out, Bp, T, D)      # out = hf, mixture rows += tanh(gate) * upd
         s = NS(q_in=q_in, kv_in=kv_in, q=q, kv=kv, o=o, lse=lse, cat=cat, u=u, a=a, upd=upd, Bp=Bp)
         return out, s
 
@@ -500,14 +497,9 @@ class EncoderEngine:
         D, H, F_ = cfg.d_model, cfg.encoder_attention_heads, cfg.encoder_ffn_dim
         Bp, rp = s.Bp, s.Bp * T
         dev = g.device
-        g4 = g.view(Bp, 2, T, D)
-        gq = g4[:, 0]                                                        # grad of q_out
         gate_p = blk.cross_gate.gate
-        tg = torch.tanh(gate_p.detach())
-        ggate = G.get(gate_p)
-        if ggate is not None:
-            ggate.add_(((gq * s.upd.view(Bp, T, D).float()).sum() * (1 - tg * tg)).reshape(-1))
-        d_upd = (gq * tg).to(BF16).contiguous().view(rp, D)
+        d_upd = _e((rp, D), BF16, dev)
+        ops.scb_gate_bwd(g, s.upd, gate_p.detach(), d_upd, G.get(gate_p), Bp, T, D)   # d_upd = bf16(g_mix * tanh(gate)); gate gradient
         tng = ops.TnGroup()                      # the block's six weight gradients: one pooled launch (400 tiles at large-v3-turbo)
         bias_grad(d_upd, G.get(blk.ffn[3].bias))
         linear_wgrad(d_upd, s.a, G.get(blk.ffn[3].weight), rp, group=tng)
@@ -535,10 +527,8 @@ class EncoderEngine:
         tng.run()
         d_qin = linear_dgrad(dq, w.att.q, rp, out_dtype=F32)
         d_kvin = linear_dgrad(dkv, w.att.kv, rp, out_dtype=F32)
-        gin = g.clone()
-        gi4 = gin.view(Bp, 2, T, D)
-        gi4[:, 0].add_(d_qin.view(Bp, T, D)).add_(d_cat[:, D:].float().view(Bp, T, D))
-        gi4[:, 1].add_(d_kvin.view(Bp, T, D))
+        gin = _e((2 * rp, D), F32, dev)
+        ops.scb_merge_bwd(g, d_qin, d_cat, d_kvin, gin, Bp, T, D)            # gin = g (+ d_qin + d_cat[:, D:] | + d_kvin)
         return gin
 
     # -- backward

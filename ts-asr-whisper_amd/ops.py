@@ -275,6 +275,30 @@ class TnGroup:
         self.items = []
 
 
+# ------------------------------------------------------------------------------------------------ speaker-communication block glue
+def scb_split(hf, q_in, kv_in, cat, Bp, T, D):
+    """hf fp32 [Bp*2*T, D] (interleaved) -> q_in / kv_in bf16 [Bp*T, D]; cat[:, D:2D] = q_in  (cat bf16 [Bp*T, 2D])."""
+    L.call("dicow_scb_split", hf.data_ptr(), q_in.data_ptr(), kv_in.data_ptr(), cat.data_ptr(), cat.stride(0), Bp, T, D, L.stream())
+
+
+def scb_merge_fwd(hf, upd, gate, out, Bp, T, D):
+    """out = hf; out[mixture rows] += tanh(gate) * upd."""
+    L.call("dicow_scb_merge_fwd", hf.data_ptr(), upd.data_ptr(), gate.data_ptr(), out.data_ptr(), Bp, T, D, L.stream())
+
+
+def scb_gate_bwd(g, upd, gate, d_upd, d_gate, Bp, T, D):
+    """d_upd = bf16(g[mixture] * tanh(gate)); d_gate += (1 - tanh^2) * sum(g[mixture] * upd)  (d_gate None: skipped)."""
+    ws = workspace(L.lib().dicow_scb_gate_bwd_ws_bytes(), g.device)
+    L.call("dicow_scb_gate_bwd", g.data_ptr(), upd.data_ptr(), gate.data_ptr(), d_upd.data_ptr(), _p(d_gate), Bp, T, D,
+           ws.data_ptr(), ws.numel(), L.stream())
+
+
+def scb_merge_bwd(g, d_qin, d_cat, d_kvin, gin, Bp, T, D):
+    """gin = g; gin[mixture] += d_qin + d_cat[:, D:]; gin[enrollment] += d_kvin."""
+    L.call("dicow_scb_merge_bwd", g.data_ptr(), d_qin.data_ptr(), d_cat.data_ptr(), d_cat.stride(0), d_kvin.data_ptr(), gin.data_ptr(),
+           Bp, T, D, L.stream())
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def _bs_rs(t, name):
     # t: [B, L, H, 64] view (any batch/row stride)
