@@ -53,6 +53,10 @@ int dicow_cast_f32_to_bf16(const float* src, void* dst, int64_t n, void* stream)
  * the transposed copy is the dgrad operand of every Linear; the strides let q/k/v land in one fused [3D,D] / [D,3D]. */
 int dicow_cast_transpose_f32_to_bf16(const float* src, void* dst, int64_t ld, void* dst_t, int64_t ld_t, int R, int C,
                                      void* stream);
+/* The same for up to 8 matrices in ONE launch (AMP's re-cast of a layer's weights after every optimizer step). */
+#define DICOW_CAST_GROUP_MAX 8
+typedef struct { const float* src; void* dst; void* dst_t; int R, C; int64_t ld, ld_t; } dicow_cast_problem;
+int dicow_cast_transpose_group(const dicow_cast_problem* p, int n, void* stream);
 /* Conv1d weight [O,C,3] fp32 -> bf16 [O,Kpad] (dst) and its transpose [Kpad,O] (dst_t; either may be NULL),
  * k = tap*C + c (tap-major), zero padded to Kpad >= 3C: the GEMM view of conv1/conv2 (encoder.py:167-168). */
 int dicow_conv_weight_pack(const float* w, void* dst, void* dst_t, int O, int C, int Kpad, void* stream);

@@ -41,6 +41,11 @@ class GemmTnArgs(C.Structure):
 
 
 TN_GROUP_MAX = 24
+CAST_GROUP_MAX = 8
+
+
+class CastProblem(C.Structure):
+    _fields_ = [("src", c_vp), ("dst", c_vp), ("dst_t", c_vp), ("R", c_i), ("C", c_i), ("ld", c_i64), ("ld_t", c_i64)]
 
 
 class GemmTnGroupArgs(C.Structure):
@@ -89,6 +94,7 @@ EPI_GELU_DAUX, EPI_MUL_AUX, EPI_COLSUM = 128, 256, 512
 # name -> argtypes ; every function returns int
 _SIGS = {
     "dicow_set_gemm_cus": [c_i],
+    "dicow_cast_transpose_group": [C.POINTER(CastProblem), c_i, c_vp],
     "dicow_gemm_dispatch_log": [c_vp, c_i],
     "dicow_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
     "dicow_cast_transpose_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp],

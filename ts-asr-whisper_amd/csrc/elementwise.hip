@@ -107,6 +107,77 @@ extern "C" int dicow_cast_transpose_f32_to_bf16(const float* src, void* dst, int
     return DICOW_OK;
 }
 
+// Several matrices in ONE launch (the six weight matrices of an encoder layer, re-cast after every optimizer step): one
+// launch per matrix moved 13-52 MB each at 1.5-3 TB/s (8.4 us average, 215 launches per step); pooled, a layer's 157 MB go at the
+// streaming rate.  Block b belongs to the problem whose tile range contains it.
+struct cast_group_kargs_t { dicow_cast_problem p[DICOW_CAST_GROUP_MAX]; int tile0[DICOW_CAST_GROUP_MAX + 1]; int n; };
+__global__ void cast_transpose4_group_kernel(const cast_group_kargs_t g) {
+    __shared__ unsigned short tile[64][68];
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < DICOW_CAST_GROUP_MAX; ++i) if (i < g.n && (int)blockIdx.x >= g.tile0[i]) pi = i;
+    const dicow_cast_problem& q = g.p[pi];
+    const int R = q.R, C = q.C;
+    const int64_t ld = q.ld, ld_t = q.ld_t;
+    const float* __restrict__ src = q.src;
+    unsigned short* __restrict__ dst = reinterpret_cast<unsigned short*>(q.dst);
+    unsigned short* __restrict__ dst_t = reinterpret_cast<unsigned short*>(q.dst_t);
+    const int lb = (int)blockIdx.x - g.tile0[pi], ntc = (C + 63) / 64;
+    const int r0 = (lb / ntc) * 64, c0 = (lb % ntc) * 64;
+    const int tq = threadIdx.x & 15, tr = threadIdx.x >> 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = k * 16 + tr, r = r0 + i, c = c0 + tq * 4;
+        uint2 u = make_uint2(0, 0);
+        if (r < R && c < C) {
+            const float4 f = *reinterpret_cast<const float4*>(src + (int64_t)r * C + c);
+            u = make_uint2(pack_bf16x2(f.x, f.y), pack_bf16x2(f.z, f.w));
+            if (dst) *reinterpret_cast<uint2*>(dst + (int64_t)r * ld + c) = u;
+        }
+        *reinterpret_cast<uint2*>(&tile[i][tq * 4]) = u;
+    }
+    __syncthreads();
+    if (!dst_t) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = k * 16 + tr, c = c0 + i, r = r0 + tq * 4;
+        if (c < C && r < R) {
+            const unsigned lo = (unsigned)tile[tq * 4][i] | ((unsigned)tile[tq * 4 + 1][i] << 16);
+            const unsigned hi = (unsigned)tile[tq * 4 + 2][i] | ((unsigned)tile[tq * 4 + 3][i] << 16);
+            *reinterpret_cast<uint2*>(dst_t + (int64_t)c * ld_t + r) = make_uint2(lo, hi);
+        }
+    }
+}
+
+extern "C" int dicow_cast_transpose_group(const dicow_cast_problem* p, int n, void* stream) {
+    DICOW_REQUIRE(p && n >= 1 && n <= DICOW_CAST_GROUP_MAX, "cast_transpose_group: 1..%d problems", DICOW_CAST_GROUP_MAX);
+    cast_group_kargs_t k;
+    memset(&k, 0, sizeof(k));
+    int tiles = 0;
+    bool vec = true;
+    for (int i = 0; i < n; ++i) {
+        const dicow_cast_problem& q = p[i];
+        DICOW_REQUIRE(q.src && (q.dst || q.dst_t) && q.R > 0 && q.C > 0, "cast_transpose_group: bad problem %d", i);
+        DICOW_REQUIRE((!q.dst || q.ld >= q.C) && (!q.dst_t || q.ld_t >= q.R), "cast_transpose_group: leading dimensions too small");
+        vec = vec && (q.R % 4 == 0) && (q.C % 4 == 0) && (q.ld % 4 == 0) && (q.ld_t % 4 == 0) && ((uintptr_t)q.src % 16 == 0) &&
+              ((uintptr_t)q.dst % 8 == 0) && ((uintptr_t)q.dst_t % 8 == 0);
+        k.p[i] = q; k.tile0[i] = tiles;
+        tiles += dicow_cdiv(q.R, 64) * dicow_cdiv(q.C, 64);
+    }
+    for (int i = n; i <= DICOW_CAST_GROUP_MAX; ++i) k.tile0[i] = tiles;
+    k.n = n;
+    if (!vec) {                                      // odd shapes / alignments: one by one through the general entry point
+        for (int i = 0; i < n; ++i) {
+            const int rc = dicow_cast_transpose_f32_to_bf16(p[i].src, p[i].dst, p[i].ld, p[i].dst_t, p[i].ld_t, p[i].R, p[i].C, stream);
+            if (rc != DICOW_OK) return rc;
+        }
+        return DICOW_OK;
+    }
+    hipLaunchKernelGGL(cast_transpose4_group_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, k);
+    DICOW_CHECK_LAUNCH("cast_transpose_group");
+    return DICOW_OK;
+}
+
 // Conv1d weight [O,C,3] -> [O,Kpad] with k = tap*C + c
 __global__ void conv_weight_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ dst,
                                         unsigned short* __restrict__ dst_t, int O, int C, int Kpad) {

@@ -329,17 +329,19 @@ class EncoderEngine:
         W.layers = []
         for lyr in enc.layers:
             w = NS()
-            w.att = prep_attention(lyr.self_attn, dev)
-            w.fc1 = prep_linear([lyr.fc1.weight], [lyr.fc1.bias], dev)
-            w.fc2 = prep_linear([lyr.fc2.weight], [lyr.fc2.bias], dev)
+            with ops.cast_group():               # the layer's six matrices: one pooled cast + transpose launch
+                w.att = prep_attention(lyr.self_attn, dev)
+                w.fc1 = prep_linear([lyr.fc1.weight], [lyr.fc1.bias], dev)
+                w.fc2 = prep_linear([lyr.fc2.weight], [lyr.fc2.bias], dev)
             W.layers.append(w)
         W.scb = []
         if cfg.use_enrollments and cfg.scb_layers:
             for blk in enc.ca_enrolls:
                 s = NS()
-                s.att = prep_attention(blk.cae.cross_attn, dev, fuse_qkv=False)
-                s.f0 = prep_linear([blk.cae.ffn[0].weight], [blk.cae.ffn[0].bias], dev)
-                s.f3 = prep_linear([blk.cae.ffn[3].weight], [blk.cae.ffn[3].bias], dev)
+                with ops.cast_group():
+                    s.att = prep_attention(blk.cae.cross_attn, dev, fuse_qkv=False)
+                    s.f0 = prep_linear([blk.cae.ffn[0].weight], [blk.cae.ffn[0].bias], dev)
+                    s.f3 = prep_linear([blk.cae.ffn[3].weight], [blk.cae.ffn[3].bias], dev)
                 W.scb.append(s)
         W.full_init = prep_full_fddt(enc.initial_fddt, dev) if (cfg.use_fddt and cfg.use_pre_pos_fddt and fddt_is_full(enc.initial_fddt)) else None
         W.full = [prep_full_fddt(f, dev) if fddt_is_full(f) else None for f in (enc.fddts if cfg.use_fddt else [])]

@@ -87,13 +87,46 @@ def cast_bf16(src: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Te
     return out
 
 
+_CAST_GROUP = None          # inside `with cast_group():` the casts are recorded and launched pooled (dicow_cast_transpose_group)
+
+
+class cast_group:
+    """Context: cast_transpose_bf16 calls inside are recorded (their tensors kept alive) and run as pooled launches of up to
+    CAST_GROUP_MAX matrices when the context exits -- a layer's weight re-cast in one launch instead of six."""
+
+    def __enter__(self):
+        global _CAST_GROUP
+        self.prev, self.items = _CAST_GROUP, []
+        _CAST_GROUP = self
+        return self
+
+    def flush(self):
+        while self.items:
+            chunk, self.items = self.items[:L.CAST_GROUP_MAX], self.items[L.CAST_GROUP_MAX:]
+            arr = (L.CastProblem * len(chunk))()
+            for i, (src, out, out_t, ld, ld_t, R, Cc) in enumerate(chunk):
+                arr[i].src, arr[i].dst, arr[i].dst_t = src.data_ptr(), _p(out), _p(out_t)
+                arr[i].R, arr[i].C, arr[i].ld, arr[i].ld_t = R, Cc, ld, ld_t
+            L.call("dicow_cast_transpose_group", arr, len(chunk), L.stream())
+
+    def __exit__(self, *exc):
+        global _CAST_GROUP
+        _CAST_GROUP = self.prev
+        if exc[0] is None:
+            self.flush()
+        return False
+
+
 def cast_transpose_bf16(src: torch.Tensor, out=None, out_t=None, ld=None, ld_t=None):
     """fp32 [R,C] -> bf16 `out` [R,C] (row stride ld) and/or `out_t` [C,R] (row stride ld_t); either may be None."""
     _req(src, F32, "cast_transpose.src")
     assert src.dim() == 2 and src.is_contiguous()
     R, Cc = src.shape
-    L.call("dicow_cast_transpose_f32_to_bf16", src.data_ptr(), _p(out), Cc if ld is None else ld, _p(out_t),
-           R if ld_t is None else ld_t, R, Cc, L.stream())
+    ld, ld_t = (Cc if ld is None else ld), (R if ld_t is None else ld_t)
+    if _CAST_GROUP is not None:
+        _CAST_GROUP.items.append((src, out, out_t, ld, ld_t, R, Cc))
+        return out, out_t
+    L.call("dicow_cast_transpose_f32_to_bf16", src.data_ptr(), _p(out), ld, _p(out_t), ld_t, R, Cc, L.stream())
     return out, out_t
 
 
