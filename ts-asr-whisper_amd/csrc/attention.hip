@@ -246,6 +246,9 @@ __global__ void __launch_bounds__(256, LOG2 ? 2 : ATTN_FWD_WGS) attn_fwd_kernel(
     f32x16_t seed, lacc;                      // LOG2: -m_ref in every entry (0 while no score has been seen); row sums on the matrix pipe
 #pragma unroll
     for (int r = 0; r < 16; ++r) { seed[r] = 0.f; lacc[r] = 0.f; }
+#if defined(DICOW_ABLATIONS) && defined(ATTN_ABL_ZSEED)
+    asm volatile("" : "+v"(seed));              // (opaque zeros: the compiler must keep the tuple in registers)
+#endif
     bf16x8_t ones;
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
@@ -316,11 +319,20 @@ __global__ void __launch_bounds__(256, LOG2 ? 2 : ATTN_FWD_WGS) attn_fwd_kernel(
                 for (int kk = 1; kk < 4; ++kk)
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
             } else {
+#if defined(DICOW_ABLATIONS) && defined(ATTN_ABL_ZSEED)
+                // diagnostic: the first MFMA takes its C operand from a 16-register tuple of zeros that is NOT its destination
+                // (what the seeded q_log2 form does) -- isolates the price of that operand form
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][0], qf[0], seed, 0, 0, 0);
+#pragma unroll
+                for (int kk = 1; kk < 4; ++kk)
+                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
+#else
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
+#endif
             }
         }
         // V^T fragments for both 32-key blocks: issued now, consumed after the softmax
