@@ -1107,8 +1107,9 @@ static void gemm_nt_setup() {
 }
 
 // 256 x 256 tiles from which the persistent ring kernel takes over from the 128 x 128 tiles (two workgroups per CU, two barriers
-// per k-step): a ring workgroup runs a tile ~2.5x faster than the small kernel runs a quarter of it, so the persistent kernel
-// wins long before it can fill the chip (whisper-base, B = 8: the N = 512 GEMMs are 94 tiles)
+// per k-step).  Below ~200 tiles the ring kernel leaves most CUs idle and its prologue / epilogue are not amortised: whisper-base
+// B = 8, whose N = 512 GEMMs are 94 tiles, measured 7.72 ms per step with the threshold at 200 and 8.01-8.03 ms at 90 or 40
+// (round 3, tools/_c32.sh)
 #ifndef NT_BIG_TILES
 #define NT_BIG_TILES 200
 #endif
