@@ -209,6 +209,54 @@ def f3_fddt():
     save("f3_fddt", **arrs)
 
 
+# ----------------------------------------------------------------------------- F4: conv stem alone, forward + backward
+def f4_conv_stem():
+    """The stem of the reference encoder (encoder.py:167-170: gelu(conv1(x)), gelu(conv2(.)), permute) on the reference's own
+    conv modules: case "a" = small_cfg (80 mels, D = 128, 200 frames, B = 2), case "b" = 128 mels, D = 64, the full 3000 frames.
+    A forward hook on the real encoder's conv2 proves the three lines below are what the reference's forward runs."""
+    arrs = {}
+    for cn, over, B in (("a", {}, 2), ("b", dict(num_mel_bins=128, d_model=64, encoder_ffn_dim=128, decoder_ffn_dim=128,
+                                                max_source_positions=1500, encoder_layers=1, decoder_layers=1), 1)):
+        cfg = small_cfg(**over)
+        torch.manual_seed(4)
+        model = DiCoWForConditionalGeneration(cfg).eval()
+        randomize_(model, 44)
+        enc = model.model.encoder
+        T = cfg.max_source_positions
+        g = torch.Generator().manual_seed(45)
+        x = torch.randn(B, cfg.num_mel_bins, 2 * T, generator=g).clamp(-1.5, 1.5).half().float()      # stored as fp16
+        go = torch.randn(B, T, cfg.d_model, generator=g)
+        seen = {}
+        hk = enc.conv2.register_forward_hook(lambda m, i, o: seen.__setitem__("c2", o.detach().clone()))
+        with torch.no_grad():
+            enc(x, stno_mask=soft_stno(B, T, 46))
+        hk.remove()
+        for q in (enc.conv1.weight, enc.conv1.bias, enc.conv2.weight, enc.conv2.bias):
+            q.grad = None
+        h1 = torch.nn.functional.gelu(enc.conv1(x))
+        c2 = enc.conv2(h1)
+        assert torch.equal(c2, seen["c2"]), "the replicated stem is not what the reference encoder's forward computed"
+        out = torch.nn.functional.gelu(c2).permute(0, 2, 1)
+        out.backward(go)
+        arrs.update({f"{cn}.cfg": np.array(repr(cfg_dict(cfg))), f"{cn}.x": x.half(), f"{cn}.gout": go, f"{cn}.out": out,
+                     f"{cn}.p.conv1.weight": enc.conv1.weight, f"{cn}.p.conv1.bias": enc.conv1.bias,
+                     f"{cn}.p.conv2.weight": enc.conv2.weight, f"{cn}.p.conv2.bias": enc.conv2.bias,
+                     f"{cn}.g.conv1.weight": enc.conv1.weight.grad, f"{cn}.g.conv1.bias": enc.conv1.bias.grad,
+                     f"{cn}.g.conv2.weight": enc.conv2.weight.grad, f"{cn}.g.conv2.bias": enc.conv2.bias.grad})
+        # the reference's own bf16-autocast deviation (the yard-stick of the GPU tolerances)
+        for q in (enc.conv1.weight, enc.conv1.bias, enc.conv2.weight, enc.conv2.bias):
+            q.grad = None
+        with torch.autocast("cpu", dtype=torch.bfloat16):
+            ob = torch.nn.functional.gelu(enc.conv2(torch.nn.functional.gelu(enc.conv1(x)))).permute(0, 2, 1)
+        ob.float().backward(go)
+        arrs[f"{cn}.bf16.out.maxdev"] = (ob.float() - out).abs().max()
+        for n_, q in (("conv1.weight", enc.conv1.weight), ("conv1.bias", enc.conv1.bias), ("conv2.weight", enc.conv2.weight),
+                      ("conv2.bias", enc.conv2.bias)):
+            ref = arrs[f"{cn}.g.{n_}"]
+            arrs[f"{cn}.bf16.g.reldev.{n_}"] = (q.grad.float() - ref).abs().max() / ref.abs().max()
+    save("f4_conv_stem", **arrs)
+
+
 # ----------------------------------------------------------------------------- configs
 def small_cfg(**over):
     kw = dict(vocab_size=512, num_mel_bins=80, d_model=128, encoder_layers=2, encoder_attention_heads=2,
@@ -941,8 +989,8 @@ def f18_fallback():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f5", "f6", "f7", "f8", "f10", "f10b", "f11", "f12", "f13", "f14", "f15", "f16", "f17", "f18"]
-    fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7", "f8", "f10", "f10b", "f11", "f12", "f13", "f14", "f15", "f16", "f17", "f18"]
+    fns = {"f1": f1_stno, "f2": f2_logmel, "f3": f3_fddt, "f4": f4_conv_stem, "f5": f5_encoder_fulllen, "f6": f6_scb, "f7": f7_e2e,
            "f8": f8_se, "f10": f10_ctc, "f10b": f10b_ctc_extra_layer, "f11": f11_augment, "f12": f12_seek, "f13": f13_ctc_prefix, "f14": f14_timestamp_rules, "f15": f15_beam_search, "f16": f16_retrieve_segment, "f17": f17_fix_timestamps, "f18": f18_fallback}
     for w in which:
         fns[w]()

@@ -371,3 +371,42 @@ def test_f6_speaker_communication_block_vs_reference_golden(pkg):
         blk.cae.cross_gate.gate.zero_()
     out0, _ = eng._scb_fwd(0, x.reshape(Bc * Tn, D).contiguous(), Bc, Tn)
     assert torch.equal(out0.view(Bc, Tn, D).cpu(), T(z, "out_gate0"))
+
+
+# ------------------------------------------------------------------------------------------------ conv stem alone (golden F4)
+@pytest.mark.parametrize("cn", ["a", "b"])
+def test_f4_conv_stem_fwd_bwd_vs_reference_golden(pkg, cn):
+    """engine.conv_stem_fwd / conv_stem_bwd (two NT GEMMs over time-major views + GELU epilogues, col2im backward) against the
+    reference's own conv modules (fixture F4, encoder.py:167-170): output within max(2e-2, 3 x the reference's bf16-autocast
+    deviation), every conv weight / bias gradient within max(2e-2, 4 x the reference's own bf16 relative deviation)."""
+    from ts_asr_whisper_amd import engine as E
+    z = load_golden("f4_conv_stem")
+    d = ast.literal_eval(str(z[cn + ".cfg"]))
+    d.setdefault("bos_token_id", d["pad_token_id"])
+    d.setdefault("eos_token_id", d["pad_token_id"])
+    model = pkg.DiCoWForConditionalGeneration(pkg.DiCoWConfig(**d)).cuda()
+    enc = model.model.encoder
+    with torch.no_grad():
+        for n in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias"):
+            mod, attr = n.split(".")
+            getattr(getattr(enc, mod), attr).copy_(T(z, f"{cn}.p.{n}"))
+    params = [enc.conv1.weight, enc.conv1.bias, enc.conv2.weight, enc.conv2.bias]
+    for p in params:
+        p.requires_grad_(True)
+    eng = E.EncoderEngine(enc)
+    W = eng.prepare()
+    x = T(z, cn + ".x").float().cuda()
+    go = T(z, cn + ".gout")
+    x2, st = E.conv_stem_fwd(enc, W, x)
+    B, Tn, D = go.shape
+    out = x2.float().view(B, Tn, D).cpu()
+    ref = T(z, cn + ".out")
+    tol = max(2e-2, 3 * float(z[cn + ".bf16.out.maxdev"]))
+    assert maxdiff(out, ref) < tol, (maxdiff(out, ref), tol)
+    G = E.GradSink(params, x.device)
+    E.conv_stem_bwd(enc, W, st, go.cuda().to(torch.bfloat16).view(B * Tn, D).contiguous(), G)
+    torch.cuda.synchronize()
+    for n, p in zip(("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias"), params):
+        g, r = G.get(p).float().cpu(), T(z, f"{cn}.g.{n}")
+        tolg = max(2e-2, 4 * float(z[f"{cn}.bf16.g.reldev.{n}"]))
+        assert rel(g, r) < tolg, (cn, n, rel(g, r), tolg)

@@ -72,6 +72,22 @@ def test_f3_fddt_fwd_bwd():
             assert maxdiff(t.grad, ref) < 1e-4 * max(1.0, float(ref.abs().max())), (vn, k)
 
 
+def test_f4_conv_stem_fwd_bwd():
+    """The oracle's stem (conv1d_k3 x 2 + exact GELU, oracle/dicow_oracle.py:100-111,201-203) against the reference's own conv
+    modules (encoder.py:167-170), forward and every parameter gradient; both fixture cases (toy and full 3000 frames)."""
+    z = load_golden("f4_conv_stem")
+    for cn in ("a", "b"):
+        p = {k[len(cn) + 3:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith(cn + ".p.")}
+        x = torch.from_numpy(z[cn + ".x"]).float()
+        h = O.gelu_erf(O.conv1d_k3(x, p["conv1.weight"], p["conv1.bias"], 1, False))
+        out = O.gelu_erf(O.conv1d_k3(h, p["conv2.weight"], p["conv2.bias"], 2, False)).permute(0, 2, 1)
+        out.backward(T(z, cn + ".gout"))
+        assert maxdiff(out, T(z, cn + ".out")) < 2e-5, cn
+        for k, t in p.items():
+            ref = T(z, f"{cn}.g.{k}")
+            assert maxdiff(t.grad, ref) < 1e-4 * max(1.0, float(ref.abs().max())), (cn, k)
+
+
 def test_f6_scb():
     z = load_golden("f6_scb")
     cfg = O.OracleConfig(d_model=128, encoder_attention_heads=2, encoder_ffn_dim=256, use_enrollments=True, scb_layers=1)
@@ -414,3 +430,14 @@ def test_f18_fallback_oracle():
         nsp = torch.from_numpy(load_golden("f18_fallback")["no_speech_prob"])
         return OF.fallback_loop(lambda rows, t: decode(rows, t)[:2], n, temps, V, pad, eos, a, b, c, nsp)
     _check_fallback(loop, OF.compression_ratio, OF.avg_logprob)
+
+
+def test_f9_deviation_table_matches_the_fixtures():
+    """tests/golden/F9_bf16_deviation.md (the stand-alone table of SURVEY 8c) is exactly what the committed fixtures hold."""
+    import importlib.util, os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_f9_table", os.path.join(here, "make_f9_table.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with open(os.path.join(here, "F9_bf16_deviation.md")) as f:
+        assert f.read() == mod.render()

@@ -312,6 +312,54 @@ def plain_layer_bwd(lyr, w, s, gb, G, B, T, H):
     return g0
 
 
+def conv_stem_fwd(enc, W, input_features):
+    """gelu(conv1(x)) -> gelu(conv2(.)) of HF WhisperEncoder (reference encoder.py:167-170: Conv1d k=3 p=1, Conv1d k=3 s=2 p=1)
+    as two NT GEMMs over time-major views: a k=3 convolution is a GEMM whose A rows are three consecutive (zero-padded) frames.
+    input_features [B, M, 2T] -> (x2 bf16 [B*T, D], saved activations for conv_stem_bwd).  W: EncoderEngine.prepare()."""
+    dev = input_features.device
+    B, M, Tin = input_features.shape
+    T, D = Tin // 2, enc.conv1.weight.shape[0]
+    xt = torch.zeros(B * (Tin + 2) * M + W.k1, dtype=BF16, device=dev)        # + slack for the K padding reads
+    ops.mel_to_timemajor(input_features.to(F32), out=xt)
+    g1p = _e((B, Tin + 2, D), BF16, dev)
+    g1p[:, 0].zero_()
+    g1p[:, Tin + 1].zero_()
+    pre1 = _e((B, Tin, D), BF16, dev)
+    ops.gemm_nt(xt, W.conv1, g1p[:, 1:], Tin, D, W.k1, lda=M, bias=enc.conv1.bias.detach(), aux=pre1, flags=L.EPI_GELU,
+                batch=B, strideA=(Tin + 2) * M, strideC=(Tin + 2) * D, strideAux=Tin * D)
+    x2 = _e((B * T, D), BF16, dev)
+    pre2 = _e((B * T, D), BF16, dev)
+    ops.gemm_nt(g1p, W.conv2, x2, T, D, 3 * D, lda=2 * D, bias=enc.conv2.bias.detach(), aux=pre2, flags=L.EPI_GELU,
+                batch=B, strideA=(Tin + 2) * D, strideC=T * D, strideAux=T * D)
+    return x2, NS(xt=xt, g1p=g1p, pre1=pre1, pre2=pre2, B=B, T=T, M=M)
+
+
+def conv_stem_bwd(enc, W, st, d_x2, G):
+    """Backward of conv_stem_fwd.  d_x2: bf16 [B*T, D] gradient wrt its output; weight / bias gradients are accumulated into
+    G.get(param) (skipped where that is None).  The mel input receives no gradient (it is data)."""
+    dev = d_x2.device
+    B, T, M = st.B, st.T, st.M
+    Tin, rows, D = 2 * T, B * T, d_x2.shape[1]
+    d_pre2 = _e((rows, D), BF16, dev)
+    ops.gelu_bwd_bf16(d_x2, st.pre2, d_pre2)
+    bias_grad(d_pre2, G.get(enc.conv2.bias))
+    gw2 = G.get(enc.conv2.weight)
+    if gw2 is not None:
+        tmp = torch.zeros(D, 3 * D, dtype=F32, device=dev)
+        ops.gemm_tn(d_pre2, st.g1p, tmp, T, D, 3 * D, lda=D, ldb=2 * D, batch=B, strideA=T * D, strideB=(Tin + 2) * D)
+        ops.conv_weight_unpack_grad(tmp, gw2)
+    dA2 = _e((rows, 3 * D), BF16, dev)
+    ops.gemm_nt(d_pre2, W.conv2_t, dA2, rows, 3 * D, D)
+    d_pre1 = _e((B, Tin, D), BF16, dev)
+    ops.conv2_col2im_gelu_bwd(dA2, st.pre1, d_pre1, B, T, D)
+    bias_grad(d_pre1.view(B * Tin, D), G.get(enc.conv1.bias))
+    gw1 = G.get(enc.conv1.weight)
+    if gw1 is not None:
+        tmp = torch.zeros(D, W.k1, dtype=F32, device=dev)
+        ops.gemm_tn(d_pre1, st.xt, tmp, Tin, D, W.k1, lda=D, ldb=M, batch=B, strideA=Tin * D, strideB=(Tin + 2) * M)
+        ops.conv_weight_unpack_grad(tmp, gw1)
+
+
 class EncoderEngine:
     def __init__(self, enc):
         self.enc = enc
@@ -362,20 +410,9 @@ class EncoderEngine:
         stno = stno_mask.to(device=dev, dtype=F32).contiguous()
         S = NS(B0=B, T=T, stno=stno, layers=[], scb=[])
         # ---- conv stem as two GEMMs over time-major views (encoder.py:167-170)
-        xt = torch.zeros(B * (Tin + 2) * M + W.k1, dtype=BF16, device=dev)        # + slack for the K padding reads
-        ops.mel_to_timemajor(input_features.to(F32), out=xt)
-        g1p = _e((B, Tin + 2, D), BF16, dev)
-        g1p[:, 0].zero_()
-        g1p[:, Tin + 1].zero_()
-        pre1 = _e((B, Tin, D), BF16, dev)
-        ops.gemm_nt(xt, W.conv1, g1p[:, 1:], Tin, D, W.k1, lda=M, bias=enc.conv1.bias.detach(), aux=pre1, flags=L.EPI_GELU,
-                    batch=B, strideA=(Tin + 2) * M, strideC=(Tin + 2) * D, strideAux=Tin * D)
-        x2 = _e((B * T, D), BF16, dev)
-        pre2 = _e((B * T, D), BF16, dev)
-        ops.gemm_nt(g1p, W.conv2, x2, T, D, 3 * D, lda=2 * D, bias=enc.conv2.bias.detach(), aux=pre2, flags=L.EPI_GELU,
-                    batch=B, strideA=(Tin + 2) * D, strideC=T * D, strideAux=T * D)
+        x2, stem = conv_stem_fwd(enc, W, input_features)
         if need_grad:
-            S.xt, S.g1p, S.pre1, S.pre2, S.x2 = xt, g1p, pre1, pre2, x2
+            S.stem, S.x2 = stem, x2
         # ---- initial FDDT + positions (encoder.py:173-180)
         rows = B * T
         pos = enc.embed_positions.weight
@@ -659,24 +696,7 @@ class EncoderEngine:
             ops.fddt_ln_bwd(S.x2, rows, D, mode=mode, stno=S.stno, T=T, w=fw, b=fb, g_res=g, g_out_bf16=d_x2, dw=dw, db=db)
         if not conv_train:
             return
-        d_pre2 = _e((rows, D), BF16, dev)
-        ops.gelu_bwd_bf16(d_x2, S.pre2, d_pre2)
-        bias_grad(d_pre2, G.get(enc.conv2.bias))
-        gw2 = G.get(enc.conv2.weight)
-        if gw2 is not None:
-            tmp = torch.zeros(D, 3 * D, dtype=F32, device=dev)
-            ops.gemm_tn(d_pre2, S.g1p, tmp, T, D, 3 * D, lda=D, ldb=2 * D, batch=B, strideA=T * D, strideB=(Tin + 2) * D)
-            ops.conv_weight_unpack_grad(tmp, gw2)
-        dA2 = _e((rows, 3 * D), BF16, dev)
-        ops.gemm_nt(d_pre2, W.conv2_t, dA2, rows, 3 * D, D)
-        d_pre1 = _e((B, Tin, D), BF16, dev)
-        ops.conv2_col2im_gelu_bwd(dA2, S.pre1, d_pre1, B, T, D)
-        bias_grad(d_pre1.view(B * Tin, D), G.get(enc.conv1.bias))
-        gw1 = G.get(enc.conv1.weight)
-        if gw1 is not None:
-            tmp = torch.zeros(D, W.k1, dtype=F32, device=dev)
-            ops.gemm_tn(d_pre1, S.xt, tmp, Tin, D, W.k1, lda=D, ldb=M, batch=B, strideA=Tin * D, strideB=(Tin + 2) * M)
-            ops.conv_weight_unpack_grad(tmp, gw1)
+        conv_stem_bwd(enc, W, S.stem, d_x2, G)
 
 
 # ------------------------------------------------------------------------------------------------ decoder + LM head + loss
