@@ -216,7 +216,8 @@ def f4_conv_stem():
     A forward hook on the real encoder's conv2 proves the three lines below are what the reference's forward runs."""
     arrs = {}
     for cn, over, B in (("a", {}, 2), ("b", dict(num_mel_bins=128, d_model=64, encoder_ffn_dim=128, decoder_ffn_dim=128,
-                                                max_source_positions=1500, encoder_layers=1, decoder_layers=1), 1)):
+                                                max_source_positions=1500, encoder_layers=1, decoder_layers=1, encoder_attention_heads=1,
+                                                decoder_attention_heads=1), 1)):
         cfg = small_cfg(**over)
         torch.manual_seed(4)
         model = DiCoWForConditionalGeneration(cfg).eval()
