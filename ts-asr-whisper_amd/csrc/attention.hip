@@ -15,6 +15,7 @@
 // K/V tiles (64 keys) stream through a 2-stage LDS ring filled by global_load_lds DMA (16 B/lane), swizzled on
 // the source address (K: ds_read_b128 conflict-free; V: tr-read conflict-free).
 #include "common.h"
+#include <type_traits>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -41,7 +42,7 @@ __device__ __forceinline__ int vswz(int row, int c) { return row * 128 + ((c ^ (
 enum { SWZ_K = 0, SWZ_V = 1, SWZ_U = 2 };
 struct tile_src_t { __amdgpu_buffer_rsrc_t rs; unsigned vo[2]; int row_bytes; };
 __device__ __forceinline__ int rev3(int x);
-template <int SWZ>
+template <int SWZ, int NI = 2>      // NI = DMA instructions per wave and tile: 2 when four waves share a tile, 1 when eight do
 __device__ __forceinline__ tile_src_t make_tile_src(const unsigned short* base, int64_t rs, int nrows, int wave, int lane) {
     tile_src_t t;
     t.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base), 0,
@@ -49,18 +50,19 @@ __device__ __forceinline__ tile_src_t make_tile_src(const unsigned short* base, 
     t.row_bytes = (int)(rs * 2);
     const int rr = lane >> 3, p = lane & 7;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 8 + rr;
+    for (int i = 0; i < NI; ++i) {
+        const int row = (wave * NI + i) * 8 + rr;
         const int c = SWZ == SWZ_V ? (p ^ (((row >> 1) & 1) << 2)) : SWZ == SWZ_K ? (p ^ ((row >> 1) & 7)) : (p ^ rev3((row >> 1) & 7));
         t.vo[i] = (unsigned)(row * (int)(rs * 2) + c * 16);
     }
     return t;
 }
+template <int NI = 2>
 __device__ __forceinline__ void stage_tile(const tile_src_t& t, int row0, char* lds, int wave) {
     const int so = row0 * t.row_bytes;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(t.rs, (lds_void_t*)(lds + (wave * 2 + i) * 1024), 16, t.vo[i], so, 0, 0);
+    for (int i = 0; i < NI; ++i)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(t.rs, (lds_void_t*)(lds + (wave * NI + i) * 1024), 16, t.vo[i], so, 0, 0);
 }
 
 // 8 transposing reads (one 32-key block x 64 d) + wait, as ONE asm statement (see gemm.hip for the rationale).
@@ -201,6 +203,9 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
 #ifndef ATTN_FWD_WGS
 #define ATTN_FWD_WGS 3          // workgroups per CU: 154 VGPRs fit three; equal time at large-v3-turbo (3840 workgroups), one round instead of 1.5 at whisper-base B = 8 (768)
 #endif
+#ifndef ATTN_FWD_NW8
+#define ATTN_FWD_NW8 0
+#endif
 #ifndef ATTN_FWD_ILP
 #define ATTN_FWD_ILP 0
 #endif
@@ -216,15 +221,16 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
 //     chain delivers s - m_ref and the per-score fma disappears -- p = 2^s' straight away;
 //   * the row sum l += sum p runs on the matrix pipe: one more MFMA per P fragment against a constant all-ones operand
 //     (D[i][q] = sum_k P^T[k][q] for every i; 4 MFMAs per tile instead of 32 v_add and the final half-wave exchange).
-template <bool LOG2>
-__global__ void __launch_bounds__(256, LOG2 ? 2 : ATTN_FWD_WGS) attn_fwd_kernel(const dicow_attn_fwd_args a) {
+template <bool LOG2, int NW = 4>    // NW waves = NW * 32 query rows per workgroup, sharing each K / V tile
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (LOG2 ? 2 : ATTN_FWD_WGS)) attn_fwd_kernel(const dicow_attn_fwd_args a) {
+    constexpr int QB = NW * 32, NI = 8 / NW;
     __shared__ __attribute__((aligned(16))) char smem[6 * TILE_BYTES];      // three (K, V) slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
     int qblk, h, b;
-    attn_block_coords((a.Lq + 127) / 128, a.H, a.B, qblk, h, b);
-    const int q0 = qblk * 128;
+    attn_block_coords((a.Lq + QB - 1) / QB, a.H, a.B, qblk, h, b);
+    const int q0 = qblk * QB;
     const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
     const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
     const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
@@ -254,17 +260,17 @@ __global__ void __launch_bounds__(256, LOG2 ? 2 : ATTN_FWD_WGS) attn_fwd_kernel(
     for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
 
     int kv_end = a.Lk;
-    if (a.causal) { const int lim = q0 + 128 < a.Lk ? q0 + 128 : a.Lk; kv_end = lim; }   // keys <= last q row of the block
+    if (a.causal) { const int lim = q0 + QB < a.Lk ? q0 + QB : a.Lk; kv_end = lim; }   // keys <= last q row of the block
     const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
 
-    const tile_src_t srcK = make_tile_src<SWZ_K>(K, a.k_rs, a.Lk, wave, lane), srcV = make_tile_src<SWZ_V>(V, a.v_rs, a.Lk, wave, lane);
+    const tile_src_t srcK = make_tile_src<SWZ_K, NI>(K, a.k_rs, a.Lk, wave, lane), srcV = make_tile_src<SWZ_V, NI>(V, a.v_rs, a.Lk, wave, lane);
     // Three-slot ring, ONE barrier per k-tile: the barrier that publishes tile t also proves every wave has left tile
     // t-1, whose slot is then refilled with tile t+2 (two tiles of DMA lead instead of one).
-    stage_tile(srcK, 0, smem, wave);
-    stage_tile(srcV, 0, smem + TILE_BYTES, wave);
+    stage_tile<NI>(srcK, 0, smem, wave);
+    stage_tile<NI>(srcV, 0, smem + TILE_BYTES, wave);
     if (nt > 1) {
-        stage_tile(srcK, KV_TILE, smem + 2 * TILE_BYTES, wave);
-        stage_tile(srcV, KV_TILE, smem + 3 * TILE_BYTES, wave);
+        stage_tile<NI>(srcK, KV_TILE, smem + 2 * TILE_BYTES, wave);
+        stage_tile<NI>(srcV, KV_TILE, smem + 3 * TILE_BYTES, wave);
     }
 #ifdef ATTN_PROFILE
     long long pacc[6] = {0, 0, 0, 0, 0, 0}, pt[7];
@@ -296,10 +302,14 @@ __global__ void __launch_bounds__(256, LOG2 ? 2 : ATTN_FWD_WGS) attn_fwd_kernel(
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
+#if defined(DICOW_ABLATIONS) && defined(ATTN_ABL_NODMA)
+        if (false) {                                       // (ablation: no DMA after the prologue; results wrong, timing valid)
+#else
         if (t + 2 < nt) {
+#endif
             char* nK = smem + (slot == 0 ? 2 : slot - 1) * 2 * TILE_BYTES;    // slot of tile t-1 == slot of tile t+2
-            stage_tile(srcK, (t + 2) * KV_TILE, nK, wave);
-            stage_tile(srcV, (t + 2) * KV_TILE, nK + TILE_BYTES, wave);
+            stage_tile<NI>(srcK, (t + 2) * KV_TILE, nK, wave);
+            stage_tile<NI>(srcV, (t + 2) * KV_TILE, nK + TILE_BYTES, wave);
         }
         PT(1)
 
@@ -533,6 +543,307 @@ __global__ void __launch_bounds__(256, LOG2 ? 2 : ATTN_FWD_WGS) attn_fwd_kernel(
 #endif
 }
 
+
+// ---- software-pipelined forward (round 3).  The loop above is VALU-bound at head_dim 64 (165 VALU against 16 MFMAs per
+// 64-key tile and wave), and each wave runs its phases strictly in sequence -- S^T MFMAs, softmax, PV MFMAs -- so the matrix
+// pipe only works while another wave of the SIMD happens to be in a different phase (SQ counters: VALU-active 66 % + MFMA-busy
+// 40 % of the SIMD cycles, overlapping by 6 %: profiles/r03_attn_fwd_variants.txt).  Here every wave overlaps its OWN phases:
+//   * S^T of tile t+1 is computed while tile t's softmax runs (two score buffers; the K fragments of tile t+2 are read from
+//     LDS during tile t), its row maximum is taken under the PV MFMAs of tile t;
+//   * the softmax of the second 32-key block runs under the PV MFMAs of the first;
+//   * sched_group_barrier pins the interleave (one MFMA, then a handful of VALU instructions, ...).
+// K ring: three slots (tile t+2 read, t+3 landing), V ring: two slots (tile t read, t+1 landing); one barrier per tile.
+#ifndef ATTN_FWD_PIPE
+#define ATTN_FWD_PIPE 0
+#endif
+#ifndef ATTN_PIPE_WGS
+#define ATTN_PIPE_WGS 2
+#endif
+#ifndef ATTN_PIPE_NOSCHED
+#define ATTN_PIPE_NOSCHED 0
+#endif
+#ifndef ATTN_PIPE_LATE_V1
+#define ATTN_PIPE_LATE_V1 1
+#endif
+#ifndef ATTN_PIPE_V1
+#define ATTN_PIPE_V1 3          // trailing VALU instructions (adds, packs) behind each S^T MFMA, after its 2 fma + 2 exp
+#endif
+#ifndef ATTN_PIPE_V2
+#define ATTN_PIPE_V2 6          // ... behind each of the first four PV MFMAs, after 4 fma + 4 exp (softmax of the second key block)
+#endif
+#ifndef ATTN_PIPE_V3
+#define ATTN_PIPE_V3 5          // ... behind each of the last four PV MFMAs (row maximum of the next tile: 16 max3 + exchange)
+#endif
+#if ATTN_PIPE_NOSCHED
+#define PIPE_SGB(m, n, i)
+#else
+#define PIPE_SGB(m, n, i) __builtin_amdgcn_sched_group_barrier(m, n, i)
+#endif
+__global__ void __launch_bounds__(256, ATTN_PIPE_WGS) attn_fwd_pipe_kernel(const dicow_attn_fwd_args a) {
+    __shared__ __attribute__((aligned(16))) char smem[5 * TILE_BYTES];      // K slots 0..2, V slots 3..4
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;
+    int qblk, h, b;
+    attn_block_coords((a.Lq + 127) / 128, a.H, a.B, qblk, h, b);
+    const int q0 = qblk * 128;
+    const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
+    const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
+    const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
+    int qrow = q0 + wave * 32 + (lane & 31);
+    const int qrow_c = qrow < a.Lq ? qrow : a.Lq - 1;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        qf[kk] = *reinterpret_cast<const bf16x8_t*>(Q + (int64_t)qrow_c * a.q_rs + kk * 16 + hh * 8);
+    f32x16_t o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_ref = -INFINITY, l_run = 0.f;
+    int kv_end = a.Lk;
+    if (a.causal) { const int lim = q0 + 128 < a.Lk ? q0 + 128 : a.Lk; kv_end = lim; }
+    const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
+    const tile_src_t srcK = make_tile_src<SWZ_K>(K, a.k_rs, a.Lk, wave, lane), srcV = make_tile_src<SWZ_V>(V, a.v_rs, a.Lk, wave, lane);
+    char* const sKr = smem;
+    char* const sVr = smem + 3 * TILE_BYTES;
+    stage_tile(srcK, 0, sKr, wave);
+    if (nt > 1) stage_tile(srcK, KV_TILE, sKr + TILE_BYTES, wave);
+    if (nt > 2) stage_tile(srcK, 2 * KV_TILE, sKr + 2 * TILE_BYTES, wave);
+    stage_tile(srcV, 0, sVr, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    bf16x8_t kfr[2][4];
+    auto read_k = [&](const char* sK) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                kfr[kb][kk] = *reinterpret_cast<const bf16x8_t*>(sK + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
+    };
+    auto qk = [&](f32x16_t (&s)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
+        }
+    };
+    // mask (tile-uniform test first) + row maximum of one tile's scores; the half-wave exchange is a VALU swap (an LDS
+    // permute here would slip into the counted LDS waits of the V fragments)
+    // (MASKED is a compile-time flag: a run-time branch here would end the scheduling region the row maximum shares with the
+    // PV MFMAs; the tiles that need the mask -- the ragged last one, the diagonal ones of a causal problem -- form a suffix)
+    auto mask_max = [&](auto masked, f32x16_t (&s)[2], int t) __attribute__((always_inline)) -> float {
+        const int k0 = t * KV_TILE;
+        if constexpr (decltype(masked)::value) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= a.Lk || (a.causal && key > qrow)) s[kb][r] = -INFINITY;
+                }
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);        // -> v_max3_f32
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+
+    f32x16_t sA[2], sB[2];
+    float mxA, mxB = 0.f;
+    read_k(sKr);
+    qk(sA);
+    read_k(sKr + TILE_BYTES);                         // tile 1 (nt == 1: never staged, the scores it yields are never used)
+    mxA = mask_max(std::true_type{}, sA, 0);
+    int ks2 = 2, ks3 = 0;                             // ring slots of K tiles t+2 and t+3
+
+    // one tile: sc / mxc = scores and row maximum of tile t (ready), sn / mxn = those of tile t+1 (produced here)
+    auto body = [&](f32x16_t (&sc)[2], float mxc, f32x16_t (&sn)[2], float& mxn, int t) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(t+2), V(t): requested one tile ago
+        __builtin_amdgcn_s_barrier();                      // ... and every wave has left tile t-1: slots of K(t), V(t-1) are free
+        asm volatile("" ::: "memory");
+        if (t + 3 < nt) stage_tile(srcK, (t + 3) * KV_TILE, sKr + ks3 * TILE_BYTES, wave);
+        if (t + 1 < nt) stage_tile(srcV, (t + 1) * KV_TILE, sVr + ((t + 1) & 1) * TILE_BYTES, wave);
+        const char* sV = sVr + (t & 1) * TILE_BYTES;
+        const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
+        tr8_t tv0, tv1;
+        tr_issue_v<0>(tv0, va0, va1);
+#if !ATTN_PIPE_LATE_V1
+        tr_issue_v<4096>(tv1, va0, va1);
+#endif
+        // lazy rescale (see attn_fwd_kernel)
+        if (__builtin_amdgcn_ballot_w64(mxc > m_ref + 8.0f * LN2) != 0) {
+            const float m_new = fmaxf(m_ref, mxc);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f((m_ref - m_use) * LOG2E);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            m_ref = m_new;
+        }
+        const float mL = (m_ref == -INFINITY) ? 0.f : m_ref * LOG2E;
+        float psum = 0.f;
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S^T of tile t+1  ||  softmax of tile t, first key block
+        qk(sn);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sc[0][r], LOG2E, -mL));
+            sc[0][r] = p;
+            psum += p;
+        }
+        const bf16x8_t pf00 = pack8(sc[0], 0), pf01 = pack8(sc[0], 8);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {          // per MFMA gap: 2 fma, 2 exp, 3 of the adds / packs that follow them
+            PIPE_SGB(0x008, 1, 0);
+            PIPE_SGB(0x002, 2, 0);
+            PIPE_SGB(0x400, 2, 0);
+            PIPE_SGB(0x002, ATTN_PIPE_V1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- PV, first key block  ||  softmax of the second
+        bf16x8_t vf[2][2];
+#if ATTN_PIPE_LATE_V1
+        tr_wait<0>(tv0);
+        tr_issue_v<4096>(tv1, va0, va1);          // the second block's V fragments fly under the first block's PV MFMAs
+#else
+        tr_wait<8>(tv0);
+#endif
+        tr_pack(vf, tv0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][d], pf00, o[d], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][d], pf01, o[d], 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sc[1][r], LOG2E, -mL));
+            sc[1][r] = p;
+            psum += p;
+        }
+        const bf16x8_t pf10 = pack8(sc[1], 0), pf11 = pack8(sc[1], 8);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            PIPE_SGB(0x008, 1, 0);
+            PIPE_SGB(0x002, 4, 0);
+            PIPE_SGB(0x400, 4, 0);
+            PIPE_SGB(0x002, ATTN_PIPE_V2, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        l_run += psum;
+        // K fragments of tile t+2 (unconditional: the counted wait below relies on exactly 8 younger reads; past the last
+        // tile this reads a stale slot and the values are never used)
+        asm volatile("" ::: "memory");
+        read_k(sKr + ks2 * TILE_BYTES);
+        asm volatile("" ::: "memory");
+        tr_wait<8>(tv1);
+        tr_pack(vf, tv1);
+        // ---- PV, second key block  ||  mask + row maximum of tile t+1
+#pragma unroll
+        for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][d], pf10, o[d], 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][d], pf11, o[d], 0, 0, 0);
+        mxn = mask_max(std::false_type{}, sn, t + 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            PIPE_SGB(0x008, 1, 0);
+            PIPE_SGB(0x002, ATTN_PIPE_V3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ks2 = ks2 == 2 ? 0 : ks2 + 1;
+        ks3 = ks3 == 2 ? 0 : ks3 + 1;
+    };
+    // tiles 0 .. nt-2 (none of them needs a mask: the kernel serves non-causal problems, only the last tile can be ragged);
+    // two copies of the body so that the two score buffers swap roles without register moves
+    for (int t = 0; t + 1 < nt; t += 2) {
+        body(sA, mxA, sB, mxB, t);
+        if (t + 2 < nt) body(sB, mxB, sA, mxA, t + 1);
+    }
+    // last tile: its scores were produced by the body before it (or the prologue); mask, maximum again, softmax, PV
+    {
+        const int t = nt - 1;
+        if (t & 1) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) sA[kb] = sB[kb];
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const char* sV = sVr + (t & 1) * TILE_BYTES;
+        const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
+        tr8_t tv0, tv1;
+        tr_issue_v<0>(tv0, va0, va1);
+        tr_issue_v<4096>(tv1, va0, va1);
+        const float mxc = mask_max(std::true_type{}, sA, t);
+        if (__builtin_amdgcn_ballot_w64(mxc > m_ref + 8.0f * LN2) != 0) {
+            const float m_new = fmaxf(m_ref, mxc);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f((m_ref - m_use) * LOG2E);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            m_ref = m_new;
+        }
+        const float mL = (m_ref == -INFINITY) ? 0.f : m_ref * LOG2E;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(sA[kb][r], LOG2E, -mL));
+                sA[kb][r] = p;
+                psum += p;
+            }
+        l_run += psum;
+        bf16x8_t vf[2][2];
+        tr_wait<8>(tv0);
+        tr_pack(vf, tv0);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const bf16x8_t pf = pack8(sA[0], 8 * x);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+        }
+        tr_wait<0>(tv1);
+        tr_pack(vf, tv1);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const bf16x8_t pf = pack8(sA[1], 8 * x);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qrow < a.Lq) {
+        unsigned short* O = reinterpret_cast<unsigned short*>(a.o) + (int64_t)b * a.o_bs + (int64_t)qrow * a.o_rs + h * HD;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int col = d * 32 + 8 * q4 + 4 * hh;
+                *reinterpret_cast<uint2*>(O + col) =
+                    make_uint2(pack_bf16x2(o[d][4 * q4] * inv_l, o[d][4 * q4 + 1] * inv_l),
+                               pack_bf16x2(o[d][4 * q4 + 2] * inv_l, o[d][4 * q4 + 3] * inv_l));
+            }
+        if (a.lse && hh == 0)
+            a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = m_ref + __builtin_amdgcn_logf(l_tot) * LN2;
+    }
+}
+
+#undef PIPE_SGB
 static int check_strides(int64_t rs, const char* n) {
     if (rs % 8 != 0) { dicow_set_error("attention: %s row stride must be a multiple of 8 elements", n); return 0; }
     return 1;
@@ -545,8 +856,18 @@ extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
     if (!check_strides(a->q_rs, "q") || !check_strides(a->k_rs, "k") || !check_strides(a->v_rs, "v") ||
         !check_strides(a->o_rs, "o")) return DICOW_ERR_INVALID;
     DICOW_REQUIRE(a->q_bs % 8 == 0 && a->k_bs % 8 == 0 && a->v_bs % 8 == 0 && a->o_bs % 4 == 0, "attn_fwd: batch strides must keep 16-byte alignment");
+    // eight-wave workgroups (256 query rows share each K / V tile: half the LDS-DMA instructions per wave, which cost the
+    // four-wave form 14 % -- profiles/r03_attn_fwd_variants.txt) once they still fill the chip twice over
+    static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
+    const int64_t wg8 = (int64_t)dicow_cdiv(a->Lq, 256) * a->H * a->B;
+    if (ATTN_FWD_NW8 && !a->q_log2 && wg8 >= 2 * ncu) {
+        hipLaunchKernelGGL((attn_fwd_kernel<false, 8>), dim3((unsigned)wg8), dim3(512), 0, (hipStream_t)stream, *a);
+        DICOW_CHECK_LAUNCH("attn_fwd (8 waves)");
+        return DICOW_OK;
+    }
     dim3 grid(dicow_cdiv(a->Lq, 128) * a->H * a->B);
     if (a->q_log2) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else if (ATTN_FWD_PIPE && !a->causal) hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("attn_fwd");
     return DICOW_OK;
