@@ -203,6 +203,9 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
 #ifndef ATTN_FWD_WGS
 #define ATTN_FWD_WGS 3          // workgroups per CU: 154 VGPRs fit three; equal time at large-v3-turbo (3840 workgroups), one round instead of 1.5 at whisper-base B = 8 (768)
 #endif
+#ifndef ATTN_FWD_REGSTAGE
+#define ATTN_FWD_REGSTAGE 0
+#endif
 #ifndef ATTN_FWD_NW8
 #define ATTN_FWD_NW8 0
 #endif
@@ -292,6 +295,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (LOG2 ? 2 : ATTN_FWD_WG
         for (int kk = 0; kk < 4; ++kk)
             kfr[kb][kk] = *reinterpret_cast<const bf16x8_t*>(smem + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
     int slot = 0;
+#if ATTN_FWD_REGSTAGE
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_rs_t;
+    u32x4_rs_t rgK[NI], rgV[NI];
+    char* rg_dst = smem;
+#endif
     for (int t = 0; t < nt; ++t) {
         PT(0)
         char* sK = smem + slot * 2 * TILE_BYTES;
@@ -308,8 +316,18 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (LOG2 ? 2 : ATTN_FWD_WG
         if (t + 2 < nt) {
 #endif
             char* nK = smem + (slot == 0 ? 2 : slot - 1) * 2 * TILE_BYTES;    // slot of tile t-1 == slot of tile t+2
+#if ATTN_FWD_REGSTAGE
+            // register staging: plain buffer loads now, ds_write at the end of this tile (same LDS image as the DMA form)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                rgK[i] = __builtin_amdgcn_raw_buffer_load_b128(srcK.rs, srcK.vo[i], (t + 2) * KV_TILE * srcK.row_bytes, 0);
+                rgV[i] = __builtin_amdgcn_raw_buffer_load_b128(srcV.rs, srcV.vo[i], (t + 2) * KV_TILE * srcV.row_bytes, 0);
+            }
+            rg_dst = nK;
+#else
             stage_tile<NI>(srcK, (t + 2) * KV_TILE, nK, wave);
             stage_tile<NI>(srcV, (t + 2) * KV_TILE, nK + TILE_BYTES, wave);
+#endif
         }
         PT(1)
 
@@ -504,6 +522,16 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (LOG2 ? 2 : ATTN_FWD_WG
             }
         }
         PT(4)
+#if ATTN_FWD_REGSTAGE
+        if (t + 2 < nt) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                *reinterpret_cast<u32x4_rs_t*>(rg_dst + (wave * NI + i) * 1024 + lane * 16) = rgK[i];
+                *reinterpret_cast<u32x4_rs_t*>(rg_dst + TILE_BYTES + (wave * NI + i) * 1024 + lane * 16) = rgV[i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the tile is in LDS before this wave reaches the barrier
+        }
+#endif
         slot = slot_n;
         PT(5)
 #ifdef ATTN_PROFILE
