@@ -13,6 +13,11 @@ Restates what happens to the parameters between two forward passes when the refe
 
 The arithmetic is torch's own ``torch.optim.AdamW`` -- the third-party code the reference calls -- so this file is the
 procedure, not a re-derivation.  Only tests/ may import it.
+
+Pinned: tests/test_trajectory.py drives oracle/dicow_oracle.py with this harness over the eight optimizer steps of fixture F20
+(tests/golden/make_golden_trajectory.py: the REAL reference's freeze_except / get_optimizer, transformers' cosine schedule and
+clip_grad_norm_ on the real model) and reproduces its per-step loss, gradient norm, learning rates, trainable-parameter counts
+and the updates of the watched parameters.
 """
 import math
 

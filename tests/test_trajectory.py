@@ -1,0 +1,57 @@
+"""Fixture F20 (a short training trajectory of the REAL reference: its freeze / unfreeze rules, get_optimizer's two AdamW
+groups, transformers' cosine schedule, clip_grad_norm_, eight optimizer steps on two alternating batches) against the oracle:
+oracle/dicow_oracle.py (the model) driven by oracle/optim.py::ReferenceHarness (the procedure).  CPU only."""
+import ast
+
+import torch
+
+import amd_pkg
+from oracle import dicow_oracle as O
+from oracle.optim import ReferenceHarness
+from tests.util import load_golden, golden_cfg, hashed_init_, f20_batches, F20_PREFIXES, subsample
+
+
+def test_f20_oracle_training_trajectory_small():
+    z = load_golden("f20_trajectory_small")
+    hp = ast.literal_eval(str(z["hp"]))
+    cfg = golden_cfg(z)
+    amd_pkg.load()
+    import ts_asr_whisper_amd as pkg
+    d = ast.literal_eval(str(z["cfg"]))
+    d.setdefault("bos_token_id", d["pad_token_id"])
+    torch.manual_seed(0)
+    model = pkg.DiCoWForConditionalGeneration(pkg.DiCoWConfig(**d))        # parameter NAMES only (the reference's key surface)
+    hashed_init_(model)
+    with torch.no_grad():
+        model.model.encoder.embed_positions.weight.copy_(O.sinusoids(cfg.max_source_positions, cfg.d_model))
+    start = {n: p.detach().clone() for n, p in model.named_parameters()}
+    h = ReferenceHarness(start, lr=hp["lr"], fddt_lr_multiplier=hp["mult"], weight_decay=hp["wd"], max_grad_norm=hp["max_norm"],
+                         warmup_steps=hp["warmup"], max_steps=hp["K"], frozen_keywords=("decoder",), preheat_prefixes=F20_PREFIXES,
+                         use_fddt_only_n_steps=hp["n_pre"])
+    # the reference starts from the HF module, whose sinusoidal table is frozen until the unfreeze rule flips every flag
+    ntrain = []
+    for k, b in enumerate(f20_batches("small", hp["K"])):
+        h.begin_step()
+        p = dict(h.p)
+        p["proj_out.weight"] = p["model.decoder.embed_tokens.weight"]
+        out = O.model_forward(p, cfg, b["input_features"], b["stno_mask"], b["labels"], b["upp_labels"])
+        lk = float(out["loss"].detach())
+        assert abs(lk - float(z["loss"][k])) < 2e-4, (k, lk, float(z["loss"][k]))
+        for q in h.p.values():
+            q.grad = None
+        out["loss"].backward()
+        grads = {n: q.grad for n, q in h.p.items() if q.requires_grad and q.grad is not None}
+        gn = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values()))
+        assert abs(float(gn) - float(z["gnorm"][k])) < 2e-3 * float(z["gnorm"][k]), (k, float(gn), float(z["gnorm"][k]))
+        assert abs(h.opt.param_groups[0]["lr"] - float(z["lr0"][k])) < 1e-12 and abs(h.opt.param_groups[1]["lr"] - float(z["lr1"][k])) < 1e-12
+        ntrain.append(sum(q.numel() for q in h.p.values() if q.requires_grad))
+        h.step(grads)
+    assert ntrain == [int(v) for v in z["ntrain"]]
+    for n in str(z["watched"]).split("\n"):
+        upd = (h.p[n].detach() - start[n]).float()
+        ref, nrm = torch.from_numpy(z["upd.sub." + n]), float(z["upd.norm." + n])
+        if nrm == 0.0:
+            assert float(upd.abs().max()) == 0.0, n
+            continue
+        assert float((subsample(upd, 512) - ref).double().norm()) < 2e-3 * float(ref.double().norm()) + 1e-9, n
+        assert abs(float(upd.double().norm()) - nrm) < 2e-3 * nrm, n
