@@ -13,7 +13,7 @@ Weights and batches are integer-hashed (tests/util.py), so the fixture holds OUT
 learning rates, sub-samples of watched parameters after the last step -- in fp32, plus the same trajectory under bf16 autocast
 (the yard-stick of the GPU tolerances).
 
-    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_trajectory.py [small tiny]
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_trajectory.py [small small_se tiny]
 """
 import os
 import sys
@@ -39,18 +39,21 @@ PREFIXES = F20_PREFIXES                       # configs/base.yaml:18 prefixes_to
 FROZEN = ["decoder"]
 HP = {  # name: (steps, preheat steps, lr, multiplier, weight decay, warm-up steps, max grad norm)
     "small": dict(K=8, n_pre=3, lr=2e-4, mult=50.0, wd=0.01, warmup=2, max_norm=1.0),
+    "small_se": dict(K=8, n_pre=3, lr=2e-4, mult=50.0, wd=0.01, warmup=2, max_norm=1.0),
     "tiny": dict(K=8, n_pre=3, lr=2e-4, mult=100.0, wd=0.01, warmup=1, max_norm=1.0),
 }
 WATCH = ["model.encoder.fddts.0.target_linear.weight", "model.encoder.fddts.1.non_target_linear.bias",
          "model.encoder.initial_fddt.silence_linear.weight", "model.encoder.layers.0.self_attn.q_proj.weight",
          "model.encoder.layers.1.fc1.weight", "model.encoder.layers.1.fc2.bias", "model.encoder.layers.0.final_layer_norm.weight",
          "model.encoder.layer_norm.bias", "model.encoder.conv1.weight", "model.encoder.conv2.bias",
-         "model.encoder.embed_positions.weight", "model.decoder.layers.0.fc1.weight", "model.decoder.embed_tokens.weight"]
+         "model.encoder.embed_positions.weight", "model.decoder.layers.0.fc1.weight", "model.decoder.embed_tokens.weight",
+         "model.encoder.ca_enrolls.0.cae.cross_attn.q_proj.weight", "model.encoder.ca_enrolls.0.cae.cross_attn.out_proj.bias",
+         "model.encoder.ca_enrolls.0.cae.ffn.0.weight", "model.encoder.ca_enrolls.0.cae.cross_gate.gate"]
 
 
 def build(case):
-    if case == "small":
-        cfg = MG.small_cfg()
+    if case.startswith("small"):
+        cfg = MG.small_cfg(**(dict(use_enrollments=True, scb_layers=1) if case == "small_se" else {}))
         B, L, T, M, vocab_hi, ts0 = 2, 10, 100, 80, 400, None
     else:
         kw = dict(RD.COMMON)
@@ -80,6 +83,8 @@ def run(case, autocast):
             for name, p in model.named_parameters():
                 p.requires_grad = not any(w in name for w in FROZEN)
             warm = False
+        if "enrollments" in b:                 # the collator's nested enrollment batch carries an attention mask (collators.py:216-220)
+            b = dict(b, enrollments=dict(b["enrollments"], attention_mask=torch.ones(b["input_features"].shape[0], b["input_features"].shape[2])))
         with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
             out = model(**b)
         out.loss.float().backward()
@@ -119,4 +124,4 @@ def main(which):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1:] or ["small", "tiny"])
+    main(sys.argv[1:] or ["small", "small_se", "tiny"])

@@ -24,7 +24,7 @@ amd_pkg.load()
 def _build(case, z):
     import ts_asr_whisper_amd as pkg
     from ts_asr_whisper_amd.modeling import sinusoids
-    if case == "small":
+    if case.startswith("small"):
         d = ast.literal_eval(str(z["cfg"]))
         d.setdefault("bos_token_id", d["pad_token_id"])
         cfg, ts0 = pkg.DiCoWConfig(**d), None
@@ -41,7 +41,7 @@ def _build(case, z):
     return model, cfg, ts0
 
 
-@pytest.mark.parametrize("case", ["small", "tiny"])
+@pytest.mark.parametrize("case", ["small", "small_se", "tiny"])
 def test_f20_training_trajectory_vs_reference(case):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
@@ -54,7 +54,7 @@ def test_f20_training_trajectory_vs_reference(case):
                    warmup_steps=hp["warmup"], max_steps=hp["K"], frozen_keywords=("decoder",), use_fddt_only_n_steps=hp["n_pre"])
     named = dict(model.named_parameters())
     for k, b in enumerate(f20_batches(case, hp["K"], ts0)):
-        loss = ts.step({n: v.cuda() for n, v in b.items()})
+        loss = ts.step({n: ({m: w.cuda() for m, w in v.items()} if isinstance(v, dict) else v.cuda()) for n, v in b.items()})
         ref, bf = float(z["loss"][k]), float(z["bf16.loss"][k])
         tol = max(5e-3, 3 * abs(bf - ref))
         assert abs(float(loss) - ref) < tol, (case, k, float(loss), ref, tol)

@@ -11,8 +11,12 @@ from oracle.optim import ReferenceHarness
 from tests.util import load_golden, golden_cfg, hashed_init_, f20_batches, F20_PREFIXES, subsample
 
 
-def test_f20_oracle_training_trajectory_small():
-    z = load_golden("f20_trajectory_small")
+import pytest
+
+
+@pytest.mark.parametrize("case", ["small", "small_se"])
+def test_f20_oracle_training_trajectory(case):
+    z = load_golden("f20_trajectory_" + case)
     hp = ast.literal_eval(str(z["hp"]))
     cfg = golden_cfg(z)
     amd_pkg.load()
@@ -30,11 +34,11 @@ def test_f20_oracle_training_trajectory_small():
                          use_fddt_only_n_steps=hp["n_pre"])
     # the reference starts from the HF module, whose sinusoidal table is frozen until the unfreeze rule flips every flag
     ntrain = []
-    for k, b in enumerate(f20_batches("small", hp["K"])):
+    for k, b in enumerate(f20_batches(case, hp["K"])):
         h.begin_step()
         p = dict(h.p)
         p["proj_out.weight"] = p["model.decoder.embed_tokens.weight"]
-        out = O.model_forward(p, cfg, b["input_features"], b["stno_mask"], b["labels"], b["upp_labels"])
+        out = O.model_forward(p, cfg, b["input_features"], b["stno_mask"], b["labels"], b["upp_labels"], enrollments=b.get("enrollments"))
         lk = float(out["loss"].detach())
         assert abs(lk - float(z["loss"][k])) < 2e-4, (k, lk, float(z["loss"][k]))
         for q in h.p.values():

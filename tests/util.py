@@ -167,15 +167,19 @@ F20_PREFIXES = ["model.encoder.additional_layer", "model.encoder.additional_self
 
 
 def f20_batches(case, K, ts0=None):
-    """case "small": 80 mels, 100 frames, B = 2, 10 labels below id 400; "tiny": whisper-tiny dimensions, B = 1, 32 labels with a
-    timestamp token (ts0 = first timestamp id) in front."""
-    B, L, T, M, vocab_hi = (2, 10, 100, 80, 400) if case == "small" else (1, 32, 1500, 80, 50257)
-    mel = torch.from_numpy(hashed_mel(2 * B, M, 2 * T)).clone() * 1.5
+    """case "small": 80 mels, 100 frames, B = 2, 10 labels below id 400; "small_se": the same with an enrollment per row
+    (SE-DiCoW); "tiny": whisper-tiny dimensions, B = 1, 32 labels with a timestamp token (ts0 = first timestamp id) in front."""
+    se = case == "small_se"
+    B, L, T, M, vocab_hi = (2, 10, 100, 80, 400) if case.startswith("small") else (1, 32, 1500, 80, 50257)
+    mel = torch.from_numpy(hashed_mel((4 if se else 2) * B, M, 2 * T)).clone() * 1.5
     two = []
     for j in range(2):
         lab = hashed_labels(B, L, 0, vocab_hi, f"f20.{case}.{j}.labels", pad_rows=(B - 1,) if B > 1 else ())
         if ts0 is not None:
             lab[:, 0] = ts0 + 7 + j
-        two.append(dict(input_features=mel[j * B:(j + 1) * B], stno_mask=hashed_stno(B, T, f"f20.{case}.{j}.stno"), labels=lab,
-                        upp_labels=lab.clone()))
+        b = dict(input_features=mel[j * B:(j + 1) * B], stno_mask=hashed_stno(B, T, f"f20.{case}.{j}.stno"), labels=lab,
+                 upp_labels=lab.clone())
+        if se:
+            b["enrollments"] = {"input_features": mel[(2 + j) * B:(3 + j) * B], "stno_mask": hashed_stno(B, T, f"f20.{case}.{j}.enr.stno")}
+        two.append(b)
     return [two[k % 2] for k in range(K)]
