@@ -203,6 +203,9 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
 #ifndef ATTN_FWD_WGS
 #define ATTN_FWD_WGS 3          // workgroups per CU: 154 VGPRs fit three; equal time at large-v3-turbo (3840 workgroups), one round instead of 1.5 at whisper-base B = 8 (768)
 #endif
+#ifndef ATTN_FWD_LATE_DMA
+#define ATTN_FWD_LATE_DMA 0
+#endif
 #ifndef ATTN_FWD_REGSTAGE
 #define ATTN_FWD_REGSTAGE 0
 #endif
@@ -227,7 +230,9 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
 template <bool LOG2, int NW = 4>    // NW waves = NW * 32 query rows per workgroup, sharing each K / V tile
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (LOG2 ? 2 : ATTN_FWD_WGS)) attn_fwd_kernel(const dicow_attn_fwd_args a) {
     constexpr int QB = NW * 32, NI = 8 / NW;
-    __shared__ __attribute__((aligned(16))) char smem[6 * TILE_BYTES];      // three (K, V) slots
+    constexpr bool LATE = ATTN_FWD_LATE_DMA && !LOG2 && NW == 4 && !ATTN_FWD_REGSTAGE;   // four slots, tile t+3 requested from inside tile t's softmax
+    constexpr int NS = LATE ? 4 : 3;
+    __shared__ __attribute__((aligned(16))) char smem[2 * NS * TILE_BYTES];      // NS (K, V) slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
@@ -275,6 +280,10 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (LOG2 ? 2 : ATTN_FWD_WG
         stage_tile<NI>(srcK, KV_TILE, smem + 2 * TILE_BYTES, wave);
         stage_tile<NI>(srcV, KV_TILE, smem + 3 * TILE_BYTES, wave);
     }
+    if (LATE && nt > 2) {
+        stage_tile<NI>(srcK, 2 * KV_TILE, smem + 4 * TILE_BYTES, wave);
+        stage_tile<NI>(srcV, 2 * KV_TILE, smem + 5 * TILE_BYTES, wave);
+    }
 #ifdef ATTN_PROFILE
     long long pacc[6] = {0, 0, 0, 0, 0, 0}, pt[7];
     const long long pstart = clock64();
@@ -304,16 +313,19 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (LOG2 ? 2 : ATTN_FWD_WG
         PT(0)
         char* sK = smem + slot * 2 * TILE_BYTES;
         char* sV = sK + TILE_BYTES;
-        const int slot_n = slot == 2 ? 0 : slot + 1;
+        const int slot_n = slot == NS - 1 ? 0 : slot + 1;
         if (t > 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // tile t+1 landed (this wave's share)
+            // tile t+1 landed (this wave's share).  LATE: tile t+2, requested half a tile ago, may still be in flight --
+            // loads complete in order, so "at most its 2 NI instructions outstanding" covers everything older
+            if (LATE && t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(LATE ? 2 * NI : 0) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
 #if defined(DICOW_ABLATIONS) && defined(ATTN_ABL_NODMA)
         if (false) {                                       // (ablation: no DMA after the prologue; results wrong, timing valid)
 #else
-        if (t + 2 < nt) {
+        if (!LATE && t + 2 < nt) {
 #endif
             char* nK = smem + (slot == 0 ? 2 : slot - 1) * 2 * TILE_BYTES;    // slot of tile t-1 == slot of tile t+2
 #if ATTN_FWD_REGSTAGE
@@ -485,6 +497,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (LOG2 ? 2 : ATTN_FWD_WG
 #if ATTN_FWD_ILP
         psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
 #endif
+        }
+        if (LATE && t + 3 < nt) {          // slot of tile t-1 (free since this tile's barrier); issued among VALU work, not in front of the MFMAs
+            char* nK = smem + (slot == 0 ? NS - 1 : slot - 1) * 2 * TILE_BYTES;
+            stage_tile<NI>(srcK, (t + 3) * KV_TILE, nK, wave);
+            stage_tile<NI>(srcV, (t + 3) * KV_TILE, nK + TILE_BYTES, wave);
         }
         l_run += psum;
         PT(3)
