@@ -203,6 +203,9 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
 #ifndef ATTN_FWD_WGS
 #define ATTN_FWD_WGS 3          // workgroups per CU: 154 VGPRs fit three; equal time at large-v3-turbo (3840 workgroups), one round instead of 1.5 at whisper-base B = 8 (768)
 #endif
+#ifndef ATTN_BWD_DKV_NW8
+#define ATTN_BWD_DKV_NW8 0
+#endif
 #ifndef ATTN_FWD_LATE_DMA
 #define ATTN_FWD_LATE_DMA 0
 #endif
@@ -1125,14 +1128,16 @@ __device__ __forceinline__ void stage_stats64(const float* lse, const float* del
     __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + (wave & 1) * 256), 4, 0, 0);
 }
 
-__global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_bwd_args a) {
+template <int NW = 4>      // NW waves = NW * 32 keys per workgroup, sharing each Q / dO tile (8: half the DMA instructions per wave)
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) attn_bwd_dkv_kernel(const dicow_attn_bwd_args a) {
+    constexpr int KB = NW * 32, NI = 8 / NW;
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 1024];   // Q0 dO0 Q1 dO1 (U images) + lse/delta x2
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hh = lane >> 5;
     int kblk, h, b;
-    attn_block_coords((a.Lk + 127) / 128, a.H, a.B, kblk, h, b);
-    const int kblk0 = kblk * 128;
+    attn_block_coords((a.Lk + KB - 1) / KB, a.H, a.B, kblk, h, b);
+    const int kblk0 = kblk * KB;
     const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
     const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
     const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
@@ -1161,10 +1166,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
 
     const int t0 = a.causal ? (kblk0 / KV_TILE) : 0;                 // query tiles entirely before the key block see none of it
     const int nt = (a.Lq + KV_TILE - 1) / KV_TILE;
-    const tile_src_t srcQ = make_tile_src<SWZ_U>(Q, a.q_rs, a.Lq, wave, lane), srcdO = make_tile_src<SWZ_U>(dO, a.do_rs, a.Lq, wave, lane);
+    const tile_src_t srcQ = make_tile_src<SWZ_U, NI>(Q, a.q_rs, a.Lq, wave, lane), srcdO = make_tile_src<SWZ_U, NI>(dO, a.do_rs, a.Lq, wave, lane);
     if (t0 < nt) {
-        stage_tile(srcQ, t0 * KV_TILE, smem, wave);
-        stage_tile(srcdO, t0 * KV_TILE, smem + TILE_BYTES, wave);
+        stage_tile<NI>(srcQ, t0 * KV_TILE, smem, wave);
+        stage_tile<NI>(srcdO, t0 * KV_TILE, smem + TILE_BYTES, wave);
         stage_stats64(lse, delta, t0 * KV_TILE, a.Lq, smem + 4 * TILE_BYTES, wave, lane);
     }
     // lane-derived row-fragment offsets (swizzle XORs) computed once: plain VALU instructions share the SIMD's issue port
@@ -1181,10 +1186,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
         char* sdO = sQ + TILE_BYTES;
         if (t + 1 < nt) {
             char* nQ = smem + ((t - t0 + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile(srcQ, (t + 1) * KV_TILE, nQ, wave);
-            stage_tile(srcdO, (t + 1) * KV_TILE, nQ + TILE_BYTES, wave);
+            stage_tile<NI>(srcQ, (t + 1) * KV_TILE, nQ, wave);
+            stage_tile<NI>(srcdO, (t + 1) * KV_TILE, nQ + TILE_BYTES, wave);
             stage_stats64(lse, delta, (t + 1) * KV_TILE, a.Lq, smem + 4 * TILE_BYTES + ((t - t0 + 1) & 1) * 512, wave, lane);
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * NI + 1) : "memory");     // this tile landed; the next one (2 NI tile pieces + 1 statistics piece) may fly
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -1193,7 +1198,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
 
         const int qt0 = t * KV_TILE;
         const float* sStat = reinterpret_cast<const float*>(smem + 4 * TILE_BYTES + ((t - t0) & 1) * 512);
-        const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + 128 > a.Lk) || (a.causal && (kblk0 + wave * 32 + 31 > qt0));
+        const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + KB > a.Lk) || (a.causal && (kblk0 + wave * 32 + 31 > qt0));
         const unsigned stg = (unsigned)(((t - t0) & 1) * 2 * TILE_BYTES);
         const unsigned q00 = qb00 + stg, q01 = qb01 + stg, q10 = qb10 + stg, q11 = qb11 + stg;
         const unsigned o00 = q00 + TILE_BYTES, o01 = q01 + TILE_BYTES, o10 = q10 + TILE_BYTES, o11 = q11 + TILE_BYTES;
@@ -1246,10 +1251,12 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dkv_kernel(const dicow_attn_b
         asm volatile("" ::: "memory");
     }
     if (a.dv_colsum) {        // v_proj bias gradient, fused: second workspace plane, partial row (b, key block, wave)
+        // partial rows are indexed by 128-key block and wave-in-block whatever the workgroup size (the reduction's layout)
         const int nqb = (a.Lq + 127) / 128, nkb = (a.Lk + 127) / 128;
+        const int kb128 = (kblk0 >> 7) + (wave >> 2);
         float* wsr = reinterpret_cast<float*>(a.cs_ws) + (int64_t)a.B * nqb * 4 * a.H * HD +
-                     ((int64_t)((b * nkb + kblk) * 4 + wave) * a.H + h) * HD;
-        tile_colsum_partial(dv, 1.0f, key < a.Lk, wsr, lane);
+                     ((int64_t)((b * nkb + kb128) * 4 + (wave & 3)) * a.H + h) * HD;
+        if (kb128 < nkb) tile_colsum_partial(dv, 1.0f, key < a.Lk, wsr, lane);
     }
     if (key < a.Lk) {
         unsigned short* DK = reinterpret_cast<unsigned short*>(a.dk) + (int64_t)b * a.dk_bs + (int64_t)key * a.dk_rs + h * HD;
@@ -1285,7 +1292,10 @@ extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(dicow_cdiv(a->Lq, 128) * a->H * a->B), dim3(256), 0, st, *a);
     DICOW_CHECK_LAUNCH("attn_bwd_dq");
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(dicow_cdiv(a->Lk, 128) * a->H * a->B), dim3(256), 0, st, *a);
+    if (ATTN_BWD_DKV_NW8 && (int64_t)dicow_cdiv(a->Lk, 256) * a->H * a->B >= 1024)
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<8>, dim3(dicow_cdiv(a->Lk, 256) * a->H * a->B), dim3(512), 0, st, *a);
+    else
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3(dicow_cdiv(a->Lk, 128) * a->H * a->B), dim3(256), 0, st, *a);
     DICOW_CHECK_LAUNCH("attn_bwd_dkv");
     if (a->dq_colsum || a->dv_colsum) {               // add the per-wave partial rows up (no atomics)
         const int64_t D = (int64_t)a->H * HD;
