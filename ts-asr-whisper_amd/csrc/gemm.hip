@@ -20,6 +20,9 @@
 #define BK 64
 #define STAGE_BYTES (BM * BK * 2)          // 16 KiB per operand per stage
 #define NT_LDS_BYTES (4 * STAGE_BYTES)     // A0 B0 A1 B1
+#ifndef NT128_THREADED
+#define NT128_THREADED 3      // 0: gemm_nt_kernel<2, false>; 3: its order with descriptor addressing (shipped); 1 / 2: one barrier per step, requests threaded / in a burst (measured slower in situ)
+#endif
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -281,6 +284,143 @@ __global__ void __launch_bounds__(256, STAGES == 2 ? 2 : 4) gemm_nt_kernel(const
     }
 
     // ---- epilogue
+    const int flags = a.flags;
+    const int hh = lane >> 5;
+    unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)bz * a.strideC;
+    float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
+    unsigned short* aux = reinterpret_cast<unsigned short*>(a.aux) + (int64_t)bz * a.strideAux;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + wm * 64 + j * 32 + (lane & 31);
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * hh;
+                if (n >= a.N) continue;
+                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+                nt_epilogue_quad(a, flags, v, m, n, Cb, Cf, aux);
+            }
+        }
+    }
+}
+
+// The 128 x 128 kernel for problems too small for the persistent ring kernel (whisper-base: M = 12000, N = 512 -- a third of that
+// step), round 3.  Same tile, LDS image, step order and epilogue as gemm_nt_kernel<2, false>; the next stage is requested through
+// a buffer descriptor with per-lane byte offsets computed ONCE and a scalar k offset -- no address arithmetic per step (the
+// pointer form costs two 64-bit adds per request: 16 VALU instructions per step next to 16 MFMAs).  whisper-base B = 8, whole
+// step from one hipGraph: 7.81-7.83 ms against 7.87-7.88 (tools/_c40.sh).
+// Also built (NT128_THREADED 1 / 2): ONE barrier per step, the 8 requests of stage t+1 threaded behind the first eight MFMAs of
+// stage t, or issued in a burst behind the barrier.  In isolation (same operands over and over: L2-warm) that form is 5-12 %
+// faster on every whisper-base shape (tools/bench_base_shapes.py: fc2 47.0 -> 42.8 us, fc1 dgrad 36.4 -> 32.1); inside the step
+// it is 3 % SLOWER (8.09-8.14 ms: the kernel's 116 launches 2.93 ms against 2.68): a stage then has half a step of flight
+// instead of a whole one, and operands that the previous kernel has just written do not arrive that fast.
+// Needs 32-bit byte offsets (the host checks) and K >= 2 k-steps.
+__global__ void __launch_bounds__(256, 2) gemm_nt128t_kernel(const dicow_gemm_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+    int tm, tn;
+    tile_coords(ntm, ntn, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int bz = blockIdx.z;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
+    const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
+    const int wm = wave >> 1, wn = wave & 1;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(B), 0, 0xffffffffu, 0x00020000);
+    unsigned offA[4], offB[4];
+    {
+        const int rr = lane >> 3, p = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = (wave * 4 + i) * 8 + rr;
+            const int c = p ^ ((row >> 1) & 7);
+            int gm = m0 + row; gm = gm < a.M ? gm : a.M - 1;
+            int gn = n0 + row; gn = gn < a.N ? gn : a.N - 1;
+            offA[i] = (unsigned)(((int64_t)gm * a.lda + c * 8) * 2);
+            offB[i] = (unsigned)(((int64_t)gn * a.ldb + c * 8) * 2);
+        }
+    }
+    // request i < 8 of this wave: i < 4 -> A row group wave*4 + i, else B row group wave*4 + i - 4; KB = k offset in bytes
+#define NT128_DMA(I, SA, KB)                                                                                                  \
+    { if ((I) < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)((SA) + (wave * 4 + (I)) * 1024), 16, offA[(I) & 3], (KB), 0, 0); \
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)((SA) + STAGE_BYTES + (wave * 4 + (I) - 4) * 1024), 16, offB[(I) & 3], (KB), 0, 0); }
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.K / BK;
+    __amdgpu_buffer_rsrc_t ra = rsA, rb = rsB;        // switched to an empty descriptor (no traffic) for the step after the last
+#pragma unroll
+    for (int i = 0; i < 8; ++i) NT128_DMA(i, smem, 0)
+    for (int t = 0; t < nk; ++t) {
+        char* sA = smem + (t & 1) * 2 * STAGE_BYTES;
+        char* sB = sA + STAGE_BYTES;
+        char* nA = smem + ((t + 1) & 1) * 2 * STAGE_BYTES;
+        const int kb = (t + 1) * BK * 2;
+        if (t + 1 == nk) {                            // keeps the step code (and its scheduling region) free of branches
+            ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, 0u, 0x00020000);
+            rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(B), 0, 0u, 0x00020000);
+        }
+#if NT128_THREADED == 3
+        // old order with the cheap addressing: requests of stage t+1 first (its slot was released by the barrier that ended step
+        // t-1), then wait for stage t -- a stage has a whole step of flight
+#pragma unroll
+        for (int e = 0; e < 8; ++e) NT128_DMA(e, nA, kb)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of stage t landed, my reads of stage t-1 done
+#endif
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#if NT128_THREADED == 2
+#pragma unroll
+        for (int e = 0; e < 8; ++e) NT128_DMA(e, nA, kb)
+#endif
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int c = kk * 2 + (lane >> 5);
+            bf16x8_t wf[2], xf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[i] = lds_frag_nt(sB, wn * 64 + i * 32 + (lane & 31), c);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) xf[j] = lds_frag_nt(sA, wm * 64 + j * 32 + (lane & 31), c);
+#if NT128_THREADED == 1
+            if (kk < 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) NT128_DMA(kk * 4 + e, nA, kb)
+            }
+#endif
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+#if NT128_THREADED == 1
+            if (kk < 2) {                             // one request behind each of this slice's four MFMAs
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+            }
+#endif
+        }
+#if NT128_THREADED == 3
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (empty-descriptor) requests
+#undef NT128_DMA
+
+    // ---- epilogue (as gemm_nt_kernel)
     const int flags = a.flags;
     const int hh = lane >> 5;
     unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)bz * a.strideC;
@@ -1077,6 +1217,7 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
 // forward thread and autograd's backward thread both launch GEMMs -- so this runs under std::call_once
 static void gemm_nt_setup() {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt128t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
 #define NTR_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS); \
                     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS)
@@ -1231,8 +1372,15 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     else if (variant == 3) hipLaunchKernelGGL((gemm_nt_kernel<1, true>), grid, dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, *a);
     else
 #endif
-    hipLaunchKernelGGL((gemm_nt_kernel<2, false>), grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
-    disp_note("gemm_nt_kernel<2, false>");
+    // (32-bit byte offsets inside one batch slice of A / B, as the persistent kernel needs them)
+    const bool t128 = NT128_THREADED && (int64_t)a->M * a->lda * 2 < (1ll << 31) && (int64_t)a->N * a->ldb * 2 < (1ll << 31) && a->K >= 2 * BK;
+    if (t128) {
+        hipLaunchKernelGGL(gemm_nt128t_kernel, grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
+        disp_note("gemm_nt128t_kernel");
+    } else {
+        hipLaunchKernelGGL((gemm_nt_kernel<2, false>), grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
+        disp_note("gemm_nt_kernel<2, false>");
+    }
     DICOW_CHECK_LAUNCH("gemm_nt");
     return DICOW_OK;
 }
