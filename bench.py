@@ -539,7 +539,7 @@ def main():
                       "buckets_per_step": len(ts.reducer.seg) if (world > 1 or ts.reducer.force) else 0,
                       "gemm_cus": a.gemm_cus or None,
                       "bytes_per_step": 4 * ts.store.n_trainable if (world > 1 or ts.reducer.force) else 0},
-        "roofline": {"bound": "mfma", "kernel": "gemm_ntr_kernel (persistent LDS-ring 256x256 / 192x320) / gemm_nt_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_ntr_kernel (persistent LDS-ring 256x256 / 192x320) / gemm_nt128t_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
                      "achieved": round(nt["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(nt["tflops"] / peak, 4),
                      "traffic": TRAFFIC, "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // nprof,
                      "share_of_step": round(prof_ms / nprof / ms, 3),

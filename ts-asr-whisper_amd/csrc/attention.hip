@@ -328,7 +328,13 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (LOG2 ? 2 : ATTN_FWD_WG
 #if defined(DICOW_ABLATIONS) && defined(ATTN_ABL_NODMA)
         if (false) {                                       // (ablation: no DMA after the prologue; results wrong, timing valid)
 #else
-        if (!LATE && t + 2 < nt) {
+        if (LATE && ATTN_FWD_LATE_DMA == 2) {              // four slots, requests right behind the barrier: two tiles of flight
+            if (t + 3 < nt) {
+                char* nK = smem + (slot == 0 ? NS - 1 : slot - 1) * 2 * TILE_BYTES;
+                stage_tile<NI>(srcK, (t + 3) * KV_TILE, nK, wave);
+                stage_tile<NI>(srcV, (t + 3) * KV_TILE, nK + TILE_BYTES, wave);
+            }
+        } else if (!LATE && t + 2 < nt) {
 #endif
             char* nK = smem + (slot == 0 ? 2 : slot - 1) * 2 * TILE_BYTES;    // slot of tile t-1 == slot of tile t+2
 #if ATTN_FWD_REGSTAGE
@@ -501,7 +507,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (LOG2 ? 2 : ATTN_FWD_WG
         psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
 #endif
         }
-        if (LATE && t + 3 < nt) {          // slot of tile t-1 (free since this tile's barrier); issued among VALU work, not in front of the MFMAs
+        if (LATE && ATTN_FWD_LATE_DMA == 1 && t + 3 < nt) {          // slot of tile t-1 (free since this tile's barrier); issued among VALU work, not in front of the MFMAs
             char* nK = smem + (slot == 0 ? NS - 1 : slot - 1) * 2 * TILE_BYTES;
             stage_tile<NI>(srcK, (t + 3) * KV_TILE, nK, wave);
             stage_tile<NI>(srcV, (t + 3) * KV_TILE, nK + TILE_BYTES, wave);
