@@ -898,6 +898,149 @@ __global__ void __launch_bounds__(256, ATTN_PIPE_WGS) attn_fwd_pipe_kernel(const
 }
 
 #undef PIPE_SGB
+
+// ---- four workgroups per CU (round 3).  Every restructuring of the forward loop that costs the third wave per SIMD loses ~12 %
+// (profiles/r03_attn_fwd_variants.txt): the loop lives on the interleave of independent waves.  This form goes the other way:
+// K fragments are read just in time instead of one tile ahead (32 registers less), the ring has two slots (32 KB), so that four
+// workgroups = four waves per SIMD fit (<= 128 VGPRs, 128 KB of LDS).
+#ifndef ATTN_FWD_OCC4
+#define ATTN_FWD_OCC4 1
+#endif
+__global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_fwd_args a) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];      // two (K, V) slots
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;
+    int qblk, h, b;
+    attn_block_coords((a.Lq + 127) / 128, a.H, a.B, qblk, h, b);
+    const int q0 = qblk * 128;
+    const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
+    const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
+    const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
+    int qrow = q0 + wave * 32 + (lane & 31);
+    const int qrow_c = qrow < a.Lq ? qrow : a.Lq - 1;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        qf[kk] = *reinterpret_cast<const bf16x8_t*>(Q + (int64_t)qrow_c * a.q_rs + kk * 16 + hh * 8);
+    f32x16_t o[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+    float m_ref = -INFINITY, l_run = 0.f;
+    int kv_end = a.Lk;
+    if (a.causal) { const int lim = q0 + 128 < a.Lk ? q0 + 128 : a.Lk; kv_end = lim; }
+    const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
+    const tile_src_t srcK = make_tile_src<SWZ_K>(K, a.k_rs, a.Lk, wave, lane), srcV = make_tile_src<SWZ_V>(V, a.v_rs, a.Lk, wave, lane);
+    stage_tile(srcK, 0, smem, wave);
+    stage_tile(srcV, 0, smem + TILE_BYTES, wave);
+    if (nt > 1) {
+        stage_tile(srcK, KV_TILE, smem + 2 * TILE_BYTES, wave);
+        stage_tile(srcV, KV_TILE, smem + 3 * TILE_BYTES, wave);
+    }
+    for (int t = 0; t < nt; ++t) {
+        char* sK = smem + (t & 1) * 2 * TILE_BYTES;
+        char* sV = sK + TILE_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t landed (this wave's share)
+        __builtin_amdgcn_s_barrier();                         // ... everybody's, and every wave has left tile t-1
+        asm volatile("" ::: "memory");
+        if (t >= 1 && t + 1 < nt) {
+            char* nK = smem + ((t + 1) & 1) * 2 * TILE_BYTES; // slot of tile t-1
+            stage_tile(srcK, (t + 1) * KV_TILE, nK, wave);
+            stage_tile(srcV, (t + 1) * KV_TILE, nK + TILE_BYTES, wave);
+        }
+        f32x16_t s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            bf16x8_t kf[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8_t*>(sK + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], s[kb], 0, 0, 0);
+        }
+        const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
+        tr8_t tv0, tv1;
+        tr_issue_v<0>(tv0, va0, va1);                         // (the second block's fragments are requested behind the first's wait: 16 registers)
+        const int k0 = t * KV_TILE;
+        const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
+        if (need_mask) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= a.Lk || (a.causal && key > qrow)) s[kb][r] = -INFINITY;
+                }
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+        if (__builtin_amdgcn_ballot_w64(mx > m_ref + 8.0f * LN2) != 0) {
+            const float m_new = fmaxf(m_ref, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f((m_ref - m_use) * LOG2E);
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+            m_ref = m_new;
+        }
+        const float mL = (m_ref == -INFINITY) ? 0.f : m_ref * LOG2E;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mL));
+                s[kb][r] = p;
+                psum += p;
+            }
+        l_run += psum;
+        bf16x8_t vf[2][2];
+        tr_wait<0>(tv0);
+        tr_issue_v<4096>(tv1, va0, va1);
+        tr_pack(vf, tv0);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const bf16x8_t pf = pack8(s[0], 8 * x);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+        }
+        tr_wait<0>(tv1);
+        tr_pack(vf, tv1);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+            const bf16x8_t pf = pack8(s[1], 8 * x);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qrow < a.Lq) {
+        unsigned short* O = reinterpret_cast<unsigned short*>(a.o) + (int64_t)b * a.o_bs + (int64_t)qrow * a.o_rs + h * HD;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int col = d * 32 + 8 * q4 + 4 * hh;
+                *reinterpret_cast<uint2*>(O + col) =
+                    make_uint2(pack_bf16x2(o[d][4 * q4] * inv_l, o[d][4 * q4 + 1] * inv_l),
+                               pack_bf16x2(o[d][4 * q4 + 2] * inv_l, o[d][4 * q4 + 3] * inv_l));
+            }
+        if (a.lse && hh == 0)
+            a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = m_ref + __builtin_amdgcn_logf(l_tot) * LN2;
+    }
+}
+
 static int check_strides(int64_t rs, const char* n) {
     if (rs % 8 != 0) { dicow_set_error("attention: %s row stride must be a multiple of 8 elements", n); return 0; }
     return 1;
@@ -921,6 +1064,7 @@ extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
     }
     dim3 grid(dicow_cdiv(a->Lq, 128) * a->H * a->B);
     if (a->q_log2) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else if (ATTN_FWD_OCC4) hipLaunchKernelGGL(attn_fwd_occ4_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
     else if (ATTN_FWD_PIPE && !a->causal) hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("attn_fwd");
