@@ -203,6 +203,9 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
 #ifndef ATTN_FWD_WGS
 #define ATTN_FWD_WGS 3          // workgroups per CU: 154 VGPRs fit three; equal time at large-v3-turbo (3840 workgroups), one round instead of 1.5 at whisper-base B = 8 (768)
 #endif
+#ifndef ATTN_DKV_JIT
+#define ATTN_DKV_JIT 0
+#endif
 #ifndef ATTN_BWD_DKV_NW8
 #define ATTN_BWD_DKV_NW8 0
 #endif
@@ -1279,7 +1282,7 @@ __device__ __forceinline__ void stage_stats64(const float* lse, const float* del
 }
 
 template <int NW = 4>      // NW waves = NW * 32 keys per workgroup, sharing each Q / dO tile (8: half the DMA instructions per wave)
-__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) attn_bwd_dkv_kernel(const dicow_attn_bwd_args a) {
+__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2)) attn_bwd_dkv_kernel(const dicow_attn_bwd_args a) {
     constexpr int KB = NW * 32, NI = 8 / NW;
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 1024];   // Q0 dO0 Q1 dO1 (U images) + lse/delta x2
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1352,6 +1355,51 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) attn_bwd_dkv_kernel(
         const unsigned stg = (unsigned)(((t - t0) & 1) * 2 * TILE_BYTES);
         const unsigned q00 = qb00 + stg, q01 = qb01 + stg, q10 = qb10 + stg, q11 = qb11 + stg;
         const unsigned o00 = q00 + TILE_BYTES, o01 = q01 + TILE_BYTES, o10 = q10 + TILE_BYTES, o11 = q11 + TILE_BYTES;
+#if ATTN_DKV_JIT
+        // the transposed Q / dO fragments (32 registers) are requested AFTER the scores are packed, not before the S^T / dP^T MFMAs:
+        // their LDS latency is no longer hidden behind this wave's own work, but the kernel fits 168 VGPRs = three waves per SIMD
+#define DKV_QBLOCK(QB)                                                                                                  \
+        {                                                                                                               \
+            f32x16_t s, dp;                       /* accumulators seeded with -lse[q], -delta[q] (see attn_bwd_dq_kernel) */ \
+            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                          \
+                const float4 lv = *reinterpret_cast<const float4*>(sStat + (QB) * 32 + 8 * q4 + 4 * hh);                 \
+                const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 64 + (QB) * 32 + 8 * q4 + 4 * hh);          \
+                s[4 * q4] = lv.x; s[4 * q4 + 1] = lv.y; s[4 * q4 + 2] = lv.z; s[4 * q4 + 3] = lv.w;                     \
+                dp[4 * q4] = dv4.x; dp[4 * q4 + 1] = dv4.y; dp[4 * q4 + 2] = dv4.z; dp[4 * q4 + 3] = dv4.w;             \
+            }                                                                                                           \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(sQ + fo[QB][kk]);                                 \
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(sdO + fo[QB][kk]);                                \
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);                                    \
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
+            }                                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * emul);                  \
+            if (need_mask) {                      /* ONE branch per block: a test inside the score loop becomes 16 */   \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
+                    const int qq = qt0 + (QB) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);                                   \
+                    if (qq >= a.Lq || key >= a.Lk || (a.causal && key > qq)) s[r] = 0.f;                                \
+                }                                                                                                       \
+            }                                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) dp[r] = s[r] * dp[r];                                        \
+            bf16x8_t pf[2], df[2];                                                                                      \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x) { pf[x] = pack8(s, 8 * x); df[x] = pack8(dp, 8 * x); }        \
+            asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(df[0]), "+v"(df[1]));   /* packed before the fragments are requested */ \
+            tr8_t tdo, tq;                                                                                              \
+            tr_issue_u<(QB) * 4096>(tdo, o00, o01, o10, o11);                                                           \
+            tr_issue_u<(QB) * 4096>(tq, q00, q01, q10, q11);                                                            \
+            bf16x8_t qtf[2][2], dotf[2][2];                                                                             \
+            tr_wait<8>(tdo);                                                                                            \
+            tr_pack(dotf, tdo);                                                                                         \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                               \
+                _Pragma("unroll") for (int d = 0; d < 2; ++d)                                                           \
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[x][d], pf[x], dv[d], 0, 0, 0);                 \
+            tr_wait<0>(tq);                                                                                             \
+            tr_pack(qtf, tq);                                                                                           \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                               \
+                _Pragma("unroll") for (int d = 0; d < 2; ++d)                                                           \
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[x][d], df[x], dk[d], 0, 0, 0);                  \
+        }
+#else
 #define DKV_QBLOCK(QB)                                                                                                  \
         {                                                                                                               \
             tr8_t tdo, tq;                                                                                              \
@@ -1393,6 +1441,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) attn_bwd_dkv_kernel(
                 }                                                                                                       \
             }                                                                                                           \
         }
+#endif
         DKV_QBLOCK(0)
         DKV_QBLOCK(1)
 #undef DKV_QBLOCK
