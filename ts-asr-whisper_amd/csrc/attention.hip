@@ -909,6 +909,7 @@ __global__ void __launch_bounds__(256, ATTN_PIPE_WGS) attn_fwd_pipe_kernel(const
 #ifndef ATTN_FWD_OCC4
 #define ATTN_FWD_OCC4 1
 #endif
+template <bool LOG2>
 __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_fwd_args a) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];      // two (K, V) slots
     const int tid = threadIdx.x, lane = tid & 63;
@@ -931,7 +932,8 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
     for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_ref = -INFINITY, l_run = 0.f;
+    float m_ref = LOG2 ? 0.f : -INFINITY, l_run = 0.f;
+    bool zero_ref = true;                                     // LOG2: m_ref == 0 in every lane of the wave (wave-uniform)
     int kv_end = a.Lk;
     if (a.causal) { const int lim = q0 + 128 < a.Lk ? q0 + 128 : a.Lk; kv_end = lim; }
     const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
@@ -985,6 +987,38 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
             mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
         }
+        float psum = 0.f;
+        if constexpr (LOG2) {
+            // the reference exponent starts at zero and p = 2^s needs nothing in front of the exponential; it moves (lazily, as in
+            // the other mode) only when a row maximum leaves [-60, 60] -- upwards at any tile, downwards at a row's first tile --
+            // and from then on this wave pays a subtraction pass per tile
+            const bool need = mx > m_ref + 60.0f || (t == 0 && mx < -60.0f && mx > -INFINITY);
+            if (__builtin_amdgcn_ballot_w64(need) != 0) {
+                const float m_new = need ? (t == 0 ? mx : fmaxf(m_ref, mx)) : m_ref;
+                const float alpha = __builtin_amdgcn_exp2f(m_ref - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < 2; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
+                m_ref = m_new;
+                zero_ref = false;
+            }
+            if (!zero_ref) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[kb][r] -= m_ref;
+            }
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[kb][r]);
+                    s[kb][r] = p;
+                    psum += p;
+                }
+        } else {
         if (__builtin_amdgcn_ballot_w64(mx > m_ref + 8.0f * LN2) != 0) {
             const float m_new = fmaxf(m_ref, mx);
             const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
@@ -997,7 +1031,6 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
             m_ref = m_new;
         }
         const float mL = (m_ref == -INFINITY) ? 0.f : m_ref * LOG2E;
-        float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -1006,6 +1039,7 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
                 s[kb][r] = p;
                 psum += p;
             }
+        }
         l_run += psum;
         bf16x8_t vf[2][2];
         tr_wait<0>(tv0);
@@ -1040,7 +1074,8 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
                                pack_bf16x2(o[d][4 * q4 + 2] * inv_l, o[d][4 * q4 + 3] * inv_l));
             }
         if (a.lse && hh == 0)
-            a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = m_ref + __builtin_amdgcn_logf(l_tot) * LN2;
+            a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = LOG2 ? (m_ref + __builtin_amdgcn_logf(l_tot)) * LN2      // (v_log_f32 is log2)
+                                                               : m_ref + __builtin_amdgcn_logf(l_tot) * LN2;
     }
 }
 
@@ -1066,8 +1101,9 @@ extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
         return DICOW_OK;
     }
     dim3 grid(dicow_cdiv(a->Lq, 128) * a->H * a->B);
-    if (a->q_log2) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    else if (ATTN_FWD_OCC4) hipLaunchKernelGGL(attn_fwd_occ4_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    if (a->q_log2 && ATTN_FWD_OCC4) hipLaunchKernelGGL(attn_fwd_occ4_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->q_log2) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else if (ATTN_FWD_OCC4) hipLaunchKernelGGL(attn_fwd_occ4_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);
     else if (ATTN_FWD_PIPE && !a->causal) hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("attn_fwd");

@@ -186,6 +186,14 @@ def full_fddt_bwd(fddt, w, hb, g, stno, bstride, G, rows, T, D):
     return gh
 
 
+# Attention scores in base-2 units (round 3): log2(e) is folded into the q-scale of the projection epilogue (q = bf16((Wx + b) *
+# head_dim^-0.5 * log2 e) -- ONE rounding, like the reference's bf16(Wx + b) * head_dim^-0.5, but not the same one), so the forward
+# kernel's probabilities are p = 2^s with no arithmetic in front of the exponential and the backward kernels lose their per-score
+# multiply.  Same softmax, same lse (natural log), same gradients; dq_scale keeps its meaning (include/dicow_hip.h).
+QK_LOG2 = True
+Q_SCALE = 0.125 * (ops.LOG2E if QK_LOG2 else 1.0)
+
+
 # ------------------------------------------------------------------------------------------------ building blocks
 def linear_fwd(x, lw, M, out_dtype=BF16, residual=None, gelu_aux=None, flags=0, scale=1.0, scale_ncols=0, out=None):
     dev = x.device
@@ -267,10 +275,10 @@ def plain_layer_fwd(lyr, w, h, B, T, H, F_):
     ln = lyr.self_attn_layer_norm
     ops.fddt_ln_fwd(h, rows, D, mode=ops.MODE_NONE, ln_w=ln.weight.detach(), ln_b=ln.bias.detach(), y_bf16=s.xln, mean=s.mean,
                     rstd=s.rstd)
-    s.qkv = linear_fwd(s.xln, w.att.qkv, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+    s.qkv = linear_fwd(s.xln, w.att.qkv, rows, flags=L.EPI_SCALE_N, scale=Q_SCALE, scale_ncols=D)
     s.o, s.lse = _e((rows, D), BF16, dev), _e((B, H, T), F32, dev)
     ops.attn_fwd(heads(s.qkv[:, :D], B, T, H), heads(s.qkv[:, D:2 * D], B, T, H), heads(s.qkv[:, 2 * D:], B, T, H),
-                 heads(s.o, B, T, H), s.lse)
+                 heads(s.o, B, T, H), s.lse, q_log2=QK_LOG2)
     s.h2 = linear_fwd(s.o, w.att.o, rows, out_dtype=F32, residual=h)
     s.xln2, s.mean2, s.rstd2 = _e((rows, D), BF16, dev), _e((rows,), F32, dev), _e((rows,), F32, dev)
     ln2 = lyr.final_layer_norm
@@ -301,7 +309,7 @@ def plain_layer_bwd(lyr, w, s, gb, G, B, T, H):
     qkv = s.qkv
     ops.attn_bwd(heads(qkv[:, :D], B, T, H), heads(qkv[:, D:2 * D], B, T, H), heads(qkv[:, 2 * D:], B, T, H),
                  heads(s.o, B, T, H), heads(d_o, B, T, H), s.lse, delta, heads(d_qkv[:, :D], B, T, H),
-                 heads(d_qkv[:, D:2 * D], B, T, H), heads(d_qkv[:, 2 * D:], B, T, H), dq_scale=0.125,
+                 heads(d_qkv[:, D:2 * D], B, T, H), heads(d_qkv[:, 2 * D:], B, T, H), dq_scale=0.125, q_log2=QK_LOG2,
                  dq_colsum=G.get(att.q_proj.bias), dv_colsum=G.get(att.v_proj.bias))
     qkv_wgrad(d_qkv, s.xln, G.get(att.q_proj.weight), G.get(att.k_proj.weight), G.get(att.v_proj.weight), rows, D)
     d_xln = linear_dgrad(d_qkv, w.att.qkv, rows)
@@ -465,14 +473,12 @@ class EncoderEngine:
                 ops.fddt_ln_fwd(hs, rows, D, mode=ops.MODE_NONE, ln_w=ln.weight.detach(), ln_b=ln.bias.detach(),
                                 y_bf16=xln, mean=mean, rstd=rstd)
             Ls.rows, Ls.B_after, Ls.hp, Ls.xln, Ls.mean, Ls.rstd = rows, Bc, hp, xln, mean, rstd
-            # ---- self-attention (HF WhisperAttention; q pre-scaled in the projection epilogue).  (The kernels also have a
-            # q_log2 mode -- log2(e) folded into this scale, S accumulators seeded with -m_ref -- which measured no faster:
-            # profiles/r03_attn_fwd_variants.txt; the encoder keeps the reference's rounding point of q.)
-            qkv = linear_fwd(xln, w.att.qkv, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+            # ---- self-attention (HF WhisperAttention; q pre-scaled in the projection epilogue, in base-2 units: Q_SCALE above)
+            qkv = linear_fwd(xln, w.att.qkv, rows, flags=L.EPI_SCALE_N, scale=Q_SCALE, scale_ncols=D)
             o = _e((rows, D), BF16, dev)
             lse = _e((Bc, H, T), F32, dev)
             ops.attn_fwd(heads(qkv[:, :D], Bc, T, H), heads(qkv[:, D:2 * D], Bc, T, H), heads(qkv[:, 2 * D:], Bc, T, H),
-                         heads(o, Bc, T, H), lse)
+                         heads(o, Bc, T, H), lse, q_log2=QK_LOG2)
             h2 = linear_fwd(o, w.att.o, rows, out_dtype=F32, residual=hp)
             # ---- feed-forward
             ln2 = lyr.final_layer_norm
@@ -514,11 +520,11 @@ class EncoderEngine:
         q_in, kv_in = _e((rp, D), BF16, dev), _e((rp, D), BF16, dev)
         cat = _e((rp, 2 * D), BF16, dev)
         ops.scb_split(hf, q_in, kv_in, cat, Bp, T, D)
-        q = linear_fwd(q_in, w.att.q, rp, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+        q = linear_fwd(q_in, w.att.q, rp, flags=L.EPI_SCALE_N, scale=Q_SCALE, scale_ncols=D)
         kv = linear_fwd(kv_in, w.att.kv, rp)
         o = _e((rp, D), BF16, dev)
         lse = _e((Bp, H, T), F32, dev)
-        ops.attn_fwd(heads(q, Bp, T, H), heads(kv[:, :D], Bp, T, H), heads(kv[:, D:], Bp, T, H), heads(o, Bp, T, H), lse)
+        ops.attn_fwd(heads(q, Bp, T, H), heads(kv[:, :D], Bp, T, H), heads(kv[:, D:], Bp, T, H), heads(o, Bp, T, H), lse, q_log2=QK_LOG2)
         ops.gemm_nt(o, w.att.o.w, cat, rp, D, D, ldc=2 * D, bias=w.att.o.b)
         u = _e((rp, F_), BF16, dev)
         a = linear_fwd(cat, w.f0, rp, gelu_aux=u)
@@ -557,7 +563,7 @@ class EncoderEngine:
         delta = _e((2, Bp, H, T), F32, dev)
         ops.attn_bwd(heads(s.q, Bp, T, H), heads(s.kv[:, :D], Bp, T, H), heads(s.kv[:, D:], Bp, T, H), heads(s.o, Bp, T, H),
                      heads(d_o, Bp, T, H), s.lse, delta, heads(dq, Bp, T, H), heads(dkv[:, :D], Bp, T, H),
-                     heads(dkv[:, D:], Bp, T, H), dq_scale=0.125)
+                     heads(dkv[:, D:], Bp, T, H), dq_scale=0.125, q_log2=QK_LOG2)
         bias_grad(dq, G.get(att.q_proj.bias))
         bias_grad(dkv[:, D:], G.get(att.v_proj.bias))
         linear_wgrad(dq, s.q_in, G.get(att.q_proj.weight), rp, group=tng)
@@ -614,7 +620,7 @@ class EncoderEngine:
             qkv = Ls.qkv
             ops.attn_bwd(heads(qkv[:, :D], Bc, T, H), heads(qkv[:, D:2 * D], Bc, T, H), heads(qkv[:, 2 * D:], Bc, T, H),
                          heads(Ls.o, Bc, T, H), heads(d_o, Bc, T, H), Ls.lse, delta, heads(d_qkv[:, :D], Bc, T, H),
-                         heads(d_qkv[:, D:2 * D], Bc, T, H), heads(d_qkv[:, 2 * D:], Bc, T, H), dq_scale=0.125,
+                         heads(d_qkv[:, D:2 * D], Bc, T, H), heads(d_qkv[:, 2 * D:], Bc, T, H), dq_scale=0.125, q_log2=QK_LOG2,
                          dq_colsum=G.get(att.q_proj.bias), dv_colsum=G.get(att.v_proj.bias))   # q / v bias grads, fused
             qkv_wgrad(d_qkv, Ls.xln, G.get(att.q_proj.weight), G.get(att.k_proj.weight), G.get(att.v_proj.weight), rows, D, group=tng,
                       params=(att.q_proj.weight, att.k_proj.weight, att.v_proj.weight))
@@ -740,20 +746,20 @@ class DecoderEngine:
             ln = lyr.self_attn_layer_norm
             Ls.x1, Ls.m1, Ls.r1 = _e((rows, D), BF16, dev), _e((rows,), F32, dev), _e((rows,), F32, dev)
             ops.fddt_ln_fwd(h, rows, D, ln_w=ln.weight.detach(), ln_b=ln.bias.detach(), y_bf16=Ls.x1, mean=Ls.m1, rstd=Ls.r1)
-            Ls.qkv = linear_fwd(Ls.x1, w.sa.qkv, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+            Ls.qkv = linear_fwd(Ls.x1, w.sa.qkv, rows, flags=L.EPI_SCALE_N, scale=Q_SCALE, scale_ncols=D)
             Ls.o1, Ls.lse1 = _e((rows, D), BF16, dev), _e((B, H, Lq), F32, dev)
             ops.attn_fwd(heads(Ls.qkv[:, :D], B, Lq, H), heads(Ls.qkv[:, D:2 * D], B, Lq, H), heads(Ls.qkv[:, 2 * D:], B, Lq, H),
-                         heads(Ls.o1, B, Lq, H), Ls.lse1, causal=True)
+                         heads(Ls.o1, B, Lq, H), Ls.lse1, causal=True, q_log2=QK_LOG2)
             Ls.h2 = linear_fwd(Ls.o1, w.sa.o, rows, out_dtype=F32, residual=h)
             # cross-attention over the encoder output
             ln = lyr.encoder_attn_layer_norm
             Ls.x2, Ls.m2, Ls.r2 = _e((rows, D), BF16, dev), _e((rows,), F32, dev), _e((rows,), F32, dev)
             ops.fddt_ln_fwd(Ls.h2, rows, D, ln_w=ln.weight.detach(), ln_b=ln.bias.detach(), y_bf16=Ls.x2, mean=Ls.m2, rstd=Ls.r2)
-            Ls.q = linear_fwd(Ls.x2, w.ca.q, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+            Ls.q = linear_fwd(Ls.x2, w.ca.q, rows, flags=L.EPI_SCALE_N, scale=Q_SCALE, scale_ncols=D)
             Ls.kv = linear_fwd(enc_bf, w.ca.kv, B * T)
             Ls.o2, Ls.lse2 = _e((rows, D), BF16, dev), _e((B, H, Lq), F32, dev)
             ops.attn_fwd(heads(Ls.q, B, Lq, H), heads(Ls.kv[:, :D], B, T, H), heads(Ls.kv[:, D:], B, T, H), heads(Ls.o2, B, Lq, H),
-                         Ls.lse2)
+                         Ls.lse2, q_log2=QK_LOG2)
             Ls.h3 = linear_fwd(Ls.o2, w.ca.o, rows, out_dtype=F32, residual=Ls.h2)
             # feed-forward
             ln = lyr.final_layer_norm
@@ -842,7 +848,7 @@ class DecoderEngine:
             delta = _e((2, B, H, Lq), F32, dev)
             ops.attn_bwd(heads(Ls.q, B, Lq, H), heads(Ls.kv[:, :D], B, T, H), heads(Ls.kv[:, D:], B, T, H), heads(Ls.o2, B, Lq, H),
                          heads(d_o2, B, Lq, H), Ls.lse2, delta, heads(dq, B, Lq, H), heads(dkv[:, :D], B, T, H),
-                         heads(dkv[:, D:], B, T, H), dq_scale=0.125)
+                         heads(dkv[:, D:], B, T, H), dq_scale=0.125, q_log2=QK_LOG2)
             bias_grad(dq, G.get(att.q_proj.bias))
             bias_grad(dkv[:, D:], G.get(att.v_proj.bias))
             linear_wgrad(dq, Ls.x2, G.get(att.q_proj.weight), rows)
@@ -864,7 +870,7 @@ class DecoderEngine:
             qkv = Ls.qkv
             ops.attn_bwd(heads(qkv[:, :D], B, Lq, H), heads(qkv[:, D:2 * D], B, Lq, H), heads(qkv[:, 2 * D:], B, Lq, H),
                          heads(Ls.o1, B, Lq, H), heads(d_o1, B, Lq, H), Ls.lse1, delta, heads(d_qkv[:, :D], B, Lq, H),
-                         heads(d_qkv[:, D:2 * D], B, Lq, H), heads(d_qkv[:, 2 * D:], B, Lq, H), causal=True, dq_scale=0.125)
+                         heads(d_qkv[:, D:2 * D], B, Lq, H), heads(d_qkv[:, 2 * D:], B, Lq, H), causal=True, dq_scale=0.125, q_log2=QK_LOG2)
             bias_grad(d_qkv[:, :D], G.get(att.q_proj.bias))
             bias_grad(d_qkv[:, 2 * D:], G.get(att.v_proj.bias))
             linear_wgrad(d_qkv[:, :D], Ls.x1, G.get(att.q_proj.weight), rows)
@@ -953,10 +959,10 @@ class CtcEngine:
                 hpad = torch.zeros(B, T + 2, D, dtype=BF16, device=dev)
                 hpad[:, 1:T + 1].copy_(h.view(B, T, D))
         elif W.att is not None:
-            S.qkv = linear_fwd(enc_bf, W.att.qkv, rows, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=D)
+            S.qkv = linear_fwd(enc_bf, W.att.qkv, rows, flags=L.EPI_SCALE_N, scale=Q_SCALE, scale_ncols=D)
             S.o, S.lse_a = _e((rows, D), BF16, dev), _e((B, H, T), F32, dev)
             ops.attn_fwd(heads(S.qkv[:, :D], B, T, H), heads(S.qkv[:, D:2 * D], B, T, H), heads(S.qkv[:, 2 * D:], B, T, H),
-                         heads(S.o, B, T, H), S.lse_a)
+                         heads(S.o, B, T, H), S.lse_a, q_log2=QK_LOG2)
             if sub:                                   # write the projection straight into the zero-padded conv input
                 hpad = _e((B, T + 2, D), BF16, dev)
                 hpad[:, 0].zero_()
@@ -1047,7 +1053,7 @@ class CtcEngine:
         qkv = S.qkv
         ops.attn_bwd(heads(qkv[:, :D], B, T, H), heads(qkv[:, D:2 * D], B, T, H), heads(qkv[:, 2 * D:], B, T, H),
                      heads(S.o, B, T, H), heads(d_o, B, T, H), S.lse_a, delta, heads(d_qkv[:, :D], B, T, H),
-                     heads(d_qkv[:, D:2 * D], B, T, H), heads(d_qkv[:, 2 * D:], B, T, H), dq_scale=0.125)
+                     heads(d_qkv[:, D:2 * D], B, T, H), heads(d_qkv[:, 2 * D:], B, T, H), dq_scale=0.125, q_log2=QK_LOG2)
         bias_grad(d_qkv[:, :D], G.get(att.q_proj.bias))
         bias_grad(d_qkv[:, 2 * D:], G.get(att.v_proj.bias))
         qkv_wgrad(d_qkv, S.enc_bf, G.get(att.q_proj.weight), G.get(att.k_proj.weight), G.get(att.v_proj.weight), rows, D)
