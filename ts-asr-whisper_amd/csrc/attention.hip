@@ -906,6 +906,9 @@ __global__ void __launch_bounds__(256, ATTN_PIPE_WGS) attn_fwd_pipe_kernel(const
 // (profiles/r03_attn_fwd_variants.txt): the loop lives on the interleave of independent waves.  This form goes the other way:
 // K fragments are read just in time instead of one tile ahead (32 registers less), the ring has two slots (32 KB), so that four
 // workgroups = four waves per SIMD fit (<= 128 VGPRs, 128 KB of LDS).
+#ifndef ATTN_OCC4_PKSUM
+#define ATTN_OCC4_PKSUM 0
+#endif
 #ifndef ATTN_FWD_OCC4
 #define ATTN_FWD_OCC4 1
 #endif
@@ -1010,6 +1013,18 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[kb][r] -= m_ref;
             }
+#if ATTN_OCC4_PKSUM
+            f32x2_t ps2 = {0.f, 0.f};
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const float p0 = __builtin_amdgcn_exp2f(s[kb][r]), p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+                    s[kb][r] = p0; s[kb][r + 1] = p1;
+                    ps2 += f32x2_t{p0, p1};                       // v_pk_add_f32: 16 instructions for the 32 row-sum adds
+                }
+            psum = ps2.x + ps2.y;
+#else
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -1018,6 +1033,7 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
                     s[kb][r] = p;
                     psum += p;
                 }
+#endif
         } else {
         if (__builtin_amdgcn_ballot_w64(mx > m_ref + 8.0f * LN2) != 0) {
             const float m_new = fmaxf(m_ref, mx);
