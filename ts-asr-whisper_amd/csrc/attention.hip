@@ -906,14 +906,24 @@ __global__ void __launch_bounds__(256, ATTN_PIPE_WGS) attn_fwd_pipe_kernel(const
 // (profiles/r03_attn_fwd_variants.txt): the loop lives on the interleave of independent waves.  This form goes the other way:
 // K fragments are read just in time instead of one tile ahead (32 registers less), the ring has two slots (32 KB), so that four
 // workgroups = four waves per SIMD fit (<= 128 VGPRs, 128 KB of LDS).
+#ifndef ATTN_OCC4_SPEC
+#define ATTN_OCC4_SPEC 1
+#endif
 #ifndef ATTN_OCC4_PKSUM
 #define ATTN_OCC4_PKSUM 0
 #endif
 #ifndef ATTN_FWD_OCC4
 #define ATTN_FWD_OCC4 1
 #endif
-template <bool LOG2>
+// SPEC (with LOG2): a speculative first pass over all tiles WITHOUT any row maximum -- p = 2^s against exponent zero, which is
+// exact while every row's sum stays inside the fp32 / bf16 exponent range; the maximum (25 of the loop's ~140 VALU instructions,
+// and the loop is VALU-bound) was only a guard.  The guard moves to the end: a row whose sum left [2^-100, 2^100] (or is not
+// finite) makes its workgroup vote for a second, ordinary pass (the loop below, with the moving reference exponent) that
+// recomputes the block from scratch.  Both passes run one barrier and one staging step per tile in every wave; the vote is
+// workgroup-uniform.
+template <bool LOG2, bool SPEC = false>
 __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_fwd_args a) {
+    static_assert(!SPEC || LOG2, "the speculative pass needs base-2 scores");
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];      // two (K, V) slots
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -947,6 +957,105 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
         stage_tile(srcK, KV_TILE, smem + 2 * TILE_BYTES, wave);
         stage_tile(srcV, KV_TILE, smem + 3 * TILE_BYTES, wave);
     }
+    bool general = true;
+    if constexpr (SPEC) {
+        for (int t = 0; t < nt; ++t) {
+            char* sK = smem + (t & 1) * 2 * TILE_BYTES;
+            char* sV = sK + TILE_BYTES;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t >= 1 && t + 1 < nt) {
+                char* nK = smem + ((t + 1) & 1) * 2 * TILE_BYTES;
+                stage_tile(srcK, (t + 1) * KV_TILE, nK, wave);
+                stage_tile(srcV, (t + 1) * KV_TILE, nK + TILE_BYTES, wave);
+            }
+            f32x16_t s[2];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb) {
+                bf16x8_t kf[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8_t*>(sK + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kk], qf[kk], s[kb], 0, 0, 0);
+            }
+            const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
+            tr8_t tv0, tv1;
+            tr_issue_v<0>(tv0, va0, va1);
+            const int k0 = t * KV_TILE;
+            const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
+            if (need_mask) {
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        if (key >= a.Lk || (a.causal && key > qrow)) s[kb][r] = -INFINITY;
+                    }
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(s[kb][r]);
+                    s[kb][r] = p;
+                    psum += p;
+                }
+            l_run += psum;
+            bf16x8_t vf[2][2];
+            tr_wait<0>(tv0);
+            tr_issue_v<4096>(tv1, va0, va1);
+            tr_pack(vf, tv0);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const bf16x8_t pf = pack8(s[0], 8 * x);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+            }
+            tr_wait<0>(tv1);
+            tr_pack(vf, tv1);
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+                const bf16x8_t pf = pack8(s[1], 8 * x);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+            }
+        }
+        // ---- the guard, and the workgroup's vote
+        const float lt = l_run + __shfl_xor(l_run, 32, 64);
+        const bool row_bad = qrow < a.Lq && !(lt > 0x1p-100f && lt < 0x1p100f);       // (false for NaN, too)
+        const bool wave_bad = __builtin_amdgcn_ballot_w64(row_bad) != 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // every wave has left the last tile: the LDS is free
+        asm volatile("" ::: "memory");
+        if (lane == 0) reinterpret_cast<volatile int*>(smem)[wave] = wave_bad ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const volatile int* vt = reinterpret_cast<const volatile int*>(smem);
+        general = (vt[0] | vt[1] | vt[2] | vt[3]) != 0;
+        general = __builtin_amdgcn_readfirstlane(general ? 1 : 0) != 0;
+        if (general) {                                        // start over: accumulators, sum, the first two tiles
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                     // the votes have been read
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
+            l_run = 0.f;
+            stage_tile(srcK, 0, smem, wave);
+            stage_tile(srcV, 0, smem + TILE_BYTES, wave);
+            if (nt > 1) {
+                stage_tile(srcK, KV_TILE, smem + 2 * TILE_BYTES, wave);
+                stage_tile(srcV, KV_TILE, smem + 3 * TILE_BYTES, wave);
+            }
+        }
+    }
+    if (general)
     for (int t = 0; t < nt; ++t) {
         char* sK = smem + (t & 1) * 2 * TILE_BYTES;
         char* sV = sK + TILE_BYTES;
@@ -1117,9 +1226,10 @@ extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
         return DICOW_OK;
     }
     dim3 grid(dicow_cdiv(a->Lq, 128) * a->H * a->B);
-    if (a->q_log2 && ATTN_FWD_OCC4) hipLaunchKernelGGL(attn_fwd_occ4_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    if (a->q_log2 && ATTN_FWD_OCC4 && ATTN_OCC4_SPEC) hipLaunchKernelGGL((attn_fwd_occ4_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->q_log2 && ATTN_FWD_OCC4) hipLaunchKernelGGL((attn_fwd_occ4_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, *a);
     else if (a->q_log2) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    else if (ATTN_FWD_OCC4) hipLaunchKernelGGL(attn_fwd_occ4_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else if (ATTN_FWD_OCC4) hipLaunchKernelGGL((attn_fwd_occ4_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, *a);
     else if (ATTN_FWD_PIPE && !a->causal) hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("attn_fwd");
