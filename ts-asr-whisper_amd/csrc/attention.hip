@@ -1279,6 +1279,7 @@ __device__ __forceinline__ void tr_read_block_u(bf16x8_t (&f)[2][2], unsigned a0
 }
 
 // ------------------------------------------------------------------------------------------------ dQ
+template <bool LOG2>        // q carries log2 e (compile-time: the per-score multiply in front of the exponential disappears)
 __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bwd_args a) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];      // K0 V0 K1 V1 (U images)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1317,8 +1318,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
     }
     dsum += __shfl_xor(dsum, 32, 64);
     // q_log2: the scores are base-2 exponents already (q carries log2 e): seed with -lse in base-2 units, exponent scale 1
-    const float emul = a.q_log2 ? 1.0f : LOG2E;
-    const float nlse = a.q_log2 ? -a.lse[stat] * LOG2E : -a.lse[stat];
+    const float nlse = LOG2 ? -a.lse[stat] * LOG2E : -a.lse[stat];
     const float ndlt = -dsum;
     if (hh == 0 && qrow < a.Lq) {
         a.delta[stat] = ndlt;
@@ -1379,7 +1379,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, dof[kk], dp, 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * emul);
+            for (int r = 0; r < 16; ++r) s[r] = LOG2 ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * LOG2E);
             if (need_mask) {                          // one branch per block: a test inside the score loop becomes 16
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1443,7 +1443,7 @@ __device__ __forceinline__ void stage_stats64(const float* lse, const float* del
     __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + (wave & 1) * 256), 4, 0, 0);
 }
 
-template <int NW = 4>      // NW waves = NW * 32 keys per workgroup, sharing each Q / dO tile (8: half the DMA instructions per wave)
+template <int NW, bool LOG2>      // NW waves = NW * 32 keys per workgroup, sharing each Q / dO tile (8: half the DMA instructions per wave); LOG2 as in attn_bwd_dq_kernel
 __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2)) attn_bwd_dkv_kernel(const dicow_attn_bwd_args a) {
     constexpr int KB = NW * 32, NI = 8 / NW;
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES + 1024];   // Q0 dO0 Q1 dO1 (U images) + lse/delta x2
@@ -1476,8 +1476,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
         for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
     // q_log2: q = log2(e) q_true and the -lse plane was published in base-2 units by the dq kernel: exponent scale 1, and
     // dK = dS^T q_true = ln 2 * dS^T q
-    const float emul = a.q_log2 ? 1.0f : LOG2E;
-    const float dk_mul = a.q_log2 ? LN2 : 1.0f;
+    constexpr float dk_mul = LOG2 ? LN2 : 1.0f;
 
     const int t0 = a.causal ? (kblk0 / KV_TILE) : 0;                 // query tiles entirely before the key block see none of it
     const int nt = (a.Lq + KV_TILE - 1) / KV_TILE;
@@ -1535,7 +1534,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);                                    \
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
             }                                                                                                           \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(s[r] * emul);                  \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) s[r] = (LOG2 ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * LOG2E));                  \
             if (need_mask) {                      /* ONE branch per block: a test inside the score loop becomes 16 */   \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
                     const int qq = qt0 + (QB) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);                                   \
@@ -1581,7 +1580,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
             }                                                                                                           \
             f32x16_t pv, dsv;                                                                                           \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = __builtin_amdgcn_exp2f(s[r] * emul);                 \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = (LOG2 ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * LOG2E));                 \
             if (need_mask) {                      /* ONE branch per block: a test inside the score loop becomes 16 */   \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
                     const int qq = qt0 + (QB) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);                                   \
@@ -1651,12 +1650,16 @@ extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
     for (int i = 0; i < 16; ++i) DICOW_REQUIRE(rs[i] % 4 == 0, "attn_bwd: strides must keep 8-byte alignment");
     DICOW_REQUIRE(a->q_rs % 8 == 0 && a->k_rs % 8 == 0 && a->v_rs % 8 == 0 && a->do_rs % 8 == 0, "attn_bwd: q/k/v/dO row strides %% 8");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(dicow_cdiv(a->Lq, 128) * a->H * a->B), dim3(256), 0, st, *a);
+    if (a->q_log2) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(dicow_cdiv(a->Lq, 128) * a->H * a->B), dim3(256), 0, st, *a);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(dicow_cdiv(a->Lq, 128) * a->H * a->B), dim3(256), 0, st, *a);
     DICOW_CHECK_LAUNCH("attn_bwd_dq");
-    if (ATTN_BWD_DKV_NW8 && (int64_t)dicow_cdiv(a->Lk, 256) * a->H * a->B >= 1024)
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<8>, dim3(dicow_cdiv(a->Lk, 256) * a->H * a->B), dim3(512), 0, st, *a);
-    else
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<4>, dim3(dicow_cdiv(a->Lk, 128) * a->H * a->B), dim3(256), 0, st, *a);
+    if (ATTN_BWD_DKV_NW8 && (int64_t)dicow_cdiv(a->Lk, 256) * a->H * a->B >= 1024) {
+        if (a->q_log2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, true>), dim3(dicow_cdiv(a->Lk, 256) * a->H * a->B), dim3(512), 0, st, *a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, false>), dim3(dicow_cdiv(a->Lk, 256) * a->H * a->B), dim3(512), 0, st, *a);
+    } else {
+        if (a->q_log2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, true>), dim3(dicow_cdiv(a->Lk, 128) * a->H * a->B), dim3(256), 0, st, *a);
+        else hipLaunchKernelGGL((attn_bwd_dkv_kernel<4, false>), dim3(dicow_cdiv(a->Lk, 128) * a->H * a->B), dim3(256), 0, st, *a);
+    }
     DICOW_CHECK_LAUNCH("attn_bwd_dkv");
     if (a->dq_colsum || a->dv_colsum) {               // add the per-wave partial rows up (no atomics)
         const int64_t D = (int64_t)a->H * HD;
