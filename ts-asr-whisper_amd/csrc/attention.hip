@@ -906,6 +906,13 @@ __global__ void __launch_bounds__(256, ATTN_PIPE_WGS) attn_fwd_pipe_kernel(const
 // (profiles/r03_attn_fwd_variants.txt): the loop lives on the interleave of independent waves.  This form goes the other way:
 // K fragments are read just in time instead of one tile ahead (32 registers less), the ring has two slots (32 KB), so that four
 // workgroups = four waves per SIMD fit (<= 128 VGPRs, 128 KB of LDS).
+#ifndef ATTN_Q_NT
+#define ATTN_Q_NT 0        // nontemporal Q loads / O stores of the four-workgroup forward kernel (each line is touched once)
+#endif
+#ifndef ATTN_O_NT
+#define ATTN_O_NT 0
+#endif
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2n_t;
 #ifndef ATTN_OCC4_SPEC
 #define ATTN_OCC4_SPEC 1
 #endif
@@ -939,7 +946,8 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
     bf16x8_t qf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
-        qf[kk] = *reinterpret_cast<const bf16x8_t*>(Q + (int64_t)qrow_c * a.q_rs + kk * 16 + hh * 8);
+        qf[kk] = ATTN_Q_NT ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(Q + (int64_t)qrow_c * a.q_rs + kk * 16 + hh * 8))
+                           : *reinterpret_cast<const bf16x8_t*>(Q + (int64_t)qrow_c * a.q_rs + kk * 16 + hh * 8);
     f32x16_t o[2];
 #pragma unroll
     for (int d = 0; d < 2; ++d)
@@ -1194,9 +1202,10 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int col = d * 32 + 8 * q4 + 4 * hh;
-                *reinterpret_cast<uint2*>(O + col) =
-                    make_uint2(pack_bf16x2(o[d][4 * q4] * inv_l, o[d][4 * q4 + 1] * inv_l),
-                               pack_bf16x2(o[d][4 * q4 + 2] * inv_l, o[d][4 * q4 + 3] * inv_l));
+                const u32x2n_t ov = {pack_bf16x2(o[d][4 * q4] * inv_l, o[d][4 * q4 + 1] * inv_l),
+                                     pack_bf16x2(o[d][4 * q4 + 2] * inv_l, o[d][4 * q4 + 3] * inv_l)};
+                if (ATTN_O_NT) __builtin_nontemporal_store(ov, reinterpret_cast<u32x2n_t*>(O + col));
+                else *reinterpret_cast<u32x2n_t*>(O + col) = ov;
             }
         if (a.lse && hh == 0)
             a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = LOG2 ? (m_ref + __builtin_amdgcn_logf(l_tot)) * LN2      // (v_log_f32 is log2)

@@ -30,6 +30,23 @@
 struct f4 { float x, y, z, w; };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+#ifndef ROWS_G_NT
+#define ROWS_G_NT 1        // generic forward body: nontemporal fp32 row loads (LayerNorm 2 reads the residual stream once: encoder forward -0.25 %)
+#endif
+typedef __attribute__((ext_vector_type(4))) float f32x4n_t;
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+    const f32x4n_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4n_t*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+#ifndef ROWS_GB_NT
+#define ROWS_GB_NT 0       // generic backward body: nontemporal h_in / d_y / g_res loads
+#endif
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2r_t;
+__device__ __forceinline__ float4 ld4_bf16_nt(const void* base, int64_t idx) {
+    const u32x2r_t u = __builtin_nontemporal_load(reinterpret_cast<const u32x2r_t*>(reinterpret_cast<const unsigned short*>(base) + idx));
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 ld4_bf16(const void* base, int64_t idx) {
     uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + idx);
@@ -198,7 +215,7 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
             const bool ok = act && row < a.rows;
             const int64_t off = (int64_t)row * D + col;
             x[r] = zero;
-            if (ok) x[r] = a.in_bf16 ? ld4_bf16(a.h_in, off) : ld4(reinterpret_cast<const float*>(a.h_in) + off);
+            if (ok) x[r] = a.in_bf16 ? ld4_bf16(a.h_in, off) : (ROWS_G_NT ? ld4_nt(reinterpret_cast<const float*>(a.h_in) + off) : ld4(reinterpret_cast<const float*>(a.h_in) + off));
             if (mode != 0 && row < a.rows) {
                 const int bi = row / a.T, t = row - bi * a.T;
                 const float* mp = a.stno + (int64_t)bi * a.stno_bstride + t;
@@ -271,6 +288,24 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
 // next trip fetched by LDS-DMA while the current trip is computed -- see fddt_ln_bwd_staged_kernel for the scheme.  The FDDT
 // arithmetic is the reference's evaluation order (fddt_diag_elem), bit-exact like the generic body.
 typedef __attribute__((address_space(3))) void lds_void_f_t;
+#ifndef ROWS_BWD_H_NT
+#define ROWS_BWD_H_NT 0    // staged backward: cache-policy bits of the h_in / g_res / d_y row requests (each is the last use)
+#endif
+#ifndef ROWS_BWD_G_NT
+#define ROWS_BWD_G_NT 0
+#endif
+#ifndef ROWS_BWD_Y_NT
+#define ROWS_BWD_Y_NT 0
+#endif
+#ifndef ROWS_FWD_ST_NT
+#define ROWS_FWD_ST_NT 0   // ... of its fp32 row stores / its bf16 LayerNorm-output stores
+#endif
+#ifndef ROWS_FWD_Y_NT
+#define ROWS_FWD_Y_NT 0
+#endif
+#ifndef ROWS_FWD_NT
+#define ROWS_FWD_NT 2      // cache-policy bits of the staged forward's row requests (2 = nt: read once; encoder forward -0.25 %)
+#endif
 #ifndef ROWS_ABL
 #define ROWS_ABL 0     // diagnostic builds (tools/build_rows_variants.sh): 1 no fp32 row store, 2 no bf16 / stats stores, 4 no block reductions, 8 no DMA wait
 #endif
@@ -299,7 +334,7 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
 #pragma unroll
         for (int r = 0; r < R; ++r)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (lds_void_f_t*)(stg + (s * R + r) * row_lds + wave * 1024), 16, vo32,
-                                                     (row0 + r) * D * 4, 0, 0);
+                                                     (row0 + r) * D * 4, 0, ROWS_FWD_NT);
     };
     float m_n[R][4];
     auto load_masks = [&](int row0) {
@@ -343,7 +378,7 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
             xh[r] = FDP(z, w, (f32x2r_t{xi.z, xi.w}));
 #undef FDP
             ov[r] = u32x4_t{__float_as_uint(xl[r].x), __float_as_uint(xl[r].y), __float_as_uint(xh[r].x), __float_as_uint(xh[r].y)};
-            if (!(ROWS_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(ov[r], rsO, vo32, (row0 + r) * D * 4, 0);
+            if (!(ROWS_ABL & 1)) __builtin_amdgcn_raw_buffer_store_b128(ov[r], rsO, vo32, (row0 + r) * D * 4, ROWS_FWD_ST_NT);
             sm[r] = (xl[r].x + xl[r].y) + (xh[r].x + xh[r].y);
         }
         if (!(ROWS_ABL & 4)) block_sum<R, ROWS_GATHER != 0, (ROWS_GATHER ? ROWS_GATHER : 16)>(sm, red[0], nwaves);
@@ -380,7 +415,7 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
             const f32x2r_t yl = (xl[r] - mu2) * rs2 * f32x2r_t{lnw.x, lnw.y} + f32x2r_t{lnb.x, lnb.y};
             const f32x2r_t yh = (xh[r] - mu2) * rs2 * f32x2r_t{lnw.z, lnw.w} + f32x2r_t{lnb.z, lnb.w};
             const u32x2_t yv = {pack_bf16x2(yl.x, yl.y), pack_bf16x2(yh.x, yh.y)};
-            if (!(ROWS_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b64(yv, rsY, vo16, (row0 + r) * D * 2, 0);
+            if (!(ROWS_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b64(yv, rsY, vo16, (row0 + r) * D * 2, ROWS_FWD_Y_NT);
             else if (yv.x == 0x12345678u) __builtin_amdgcn_raw_buffer_store_b64(yv, rsY, vo16, (row0 + r) * D * 2, 0);
         }
     }
@@ -509,9 +544,9 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_bwd_kernel(const dicow_fddt_ln_b
             const int64_t off = (int64_t)row * D + col;
             hin[r] = zero; dy[r] = zero; rs[r] = 0.f;
             float mu = 0.f;
-            if (ok) hin[r] = a.in_bf16 ? ld4_bf16(a.h_in, off) : ld4(reinterpret_cast<const float*>(a.h_in) + off);
-            if (ok && do_ln) dy[r] = a.dy_f32 ? ld4(reinterpret_cast<const float*>(a.d_y) + off) : ld4_bf16(a.d_y, off);
-            gr[r] = (ok && a.g_res) ? ld4(a.g_res + off) : zero;      // issued with the other loads, ahead of the reduction
+            if (ok) hin[r] = a.in_bf16 ? ld4_bf16(a.h_in, off) : ROWS_GB_NT ? ld4_nt(reinterpret_cast<const float*>(a.h_in) + off) : ld4(reinterpret_cast<const float*>(a.h_in) + off);
+            if (ok && do_ln) dy[r] = a.dy_f32 ? ld4(reinterpret_cast<const float*>(a.d_y) + off) : ROWS_GB_NT ? ld4_bf16_nt(a.d_y, off) : ld4_bf16(a.d_y, off);
+            gr[r] = (ok && a.g_res) ? (ROWS_GB_NT ? ld4_nt(a.g_res + off) : ld4(a.g_res + off)) : zero;      // issued with the other loads, ahead of the reduction
             if (do_ln && row < a.rows) { mu = a.mean[row]; rs[r] = a.rstd[row]; }
             if (mode != 0 && row < a.rows) {
                 const int bi = row / a.T, t = row - bi * a.T;
@@ -648,10 +683,10 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
         for (int r = 0; r < R; ++r) {
             char* base = stg + (s * R + r) * row_lds;
             const int so32 = (row0 + r) * D * 4, so16 = (row0 + r) * D * 2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (lds_void_t*)(base + wave * 1024), 16, vo32, so32, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_void_t*)(base + 4 * D + wave * 1024), 16, vo32, so32, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (lds_void_t*)(base + wave * 1024), 16, vo32, so32, 0, ROWS_BWD_H_NT);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_void_t*)(base + 4 * D + wave * 1024), 16, vo32, so32, 0, ROWS_BWD_G_NT);
             if (lane < 32 && (int)voY < 2 * D)       // (a last, partly filled wave: only the lanes inside the row)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void_t*)(base + 8 * D + wave * 512), 16, voY, so16, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void_t*)(base + 8 * D + wave * 512), 16, voY, so16, 0, ROWS_BWD_Y_NT);
         }
     };
     // per-row scalars (mean, rstd, 4 STNO masks) of a trip are ordinary loads: they are requested one trip ahead, BEFORE
