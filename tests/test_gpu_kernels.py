@@ -148,6 +148,32 @@ def test_gemm_nt_plain(ops, M, N, K):
     assert maxdiff(Cb.float().cpu(), ref) < 1e-2 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(1024, 512, 512), (1024, 1536, 512), (1024, 2048, 512), (1024, 512, 2048), (1000, 500, 128),
+                                   (70, 68, 448)])
+def test_gemm_nt64_decoder_shapes(ops, M, N, K):
+    """The 64 x 64 deep-ring kernel (few 128 x 128 tiles: the decoder's GEMMs at training time): it is the kernel that runs, its
+    result equals the fp64 product to fp32-accumulation accuracy, ragged edges and the fp32-residual epilogue included."""
+    g = torch.Generator().manual_seed(M * 7 + N + K)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * K ** -0.5)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = A.double() @ B.double().t()
+    Ad, Bd = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
+    before = ops.gemm_dispatch_log()
+    Cf = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_nt(Ad, Bd, Cf, M, N, K)
+    after = ops.gemm_dispatch_log()
+    ran = [k for k in after if after[k] != before.get(k, 0)]
+    assert len(ran) == 1 and ran[0].startswith("gemm_nt64_kernel"), ran
+    assert maxdiff(Cf.cpu(), ref) < 1e-4 * max(1.0, float(ref.abs().max()))
+    C3 = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_nt(Ad, Bd, C3, M, N, K, bias=dev(bias), residual=dev(res))
+    assert maxdiff(C3.cpu(), _bf((ref + bias).float()) + res) < 3e-2
+    # same bits as the 128 x 128 kernel's order of additions is NOT required; determinism is: two runs agree exactly
+    C4 = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(Ad, Bd, C4, M, N, K)
+    assert torch.equal(C4, Cf)
+
+
 @pytest.mark.parametrize("R,C,ld,ld_t", [(1280, 1280, None, None), (3840, 1280, None, None), (200, 136, 144, 208), (77, 130, None, None)])
 def test_cast_transpose(ops, R, C, ld, ld_t):
     """AMP weight copies: bf16 [R,C] and bf16 [C,R] of an fp32 matrix (vectorised kernel and the scalar fallback)."""

@@ -443,6 +443,104 @@ __global__ void __launch_bounds__(256, 2) gemm_nt128t_kernel(const dicow_gemm_ar
     }
 }
 
+// ------------------------------------------------------------------------------------------------ NT, 64 x 64 tiles, deep ring
+// The decoder's GEMMs at training time (whisper-base B = 8: M = 1024 rows, N = 512 ... 2048, K = 512 / 2048 -- 74 launches per
+// step) are 32-128 tiles of 128 x 128: most CUs idle, and each workgroup walks its 8-32 k-steps with ONE stage in flight, i.e. a
+// full memory round trip per step (15-28 us per launch for 0.5-2 GFLOP: a fifth of that step).  Here the tile is 64 x 64 (four
+// waves, one 32 x 32 accumulator block each: 4x the workgroups) and the LDS holds a ring of S stages of 16 KiB (A 64 rows x 128 B,
+// B likewise) with S - 1 of them in flight: for K = 512 every k-step of the tile is requested before the first one is computed, so
+// the launch costs about one round trip instead of eight.  Same LDS image, fragment reads and epilogue as gemm_nt128t_kernel;
+// one barrier per step: a wave waits for its own share of stage t (vmcnt), the barrier makes everybody's visible AND says every
+// wave has finished reading stage t - 1, whose slot then receives stage t + S - 1.  After the last stage the requests go to an
+// empty buffer descriptor (no traffic) so that the counted waits stay uniform.  Needs 32-bit byte offsets and K % 64 == 0.
+template <int S>
+__global__ void __launch_bounds__(256, S > 4 ? 1 : 2) gemm_nt64_kernel(const dicow_gemm_args a) {
+    constexpr int SB = 16384;                          // stage bytes: A 8 KiB + B 8 KiB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntm = (a.M + 63) / 64, ntn = (a.N + 63) / 64;
+    int tm, tn;
+    tile_coords(ntm, ntn, tm, tn);
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int bz = blockIdx.z;
+    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
+    const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
+    const int wm = wave >> 1, wn = wave & 1;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(B), 0, 0xffffffffu, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsE = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, 0u, 0x00020000);
+    unsigned offA[2], offB[2];
+    {
+        const int rr = lane >> 3, p = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = (wave * 2 + i) * 8 + rr;          // row group wave*2 + i of the 64-row image (8 rows x 128 B per request)
+            const int c = p ^ ((row >> 1) & 7);
+            int gm = m0 + row; gm = gm < a.M ? gm : a.M - 1;
+            int gn = n0 + row; gn = gn < a.N ? gn : a.N - 1;
+            offA[i] = (unsigned)(((int64_t)gm * a.lda + c * 8) * 2);
+            offB[i] = (unsigned)(((int64_t)gn * a.ldb + c * 8) * 2);
+        }
+    }
+    const int nk = a.K / BK;
+    // stage T (k offset T * 64) -> slot T % S; past the end: the empty descriptor
+#define NT64_STAGE(T)                                                                                                          \
+    {                                                                                                                          \
+        const int t_ = (T);                                                                                                    \
+        const bool live_ = t_ < nk;                                                                                            \
+        const __amdgpu_buffer_rsrc_t ra_ = live_ ? rsA : rsE, rb_ = live_ ? rsB : rsE;                                         \
+        char* d_ = smem + (t_ % S) * SB;                                                                                       \
+        const int kb_ = t_ * BK * 2;                                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                                        \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra_, (lds_void_t*)(d_ + (wave * 2 + i) * 1024), 16, offA[i], kb_, 0, 0);  \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb_, (lds_void_t*)(d_ + 8192 + (wave * 2 + i) * 1024), 16, offB[i], kb_, 0, 0); \
+        }                                                                                                                      \
+    }
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t) NT64_STAGE(t)
+    for (int t = 0; t < nk; ++t) {
+        // outstanding here: stages t .. t + S - 2 (4 requests each, in order): the oldest one must have landed
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "i"(4 * (S - 2)) : "memory");   // (and my fragment reads of stage t - 1 are done)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        NT64_STAGE(t + S - 1)
+        const char* sA = smem + (t % S) * SB;
+        const char* sB = sA + 8192;
+        bf16x8_t wf[4], xf[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int c = kk * 2 + (lane >> 5);
+            wf[kk] = lds_frag_nt(sB, wn * 32 + (lane & 31), c);
+            xf[kk] = lds_frag_nt(sA, wm * 32 + (lane & 31), c);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk], xf[kk], acc, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (empty-descriptor) requests
+#undef NT64_STAGE
+
+    // ---- epilogue (as gemm_nt_kernel)
+    const int flags = a.flags;
+    const int hh = lane >> 5;
+    unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)bz * a.strideC;
+    float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
+    unsigned short* aux = reinterpret_cast<unsigned short*>(a.aux) + (int64_t)bz * a.strideAux;
+    const int m = m0 + wm * 32 + (lane & 31);
+    if (m < a.M) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * 32 + 8 * q + 4 * hh;
+            if (n >= a.N) continue;
+            float v[4] = {acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]};
+            nt_epilogue_quad(a, flags, v, m, n, Cb, Cf, aux);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ NT, skinny (M <= 16)
 // One decoder step of a batch of <= 16 hypotheses: C[M, N] = x[M, K] W[N, K]^T streams the whole weight matrix once for a
 // handful of rows -- HBM-bound, and the 128-row tiles above spend 25 us per call on it with N / 128 workgroups.  Here a
@@ -1218,6 +1316,8 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
 static void gemm_nt_setup() {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt128t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm_nt64_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+    (void)hipFuncSetAttribute((const void*)gemm_nt64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
 #define NTR_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS); \
                     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<F, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS)
@@ -1251,6 +1351,19 @@ static void gemm_nt_setup() {
 // per k-step).  Below ~200 tiles the ring kernel leaves most CUs idle and its prologue / epilogue are not amortised: whisper-base
 // B = 8, whose N = 512 GEMMs are 94 tiles, measured 7.72 ms per step with the threshold at 200 and 8.01-8.03 ms at 90 or 40
 // (round 3, tools/_c32.sh)
+// 128 x 128 tile count up to which the 64 x 64 deep-ring kernel takes the problem (0: never)
+#ifndef NT64_MAX_TILES128
+#define NT64_MAX_TILES128 128
+#endif
+#ifndef NT64_SMALLK
+#define NT64_SMALLK 0             // ... and problems of up to NT64_SMALLK_TILES128 tiles whose contraction is this short (latency-bound walks)
+#endif
+#ifndef NT64_SMALLK_TILES128
+#define NT64_SMALLK_TILES128 1024
+#endif
+#ifndef NT64_DEEP_ALWAYS
+#define NT64_DEEP_ALWAYS 0
+#endif
 #ifndef NT_BIG_TILES
 #define NT_BIG_TILES 200
 #endif
@@ -1374,7 +1487,19 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
 #endif
     // (32-bit byte offsets inside one batch slice of A / B, as the persistent kernel needs them)
     const bool t128 = NT128_THREADED && (int64_t)a->M * a->lda * 2 < (1ll << 31) && (int64_t)a->N * a->ldb * 2 < (1ll << 31) && a->K >= 2 * BK;
-    if (t128) {
+    // few 128 x 128 tiles (the decoder at training time: M = batch x label length): 64 x 64 tiles on a deep ring (gemm_nt64_kernel)
+    const int64_t t64 = (int64_t)dicow_cdiv(a->M, 64) * dicow_cdiv(a->N, 64) * batch;
+    if (NT64_MAX_TILES128 > 0 && t128 && variant == 0 &&
+        ((int64_t)ntm * ntn * batch <= NT64_MAX_TILES128 || (a->K <= NT64_SMALLK && (int64_t)ntm * ntn * batch <= NT64_SMALLK_TILES128))) {
+        const dim3 g64(dicow_cdiv(a->M, 64) * dicow_cdiv(a->N, 64), 1, batch);
+        if (NT64_DEEP_ALWAYS || t64 <= g_ncu_all) {   // one workgroup per CU anyway: the whole 128 KiB ring
+            hipLaunchKernelGGL(gemm_nt64_kernel<8>, g64, dim3(256), 8 * 16384, (hipStream_t)stream, *a);
+            disp_note("gemm_nt64_kernel<8>");
+        } else {
+            hipLaunchKernelGGL(gemm_nt64_kernel<4>, g64, dim3(256), 4 * 16384, (hipStream_t)stream, *a);
+            disp_note("gemm_nt64_kernel<4>");
+        }
+    } else if (t128) {
         hipLaunchKernelGGL(gemm_nt128t_kernel, grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
         disp_note("gemm_nt128t_kernel");
     } else {
