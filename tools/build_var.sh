@@ -1,18 +1,19 @@
 #!/bin/bash
-# Build A/B variants of the library that differ in the -D flags of gemm.hip, fddt_ln.hip and attention.hip:
-#   tools/build_var.sh name "gemm flags" "fddt_ln flags" "attention flags" [name ...]     ("" = the shipped object)
+# Build A/B variants of the library that differ in the -D flags of gemm.hip, fddt_ln.hip, attention.hip and elementwise.hip:
+#   tools/build_var.sh name "gemm flags" "fddt_ln flags" "attention flags" "elementwise flags" [name ...]     ("" = the shipped object)
 # -> tools/libv_<name>.so (git-ignored; travels to the GPU box).  Used with DICOW_HIP_LIB=...
 set -e
 cd "$(dirname "$0")/../ts-asr-whisper_amd/csrc"
 bash build.sh > /dev/null
 pids=""
 names=()
-while [ $# -gt 3 ]; do
-  n=$1; g=$2; f=$3; t=$4; shift 4
+while [ $# -gt 4 ]; do
+  n=$1; g=$2; f=$3; t=$4; e=$5; shift 5
   names+=("$n")
-  rm -f build/gemm_v_$n.o build/fddt_ln_v_$n.o build/attention_v_$n.o
+  rm -f build/gemm_v_$n.o build/fddt_ln_v_$n.o build/attention_v_$n.o build/elementwise_v_$n.o
   if [ -n "$g" ]; then ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c gemm.hip -o build/gemm_v_$n.o $g ) & pids="$pids $!"; fi
   if [ -n "$f" ]; then ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c fddt_ln.hip -o build/fddt_ln_v_$n.o $f ) & pids="$pids $!"; fi
+  if [ -n "$e" ]; then ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c elementwise.hip -o build/elementwise_v_$n.o $e ) & pids="$pids $!"; fi
   if [ -n "$t" ]; then ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c attention.hip -o build/attention_v_$n.o $t ) & pids="$pids $!"; fi
 done
 for p in $pids; do wait $p; done

@@ -913,6 +913,9 @@ __global__ void __launch_bounds__(256, ATTN_PIPE_WGS) attn_fwd_pipe_kernel(const
 #define ATTN_O_NT 0
 #endif
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2n_t;
+#ifndef ATTN_OCC4_PRIO
+#define ATTN_OCC4_PRIO 0   // experiments: 1 = priority 1 in the S^T segment, 2 = in the softmax + PV segment, 3 / 4 = static by workgroup parity
+#endif
 #ifndef ATTN_OCC4_SPEC
 #define ATTN_OCC4_SPEC 1
 #endif
@@ -967,6 +970,8 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
     }
     bool general = true;
     if constexpr (SPEC) {
+        if (ATTN_OCC4_PRIO == 3 && (blockIdx.x & 1)) __builtin_amdgcn_s_setprio(1);
+        if (ATTN_OCC4_PRIO == 4 && (blockIdx.x & 2)) __builtin_amdgcn_s_setprio(1);
         for (int t = 0; t < nt; ++t) {
             char* sK = smem + (t & 1) * 2 * TILE_BYTES;
             char* sV = sK + TILE_BYTES;
@@ -978,6 +983,8 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
                 stage_tile(srcK, (t + 1) * KV_TILE, nK, wave);
                 stage_tile(srcV, (t + 1) * KV_TILE, nK + TILE_BYTES, wave);
             }
+            if (ATTN_OCC4_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+            if (ATTN_OCC4_PRIO == 2) __builtin_amdgcn_s_setprio(0);
             f32x16_t s[2];
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
@@ -1003,6 +1010,8 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
                         if (key >= a.Lk || (a.causal && key > qrow)) s[kb][r] = -INFINITY;
                     }
             }
+            if (ATTN_OCC4_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+            if (ATTN_OCC4_PRIO == 2) __builtin_amdgcn_s_setprio(1);
             float psum = 0.f;
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)

@@ -522,6 +522,10 @@ extern "C" int dicow_sumsq_f32(const float* x, int64_t n, float* out, void* stre
     return DICOW_OK;
 }
 
+#ifndef ADAMW_NT
+#define ADAMW_NT 0         // 1: nontemporal loads, 2: nontemporal stores (everything here is touched once per step)
+#endif
+typedef __attribute__((ext_vector_type(4))) float f32x4a_t;
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              int64_t n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
                              const float* __restrict__ gnorm_sq, float max_norm, const float* __restrict__ hyper) {
@@ -533,8 +537,16 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        float4 pp = reinterpret_cast<float4*>(p)[i], gg = reinterpret_cast<const float4*>(g)[i];
-        float4 mm = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+        float4 pp, gg, mm, vv;
+        if (ADAMW_NT & 1) {
+            const f32x4a_t p_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4a_t*>(p) + i), g_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4a_t*>(g) + i);
+            const f32x4a_t m_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4a_t*>(m) + i), v_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4a_t*>(v) + i);
+            pp = make_float4(p_.x, p_.y, p_.z, p_.w); gg = make_float4(g_.x, g_.y, g_.z, g_.w);
+            mm = make_float4(m_.x, m_.y, m_.z, m_.w); vv = make_float4(v_.x, v_.y, v_.z, v_.w);
+        } else {
+            pp = reinterpret_cast<float4*>(p)[i]; gg = reinterpret_cast<const float4*>(g)[i];
+            mm = reinterpret_cast<float4*>(m)[i]; vv = reinterpret_cast<float4*>(v)[i];
+        }
         float* pa = &pp.x; float* ga = &gg.x; float* ma = &mm.x; float* va = &vv.x;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -545,7 +557,13 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
             const float denom = sqrtf(va[e]) / sqrtf(bc2) + eps;
             pa[e] -= (lr / bc1) * (ma[e] / denom);
         }
-        reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+        if (ADAMW_NT & 2) {
+            __builtin_nontemporal_store(f32x4a_t{pp.x, pp.y, pp.z, pp.w}, reinterpret_cast<f32x4a_t*>(p) + i);
+            __builtin_nontemporal_store(f32x4a_t{mm.x, mm.y, mm.z, mm.w}, reinterpret_cast<f32x4a_t*>(m) + i);
+            __builtin_nontemporal_store(f32x4a_t{vv.x, vv.y, vv.z, vv.w}, reinterpret_cast<f32x4a_t*>(v) + i);
+        } else {
+            reinterpret_cast<float4*>(p)[i] = pp; reinterpret_cast<float4*>(m)[i] = mm; reinterpret_cast<float4*>(v)[i] = vv;
+        }
     }
     for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float gr = g[i] * clip;
