@@ -283,6 +283,172 @@ __global__ void __launch_bounds__(MAXT) fddt_ln_fwd_kernel(const dicow_fddt_ln_f
     }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, LayerNorm only, a wave per row
+// The LayerNorm that follows every attention block (and the encoder's final one): fp32 rows in, bf16 (and optionally fp32) rows,
+// mean, rstd out.  The column-owner body above pays two block-wide reductions (two barriers) per trip of R rows and runs at
+// 4.7 TB/s where its own copy mode reaches 6; the forward has no column sums to keep, so here a WAVE owns whole rows: lane l holds
+// the float4 at columns 4 l + 256 k, k < NC (D = 256 NC: 1280 -> 5), both statistics are DPP reductions inside the wave -- no LDS,
+// no barrier, nothing shared between the waves of a workgroup -- and the affine vectors live in registers (2 x 4 NC).  R rows are
+// requested together.  Same two-pass arithmetic (mean, then centred sum of squares) as the block form.
+#ifndef LNW_ON
+#define LNW_ON 1
+#endif
+#ifndef LNW_R
+#define LNW_R 2
+#endif
+#ifndef LNW_WAVES
+#define LNW_WAVES 8       // (4 or 8 waves per workgroup, 1 / 2 / 4 rows per request group: equal within 0.1 % of the encoder forward)
+#endif
+template <int NC>
+__global__ void __launch_bounds__(LNW_WAVES * 64) ln_fwd_wave_kernel(const dicow_fddt_ln_fwd_args a) {
+    constexpr int R = LNW_R;
+    const int lane = threadIdx.x & 63;
+    const int D = a.D;
+    const int wave = blockIdx.x * LNW_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * LNW_WAVES;
+    float4 lw[NC], lb[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { lw[k] = ld4(a.ln_w + 4 * lane + 256 * k); lb[k] = ld4(a.ln_b + 4 * lane + 256 * k); }
+    const float inv_d = 1.0f / (float)D;
+    const float* H = reinterpret_cast<const float*>(a.h_in);
+    for (int row0 = wave * R; row0 < a.rows; row0 += nwaves * R) {
+        float4 x[R][NC];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r < a.rows ? row0 + r : a.rows - 1;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) x[r][k] = ROWS_G_NT ? ld4_nt(H + (int64_t)row * D + 4 * lane + 256 * k) : ld4(H + (int64_t)row * D + 4 * lane + 256 * k);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) sm += (x[r][k].x + x[r][k].y) + (x[r][k].z + x[r][k].w);
+            const float mu = wave_sum_dpp(sm) * inv_d;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const float dx = x[r][k].x - mu, dy = x[r][k].y - mu, dz = x[r][k].z - mu, dw = x[r][k].w - mu;
+                q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            }
+            const float rs = rsqrtf(wave_sum_dpp(q) * inv_d + a.eps);
+            if (row >= a.rows) continue;                      // (wave-uniform)
+            if (lane == 0) {
+                if (a.mean) a.mean[row] = mu;
+                if (a.rstd) a.rstd[row] = rs;
+            }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                float4 y;
+                y.x = (x[r][k].x - mu) * rs * lw[k].x + lb[k].x;
+                y.y = (x[r][k].y - mu) * rs * lw[k].y + lb[k].y;
+                y.z = (x[r][k].z - mu) * rs * lw[k].z + lb[k].z;
+                y.w = (x[r][k].w - mu) * rs * lw[k].w + lb[k].w;
+                const int64_t off = (int64_t)row * D + 4 * lane + 256 * k;
+                if (a.y_bf16) st4_bf16(a.y_bf16, off, y);
+                if (a.y_f32) st4(a.y_f32 + off, y);
+            }
+        }
+    }
+}
+
+// FDDT(diag) + LayerNorm forward of every encoder layer in the same wave-per-row form: the eight FDDT vectors (4 classes x weight,
+// bias) and the two LayerNorm affine vectors (10 x 4 D bytes = 50 KiB at D = 1280) live in LDS, written once per workgroup -- the only barrier of the kernel -- and read
+// back as conflict-free 16-byte fragments (10 x NC ds_read_b128 per row and lane against NC 16-byte HBM loads and 3 NC stores).
+// The FDDT arithmetic is the reference's evaluation order (fddt_diag_pair: packed
+// IEEE multiplies / adds, no contraction), bit-exact like the other bodies.  fp32 rows leave in 8-byte stores (see the note on
+// 16-byte stores in the staged kernel).
+#ifndef FLW_R
+#define FLW_R 1
+#endif
+#ifndef FLW_WAVES
+#define FLW_WAVES 8
+#endif
+#ifndef FLW_ON
+#define FLW_ON 0        // measured equal to the LDS-staged column-owner kernel (62-68 against 64.5 us in isolation, encoder forward +-0.1 ms over
+#endif                  // 1 / 2 rows x 4 / 8 / 16 waves: profiles/r03_rows_wave.txt): that kernel is not bound by its barriers; kept for A/B builds
+#ifndef FLW_MINWG
+#define FLW_MINWG 2       // resident workgroups per CU the register budget is cut for (8 waves each: 128 VGPRs)
+#endif
+template <int NC>
+__global__ void __launch_bounds__(FLW_WAVES * 64, FLW_MINWG) fddt_ln_fwd_wave_kernel(const dicow_fddt_ln_fwd_args a) {
+    constexpr int R = FLW_R;
+    extern __shared__ __attribute__((aligned(16))) char prm[];        // [10 vectors][D] fp32: w0 b0 w1 b1 w2 b2 w3 b3 ln_w ln_b
+    const int lane = threadIdx.x & 63, D = a.D;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int i = threadIdx.x * 4; i < 10 * D; i += FLW_WAVES * 64 * 4) {
+        const int v = i / D, c = i - v * D;
+        const float* src = v == 8 ? a.ln_w : v == 9 ? a.ln_b : (v & 1) ? a.b[v >> 1] : a.w[v >> 1];
+        *reinterpret_cast<float4*>(prm + (int64_t)i * 4) = ld4(src + c);
+    }
+    __syncthreads();
+    const float inv_d = 1.0f / (float)D;
+    const float* H = reinterpret_cast<const float*>(a.h_in);
+    const int wave = blockIdx.x * FLW_WAVES + wv, nwaves = gridDim.x * FLW_WAVES;
+    for (int row0 = wave * R; row0 < a.rows; row0 += nwaves * R) {
+        float4 xi[R][NC];
+        float m[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r < a.rows ? row0 + r : a.rows - 1;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) xi[r][k] = ROWS_G_NT ? ld4_nt(H + (int64_t)row * D + 4 * lane + 256 * k) : ld4(H + (int64_t)row * D + 4 * lane + 256 * k);
+            const int bi = row / a.T, t = row - bi * a.T;
+            const float* mp = a.stno + (int64_t)bi * a.stno_bstride + t;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m[r][c] = mp[(int64_t)c * a.T];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int row = row0 + r;
+            float m0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m[r][0]))), m1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m[r][1])));
+            float m2 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m[r][2]))), m3 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m[r][3])));
+            f32x2r_t xl[NC], xh[NC];
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                float4 pv[8];
+#pragma unroll
+                for (int v = 0; v < 8; ++v) pv[v] = *reinterpret_cast<const float4*>(prm + ((int64_t)v * D + 4 * lane + 256 * k) * 4);
+#define FLW_P(v, lo, hi) f32x2r_t{pv[v].lo, pv[v].hi}
+                xl[k] = fddt_diag_pair(f32x2r_t{xi[r][k].x, xi[r][k].y}, FLW_P(0, x, y), FLW_P(1, x, y), FLW_P(2, x, y), FLW_P(3, x, y),
+                                       FLW_P(4, x, y), FLW_P(5, x, y), FLW_P(6, x, y), FLW_P(7, x, y), m0, m1, m2, m3);
+                xh[k] = fddt_diag_pair(f32x2r_t{xi[r][k].z, xi[r][k].w}, FLW_P(0, z, w), FLW_P(1, z, w), FLW_P(2, z, w), FLW_P(3, z, w),
+                                       FLW_P(4, z, w), FLW_P(5, z, w), FLW_P(6, z, w), FLW_P(7, z, w), m0, m1, m2, m3);
+#undef FLW_P
+                sm += (xl[k].x + xl[k].y) + (xh[k].x + xh[k].y);
+                asm volatile("" ::: "memory");                // (keeps the parameter fragments of the NC chunks from being read all at once: 32 registers each)
+            }
+            const float mu = wave_sum_dpp(sm) * inv_d;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+#pragma clang fp contract(off)
+                const f32x2r_t mu2 = {mu, mu};
+                const f32x2r_t dl = xl[k] - mu2, dh = xh[k] - mu2;
+                const f32x2r_t ql = dl * dl, qh = dh * dh;
+                q += (ql.x + ql.y) + (qh.x + qh.y);
+            }
+            const float rs = rsqrtf(wave_sum_dpp(q) * inv_d + a.eps);
+            if (row >= a.rows) continue;                      // (wave-uniform)
+            if (lane == 0) { a.mean[row] = mu; a.rstd[row] = rs; }
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+#pragma clang fp contract(off)
+                const int64_t off = (int64_t)row * D + 4 * lane + 256 * k;
+                *reinterpret_cast<u32x2r_t*>(a.h_out + off) = u32x2r_t{__float_as_uint(xl[k].x), __float_as_uint(xl[k].y)};
+                *reinterpret_cast<u32x2r_t*>(a.h_out + off + 2) = u32x2r_t{__float_as_uint(xh[k].x), __float_as_uint(xh[k].y)};
+                const float4 lw = *reinterpret_cast<const float4*>(prm + ((int64_t)8 * D + 4 * lane + 256 * k) * 4);
+                const float4 lb = *reinterpret_cast<const float4*>(prm + ((int64_t)9 * D + 4 * lane + 256 * k) * 4);
+                const f32x2r_t mu2 = {mu, mu}, rs2 = {rs, rs};
+                const f32x2r_t yl = (xl[k] - mu2) * rs2 * f32x2r_t{lw.x, lw.y} + f32x2r_t{lb.x, lb.y};
+                const f32x2r_t yh = (xh[k] - mu2) * rs2 * f32x2r_t{lw.z, lw.w} + f32x2r_t{lb.z, lb.w};
+                *reinterpret_cast<u32x2r_t*>(reinterpret_cast<unsigned short*>(a.y_bf16) + off) = u32x2r_t{pack_bf16x2(yl.x, yl.y), pack_bf16x2(yh.x, yh.y)};
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward, LDS-staged rows
 // The FDDT(diag) + LayerNorm forward of every encoder layer (fp32 in, fp32 h_out, bf16 y, mean / rstd), with the rows of the
 // next trip fetched by LDS-DMA while the current trip is computed -- see fddt_ln_bwd_staged_kernel for the scheme.  The FDDT
@@ -457,6 +623,29 @@ extern "C" int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream) 
     const bool staged = fwd_env != 9 && block <= 512 && block * 4 == a->D && a->mode == 1 && a->ln_w && !a->in_bf16 && a->h_out &&
                         a->y_bf16 && !a->y_f32 && a->mean && a->rstd && !a->pos && a->w[0] && a->w[1] && a->w[2] && a->w[3] &&
                         a->b[0] && a->b[1] && a->b[2] && a->b[3] && (int64_t)a->rows * a->D * 4 < (1ll << 31);
+    if (staged && FLW_ON && fwd_env == 0 && a->D % 256 == 0 && a->D >= 512 && a->D <= 1280) {
+        const int nc = a->D / 256;
+        const int lds = 10 * a->D * 4;
+        const void* fn = nc == 5 ? (const void*)fddt_ln_fwd_wave_kernel<5> : nc == 4 ? (const void*)fddt_ln_fwd_wave_kernel<4>
+                       : nc == 3 ? (const void*)fddt_ln_fwd_wave_kernel<3> : (const void*)fddt_ln_fwd_wave_kernel<2>;
+        static int occf[6] = {0};
+        int per_cu = __atomic_load_n(&occf[nc], __ATOMIC_RELAXED);
+        if (per_cu == 0) {
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FLW_WAVES * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            __atomic_store_n(&occf[nc], per_cu, __ATOMIC_RELAXED);
+        }
+        int gw = dicow_cdiv(a->rows, FLW_R * FLW_WAVES);
+        if (gw > 256 * per_cu) gw = 256 * per_cu;
+        switch (nc) {
+            case 5: hipLaunchKernelGGL(fddt_ln_fwd_wave_kernel<5>, dim3(gw), dim3(FLW_WAVES * 64), lds, (hipStream_t)stream, *a); break;
+            case 4: hipLaunchKernelGGL(fddt_ln_fwd_wave_kernel<4>, dim3(gw), dim3(FLW_WAVES * 64), lds, (hipStream_t)stream, *a); break;
+            case 3: hipLaunchKernelGGL(fddt_ln_fwd_wave_kernel<3>, dim3(gw), dim3(FLW_WAVES * 64), lds, (hipStream_t)stream, *a); break;
+            default: hipLaunchKernelGGL(fddt_ln_fwd_wave_kernel<2>, dim3(gw), dim3(FLW_WAVES * 64), lds, (hipStream_t)stream, *a); break;
+        }
+        DICOW_CHECK_LAUNCH("fddt_ln_fwd_wave");
+        return DICOW_OK;
+    }
     if (staged) {
         static const bool attr = [] {
             (void)hipFuncSetAttribute((const void*)fddt_ln_fwd_staged_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * 4 * 2048);
@@ -479,6 +668,30 @@ extern "C" int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream) 
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL((fddt_ln_fwd_staged_kernel<4>), dim3(grid), dim3(block), 2 * R * 4 * a->D, (hipStream_t)stream, *a);
         DICOW_CHECK_LAUNCH("fddt_ln_fwd_staged");
+        return DICOW_OK;
+    }
+    // LayerNorm only, fp32 rows of 256 NC columns: a wave per row (no barrier, no LDS)
+    if (LNW_ON && a->mode == 0 && a->ln_w && !a->in_bf16 && !a->h_out && !a->pos && a->D % 256 == 0 && a->D >= 512 && a->D <= 1280 &&
+        (a->y_bf16 || a->y_f32)) {
+        static int occw[6] = {0};
+        const int nc = a->D / 256;
+        int per_cu = __atomic_load_n(&occw[nc], __ATOMIC_RELAXED);
+        if (per_cu == 0) {
+            const void* fn = nc == 5 ? (const void*)ln_fwd_wave_kernel<5> : nc == 4 ? (const void*)ln_fwd_wave_kernel<4>
+                           : nc == 3 ? (const void*)ln_fwd_wave_kernel<3> : (const void*)ln_fwd_wave_kernel<2>;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, LNW_WAVES * 64, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+            __atomic_store_n(&occw[nc], per_cu, __ATOMIC_RELAXED);
+        }
+        int gw = dicow_cdiv(a->rows, LNW_R * LNW_WAVES);
+        const int capw = 256 * per_cu;
+        if (gw > capw) gw = capw;
+        switch (nc) {
+            case 5: hipLaunchKernelGGL(ln_fwd_wave_kernel<5>, dim3(gw), dim3(LNW_WAVES * 64), 0, (hipStream_t)stream, *a); break;
+            case 4: hipLaunchKernelGGL(ln_fwd_wave_kernel<4>, dim3(gw), dim3(LNW_WAVES * 64), 0, (hipStream_t)stream, *a); break;
+            case 3: hipLaunchKernelGGL(ln_fwd_wave_kernel<3>, dim3(gw), dim3(LNW_WAVES * 64), 0, (hipStream_t)stream, *a); break;
+            default: hipLaunchKernelGGL(ln_fwd_wave_kernel<2>, dim3(gw), dim3(LNW_WAVES * 64), 0, (hipStream_t)stream, *a); break;
+        }
+        DICOW_CHECK_LAUNCH("ln_fwd_wave");
         return DICOW_OK;
     }
     static int occ[4][17] = {{0}};
