@@ -1034,6 +1034,96 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
     }
 }
 
+// ------------------------------------------------------------------------------------------------ backward, LayerNorm only, a wave per row
+// LayerNorm backward + residual gradient of LN2 / the final LayerNorm / the decoder's LayerNorms (mode 0): like ln_fwd_wave_kernel a
+// WAVE owns whole rows (lane l: the float4 at columns 4 l + 256 k), the two row sums are DPP reductions -- no barrier per trip -- and
+// the three column sums (d ln_w, d ln_b, the bias gradient of the producing Linear) accumulate in 3 x 4 NC registers per lane.  They
+// meet once, at the end, in LDS (wave after wave, in order: deterministic) and leave as this workgroup's row of the same
+// [workgroup][11][D] workspace the column-owner bodies write.  Same arithmetic per element as fddt_ln_bwd_kernel.
+#ifndef LBW_ON
+#define LBW_ON 1
+#endif
+#ifndef LBW_WAVES
+#define LBW_WAVES 8
+#endif
+#ifndef LBW_MINWG
+#define LBW_MINWG 1
+#endif
+template <int NC>
+__global__ void __launch_bounds__(LBW_WAVES * 64, LBW_MINWG) ln_bwd_wave_kernel(const dicow_fddt_ln_bwd_args a) {
+    extern __shared__ __attribute__((aligned(16))) char csum[];       // [3][D] fp32
+    const int lane = threadIdx.x & 63, D = a.D;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const float4 zero = make_float4(0, 0, 0, 0);
+    float4 lw[NC], acc_w[NC], acc_b[NC], acc_c[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { lw[k] = ld4(a.ln_w + 4 * lane + 256 * k); acc_w[k] = zero; acc_b[k] = zero; acc_c[k] = zero; }
+    const float inv_d = 1.0f / (float)D;
+    const float* H = reinterpret_cast<const float*>(a.h_in);
+    const int wave = blockIdx.x * LBW_WAVES + wv, nwaves = gridDim.x * LBW_WAVES;
+    for (int row = wave; row < a.rows; row += nwaves) {
+        float4 x[NC], dy[NC], g[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int64_t off = (int64_t)row * D + 4 * lane + 256 * k;
+            x[k] = ld4(H + off);
+            dy[k] = a.dy_f32 ? ld4(reinterpret_cast<const float*>(a.d_y) + off) : ld4_bf16(a.d_y, off);
+            g[k] = a.g_res ? ld4(a.g_res + off) : zero;
+        }
+        const float mu = a.mean[row], rs = a.rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            x[k] = make_float4((x[k].x - mu) * rs, (x[k].y - mu) * rs, (x[k].z - mu) * rs, (x[k].w - mu) * rs);      // x-hat
+            const float4 dxh = make_float4(dy[k].x * lw[k].x, dy[k].y * lw[k].y, dy[k].z * lw[k].z, dy[k].w * lw[k].w);
+            s1 += (dxh.x + dxh.y) + (dxh.z + dxh.w);
+            s2 += (dxh.x * x[k].x + dxh.y * x[k].y) + (dxh.z * x[k].z + dxh.w * x[k].w);
+        }
+        const float c1 = wave_sum_dpp(s1) * inv_d, c2 = wave_sum_dpp(s2) * inv_d;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            g[k].x += rs * (dy[k].x * lw[k].x - c1 - x[k].x * c2);
+            g[k].y += rs * (dy[k].y * lw[k].y - c1 - x[k].y * c2);
+            g[k].z += rs * (dy[k].z * lw[k].z - c1 - x[k].z * c2);
+            g[k].w += rs * (dy[k].w * lw[k].w - c1 - x[k].w * c2);
+            F4_FMA(acc_w[k], dy[k], x[k]);
+            F4_ADD(acc_b[k], dy[k]);
+            F4_ADD(acc_c[k], g[k]);
+            const int64_t off = (int64_t)row * D + 4 * lane + 256 * k;
+            if (a.g_out) {                                     // (8-byte stores: see the note on 16-byte stores in the staged kernels)
+                *reinterpret_cast<u32x2r_t*>(a.g_out + off) = u32x2r_t{__float_as_uint(g[k].x), __float_as_uint(g[k].y)};
+                *reinterpret_cast<u32x2r_t*>(a.g_out + off + 2) = u32x2r_t{__float_as_uint(g[k].z), __float_as_uint(g[k].w)};
+            }
+            if (a.g_out_bf16) st4_bf16(a.g_out_bf16, off, g[k]);
+        }
+    }
+    // column sums: wave after wave into LDS, then this workgroup's row of the workspace
+    float* cs = reinterpret_cast<float*>(csum);
+    for (int w = 0; w < LBW_WAVES; ++w) {
+        if (wv == w) {
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int c = 4 * lane + 256 * k;
+                float4 t0 = acc_w[k], t1 = acc_b[k], t2 = acc_c[k];
+                if (w > 0) {
+                    const float4 o0 = *reinterpret_cast<const float4*>(cs + c), o1 = *reinterpret_cast<const float4*>(cs + D + c),
+                                 o2 = *reinterpret_cast<const float4*>(cs + 2 * D + c);
+                    t0 = make_float4(o0.x + t0.x, o0.y + t0.y, o0.z + t0.z, o0.w + t0.w);
+                    t1 = make_float4(o1.x + t1.x, o1.y + t1.y, o1.z + t1.z, o1.w + t1.w);
+                    t2 = make_float4(o2.x + t2.x, o2.y + t2.y, o2.z + t2.z, o2.w + t2.w);
+                }
+                *reinterpret_cast<float4*>(cs + c) = t0; *reinterpret_cast<float4*>(cs + D + c) = t1; *reinterpret_cast<float4*>(cs + 2 * D + c) = t2;
+            }
+        }
+        __syncthreads();
+    }
+    float* part = reinterpret_cast<float*>(a.ws) + (int64_t)blockIdx.x * 11 * D;
+    for (int i = threadIdx.x * 4; i < 3 * D; i += LBW_WAVES * 64 * 4) {
+        const int v = i / D, c = i - v * D;
+        if ((v == 0 && a.dln_w) || (v == 1 && a.dln_b) || (v == 2 && a.colsum_out)) st4(part + (int64_t)v * D + c, *reinterpret_cast<const float4*>(cs + i));
+    }
+}
+
 #ifndef BWD_DEPTH
 #define BWD_DEPTH 1       // row DMA trips in flight in the staged backward (1: two LDS stages, 2: three -- measured equal: 124-126 us
                           // either way, profiles/r03_rows_depth.txt; the barrier of the per-trip block reduction is the limit, not the DMA latency)
@@ -1094,6 +1184,30 @@ extern "C" int dicow_fddt_ln_bwd(const dicow_fddt_ln_bwd_args* a, void* stream) 
     DICOW_REQUIRE(!any || (a->ws && a->ws_bytes >= (int64_t)grid * 11 * D * 4),
                   "fddt_ln_bwd: workspace too small (need %ld bytes)", (long)grid * 11 * D * 4);
     hipStream_t st = (hipStream_t)stream;
+    if (LBW_ON && ln0 && r_env == 0 && !a->in_bf16 && !a->pos && a->D % 256 == 0 && a->D >= 512 && a->D <= 1280 && (a->g_out || a->g_out_bf16)) {
+        const int nc = a->D / 256;
+        const void* fn = nc == 5 ? (const void*)ln_bwd_wave_kernel<5> : nc == 4 ? (const void*)ln_bwd_wave_kernel<4>
+                       : nc == 3 ? (const void*)ln_bwd_wave_kernel<3> : (const void*)ln_bwd_wave_kernel<2>;
+        static int occb[6] = {0};
+        int per_cu = __atomic_load_n(&occb[nc], __ATOMIC_RELAXED);
+        const int lds = 3 * D * 4;
+        if (per_cu == 0) {
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, LBW_WAVES * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            __atomic_store_n(&occb[nc], per_cu, __ATOMIC_RELAXED);
+        }
+        int gw = dicow_cdiv(a->rows, LBW_WAVES);
+        if (gw > 256 * per_cu) gw = 256 * per_cu;
+        if (gw > grid) gw = grid;                                // (the workspace is sized for `grid` partial rows)
+        switch (nc) {
+            case 5: hipLaunchKernelGGL(ln_bwd_wave_kernel<5>, dim3(gw), dim3(LBW_WAVES * 64), lds, st, *a); break;
+            case 4: hipLaunchKernelGGL(ln_bwd_wave_kernel<4>, dim3(gw), dim3(LBW_WAVES * 64), lds, st, *a); break;
+            case 3: hipLaunchKernelGGL(ln_bwd_wave_kernel<3>, dim3(gw), dim3(LBW_WAVES * 64), lds, st, *a); break;
+            default: hipLaunchKernelGGL(ln_bwd_wave_kernel<2>, dim3(gw), dim3(LBW_WAVES * 64), lds, st, *a); break;
+        }
+        DICOW_CHECK_LAUNCH("ln_bwd_wave");
+        if (any) return dicow_launch_reduce_multi(reinterpret_cast<const float*>(a->ws), gw, (int64_t)11 * D, D, outs, 11, D, st);
+        return DICOW_OK;
+    }
     if (block > 512)
         hipLaunchKernelGGL((fddt_ln_bwd_kernel<2, 1024>), dim3(grid), dim3(block), 0, st, *a);
     else if (r_env == 9)                                                                    // generic body (ablation)
