@@ -913,6 +913,10 @@ __global__ void __launch_bounds__(256, ATTN_PIPE_WGS) attn_fwd_pipe_kernel(const
 #define ATTN_O_NT 0
 #endif
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2n_t;
+#ifndef ATTN_OCC4_TAIL
+#define ATTN_OCC4_TAIL 1   // skip the all-padding second key block of the last tile and the all-padding waves of the last query block
+#endif
+template <int N> struct attn_ic { static constexpr int value = N; };
 #ifndef ATTN_OCC4_PRIO
 #define ATTN_OCC4_PRIO 0   // experiments: 1 = priority 1 in the S^T segment, 2 = in the softmax + PV segment, 3 / 4 = static by workgroup parity
 #endif
@@ -972,7 +976,13 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
     if constexpr (SPEC) {
         if (ATTN_OCC4_PRIO == 3 && (blockIdx.x & 1)) __builtin_amdgcn_s_setprio(1);
         if (ATTN_OCC4_PRIO == 4 && (blockIdx.x & 2)) __builtin_amdgcn_s_setprio(1);
-        for (int t = 0; t < nt; ++t) {
+        // Padding: Lk = 1500 is 23.44 tiles of 64 keys and 11.7 blocks of 128 queries.  When the LAST tile's second key block lies
+        // entirely past Lk it is not computed (NKB = 1: 1/48 of the matrix and softmax work of every workgroup), and a wave whose 32
+        // query rows all lie past Lq (the fourth wave of the last query block) only keeps the barriers and its share of the staging.
+        const bool tail_half = ATTN_OCC4_TAIL && !a.causal && nt * KV_TILE - a.Lk >= 32;
+        const bool wave_live = !ATTN_OCC4_TAIL || q0 + wave * 32 < a.Lq;
+        auto spec_tile = [&](int t, auto nkb_tag) {
+            constexpr int NKB = decltype(nkb_tag)::value;
             char* sK = smem + (t & 1) * 2 * TILE_BYTES;
             char* sV = sK + TILE_BYTES;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -983,11 +993,12 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
                 stage_tile(srcK, (t + 1) * KV_TILE, nK, wave);
                 stage_tile(srcV, (t + 1) * KV_TILE, nK + TILE_BYTES, wave);
             }
+            if (!wave_live) return;
             if (ATTN_OCC4_PRIO == 1) __builtin_amdgcn_s_setprio(1);
             if (ATTN_OCC4_PRIO == 2) __builtin_amdgcn_s_setprio(0);
             f32x16_t s[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < NKB; ++kb) {
                 bf16x8_t kf[4];
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) kf[kk] = *reinterpret_cast<const bf16x8_t*>(sK + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
@@ -1000,10 +1011,10 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
             tr8_t tv0, tv1;
             tr_issue_v<0>(tv0, va0, va1);
             const int k0 = t * KV_TILE;
-            const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
+            const bool need_mask = (k0 + NKB * 32 > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
             if (need_mask) {
 #pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -1014,7 +1025,7 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
             if (ATTN_OCC4_PRIO == 2) __builtin_amdgcn_s_setprio(1);
             float psum = 0.f;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float p = __builtin_amdgcn_exp2f(s[kb][r]);
@@ -1024,7 +1035,7 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
             l_run += psum;
             bf16x8_t vf[2][2];
             tr_wait<0>(tv0);
-            tr_issue_v<4096>(tv1, va0, va1);
+            if constexpr (NKB == 2) tr_issue_v<4096>(tv1, va0, va1);
             tr_pack(vf, tv0);
 #pragma unroll
             for (int x = 0; x < 2; ++x) {
@@ -1032,15 +1043,20 @@ __global__ void __launch_bounds__(256, 4) attn_fwd_occ4_kernel(const dicow_attn_
 #pragma unroll
                 for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
             }
-            tr_wait<0>(tv1);
-            tr_pack(vf, tv1);
+            if constexpr (NKB == 2) {
+                tr_wait<0>(tv1);
+                tr_pack(vf, tv1);
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const bf16x8_t pf = pack8(s[1], 8 * x);
+                for (int x = 0; x < 2; ++x) {
+                    const bf16x8_t pf = pack8(s[1], 8 * x);
 #pragma unroll
-                for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+                    for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
+                }
             }
-        }
+        };
+        const int nfull = tail_half ? nt - 1 : nt;
+        for (int t = 0; t < nfull; ++t) spec_tile(t, attn_ic<2>{});
+        if (tail_half) spec_tile(nt - 1, attn_ic<1>{});
         // ---- the guard, and the workgroup's vote
         const float lt = l_run + __shfl_xor(l_run, 32, 64);
         const bool row_bad = qrow < a.Lq && !(lt > 0x1p-100f && lt < 0x1p100f);       // (false for NaN, too)
