@@ -916,6 +916,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2n_t;
 #ifndef ATTN_OCC4_TAIL
 #define ATTN_OCC4_TAIL 1   // skip the all-padding second key block of the last tile and the all-padding waves of the last query block
 #endif
+#ifndef ATTN_BWD_TAIL
+#define ATTN_BWD_TAIL 1
+#endif
 template <int N> struct attn_ic { static constexpr int value = N; };
 #ifndef ATTN_OCC4_PRIO
 #define ATTN_OCC4_PRIO 0   // experiments: 1 = priority 1 in the S^T segment, 2 = in the softmax + PV segment, 3 / 4 = static by workgroup parity
@@ -1377,7 +1380,12 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
     const unsigned kb10 = tr_base_u(smem, lane, 1, 0), kb11 = tr_base_u(smem, lane, 1, 1);
     stage_tile(srcK, 0, smem, wave);
     stage_tile(srcV, 0, smem + TILE_BYTES, wave);
-    for (int t = 0; t < nt; ++t) {
+    // (padding, as in attn_fwd_occ4_kernel: the last tile's all-padding second key block is not computed, an all-padding wave of the
+    // last query block keeps only the barriers and its share of the staging)
+    const bool tail_half = ATTN_BWD_TAIL && !a.causal && nt * KV_TILE - a.Lk >= 32;
+    const bool wave_live = !ATTN_BWD_TAIL || q0 + wave * 32 < a.Lq;
+    auto dq_tile = [&](int t, auto nkb_tag) {
+        constexpr int NKB = decltype(nkb_tag)::value;
         char* sK = smem + (t & 1) * 2 * TILE_BYTES;
         char* sV = sK + TILE_BYTES;
         if (t + 1 < nt) {
@@ -1391,17 +1399,18 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
 
+        if (wave_live) {
         const int k0 = t * KV_TILE;
-        const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
+        const bool need_mask = (k0 + NKB * 32 > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
         // K^T fragments for the dQ product: issued now, consumed after S / dP / dS
         const unsigned stg = (unsigned)((t & 1) * 2 * TILE_BYTES);
         const unsigned k00 = kb00 + stg, k01 = kb01 + stg, k10 = kb10 + stg, k11 = kb11 + stg;
         tr8_t tk0, tk1;
         tr_issue_u<0>(tk0, k00, k01, k10, k11);
-        tr_issue_u<4096>(tk1, k00, k01, k10, k11);
+        if constexpr (NKB == 2) tr_issue_u<4096>(tk1, k00, k01, k10, k11);
         f32x16_t ds[2];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
+        for (int kb = 0; kb < NKB; ++kb) {
             // the first MFMA of each chain takes the loop-invariant seed registers as C and writes a fresh D: no per-tile
             // v_mov of 2 x 16 seed values (they were a quarter of this loop's VALU instructions)
             f32x16_t s = seed_s, dp = seed_p;
@@ -1435,6 +1444,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
 #pragma unroll
                 for (int d = 0; d < 2; ++d) dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[x][d], pf, dq[d], 0, 0, 0);
             }
+            if constexpr (NKB == 2) {
             tr_wait<0>(tk1);
             tr_pack(ktf, tk1);
 #pragma unroll
@@ -1443,10 +1453,17 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bw
 #pragma unroll
                 for (int d = 0; d < 2; ++d) dq[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[x][d], pf, dq[d], 0, 0, 0);
             }
+            }
+        }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    };
+    {
+        const int nfull = tail_half ? nt - 1 : nt;
+        for (int t = 0; t < nfull; ++t) dq_tile(t, attn_ic<2>{});
+        if (tail_half) dq_tile(nt - 1, attn_ic<1>{});
     }
     if (a.dq_colsum) {        // q_proj bias gradient, fused: partial row (b, q block, wave) of the first workspace plane
         const int nqb = (a.Lq + 127) / 128;
@@ -1529,7 +1546,12 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
         for (int kk = 0; kk < 4; ++kk) fo[qb][kk] = uswz(qb * 32 + (lane & 31), kk * 2 + hh);
     const unsigned qb00 = tr_base_u(smem, lane, 0, 0), qb01 = tr_base_u(smem, lane, 0, 1);
     const unsigned qb10 = tr_base_u(smem, lane, 1, 0), qb11 = tr_base_u(smem, lane, 1, 1);
-    for (int t = t0; t < nt; ++t) {
+    // (padding, as in the other attention kernels: the all-padding second query block of the last tile is not computed; a wave whose
+    // 32 keys all lie past Lk keeps only the barriers and its share of the staging)
+    const bool tail_half = ATTN_BWD_TAIL && nt * KV_TILE - a.Lq >= 32 && nt - 1 > t0;
+    const bool wave_live = !ATTN_BWD_TAIL || kblk0 + wave * 32 < a.Lk;
+    auto dkv_tile = [&](int t, auto nqb_tag) {
+        constexpr int NQB = decltype(nqb_tag)::value;
         char* sQ = smem + ((t - t0) & 1) * 2 * TILE_BYTES;
         char* sdO = sQ + TILE_BYTES;
         if (t + 1 < nt) {
@@ -1637,12 +1659,19 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
             }                                                                                                           \
         }
 #endif
-        DKV_QBLOCK(0)
-        DKV_QBLOCK(1)
+        if (wave_live) {
+            DKV_QBLOCK(0)
+            if constexpr (NQB == 2) DKV_QBLOCK(1)
+        }
 #undef DKV_QBLOCK
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+    };
+    {
+        const int nfull = tail_half ? nt - 1 : nt;
+        for (int t = t0; t < nfull; ++t) dkv_tile(t, attn_ic<2>{});
+        if (tail_half) dkv_tile(nt - 1, attn_ic<1>{});
     }
     if (a.dv_colsum) {        // v_proj bias gradient, fused: second workspace plane, partial row (b, key block, wave)
         // partial rows are indexed by 128-key block and wave-in-block whatever the workgroup size (the reduction's layout)
