@@ -1364,6 +1364,9 @@ static void gemm_nt_setup() {
 #ifndef NT64_DEEP_ALWAYS
 #define NT64_DEEP_ALWAYS 0
 #endif
+#ifndef NT_WIDE35
+#define NT_WIDE35 0
+#endif
 #ifndef NT_BIG_TILES
 #define NT_BIG_TILES 200
 #endif
@@ -1424,7 +1427,11 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             const int64_t w44 = dicow_cdiv(t44, ncu) * 256 * 256, w35 = dicow_cdiv(t35, ncu) * 192 * 320;
             // (round 3: with the cheaper GELU the inference fc1 -- bias + GELU, no saved derivative -- gains 8 us per launch from
             // the smaller tiles at N = 5120 too: encoder forward 38.86 -> 38.60 ms in-situ; the training epilogues still lose)
-            const bool wide_ok = a->N <= 2048 || a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU);
+            const bool wide_ok = a->N <= 2048 || a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU) ||
+                                 ((NT_WIDE35 & 1) && (a->flags & DICOW_EPI_MUL_AUX)) ||                     // experiments: the dgrad x gelu' epilogue,
+                                 ((NT_WIDE35 & 2) && (a->flags & DICOW_EPI_GELU_DAUX)) ||                   // the training fc1,
+                                 ((NT_WIDE35 & 4) && a->flags == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N)) ||   // qkv,
+                                 ((NT_WIDE35 & 8) && a->flags == 0);                                        // plain dgrad
             const bool use35 = variant == 13 || variant == 22 || (variant != 12 && variant != 21 && a->N >= 320 && wide_ok && w35 < w44);
             const int total = (int)(use35 ? t35 : t44);
             // balanced grid: with r = ceil(total / ncu) rounds needed anyway, ceil(total / r) workgroups each take r (or
