@@ -916,6 +916,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2n_t;
 #ifndef ATTN_OCC4_TAIL
 #define ATTN_OCC4_TAIL 1   // skip the all-padding second key block of the last tile and the all-padding waves of the last query block
 #endif
+#ifndef ATTN_DQ_WGS
+#define ATTN_DQ_WGS 2      // resident workgroups per CU the dq kernel's registers are cut for (3: 168 VGPRs)
+#endif
 #ifndef ATTN_BWD_TAIL
 #define ATTN_BWD_TAIL 1
 #endif
@@ -1317,7 +1320,7 @@ __device__ __forceinline__ void tr_read_block_u(bf16x8_t (&f)[2][2], unsigned a0
 
 // ------------------------------------------------------------------------------------------------ dQ
 template <bool LOG2>        // q carries log2 e (compile-time: the per-score multiply in front of the exponential disappears)
-__global__ void __launch_bounds__(256, 2) attn_bwd_dq_kernel(const dicow_attn_bwd_args a) {
+__global__ void __launch_bounds__(256, ATTN_DQ_WGS) attn_bwd_dq_kernel(const dicow_attn_bwd_args a) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];      // K0 V0 K1 V1 (U images)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
