@@ -367,16 +367,19 @@ __global__ void __launch_bounds__(LNW_WAVES * 64) ln_fwd_wave_kernel(const dicow
 #ifndef FLW_ON
 #define FLW_ON 0        // measured equal to the LDS-staged column-owner kernel (62-68 against 64.5 us in isolation, encoder forward +-0.1 ms over
 #endif                  // 1 / 2 rows x 4 / 8 / 16 waves: profiles/r03_rows_wave.txt): that kernel is not bound by its barriers; kept for A/B builds
+#ifndef FLW_INIT_ON
+#define FLW_INIT_ON 1
+#endif
 #ifndef FLW_MINWG
 #define FLW_MINWG 2       // resident workgroups per CU the register budget is cut for (8 waves each: 128 VGPRs)
 #endif
-template <int NC>
+template <int NC, bool INIT = false>      // INIT: the encoder's initial FDDT -- bf16 rows in, + positions, fp32 rows out, no LayerNorm
 __global__ void __launch_bounds__(FLW_WAVES * 64, FLW_MINWG) fddt_ln_fwd_wave_kernel(const dicow_fddt_ln_fwd_args a) {
     constexpr int R = FLW_R;
     extern __shared__ __attribute__((aligned(16))) char prm[];        // [10 vectors][D] fp32: w0 b0 w1 b1 w2 b2 w3 b3 ln_w ln_b
     const int lane = threadIdx.x & 63, D = a.D;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x * 4; i < 10 * D; i += FLW_WAVES * 64 * 4) {
+    for (int i = threadIdx.x * 4; i < (INIT ? 8 : 10) * D; i += FLW_WAVES * 64 * 4) {
         const int v = i / D, c = i - v * D;
         const float* src = v == 8 ? a.ln_w : v == 9 ? a.ln_b : (v & 1) ? a.b[v >> 1] : a.w[v >> 1];
         *reinterpret_cast<float4*>(prm + (int64_t)i * 4) = ld4(src + c);
@@ -392,7 +395,8 @@ __global__ void __launch_bounds__(FLW_WAVES * 64, FLW_MINWG) fddt_ln_fwd_wave_ke
         for (int r = 0; r < R; ++r) {
             const int row = row0 + r < a.rows ? row0 + r : a.rows - 1;
 #pragma unroll
-            for (int k = 0; k < NC; ++k) xi[r][k] = ROWS_G_NT ? ld4_nt(H + (int64_t)row * D + 4 * lane + 256 * k) : ld4(H + (int64_t)row * D + 4 * lane + 256 * k);
+            for (int k = 0; k < NC; ++k) xi[r][k] = INIT ? ld4_bf16(a.h_in, (int64_t)row * D + 4 * lane + 256 * k)
+                                                         : ROWS_G_NT ? ld4_nt(H + (int64_t)row * D + 4 * lane + 256 * k) : ld4(H + (int64_t)row * D + 4 * lane + 256 * k);
             const int bi = row / a.T, t = row - bi * a.T;
             const float* mp = a.stno + (int64_t)bi * a.stno_bstride + t;
 #pragma unroll
@@ -416,9 +420,22 @@ __global__ void __launch_bounds__(FLW_WAVES * 64, FLW_MINWG) fddt_ln_fwd_wave_ke
                 xh[k] = fddt_diag_pair(f32x2r_t{xi[r][k].z, xi[r][k].w}, FLW_P(0, z, w), FLW_P(1, z, w), FLW_P(2, z, w), FLW_P(3, z, w),
                                        FLW_P(4, z, w), FLW_P(5, z, w), FLW_P(6, z, w), FLW_P(7, z, w), m0, m1, m2, m3);
 #undef FLW_P
+                if constexpr (INIT) {                          // + positions, straight out (separate IEEE adds, as the column-owner body)
+#pragma clang fp contract(off)
+                    const int t = row - (row / a.T) * a.T;
+                    const float4 pz = ld4(a.pos + (int64_t)t * D + 4 * lane + 256 * k);
+                    xl[k] = xl[k] + f32x2r_t{pz.x, pz.y};
+                    xh[k] = xh[k] + f32x2r_t{pz.z, pz.w};
+                    if (row0 + r < a.rows) {
+                        const int64_t off = (int64_t)row * D + 4 * lane + 256 * k;
+                        *reinterpret_cast<u32x2r_t*>(a.h_out + off) = u32x2r_t{__float_as_uint(xl[k].x), __float_as_uint(xl[k].y)};
+                        *reinterpret_cast<u32x2r_t*>(a.h_out + off + 2) = u32x2r_t{__float_as_uint(xh[k].x), __float_as_uint(xh[k].y)};
+                    }
+                }
                 sm += (xl[k].x + xl[k].y) + (xh[k].x + xh[k].y);
                 asm volatile("" ::: "memory");                // (keeps the parameter fragments of the NC chunks from being read all at once: 32 registers each)
             }
+            if constexpr (INIT) continue;
             const float mu = wave_sum_dpp(sm) * inv_d;
             float q = 0.f;
 #pragma unroll
@@ -668,6 +685,32 @@ extern "C" int dicow_fddt_ln_fwd(const dicow_fddt_ln_fwd_args* a, void* stream) 
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL((fddt_ln_fwd_staged_kernel<4>), dim3(grid), dim3(block), 2 * R * 4 * a->D, (hipStream_t)stream, *a);
         DICOW_CHECK_LAUNCH("fddt_ln_fwd_staged");
+        return DICOW_OK;
+    }
+    // the encoder's initial FDDT(diag) + positions (bf16 rows in, fp32 rows out, no LayerNorm): the wave-per-row form with the eight
+    // vectors in LDS (the column-owner body runs this shape at 1.8 TB/s: scalar FDDT arithmetic at two workgroups per CU)
+    if (FLW_INIT_ON && a->mode == 1 && !a->ln_w && a->in_bf16 && a->h_out && a->pos && !a->y_bf16 && !a->y_f32 && a->D % 256 == 0 &&
+        a->D >= 512 && a->D <= 1280 && a->w[0] && a->w[1] && a->w[2] && a->w[3] && a->b[0] && a->b[1] && a->b[2] && a->b[3]) {
+        const int nc = a->D / 256;
+        const int lds = 8 * a->D * 4;
+        const void* fn = nc == 5 ? (const void*)fddt_ln_fwd_wave_kernel<5, true> : nc == 4 ? (const void*)fddt_ln_fwd_wave_kernel<4, true>
+                       : nc == 3 ? (const void*)fddt_ln_fwd_wave_kernel<3, true> : (const void*)fddt_ln_fwd_wave_kernel<2, true>;
+        static int occi[6] = {0};
+        int per_cu = __atomic_load_n(&occi[nc], __ATOMIC_RELAXED);
+        if (per_cu == 0) {
+            (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, FLW_WAVES * 64, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+            __atomic_store_n(&occi[nc], per_cu, __ATOMIC_RELAXED);
+        }
+        int gw = dicow_cdiv(a->rows, FLW_R * FLW_WAVES);
+        if (gw > 256 * per_cu) gw = 256 * per_cu;
+        switch (nc) {
+            case 5: hipLaunchKernelGGL((fddt_ln_fwd_wave_kernel<5, true>), dim3(gw), dim3(FLW_WAVES * 64), lds, (hipStream_t)stream, *a); break;
+            case 4: hipLaunchKernelGGL((fddt_ln_fwd_wave_kernel<4, true>), dim3(gw), dim3(FLW_WAVES * 64), lds, (hipStream_t)stream, *a); break;
+            case 3: hipLaunchKernelGGL((fddt_ln_fwd_wave_kernel<3, true>), dim3(gw), dim3(FLW_WAVES * 64), lds, (hipStream_t)stream, *a); break;
+            default: hipLaunchKernelGGL((fddt_ln_fwd_wave_kernel<2, true>), dim3(gw), dim3(FLW_WAVES * 64), lds, (hipStream_t)stream, *a); break;
+        }
+        DICOW_CHECK_LAUNCH("fddt_fwd_wave_init");
         return DICOW_OK;
     }
     // LayerNorm only, fp32 rows of 256 NC columns: a wave per row (no barrier, no LDS)

@@ -320,7 +320,7 @@ def plain_layer_bwd(lyr, w, s, gb, G, B, T, H):
     return g0
 
 
-def conv_stem_fwd(enc, W, input_features):
+def conv_stem_fwd(enc, W, input_features, need_grad=True):
     """gelu(conv1(x)) -> gelu(conv2(.)) of HF WhisperEncoder (reference encoder.py:167-170: Conv1d k=3 p=1, Conv1d k=3 s=2 p=1)
     as two NT GEMMs over time-major views: a k=3 convolution is a GEMM whose A rows are three consecutive (zero-padded) frames.
     input_features [B, M, 2T] -> (x2 bf16 [B*T, D], saved activations for conv_stem_bwd).  W: EncoderEngine.prepare()."""
@@ -332,11 +332,12 @@ def conv_stem_fwd(enc, W, input_features):
     g1p = _e((B, Tin + 2, D), BF16, dev)
     g1p[:, 0].zero_()
     g1p[:, Tin + 1].zero_()
-    pre1 = _e((B, Tin, D), BF16, dev)
+    # (the pre-activations are only kept for the backward pass: an inference forward does not write them -- 184 MB at B = 16)
+    pre1 = _e((B, Tin, D), BF16, dev) if need_grad else None
     ops.gemm_nt(xt, W.conv1, g1p[:, 1:], Tin, D, W.k1, lda=M, bias=enc.conv1.bias.detach(), aux=pre1, flags=L.EPI_GELU,
                 batch=B, strideA=(Tin + 2) * M, strideC=(Tin + 2) * D, strideAux=Tin * D)
     x2 = _e((B * T, D), BF16, dev)
-    pre2 = _e((B * T, D), BF16, dev)
+    pre2 = _e((B * T, D), BF16, dev) if need_grad else None
     ops.gemm_nt(g1p, W.conv2, x2, T, D, 3 * D, lda=2 * D, bias=enc.conv2.bias.detach(), aux=pre2, flags=L.EPI_GELU,
                 batch=B, strideA=(Tin + 2) * D, strideC=T * D, strideAux=T * D)
     return x2, NS(xt=xt, g1p=g1p, pre1=pre1, pre2=pre2, B=B, T=T, M=M)
@@ -418,7 +419,7 @@ class EncoderEngine:
         stno = stno_mask.to(device=dev, dtype=F32).contiguous()
         S = NS(B0=B, T=T, stno=stno, layers=[], scb=[])
         # ---- conv stem as two GEMMs over time-major views (encoder.py:167-170)
-        x2, stem = conv_stem_fwd(enc, W, input_features)
+        x2, stem = conv_stem_fwd(enc, W, input_features, need_grad=need_grad)
         if need_grad:
             S.stem, S.x2 = stem, x2
         # ---- initial FDDT + positions (encoder.py:173-180)
