@@ -129,6 +129,60 @@ def test_fddt_ln_fused_fwd_bwd_vs_oracle(ops, D, rows, Tn):
     assert maxdiff(cs.cpu(), hp.grad.sum((0, 1))) < 3e-4 * scale
 
 
+@pytest.mark.parametrize("D,B,Tn", [(512, 3, 101), (768, 2, 250), (1024, 1, 333), (1280, 5, 201)])
+def test_wave_per_row_layernorm_and_initial_fddt(ops, D, B, Tn):
+    """The wave-per-row row kernels at every instantiated width (D = 256 NC, NC = 2..5; ragged row counts): LayerNorm forward
+    (bf16 + fp32 outputs, mean, rstd), LayerNorm backward with residual gradient and its three column sums, and the encoder's
+    initial FDDT + positions from bf16 rows (bit-exact against the column-owner arithmetic restated in torch: separate fp32
+    multiplies / adds in the reference's order)."""
+    g = torch.Generator().manual_seed(D + B)
+    rows = B * Tn
+    x = torch.randn(rows, D, generator=g) * 2 + 0.3
+    lw, lb = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    # ---- LayerNorm forward
+    xd = dev(x)
+    yb = torch.empty(rows, D, dtype=torch.bfloat16, device="cuda"); yf = torch.empty(rows, D, device="cuda")
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.fddt_ln_fwd(xd, rows, D, mode=ops.MODE_NONE, ln_w=dev(lw), ln_b=dev(lb), y_bf16=yb, y_f32=yf, mean=mean, rstd=rstd)
+    xr = x.double()
+    mu = xr.mean(1, keepdim=True); var = ((xr - mu) ** 2).mean(1, keepdim=True)
+    ref = ((xr - mu) / torch.sqrt(var + 1e-5)) * lw.double() + lb.double()
+    assert maxdiff(yf.cpu(), ref) < 2e-5 * float(ref.abs().max())
+    assert maxdiff(yb.float().cpu(), ref) < 1e-2 * float(ref.abs().max())
+    assert maxdiff(mean.cpu(), mu[:, 0]) < 1e-5 and maxdiff(rstd.cpu() * torch.sqrt(var[:, 0] + 1e-5).float(), torch.ones(rows)) < 1e-5
+    # ---- LayerNorm backward (+ residual gradient, column sums)
+    dy = torch.randn(rows, D, generator=g).bfloat16()
+    gres = torch.randn(rows, D, generator=g)
+    xa = x.clone().double().requires_grad_(True); lwa = lw.clone().double().requires_grad_(True); lba = lb.clone().double().requires_grad_(True)
+    mu_a = xa.mean(1, keepdim=True); var_a = ((xa - mu_a) ** 2).mean(1, keepdim=True)
+    ya = ((xa - mu_a) / torch.sqrt(var_a + 1e-5)) * lwa + lba
+    ya.backward(dy.double())
+    gref = xa.grad + gres.double()
+    g0 = torch.empty(rows, D, device="cuda"); g0b = torch.empty(rows, D, dtype=torch.bfloat16, device="cuda")
+    dlw, dlb, cs = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), torch.full((D,), 0.25, device="cuda")
+    ops.fddt_ln_bwd(xd, rows, D, mode=ops.MODE_NONE, ln_w=dev(lw), mean=mean, rstd=rstd, d_y=dev(dy, torch.bfloat16), g_res=dev(gres),
+                    g_out=g0, g_out_bf16=g0b, dln_w=dlw, dln_b=dlb, colsum_out=cs)
+    sc = float(gref.abs().max())
+    assert maxdiff(g0.cpu(), gref) < 2e-5 * sc
+    assert maxdiff(g0b.float().cpu(), gref) < 1e-2 * sc
+    assert maxdiff(dlw.cpu(), lwa.grad) < 3e-4 * max(1.0, float(lwa.grad.abs().max()))
+    assert maxdiff(dlb.cpu(), lba.grad) < 3e-4 * max(1.0, float(lba.grad.abs().max()))
+    assert maxdiff(cs.cpu(), 0.25 + gref.sum(0)) < 3e-4 * max(1.0, float(gref.sum(0).abs().max()))
+    # ---- initial FDDT (diag) + positions from bf16 rows: bit-exact
+    xb = (torch.randn(rows, D, generator=g)).bfloat16()
+    st = torch.softmax(torch.randn(B, 4, Tn, generator=g), 1)
+    w = [1 + 0.1 * torch.randn(D, generator=g) for _ in range(4)]
+    b = [0.1 * torch.randn(D, generator=g) for _ in range(4)]
+    pos = torch.randn(Tn, D, generator=g)
+    out = torch.full((rows, D), float("nan"), device="cuda")
+    ops.fddt_ln_fwd(dev(xb, torch.bfloat16), rows, D, mode=ops.MODE_DIAG, stno=dev(st), T=Tn, w=[dev(t) for t in w], b=[dev(t) for t in b],
+                    pos=dev(pos), h_out=out)
+    hf = xb.float().view(B, Tn, D)
+    t = [(hf * w[c] + b[c]) * st[:, c, :, None] for c in range(4)]
+    refi = (((t[0] + t[1]) + t[2]) + t[3]) + pos[None]
+    assert torch.equal(out.cpu().view(B, Tn, D), refi), maxdiff(out.cpu().view(B, Tn, D), refi)
+
+
 # ------------------------------------------------------------------------------------------------ GEMM
 def _bf(x):
     return x.bfloat16().float()
