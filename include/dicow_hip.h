@@ -32,7 +32,7 @@ extern "C" {
 #define DICOW_ERR_INVALID (-1)  /* bad argument / unsupported shape */
 #define DICOW_ERR_LAUNCH (-2)   /* HIP launch failure */
 
-#define DICOW_ABI_VERSION 2
+#define DICOW_ABI_VERSION 3
 
 int dicow_abi_version(void);
 /* Number of CUs the persistent NT GEMM may occupy (0 = all, the default).  Its workgroups own a whole CU each for the
@@ -170,6 +170,7 @@ int dicow_fddt_full_combine_bwd(const float* g, const float* stno, int64_t stno_
 #define DICOW_EPI_MUL_AUX  256   /* C = acc * aux[m,n]  (aux = saved gelu' from GELU_DAUX, bf16)                      */
 #define DICOW_EPI_COLSUM   512   /* colsum_out[n] += sum_m C[m,n] (bias gradient of the layer that produced the GEMM's */
                                  /* input gradient); needs colsum_ws of dicow_gemm_nt_colsum_ws_bytes(M, N) bytes     */
+#define DICOW_EPI_FDDT    1024   /* with BIAS | RESIDUAL | OUT_F32: C = FDDT_next(bf16(acc + bias) + residual); persistent kernel only  */
 typedef struct {
     const void* A; const void* B; void* C;
     const float* bias; const float* residual; void* aux;
@@ -178,7 +179,15 @@ typedef struct {
     int batch; int64_t strideA, strideB, strideC, strideAux;   /* grid.z batches (conv stem: per-utterance strided views) */
     int flags; float scale; int scale_ncols;
     float* colsum_out; void* colsum_ws; int64_t colsum_ws_bytes;   /* DICOW_EPI_COLSUM only (else NULL / 0) */
+    /* DICOW_EPI_FDDT only (ABI 3): the diagonal FDDT of the NEXT encoder layer applied to the fp32 result row by row
+       (reference FDDT.py:41-63 in its evaluation order, bit-identical to dicow_fddt_ln_fwd's h_out):
+       fddt_w[c] / fddt_b[c] = the [N] fp32 weight / bias vectors of class c (S, T, N, O), fddt_rowmask = [>= M rounded up to the
+       tile height + 64 rows][4] fp32, row m = the four STNO class masks of output row m */
+    const float* fddt_w[4]; const float* fddt_b[4]; const float* fddt_rowmask;
 } dicow_gemm_args;
+/* 1 when dicow_gemm_nt will run this problem on the persistent ring kernel with a compile-time epilogue (the only path
+   that implements DICOW_EPI_FDDT), else 0 */
+int dicow_gemm_nt_is_persistent(const dicow_gemm_args* a);
 int dicow_gemm_nt(const dicow_gemm_args* a, void* stream);
 int64_t dicow_gemm_nt_colsum_ws_bytes(int M, int N);
 /* Deep contraction, small output (K >= 8192, fewer 128 x 128 tiles than workgroup slots, no epilogue: the tied LM head's dgrad,

@@ -228,6 +228,36 @@ def test_gemm_nt64_decoder_shapes(ops, M, N, K):
     assert torch.equal(C4, Cf)
 
 
+@pytest.mark.parametrize("M,N,K,Tn", [(6100, 2244, 128, 305), (12200, 1284, 192, 1525), (24000, 1280, 128, 1500)])
+def test_gemm_nt_fddt_epilogue_bit_exact(ops, M, N, K, Tn):
+    """DICOW_EPI_FDDT: the next layer's diagonal FDDT applied in the fp32-residual epilogue of the persistent GEMM equals, bit for
+    bit, the same GEMM without it followed by the FDDT row kernel (ragged rows / columns, tail column block included); problems
+    below the persistent kernel's threshold are refused."""
+    from ts_asr_whisper_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N)
+    B = M // Tn
+    assert B * Tn == M
+    A, Bm = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * K ** -0.5)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    st = torch.softmax(torch.randn(B, 4, Tn, generator=g), 1)
+    w = [dev(1 + 0.1 * torch.randn(N, generator=g)) for _ in range(4)]
+    b = [dev(0.1 * torch.randn(N, generator=g)) for _ in range(4)]
+    Ad, Bd, biasd, resd, std = dev(A, torch.bfloat16), dev(Bm, torch.bfloat16), dev(bias), dev(res), dev(st)
+    assert ops.gemm_nt(Ad, Bd, resd, M, N, K, bias=biasd, residual=resd, query_persistent=True)
+    rowmask = torch.zeros((M + 191) // 192 * 192 + 64, 4, device="cuda")
+    rowmask[:M].view(B, Tn, 4).copy_(std.permute(0, 2, 1))
+    C1 = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_nt(Ad, Bd, C1, M, N, K, bias=biasd, residual=resd, fddt=(w, b, rowmask))
+    C0 = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(Ad, Bd, C0, M, N, K, bias=biasd, residual=resd)
+    ref = torch.empty(M, N, device="cuda")
+    ops.fddt_ln_fwd(C0, M, N, mode=ops.MODE_DIAG, stno=std, T=Tn, w=w, b=b, h_out=ref)
+    assert torch.equal(C1, ref), float((C1 - ref).abs().max())
+    with pytest.raises(L.DicowError):
+        small = torch.empty(300, N, device="cuda")
+        ops.gemm_nt(Ad[:300], Bd, small, 300, N, K, bias=biasd, residual=resd[:300], fddt=(w, b, rowmask))
+
+
 @pytest.mark.parametrize("R,C,ld,ld_t", [(1280, 1280, None, None), (3840, 1280, None, None), (200, 136, 144, 208), (77, 130, None, None)])
 def test_cast_transpose(ops, R, C, ld, ld_t):
     """AMP weight copies: bf16 [R,C] and bf16 [C,R] of an fp32 matrix (vectorised kernel and the scalar fallback)."""

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()                       # raises loudly if the .so has not been built
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dicow_abi_version() == 2
+    assert lib.dicow_abi_version() == 3
 
 
 def test_no_cpu_fallback_and_oracle_not_imported_by_product():

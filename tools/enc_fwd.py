@@ -9,6 +9,9 @@ pkg = amd_pkg.load()
 from ts_asr_whisper_amd.data import synthetic_batch
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+if os.environ.get("ENC_NO_FUSE") == "1":            # A/B: the next layer's FDDT as its own row kernel again
+    from ts_asr_whisper_amd import engine as _eng
+    _eng.FUSE_NEXT_FDDT = False
 model_name = os.environ.get("ENC_MODEL", "whisper-large-v3-turbo")
 B = int(os.environ.get("ENC_BATCH", "16"))
 cfg = pkg.DiCoWConfig.preset(model_name, use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True, fddt_init="suppressive",

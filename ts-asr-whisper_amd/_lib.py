@@ -30,7 +30,8 @@ class GemmArgs(C.Structure):
                 ("lda", c_i64), ("ldb", c_i64), ("ldc", c_i64), ("ldr", c_i64), ("ldaux", c_i64),
                 ("batch", c_i), ("strideA", c_i64), ("strideB", c_i64), ("strideC", c_i64), ("strideAux", c_i64),
                 ("flags", c_i), ("scale", c_f), ("scale_ncols", c_i),
-                ("colsum_out", c_vp), ("colsum_ws", c_vp), ("colsum_ws_bytes", c_i64)]
+                ("colsum_out", c_vp), ("colsum_ws", c_vp), ("colsum_ws_bytes", c_i64),
+                ("fddt_w", c_vp * 4), ("fddt_b", c_vp * 4), ("fddt_rowmask", c_vp)]
 
 
 class GemmTnArgs(C.Structure):
@@ -89,7 +90,7 @@ class CtcPrefixArgs(C.Structure):
 
 
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_SCALE_N, EPI_GELU_BWD, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
-EPI_GELU_DAUX, EPI_MUL_AUX, EPI_COLSUM = 128, 256, 512
+EPI_GELU_DAUX, EPI_MUL_AUX, EPI_COLSUM, EPI_FDDT = 128, 256, 512, 1024
 
 # name -> argtypes ; every function returns int
 _SIGS = {
@@ -112,6 +113,7 @@ _SIGS = {
     "dicow_fddt_full_combine_fwd": [c_vp, c_vp, c_i, c_vp, c_i64, c_i, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_fddt_full_combine_bwd": [c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_gemm_nt": [C.POINTER(GemmArgs), c_vp],
+    "dicow_gemm_nt_is_persistent": [C.POINTER(GemmArgs)],
     "dicow_gemm_tn": [C.POINTER(GemmTnArgs), c_vp],
     "dicow_gemm_tn_group": [C.POINTER(GemmTnGroupArgs), c_vp],
     "dicow_attn_fwd": [C.POINTER(AttnFwdArgs), c_vp],

@@ -20,6 +20,10 @@
 #define BK 64
 #define STAGE_BYTES (BM * BK * 2)          // 16 KiB per operand per stage
 #define NT_LDS_BYTES (4 * STAGE_BYTES)     // A0 B0 A1 B1
+#define NT_FDDT_FLAGS (DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32 | DICOW_EPI_FDDT)
+#ifndef NT_BIG_TILES
+#define NT_BIG_TILES 200      // (see gemm_nt_impl)
+#endif
 #ifndef NT128_THREADED
 #define NT128_THREADED 3      // 0: gemm_nt_kernel<2, false>; 3: its order with descriptor addressing (shipped); 1 / 2: one barrier per step, requests threaded / in a burst (measured slower in situ)
 #endif
@@ -134,6 +138,29 @@ __device__ __forceinline__ void nt_epilogue_math(const dicow_gemm_args& a, int r
 
 // NQ quads of one pass at once (compile-time flags only), stage-major like gelu_cdf_pdf_n: v / dg hold 4 * NQ values, quad u
 // at [4u, 4u + 4).  All quads share the column quad n (one bias quad); pre_aux / pre_res point at NQ consecutive entries.
+// The diagonal FDDT of one output quad in the reference's evaluation order (FDDT.py:41-63: separate fp32 multiplies / adds, no
+// contraction -- the same packed IEEE operations as fddt_ln.hip's fddt_diag_pair, so the result is bit-identical to the row kernel's)
+typedef __attribute__((ext_vector_type(2))) float f32x2g_t;
+__device__ __forceinline__ void nt_fddt_quad(float* v, const float4* w, const float4* b, const float* m) {
+#pragma clang fp contract(off)
+    const f32x2g_t hl = {v[0], v[1]}, hr = {v[2], v[3]};
+    f32x2g_t tl[4], tr[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x2g_t mc = {m[c], m[c]};
+        tl[c] = (hl * f32x2g_t{w[c].x, w[c].y} + f32x2g_t{b[c].x, b[c].y}) * mc;
+        tr[c] = (hr * f32x2g_t{w[c].z, w[c].w} + f32x2g_t{b[c].z, b[c].w}) * mc;
+    }
+    const f32x2g_t ol = ((tl[0] + tl[1]) + tl[2]) + tl[3], orr = ((tr[0] + tr[1]) + tr[2]) + tr[3];
+    v[0] = ol.x; v[1] = ol.y; v[2] = orr.x; v[3] = orr.y;
+}
+#ifndef NTR_FDDT_DUMMY
+#define NTR_FDDT_DUMMY 0
+#endif
+__device__ __forceinline__ float rv_dummy(const float4* pr, int e, int c) {      // (row-dependent stand-in for a mask value)
+    const float4 q = pr[(e >> 2)];
+    return c == 0 ? q.x * 1e-9f : c == 1 ? q.y * 1e-9f : c == 2 ? q.z * 1e-9f : q.w * 1e-9f;
+}
 template <int FLAGS, int NQ>
 __device__ __forceinline__ void nt_epilogue_math_n(const dicow_gemm_args& a, float (&v)[4 * NQ], float (&dg)[4 * NQ], int n,
                                                    const float4& bv, const uint2* pre_aux, const float4* pre_res) {
@@ -194,6 +221,22 @@ __device__ __forceinline__ void nt_epilogue_math_n(const dicow_gemm_args& a, flo
             v[4 * u] = bf2f(f2bf(v[4 * u])) + rv.x; v[4 * u + 1] = bf2f(f2bf(v[4 * u + 1])) + rv.y;
             v[4 * u + 2] = bf2f(f2bf(v[4 * u + 2])) + rv.z; v[4 * u + 3] = bf2f(f2bf(v[4 * u + 3])) + rv.w;
         }
+#if NTR_FDDT_DUMMY
+        // timing experiment only (results wrong): the arithmetic an FDDT of the NEXT layer would add to this epilogue -- four
+        // (h w_c + b_c) m_c terms and their ordered sum per element, stand-in operands
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const float h = v[e];
+                // (operands chosen so that the result stays ~h: the step's timing depends on the DATA the following GEMMs see)
+                const float w0 = 1.0f + 1e-9f * bv.x, w1 = 1.0f + 1e-9f * bv.y, w2 = 1.0f + 1e-9f * bv.z, w3 = 1.0f + 1e-9f * bv.w;
+                const float t0 = (h * w0 + 1e-9f * bv.y) * (0.25f + rv_dummy(pre_res, e, 0)), t1 = (h * w1 + 1e-9f * bv.z) * (0.25f + rv_dummy(pre_res, e, 1));
+                const float t2 = (h * w2 + 1e-9f * bv.w) * (0.25f + rv_dummy(pre_res, e, 2)), t3 = (h * w3 + 1e-9f * bv.x) * (0.25f + rv_dummy(pre_res, e, 3));
+                v[e] = ((t0 + t1) + t2) + t3;
+            }
+        }
+#endif
     }
 }
 
@@ -1278,6 +1321,15 @@ __global__ void nt_splitk_reduce_kernel(const float* __restrict__ ws, int splits
     }
 }
 
+extern "C" int dicow_gemm_nt_is_persistent(const dicow_gemm_args* a) {
+    if (!a || a->M < 256 || a->N < 256 || a->K < 2 * BK || a->K % BK != 0) return 0;
+    const int batch = a->batch > 0 ? a->batch : 1;
+    const bool off32 = (int64_t)a->M * a->lda * 2 < (1ll << 31) && (int64_t)a->N * a->ldb * 2 < (1ll << 31) &&
+                       (int64_t)a->M * a->ldc * 4 < (1ll << 31) && (int64_t)a->M * a->ldaux * 2 < (1ll << 31) &&
+                       (int64_t)a->M * a->ldr * 4 < (1ll << 31);
+    return (off32 && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= NT_BIG_TILES) ? 1 : 0;
+}
+
 extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     DICOW_REQUIRE(a && a->A && a->B && a->C, "gemm_nt: null operand");
     if (!(a->flags & DICOW_EPI_COLSUM)) {
@@ -1326,6 +1378,7 @@ static void gemm_nt_setup() {
     NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTR_ATTR(DICOW_EPI_MUL_AUX);
     NTR_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
 #undef NTR_ATTR
+    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FDDT_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
 #ifdef DICOW_ABLATIONS
     (void)hipFuncSetAttribute((const void*)gemm_nt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NTS_LDS);
 #define NTW_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntw_kernel<F, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS); \
@@ -1414,6 +1467,8 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     constexpr int big_tiles = NT_BIG_TILES;
 #endif
     const bool big = off32 && a->K >= 2 * BK && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= big_tiles;
+    DICOW_REQUIRE(!(a->flags & DICOW_EPI_FDDT) || (variant == 0 && big && a->M >= 256 && a->N >= 320),
+                  "gemm_nt: EPI_FDDT is implemented by the persistent kernel only (M=%d N=%d K=%d is below its threshold: ask dicow_gemm_nt_is_persistent)", a->M, a->N, a->K);
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
         if (variant == 0 || variant >= 11) {
             const int lim = g_gemm_cus.load();
@@ -1432,7 +1487,12 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
                                  ((NT_WIDE35 & 2) && (a->flags & DICOW_EPI_GELU_DAUX)) ||                   // the training fc1,
                                  ((NT_WIDE35 & 4) && a->flags == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N)) ||   // qkv,
                                  ((NT_WIDE35 & 8) && a->flags == 0);                                        // plain dgrad
-            const bool use35 = variant == 13 || variant == 22 || (variant != 12 && variant != 21 && a->N >= 320 && wide_ok && w35 < w44);
+            const bool fddt = (a->flags & DICOW_EPI_FDDT) != 0;      // (only the 192 x 320 instantiation carries that epilogue)
+            DICOW_REQUIRE(!fddt || (a->flags == NT_FDDT_FLAGS && variant == 0 && a->N >= 320 && batch == 1 && a->fddt_rowmask &&
+                                    a->fddt_w[0] && a->fddt_w[1] && a->fddt_w[2] && a->fddt_w[3] && a->fddt_b[0] && a->fddt_b[1] &&
+                                    a->fddt_b[2] && a->fddt_b[3]),
+                          "gemm_nt: EPI_FDDT needs BIAS | RESIDUAL | OUT_F32, N >= 320, one batch, the eight vectors and the row masks");
+            const bool use35 = fddt || variant == 13 || variant == 22 || (variant != 12 && variant != 21 && a->N >= 320 && wide_ok && w35 < w44);
             const int total = (int)(use35 ? t35 : t44);
             // balanced grid: with r = ceil(total / ncu) rounds needed anyway, ceil(total / r) workgroups each take r (or
             // r - 1) tiles -- e.g. 470 tiles run on 235 workgroups x 2 instead of 214 x 2 + 42 x 1: same makespan, fewer
@@ -1455,7 +1515,7 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
                 const int f_ = a->flags;
                 const bool ct_ = variant != 11 && (f_ == 0 || f_ == DICOW_EPI_BIAS || f_ == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N) || f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU) ||
                                                    f_ == (DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32) || f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX) ||
-                                                   f_ == DICOW_EPI_MUL_AUX || f_ == (DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM));
+                                                   f_ == DICOW_EPI_MUL_AUX || f_ == (DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM) || f_ == NT_FDDT_FLAGS);
                 disp_note("gemm_ntr_kernel<%d, %d, %d>", ct_ ? f_ : -1, use35 ? 3 : 4, use35 ? 5 : 4);
             }
             switch (variant == 11 ? -1 : a->flags) {   // compile-time epilogues for the flag sets the training step uses
@@ -1465,6 +1525,7 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
                 case DICOW_EPI_BIAS | DICOW_EPI_GELU: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_GELU); break;
                 case DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32); break;
                 case DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); break;
+                case NT_FDDT_FLAGS: hipLaunchKernelGGL((gemm_ntr_kernel<NT_FDDT_FLAGS, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); break;
                 case DICOW_EPI_MUL_AUX: NTW_LAUNCH(DICOW_EPI_MUL_AUX); break;
                 case DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM: NTW_LAUNCH(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM); break;
                 default: NTW_LAUNCH(-1); break;

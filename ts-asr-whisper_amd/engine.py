@@ -191,16 +191,17 @@ def full_fddt_bwd(fddt, w, hb, g, stno, bstride, G, rows, T, D):
 # kernel's probabilities are p = 2^s with no arithmetic in front of the exponential and the backward kernels lose their per-score
 # multiply.  Same softmax, same lse (natural log), same gradients; dq_scale keeps its meaning (include/dicow_hip.h).
 QK_LOG2 = True
+FUSE_NEXT_FDDT = True         # inference forward: the next layer's diagonal FDDT in the fc2 epilogue (see EncoderEngine.forward)
 Q_SCALE = 0.125 * (ops.LOG2E if QK_LOG2 else 1.0)
 
 
 # ------------------------------------------------------------------------------------------------ building blocks
-def linear_fwd(x, lw, M, out_dtype=BF16, residual=None, gelu_aux=None, flags=0, scale=1.0, scale_ncols=0, out=None):
+def linear_fwd(x, lw, M, out_dtype=BF16, residual=None, gelu_aux=None, flags=0, scale=1.0, scale_ncols=0, out=None, fddt=None):
     dev = x.device
     if out is None:
         out = _e((M, lw.N), out_dtype, dev)
     ops.gemm_nt(x, lw.w, out, M, lw.N, lw.K, bias=lw.b, residual=residual, aux=gelu_aux,
-                flags=flags | ((L.EPI_GELU | L.EPI_GELU_DAUX) if gelu_aux is not None else 0), scale=scale, scale_ncols=scale_ncols)
+                flags=flags | ((L.EPI_GELU | L.EPI_GELU_DAUX) if gelu_aux is not None else 0), scale=scale, scale_ncols=scale_ncols, fddt=fddt)
     return out
 
 
@@ -435,12 +436,27 @@ class EncoderEngine:
             ops.fddt_ln_fwd(x2, rows, D, mode=mode, stno=stno, T=T, w=fw, b=fb, pos=pos.detach(), h_out=h)
         bstride = 4 * T
         Bc = B
+        # Inference forward: nothing reads the un-conditioned residual stream, and the diagonal FDDT is element-wise given a row's four
+        # masks and a column's eight parameters -- layer i's fc2 epilogue writes FDDT_(i+1)(h) directly (DICOW_EPI_FDDT, bit-identical
+        # to the row kernel) and layer i+1 starts with a plain LayerNorm.  Needs the row masks row-major: [rows (+ tile padding), 4].
+        fuse_next = (FUSE_NEXT_FDDT and not need_grad and cfg.use_fddt and not cfg.use_enrollments and all(f is None for f in W.full)
+                     and ops.gemm_nt(h, W.layers[0].fc2.w, h, rows, D, F_, residual=h, bias=W.layers[0].fc2.b, query_persistent=True))
+        rowmask = None
+        if fuse_next:
+            rowmask = torch.zeros(_ceil(rows, 192) + 64, 4, dtype=F32, device=dev)
+            rowmask[:rows].view(B, T, 4).copy_(stno.permute(0, 2, 1))
+        fddt_done = False                                # h already carries this layer's FDDT (written by the previous fc2)
         for i, lyr in enumerate(enc.layers):
             w = W.layers[i]
             Ls = NS(h_in=h, B=Bc, bstride=bstride)
             rows = Bc * T
             fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None
             mode, fw, fb = fddt_ptrs(fd, cfg)
+            if fddt_done:
+                mode, fw, fb = ops.MODE_NONE, (None,) * 4, (None,) * 4
+            nfd = enc.fddts[i + 1] if (fuse_next and i + 1 < len(enc.layers) and i + 1 < len(enc.fddts)) else None
+            nmode, nfw, nfb = fddt_ptrs(nfd, cfg)
+            fuse_here = nfd is not None and nmode == ops.MODE_DIAG and all(t is not None for t in nfw) and all(t is not None for t in nfb)
             use_scb = cfg.use_enrollments and cfg.scb_layers is not None and i < cfg.scb_layers
             wfull = W.full[i] if (fd is not None and i < len(W.full)) else None
             if wfull is not None:                    # dense FDDT: its own GEMM + combine, the rest of the layer sees "no FDDT"
@@ -492,7 +508,9 @@ class EncoderEngine:
                 a = linear_fwd(xln2, w.fc1, rows, gelu_aux=u)
             else:
                 u, a = None, linear_fwd(xln2, w.fc1, rows, flags=L.EPI_GELU)
-            h = linear_fwd(a, w.fc2, rows, out_dtype=F32, residual=h2)
+            h = linear_fwd(a, w.fc2, rows, out_dtype=F32, residual=h2,
+                           fddt=(tuple(t.detach() for t in nfw), tuple(t.detach() for t in nfb), rowmask) if fuse_here else None)
+            fddt_done = fuse_here
             if need_grad:                                         # inference: nothing is kept, buffers recycle per layer
                 Ls.qkv, Ls.o, Ls.lse, Ls.h2, Ls.xln2, Ls.mean2, Ls.rstd2, Ls.u, Ls.a = qkv, o, lse, h2, xln2, mean2, rstd2, u, a
                 S.layers.append(Ls)

@@ -211,10 +211,17 @@ def fddt_ln_bwd(h_in, rows, D, *, mode=MODE_NONE, stno=None, stno_bstride=None, 
 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residual=None, ldr=None, aux=None,
-            ldaux=None, flags=0, scale=1.0, scale_ncols=0, batch=1, strideA=0, strideB=0, strideC=0, strideAux=0, colsum_out=None):
+            ldaux=None, flags=0, scale=1.0, scale_ncols=0, batch=1, strideA=0, strideB=0, strideC=0, strideAux=0, colsum_out=None,
+            fddt=None, query_persistent=False):
     """C[M,N] = epilogue(A[M,K] @ B[N,K]^T).  Pointers + leading dimensions; see include/dicow_hip.h.
-    colsum_out [N] fp32: += column sums of the result (a bias gradient), fused into the epilogue."""
+    colsum_out [N] fp32: += column sums of the result (a bias gradient), fused into the epilogue.
+    fddt = (w[4], b[4], rowmask): DICOW_EPI_FDDT, the next layer's diagonal FDDT applied to the fp32 result (persistent kernel only).
+    query_persistent: launch nothing, return dicow_gemm_nt_is_persistent for this problem."""
     a = L.GemmArgs()
+    if fddt is not None:
+        fw, fb, rowmask = fddt
+        a.fddt_w, a.fddt_b, a.fddt_rowmask = _arr4(fw), _arr4(fb), rowmask.data_ptr()
+        flags |= L.EPI_FDDT
     a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), C_out.data_ptr()
     a.bias, a.residual, a.aux = _p(bias), _p(residual), _p(aux)
     a.M, a.N, a.K = M, N, K
@@ -235,6 +242,8 @@ def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, re
         ws = workspace(L.lib().dicow_gemm_nt_colsum_ws_bytes(M, N), C_out.device)
         a.colsum_out, a.colsum_ws, a.colsum_ws_bytes = colsum_out.data_ptr(), ws.data_ptr(), ws.numel()
     a.flags, a.scale, a.scale_ncols = flags, scale, scale_ncols
+    if query_persistent:
+        return bool(L.lib().dicow_gemm_nt_is_persistent(C.byref(a)))
     if K >= 8192 and colsum_out is None:             # deep contraction, small output: split ranges + ordered sum (LM-head dgrad)
         need = L.lib().dicow_gemm_nt_splitk_ws_bytes(C.byref(a))
         if need:
