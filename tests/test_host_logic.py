@@ -40,6 +40,27 @@ def test_library_exports_every_declared_symbol():
     assert lib.dicow_abi_version() == 3
 
 
+def test_gemm_nt_is_persistent_host_logic():
+    """dicow_gemm_nt_is_persistent is host logic (no launch): the headline fc2 shape runs on the persistent kernel -- the only one
+    that implements DICOW_EPI_FDDT -- and a decoder-sized or ragged-K problem does not.  Also pins the ctypes layout of
+    dicow_gemm_args up to the fields the predicate reads."""
+    import ctypes as C
+    from ts_asr_whisper_amd import _lib
+    lib = _lib.lib()
+
+    def q(M, N, K, batch=1):
+        a = _lib.GemmArgs()
+        a.A = a.B = a.C = 1 << 20
+        a.M, a.N, a.K = M, N, K
+        a.lda, a.ldb, a.ldc, a.ldr, a.ldaux, a.batch = K, K, N, N, N, batch
+        return lib.dicow_gemm_nt_is_persistent(C.byref(a))
+
+    assert q(24000, 1280, 5120) == 1 and q(24000, 5120, 1280) == 1 and q(12000, 1536, 512) == 1
+    assert q(1024, 512, 512) == 0 and q(24000, 1280, 64) == 0 and q(200, 1280, 1280) == 0
+    assert q(12000, 512, 2048) == 0                      # whisper-base's N = 512 shapes stay on the 128 x 128 kernel
+    assert _lib.EPI_FDDT == 1024 and C.sizeof(_lib.GemmArgs) % 8 == 0
+
+
 def test_no_cpu_fallback_and_oracle_not_imported_by_product():
     src_dir = os.path.join(ROOT, "ts-asr-whisper_amd")
     for fn in os.listdir(src_dir):
