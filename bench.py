@@ -569,21 +569,38 @@ def main():
         if a.se:
             kw_e["enrollments"] = b0["enrollments"]
             enc_flops = None                                   # (the SE encoder's count differs; report the time only)
-        with torch.no_grad():
-            for _ in range(2):
-                model.model.encoder(b0["input_features"], **kw_e)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(5):
-                model.model.encoder(b0["input_features"], **kw_e)
-            e1.record()
-            torch.cuda.synchronize()
-        enc_ms = e0.elapsed_time(e1) / 5
-        out["encoder_forward"] = {"ms": round(enc_ms, 2), "batch": a.batch,
-                                  "tflops": None if enc_flops is None else round(enc_flops / enc_ms / 1e9, 1),
-                                  "mfma_frac": None if enc_flops is None else round(enc_flops / enc_ms / 1e9 / peak, 4),
-                                  "note": "encoder forward only, torch.no_grad(), algorithmic FLOPs of SURVEY 8d / dense bf16 peak 2.5 PF"}
+        def time_encoder(grad):
+            # grad = False: torch.no_grad(), nothing kept for a backward pass (the inference-specialised forward: the next layer's
+            # FDDT in the fc2 epilogue, no gelu' / pre-activation stores).  grad = True: the forward the TRAINING STEP runs
+            # (need_grad: FDDT + LayerNorm row kernel, gelu' saved by fc1, every activation of every layer kept until the output
+            # is dropped) -- the same launches as the forward half of a timed step, timed alone.
+            with torch.set_grad_enabled(grad):
+                for _ in range(2):
+                    o_ = model.model.encoder(b0["input_features"], **kw_e)
+                    del o_
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    o_ = model.model.encoder(b0["input_features"], **kw_e)
+                    del o_
+                e1.record()
+                torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 5
+
+        def enc_entry(ms_, note):
+            return {"ms": round(ms_, 2), "batch": a.batch, "tflops": None if enc_flops is None else round(enc_flops / ms_ / 1e9, 1),
+                    "mfma_frac": None if enc_flops is None else round(enc_flops / ms_ / 1e9 / peak, 4), "note": note}
+
+        enc_ms = time_encoder(False)
+        out["encoder_forward"] = enc_entry(enc_ms, "encoder forward only, torch.no_grad() (inference-specialised launches), algorithmic "
+                                                   "FLOPs of SURVEY 8d / dense bf16 peak 2.5 PF")
+        try:
+            assert any(p_.requires_grad for p_ in model.model.encoder.parameters())
+            out["encoder_forward_train"] = enc_entry(time_encoder(True), "encoder forward only, gradients enabled: the forward the training "
+                                                     "step runs (activations, gelu' and LayerNorm statistics saved for the backward pass)")
+        except Exception as ex:
+            out["encoder_forward_train"] = {"ms": None, "note": f"failed: {ex!r}"}
     except Exception as ex:
         out["encoder_forward"] = {"ms": None, "note": f"failed: {ex!r}"}
     out["roofline"]["traffic"] = pmc_traffic(ops.gemm_dispatch_log())

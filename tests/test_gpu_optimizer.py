@@ -76,6 +76,7 @@ def test_train_step_update_rule_with_staged_freezing():
         for n in names:
             grads[n] = torch.randn(named[n].shape, generator=g) * (0.05 if "fddt" in n else 0.002)
             named[n].grad.copy_(grads[n])                     # the flat-store view the engine accumulates into
+            named[n]._grad_overwrite = False                  # (what the engine's first-writer GEMM does: "this gradient was written")
         ts.finish_step()
         ref.step(grads)
         worst = max(float((named[n].detach().cpu() - ref.p[n].detach()).abs().max()) for n in named)

@@ -91,6 +91,10 @@ ts = TrainStep(model, lr=1e-4, fddt_lr_multiplier=10.0, use_fddt_only_n_steps=1,
                preheat_prefixes=("model.encoder.fddts", "model.encoder.initial_fddt"))
 if use_pg:
     assert ts.reducer.force and ts.reducer.stream is not None and ts.reducer.world == 1
+    # start-up replica sync (DDP's constructor broadcast) ran through RCCL: flat store + frozen parameters + buffers, a no-op in value
+    assert ts.replica_sync == "broadcast" and ts.replica_sync_bytes >= 4 * ts.store.numel, ts.replica_sync_bytes
+else:
+    assert ts.replica_sync_bytes == 0
 batches = [synthetic_batch(cfg, 2, 12, seed=40 + i) for i in range(2)]
 losses = [float(ts.step(batches[i % 2])) for i in range(3)]          # step 1: preheat-only exchange, then the bucketed one
 losses.append(float(ts.step([batches[0], batches[1]])))              # gradient accumulation: one exchange after the last micro-batch

@@ -211,3 +211,101 @@ def test_configs2_batch16_step_row0_vs_reference_golden_and_loss_is_the_mean_of_
         if p.requires_grad:
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
     print("configs[2] B=16: worst row-vs-B=1 encoder deviation", worst_inv, "loss", float(out.loss), "mean of rows", mean_rows)
+    worst = _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checked=20)
+    print("configs[2] B=16: worst watched gradient, B=16 step vs mean of the 16 B=1 steps (rel-L2):", worst)
+
+
+def _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checked, prefix="hard"):
+    """The B = 16 BACKWARD as a step (24000-row dgrad rings, the pooled weight-gradient launch, the staged row backward, first-writer
+    gradients -- variants no B = 1 run reaches), value-checked: the hard loss is the mean over ALL B x L label positions
+    (modeling_dicow.py:310-323), i.e. the mean of the rows' own B = 1 losses, so for every watched parameter
+        grad(B = 16 step) == (1 / 16) * sum_r grad(B = 1 step on row r)
+    within the golden's gradient tolerance max(5e-2, 4 x the reference's bf16 deviation); and row 0's B = 1 gradients are the
+    golden's own case, checked against the reference directly.  Expects model's .grad to hold the B = 16 step's gradients."""
+    names = [n for n in str(z["watched"]).split("\n")]
+    named = dict(model.named_parameters())
+    names = [n for n in names if n in named and named[n].grad is not None]
+    g16 = {n: named[n].grad.detach().float().clone() for n in names}
+    acc = {n: torch.zeros_like(g16[n], dtype=torch.float64) for n in names}
+    for r in range(B):
+        model.zero_grad(set_to_none=True)
+        row = {k: ({kk: vv[r:r + 1] for kk, vv in v.items()} if isinstance(v, dict) else v[r:r + 1]) for k, v in batch.items()}
+        o1 = model(**row)
+        o1.loss.backward()
+        if r == 0:                                          # the golden's own sample: its gradients vs the reference's
+            _check_grads(z, model, prefix, names, min_checked=min_checked)
+        for n in names:
+            acc[n] += named[n].grad.detach().double()
+    worst, checked = (0.0, None), 0
+    kinds = set()
+    for n in names:
+        mean = (acc[n] / B).float()
+        key = f"bf16.g.reldev.{n}"
+        dev = float(z[key]) if key in z.files else 0.0
+        tol = max(5e-2, 4 * dev)
+        rel = _rel_l2(g16[n], mean)
+        assert rel < tol, (n, rel, tol)
+        worst = max(worst, (rel, n))
+        checked += 1
+        kinds.add("fddt" if "fddt" in n else "ln" if "layer_norm" in n else "conv" if ".conv" in n else
+                  "scb" if "ca_enrolls" in n else "matrix" if named[n].dim() == 2 else "vector")
+    assert checked >= 12 and {"fddt", "ln", "conv", "matrix", "vector"} <= kinds, (checked, kinds)
+    return worst
+
+
+def test_configs4_per_rank_workload_se_dicow_batch16_mixed_length_vs_reference_golden_and_rows():
+    """BASELINE.json configs[4]'s PER-RANK workload at its own batch size: SE-DiCoW large-v3-turbo, scb_layers = 8, B = 16
+    mixture + enrollment pairs, mixed-length clips (10-30 s mixtures, 5-30 s enrollments, padding frames = silence,
+    collators.py:157-161), hashed weights.  Row 0 is golden rd_turbo_se's sample (the real reference's run):
+      * row 0's encoder output / logits within rd_turbo_se's tolerances when computed inside the B = 16 batch;
+      * every row's encoder output equals its own B = 1 forward; the loss is the mean of the rows' losses;
+      * the B = 16 backward's watched gradients (incl. the speaker-communication blocks') are the mean of the 16 B = 1
+        backwards', and row 0's B = 1 gradients match the reference.
+    Matches modeling_dicow.py:248-354, encoder.py:152-154 (interleave), :210-213 (enrollment rows dropped after the last block)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import types
+    from tests.util import hashed_stno, hashed_labels
+    z = load_golden("rd_turbo_se")
+    model, cfg = _build(z)
+    assert cfg.use_enrollments and cfg.scb_layers == 8
+    B, L, T = 16, int(z["L"]), cfg.max_source_positions
+    b1 = _batch(z, cfg)
+    x = torch.from_numpy(hashed_mel(2 * B, cfg.num_mel_bins, 2 * T)).clone() * 1.5
+    st = hashed_stno(2 * B, T, "rd_turbo_se_b16.stno")
+    # clip lengths: mixtures 10-30 s, enrollments 5-30 s, a fixed spread (frames of 20 ms)
+    lens = [int(T * (1.0 / 3.0 + (2.0 / 3.0) * ((7 * i + 3) % 16) / 15.0)) for i in range(B)] + \
+           [int(T * (1.0 / 6.0 + (5.0 / 6.0) * ((5 * i + 1) % 16) / 15.0)) for i in range(B)]
+    for i, n in enumerate(lens):
+        x[i, :, 2 * n:] = -1.5
+        st[i, :, n:] = 0.0
+        st[i, 0, n:] = 1.0
+    lab = hashed_labels(B, L, 0, 50257, "rd_turbo_se_b16.labels", pad_rows=(2, 5, 11))
+    upp = lab.clone()
+    x[0], st[0], lab[0], upp[0] = b1["input_features"][0].cpu(), b1["stno_mask"][0].cpu(), b1["labels"][0].cpu(), b1["upp_labels"][0].cpu()
+    x[B], st[B] = b1["enrollments"]["input_features"][0].cpu(), b1["enrollments"]["stno_mask"][0].cpu()
+    batch = dict(input_features=x[:B].cuda(), stno_mask=st[:B].cuda(), labels=lab.cuda(), upp_labels=upp.cuda(),
+                 enrollments={"input_features": x[B:].cuda(), "stno_mask": st[B:].cuda()})
+    out = model(**batch)
+    enc, logits = out.encoder_last_hidden_state.float(), out.logits.float()
+    assert enc.shape == (B, T, cfg.d_model) and logits.shape[:2] == (B, L)
+    rows_loss, worst_inv = [], 0.0
+    with torch.no_grad():
+        for r in range(B):
+            row = {k: ({kk: vv[r:r + 1] for kk, vv in v.items()} if isinstance(v, dict) else v[r:r + 1]) for k, v in batch.items()}
+            o1 = model(**row)
+            rows_loss.append(float(o1.loss))
+            worst_inv = max(worst_inv, float((o1.encoder_last_hidden_state.float() - enc[r:r + 1]).abs().max()))
+    _check_forward(z, types.SimpleNamespace(encoder_last_hidden_state=enc[:1], logits=logits[:1], loss=torch.tensor(rows_loss[0])))
+    assert worst_inv < 6e-2, worst_inv
+    mean_rows = sum(rows_loss) / B
+    assert abs(float(out.loss) - mean_rows) < 2e-3 * abs(mean_rows), (float(out.loss), mean_rows)
+    out.loss.backward()
+    for n, p in model.named_parameters():
+        if p.requires_grad:
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+    worst = _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checked=20)
+    names = [n for n in str(z["watched"]).split("\n")]
+    assert any("ca_enrolls" in n for n in names)
+    print("configs[4] per-rank SE-DiCoW B=16 mixed-length: worst row-vs-B=1 encoder deviation", worst_inv, "loss", float(out.loss),
+          "worst watched gradient vs the mean of the rows:", worst)

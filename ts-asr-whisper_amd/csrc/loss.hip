@@ -46,15 +46,27 @@ __device__ float target_dot(const unsigned short* row, int64_t label, const dico
     return block_reduce_sum(s, red);
 }
 
-// The step's loss is the sum of the row losses IN ROW ORDER: the workgroup that finishes last (ticket) adds row_loss[] up with a
-// fixed assignment of rows to threads and a fixed tree, so the logged loss is bit-reproducible from run to run (a float
-// atomicAdd per row made its last bits depend on the order the workgroups retired in).  One ce_fwd in flight per device.
-__device__ unsigned g_ce_ticket = 0;
+// The step's loss is the sum of the row losses IN ROW ORDER: ce_sum_kernel, a one-workgroup launch that follows ce_fwd_kernel on the
+// same stream, adds row_loss[] up with a fixed assignment of rows to threads and a fixed tree, so the logged loss is
+// bit-reproducible from run to run (a float atomicAdd per row made its last bits depend on the order the workgroups retired in).
+// (Round 3 had the LAST workgroup of ce_fwd_kernel do this, elected through a __device__ global ticket: two launches in flight on
+// one device -- two streams, a graph replay beside an eager step, a second model -- shared that counter and could drop or
+// truncate the sum, and an aborted launch poisoned every later one.  Stream order needs no shared state.)
+__global__ void __launch_bounds__(LOSS_THREADS) ce_sum_kernel(const float* row_loss, int rows, float* loss_sum) {
+    __shared__ float tot[LOSS_THREADS];
+    float t = 0.f;
+    for (int i = threadIdx.x; i < rows; i += LOSS_THREADS) t += row_loss[i];
+    tot[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = LOSS_THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) tot[threadIdx.x] += tot[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_sum[0] += tot[0];
+}
 
 __global__ void __launch_bounds__(LOSS_THREADS) ce_fwd_kernel(const dicow_ce_args a) {
     __shared__ float red[LOSS_THREADS / 64];
-    __shared__ float tot[LOSS_THREADS];
-    __shared__ bool last;
     const int r = blockIdx.x;
     const unsigned short* row = reinterpret_cast<const unsigned short*>(a.logits) + (int64_t)r * a.ld;
     // online max / sum-exp, 8 bf16 per load
@@ -109,23 +121,6 @@ __global__ void __launch_bounds__(LOSS_THREADS) ce_fwd_kernel(const dicow_ce_arg
         a.row_loss[r] = l;
         a.choice[r] = choice;
         if (valid_lo) atomicAdd(a.count, 1.0f);           // (a count of ones: exact in any order)
-        __threadfence();
-        last = atomicAdd(&g_ce_ticket, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    float t = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += LOSS_THREADS) t += __builtin_nontemporal_load(&a.row_loss[i]);
-    tot[threadIdx.x] = t;
-    __syncthreads();
-    for (int o = LOSS_THREADS / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) tot[threadIdx.x] += tot[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        a.loss_sum[0] += tot[0];
-        g_ce_ticket = 0;
     }
 }
 
@@ -169,6 +164,8 @@ extern "C" int dicow_ce_loss_fwd(const dicow_ce_args* a, void* stream) {
     DICOW_REQUIRE(a->n_ts == 0 || (a->ts_index && a->ts_ids && a->ts_w), "ce_loss_fwd: timestamp tables missing");
     hipLaunchKernelGGL(ce_fwd_kernel, dim3(a->rows), dim3(LOSS_THREADS), 0, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("ce_loss_fwd");
+    hipLaunchKernelGGL(ce_sum_kernel, dim3(1), dim3(LOSS_THREADS), 0, (hipStream_t)stream, a->row_loss, a->rows, a->loss_sum);
+    DICOW_CHECK_LAUNCH("ce_loss_fwd (ordered sum)");
     return DICOW_OK;
 }
 

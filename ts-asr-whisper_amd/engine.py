@@ -12,6 +12,7 @@ per-layer FDDT + optional speaker-communication block + WhisperEncoderLayer, fin
 layers.py:145-193 (SCB), HF modeling_whisper.py WhisperEncoderLayer / WhisperDecoderLayer / WhisperAttention,
 modeling_dicow.py:248-338 (shift, tied LM head, losses).
 """
+import os
 from types import SimpleNamespace as NS
 
 import torch
@@ -190,7 +191,8 @@ def full_fddt_bwd(fddt, w, hb, g, stno, bstride, G, rows, T, D):
 # head_dim^-0.5 * log2 e) -- ONE rounding, like the reference's bf16(Wx + b) * head_dim^-0.5, but not the same one), so the forward
 # kernel's probabilities are p = 2^s with no arithmetic in front of the exponential and the backward kernels lose their per-score
 # multiply.  Same softmax, same lse (natural log), same gradients; dq_scale keeps its meaning (include/dicow_hip.h).
-QK_LOG2 = True
+# (DICOW_QK_LOG2=0 in the environment selects the plain form for A/B runs -- tools used to edit this file in place.)
+QK_LOG2 = os.environ.get("DICOW_QK_LOG2", "1") != "0"
 FUSE_NEXT_FDDT = True         # inference forward: the next layer's diagonal FDDT in the fc2 epilogue (see EncoderEngine.forward)
 Q_SCALE = 0.125 * (ops.LOG2E if QK_LOG2 else 1.0)
 

@@ -568,6 +568,9 @@ class _DecoderLossFn(torch.autograd.Function):
         return (None, d_enc, None, None, None) + tuple(G.result(p) for p in ctx.params)
 
 
+_KEYWORD_ONLY_GENERATE_ARGS = ("temperature",)     # read from generate()'s keywords, never from the generation config
+
+
 class DiCoWForConditionalGeneration(nn.Module):
     config_class = DiCoWConfig
 
@@ -671,7 +674,12 @@ class DiCoWForConditionalGeneration(nn.Module):
         from .generation import GreedyDecoder
         gc = generation_config if generation_config is not None else self.generation_config
         # (explicit keyword arguments win over the generation config, as in HF's generate)
-        get = (lambda k, d=None: kwargs[k] if kwargs.get(k) is not None else (getattr(gc, k, d) if gc is not None else d))
+        # -- except `temperature`, which HF's WhisperGenerationMixin.generate (the method the reference delegates to) takes from
+        # the explicit keyword ONLY: a GenerationConfig carries temperature = 1.0 by default under the reference's pinned
+        # transformers 4.55 (also when loaded from a Whisper checkpoint's generation_config.json), and greedy / beam decoding
+        # never consult it.
+        get = (lambda k, d=None: kwargs[k] if kwargs.get(k) is not None else
+               (d if k in _KEYWORD_ONLY_GENERATE_ARGS else (getattr(gc, k, d) if gc is not None else d)))
         beams = max(num_beams or 1, get("num_beams", 1) or 1)
         self.stno_mask = stno_mask                            # reference generate() keeps it for detect_language (generation.py:556)
         cfg = self.config

@@ -12,6 +12,7 @@ layer's slice is all-reduced (RCCL over xGMI, ``torch.distributed`` backend "ncc
 layer's backward has been enqueued, overlapped with the remaining backward.
 """
 import collections
+import logging
 import math
 import os
 
@@ -19,9 +20,11 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from . import tracing
 from .engine import GradSink
 
 F32 = torch.float32
+log = logging.getLogger(__name__)
 
 
 def freeze_by_keyword(model, frozen_keywords=("decoder",)):
@@ -103,6 +106,7 @@ class FlatStore:
         self.exp_avg = torch.zeros(off, dtype=F32, device=dev)
         self.exp_avg_sq = torch.zeros(off, dtype=F32, device=dev)
         self.entries = entries
+        self._names = names
         for p, o, n, pre in entries:
             self.params[o:o + n].copy_(p.data.reshape(-1))
             p.data = self.params[o:o + n].view(p.shape)
@@ -131,6 +135,10 @@ class FlatStore:
             keep.append((cur, self.numel))
         self._zero_ranges = keep                     # the complement of the overwritable matrices: ~one range per layer
 
+    def fingerprint(self):
+        """(parameter name, offset, numel) of every entry, in flat-buffer order: what an optimizer checkpoint must agree with."""
+        return [(self._names[id(p)], int(o), int(n)) for p, o, n, _ in self.entries]
+
     def zero_grad(self, first_writer=False):
         """first_writer: only valid when every flagged matrix is certain to receive its gradient in the coming backward pass
         (the full training phase; TrainStep decides)."""
@@ -141,8 +149,22 @@ class FlatStore:
             return
         for a, b in self._zero_ranges:
             self.grads[a:b].zero_()
-        for p, _, _ in self._over:
+        for p, o, n in self._over:
             p._grad_overwrite = bool(p.requires_grad)
+            if not p.requires_grad:                   # frozen after the store was built: no GEMM will write it, keep it zero
+                self.grads[o:o + n].zero_()
+
+    def settle_first_writers(self):
+        """After a backward pass under zero_grad(first_writer=True): a flagged matrix whose weight-gradient GEMM did NOT run
+        (its flag is still set -- the encoder backward was not reached, or skipped that matrix) holds the PREVIOUS step's
+        gradient; zero it so that neither the clip norm nor AdamW sees stale values.  Returns how many were settled."""
+        n_left = 0
+        for p, o, n in self._over:
+            if getattr(p, "_grad_overwrite", False):
+                self.grads[o:o + n].zero_()
+                p._grad_overwrite = False
+                n_left += 1
+        return n_left
 
 
 class FusedAdamW:
@@ -218,6 +240,90 @@ class FusedAdamW:
         """preheat_only: update only the runs of the preheat group (the others are frozen: no gradient, no update)."""
         self.advance(preheat_only)
         self.launch(preheat_only)
+
+
+# ------------------------------------------------------------------------------------------------ replica consistency
+def _bit_checksum(t):
+    """Order-independent 64-bit checksum of a tensor's BITS (any dtype of 1, 2, 4 or 8 bytes per element), as a Python int:
+    two replicas that differ in any single bit differ in it.  Chunked: the int64 temporary stays small."""
+    flat = t.detach().reshape(-1)
+    if flat.numel() == 0:
+        return 0
+    view = {1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[flat.element_size()]
+    bits = flat.view(view)
+    total, step = 0, 1 << 24
+    for a in range(0, bits.numel(), step):
+        c = bits[a:a + step].to(torch.int64)
+        idx = torch.arange(a, a + c.numel(), device=c.device, dtype=torch.int64)
+        total = (total + int((c * (2 * (idx % 1000003) + 1)).sum().item())) & 0xFFFFFFFFFFFFFFFF
+    return total
+
+
+def sync_replicas(model, store=None, process_group=None, mode="broadcast", src=0, extra=()):
+    """Make (or check that) every rank of the data-parallel group holds rank ``src``'s model state -- what
+    ``torch.nn.parallel.DistributedDataParallel`` does in its constructor (it broadcasts rank 0's parameters and buffers;
+    the reference gets it from the HF Trainer's DDP wrap, scripts/submit_slurm.sh:34, configs/base.yaml:73).  Without it
+    ranks that built the model from different RNG states, or loaded different files, train silently diverging replicas.
+
+    mode "broadcast": rank ``src``'s flat parameter store (ONE collective for all trainable parameters), then the parameters
+    outside the store (frozen ones) and the buffers coalesced per dtype, then ``extra`` tensors (Adam moments on resume).
+    mode "verify": nothing is overwritten; a 64-bit checksum of every tensor's bits is all-gathered and a mismatch raises
+    ``RuntimeError`` naming the ranks.  mode "none": no-op.  Returns the number of bytes put on the wire (0 for world 1 /
+    "none"; the checksum exchange of "verify" counts its 8 bytes per rank).  Logged at INFO level."""
+    if mode not in ("broadcast", "verify", "none"):
+        raise ValueError(f"replica_sync must be 'broadcast', 'verify' or 'none', not {mode!r}")
+    if mode == "none" or not dist.is_initialized():
+        return 0
+    world = dist.get_world_size(process_group)
+    in_store = set()
+    tensors = []
+    if store is not None:
+        in_store = {id(p) for p, _, _, _ in store.entries}
+        tensors.append(store.params)
+    seen = set()
+    rest = []
+    for t in list(model.parameters()) + list(model.buffers()):
+        if id(t) in in_store or id(t) in seen or t.data_ptr() in seen:
+            continue                                  # (tied weights share storage: once)
+        seen.add(id(t))
+        seen.add(t.data_ptr())
+        rest.append(t.data)
+    rest += [t for t in extra if t is not None]
+    src_global = dist.get_global_rank(process_group, src) if process_group is not None else src
+    if mode == "verify":
+        mine = 0
+        for t in tensors + rest:
+            mine = (mine * 1000003 + _bit_checksum(t)) & 0x7FFFFFFFFFFFFFFF
+        dev = tensors[0].device if tensors else (rest[0].device if rest else torch.device("cpu"))
+        got = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([mine], dtype=torch.int64, device=dev), group=process_group)
+        sums = [int(g.item()) for g in got]
+        if len(set(sums)) != 1:
+            bad = [r for r, v in enumerate(sums) if v != sums[src]]
+            raise RuntimeError(f"data-parallel replicas differ at start-up: ranks {bad} do not hold rank {src}'s parameters / buffers "
+                               f"(checksums {[hex(v) for v in sums]}); construct TrainStep with replica_sync='broadcast' or load the "
+                               f"same checkpoint on every rank")
+        log.info("replica check: %d ranks hold identical state (checksum %s)", world, hex(sums[0]))
+        return 8 * world
+    nbytes = 0
+    if world > 1 or os.environ.get("DICOW_FORCE_REDUCE") == "1":
+        for t in tensors:
+            dist.broadcast(t, src=src_global, group=process_group)
+            nbytes += t.numel() * t.element_size()
+        by_dtype = collections.OrderedDict()
+        for t in rest:
+            by_dtype.setdefault((t.dtype, t.device), []).append(t)
+        for (dt, dev), ts in by_dtype.items():
+            flat = torch.cat([t.reshape(-1) for t in ts]) if len(ts) > 1 else ts[0].reshape(-1).clone()
+            dist.broadcast(flat, src=src_global, group=process_group)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view(t.shape))
+                off += t.numel()
+            nbytes += flat.numel() * flat.element_size()
+        log.info("replica sync: rank %d's state broadcast to %d ranks (%d bytes: %d in the flat store)", src, world, nbytes,
+                 sum(t.numel() * t.element_size() for t in tensors))
+    return nbytes
 
 
 class GradReducer:
@@ -312,7 +418,7 @@ class TrainStep:
     def __init__(self, model, lr=2e-6, fddt_lr_multiplier=100.0, weight_decay=0.0, max_grad_norm=1.0, warmup_steps=0,
                  max_steps=0, frozen_keywords=("decoder",), preheat_prefixes=None,
                  process_group=None, augmenter=None, use_fddt_only_n_steps=0, graph=False, use_fddt_only_n_epochs=0,
-                 steps_per_epoch=None):
+                 steps_per_epoch=None, replica_sync="broadcast"):
         self.model = model
         # preheat_prefixes=None: the reference's model.prefixes_to_preheat (REFERENCE_PREHEAT_PREFIXES).
         # use_fddt_only_n_epochs (base.yaml:59) is the reference's second phase condition (trainers.py:122: epoch >= n_epochs
@@ -343,6 +449,14 @@ class TrainStep:
         self.opt = FusedAdamW(self.store, lr, fddt_lr_multiplier, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
                               warmup_steps=warmup_steps, max_steps=max_steps)
         self.reducer = GradReducer(self.store, process_group)
+        # Like DistributedDataParallel's constructor (the reference's DP wrapper): every rank starts from rank 0's parameters
+        # and buffers ("broadcast"), or the ranks prove they already agree ("verify": checksums, raises on a mismatch).
+        self.replica_sync = replica_sync
+        self.replica_sync_bytes = sync_replicas(model, self.store, process_group, mode=replica_sync)
+        if self.replica_sync_bytes and replica_sync == "broadcast":      # every bf16 compute copy is stale now, frozen decoder included
+            model.model.encoder._sig = None
+            model.model.encoder._ctc_sig = None
+            model._sig = None
         model.model.encoder._segment_hook = self.reducer.segment_ready
         model._segment_hook = self.reducer.segment_ready
         # Staged freezing (reference train.py:174-178 + trainers.py:122-137, dicow_v3.yaml:68 use_fddt_only_n_steps 2000):
@@ -375,8 +489,12 @@ class TrainStep:
 
     def finish_step(self):
         """Gradients are in the flat store: exchange (DP), clip, AdamW, invalidate the bf16 compute copies."""
-        self.reducer.finish()
-        self.opt.step(preheat_only=self.warmup_phase)
+        if self.first_writer and not self.warmup_phase:
+            self.store.settle_first_writers()
+        with tracing.range("exchange"):               # (the buckets themselves leave during "backward", on the side stream)
+            self.reducer.finish()
+        with tracing.range("optimizer"):
+            self.opt.step(preheat_only=self.warmup_phase)
         # the fused optimizer writes through raw pointers (no torch version bump): invalidate the bf16 weight copies --
         # except in the preheat phase when only diagonal / bias FDDT vectors moved (the row kernels read those in fp32)
         enc = self.model.model.encoder
@@ -389,8 +507,10 @@ class TrainStep:
     def _micro(self, batch, scale):
         if self.augmenter is not None:      # enrollments are collated "nested" and stay clean (collators.py:189,216-220)
             batch = self.augmenter(dict(batch))
-        out = self.model(**batch)
-        (out.loss if scale == 1.0 else out.loss * scale).backward()
+        with tracing.range("forward"):
+            out = self.model(**batch)
+        with tracing.range("backward"):
+            (out.loss if scale == 1.0 else out.loss * scale).backward()
         return out.loss.detach()
 
     # ---- whole-step hipGraph
@@ -494,15 +614,27 @@ class TrainStep:
         o = self.opt
         return {"global_step": o.t, "run_t": list(o.run_t), "warmup_phase": self.warmup_phase,
                 "exp_avg": self.store.exp_avg.clone(), "exp_avg_sq": self.store.exp_avg_sq.clone(),
-                "layout": [(a, b, pre) for a, b, pre in self.store.runs]}
+                "layout": [(a, b, pre) for a, b, pre in self.store.runs], "entries": self.store.fingerprint()}
 
     def load_state_dict(self, sd):
         if [tuple(r) for r in sd["layout"]] != [tuple(r) for r in self.store.runs]:
             raise ValueError("optimizer state was saved for a different set of trainable parameters")
+        # the runs only fix the run BOUNDARIES; the order of the parameters inside them is part of the layout too (it changed in
+        # round 3: weight matrices before vectors) -- moments saved under another order would land on the wrong parameters
+        if "entries" not in sd:
+            raise ValueError("optimizer state has no per-parameter layout fingerprint (saved by an older version): the order of the "
+                             "parameters inside the flat buffers cannot be checked; re-save it with this version")
+        if [tuple(e) for e in sd["entries"]] != self.store.fingerprint():
+            mine = {e[0]: e for e in self.store.fingerprint()}
+            diff = [e[0] for e in sd["entries"] if tuple(e) != mine.get(e[0])][:4]
+            raise ValueError(f"optimizer state was saved under a different flat-buffer layout (first differing parameters: {diff})")
         self.opt.t, self.opt.run_t = int(sd["global_step"]), list(sd["run_t"])
         self.opt.sync_counters()
         self.store.exp_avg.copy_(sd["exp_avg"])
         self.store.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if self.replica_sync != "none" and self.reducer.world > 1:        # resume: the moments follow the parameters (rank 0's, or checked)
+            sync_replicas(torch.nn.Module(), None, self.reducer.pg, mode=self.replica_sync,
+                          extra=(self.store.exp_avg, self.store.exp_avg_sq, self.opt.counters))
         if bool(sd["warmup_phase"]) != self.warmup_phase:
             self._set_phase(preheat_only=bool(sd["warmup_phase"]))
             self.warmup_phase = bool(sd["warmup_phase"])
