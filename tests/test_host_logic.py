@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()                       # raises loudly if the .so has not been built
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dicow_abi_version() == 3
+    assert lib.dicow_abi_version() == 4
 
 
 def test_gemm_nt_is_persistent_host_logic():

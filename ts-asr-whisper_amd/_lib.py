@@ -31,7 +31,8 @@ class GemmArgs(C.Structure):
                 ("batch", c_i), ("strideA", c_i64), ("strideB", c_i64), ("strideC", c_i64), ("strideAux", c_i64),
                 ("flags", c_i), ("scale", c_f), ("scale_ncols", c_i),
                 ("colsum_out", c_vp), ("colsum_ws", c_vp), ("colsum_ws_bytes", c_i64),
-                ("fddt_w", c_vp * 4), ("fddt_b", c_vp * 4), ("fddt_rowmask", c_vp)]
+                ("fddt_w", c_vp * 4), ("fddt_b", c_vp * 4), ("fddt_rowmask", c_vp),
+                ("lnstat", c_vp), ("ln_c", c_vp), ("ln_inv_dim", c_f), ("ln_eps", c_f), ("ln_nslots", c_i)]
 
 
 class GemmTnArgs(C.Structure):
@@ -91,6 +92,7 @@ class CtcPrefixArgs(C.Structure):
 
 EPI_BIAS, EPI_GELU, EPI_RESIDUAL, EPI_OUT_F32, EPI_SCALE_N, EPI_GELU_BWD, EPI_ACCUM = 1, 2, 4, 8, 16, 32, 64
 EPI_GELU_DAUX, EPI_MUL_AUX, EPI_COLSUM, EPI_FDDT = 128, 256, 512, 1024
+EPI_LNSTAT, EPI_LNFOLD, LN_SLOTS = 2048, 4096, 16
 
 # name -> argtypes ; every function returns int
 _SIGS = {
@@ -114,10 +116,12 @@ _SIGS = {
     "dicow_fddt_full_combine_bwd": [c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_gemm_nt": [C.POINTER(GemmArgs), c_vp],
     "dicow_gemm_nt_is_persistent": [C.POINTER(GemmArgs)],
+    "dicow_gemm_nt_lnstat_ok": [C.POINTER(GemmArgs)],
     "dicow_gemm_tn": [C.POINTER(GemmTnArgs), c_vp],
     "dicow_gemm_tn_group": [C.POINTER(GemmTnGroupArgs), c_vp],
     "dicow_attn_fwd": [C.POINTER(AttnFwdArgs), c_vp],
     "dicow_attn_bwd": [C.POINTER(AttnBwdArgs), c_vp],
+    "dicow_lnfold_prep": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i, c_i, c_vp],
     "dicow_ce_loss_fwd": [C.POINTER(CeArgs), c_vp],
     "dicow_ce_loss_bwd": [C.POINTER(CeArgs), c_vp, c_vp],
     "dicow_ctc_loss_fwd": [C.POINTER(CtcArgs), c_vp],

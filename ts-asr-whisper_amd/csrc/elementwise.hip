@@ -771,3 +771,42 @@ extern "C" int dicow_scb_merge_bwd(const float* g, const float* d_qin, const voi
     DICOW_CHECK_LAUNCH("scb_merge_bwd");
     return DICOW_OK;
 }
+
+// ------------------------------------------------------------------------------------------------ LayerNorm fold: weight preparation
+// (include/dicow_hip.h: dicow_lnfold_prep).  One workgroup per output row n; fixed-order block sums (bit-reproducible).
+__global__ void __launch_bounds__(256) lnfold_prep_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ bias,
+                                                          unsigned short* __restrict__ Wf, int64_t ldw, float* __restrict__ c,
+                                                          float* __restrict__ bf, int K) {
+    __shared__ float red[2][4];
+    const int n = blockIdx.x;
+    const float* w = W + (int64_t)n * K;
+    unsigned short* o = Wf + (int64_t)n * ldw;
+    float sc = 0.f, sb = 0.f;
+    for (int k = threadIdx.x * 2; k < K; k += 512) {          // (K even: host-checked)
+        const float w0 = w[k], w1 = w[k + 1];
+        const unsigned pf = pack_bf16x2(w0 * gamma[k], w1 * gamma[k + 1]);
+        *reinterpret_cast<unsigned*>(o + k) = pf;
+        sc += __uint_as_float(pf << 16) + __uint_as_float(pf & 0xffff0000u);
+        const unsigned pw = pack_bf16x2(w0, w1);              // what the forward's plain bf16 copy of W holds
+        sb = fmaf(beta[k], __uint_as_float(pw << 16), sb);
+        sb = fmaf(beta[k + 1], __uint_as_float(pw & 0xffff0000u), sb);
+    }
+    sc = wave_sum_dpp(sc); sb = wave_sum_dpp(sb);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sc; red[1][threadIdx.x >> 6] = sb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        c[n] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        bf[n] = (bias ? bias[n] : 0.f) + ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+    }
+}
+
+extern "C" int dicow_lnfold_prep(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, int64_t ldw, float* c,
+                                 float* bf, int N, int K, void* stream) {
+    DICOW_REQUIRE(W && gamma && beta && Wf && c && bf, "lnfold_prep: null operand");
+    DICOW_REQUIRE(N > 0 && K > 0 && K % 2 == 0 && ldw >= K && ldw % 2 == 0, "lnfold_prep: need K %% 2 == 0 and ldw >= K (N=%d K=%d)", N, K);
+    hipLaunchKernelGGL(lnfold_prep_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, W, gamma, beta, bias,
+                       reinterpret_cast<unsigned short*>(Wf), ldw, c, bf, K);
+    DICOW_CHECK_LAUNCH("lnfold_prep");
+    return DICOW_OK;
+}

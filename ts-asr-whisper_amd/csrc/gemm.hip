@@ -21,6 +21,12 @@
 #define STAGE_BYTES (BM * BK * 2)          // 16 KiB per operand per stage
 #define NT_LDS_BYTES (4 * STAGE_BYTES)     // A0 B0 A1 B1
 #define NT_FDDT_FLAGS (DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32 | DICOW_EPI_FDDT)
+#define NT_RES_FLAGS (DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32)
+#define NT_RES_LN_FLAGS (NT_RES_FLAGS | DICOW_EPI_LNSTAT)                      /* out-proj / fc2 producing bf16 copy + row partials */
+#define NT_FDDT_LN_FLAGS (NT_FDDT_FLAGS | DICOW_EPI_LNSTAT)                    /* fc2 + next layer's FDDT + partials of the conditioned rows */
+#define NT_QKV_LN_FLAGS (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N | DICOW_EPI_LNFOLD)
+#define NT_FC1I_LN_FLAGS (DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_LNFOLD)
+#define NT_FC1T_LN_FLAGS (DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX | DICOW_EPI_LNFOLD)
 #ifndef NT_BIG_TILES
 #define NT_BIG_TILES 200      // (see gemm_nt_impl)
 #endif
@@ -1127,6 +1133,25 @@ __global__ void __launch_bounds__(256) gemm_ntw_kernel(const dicow_gemm_args a) 
 
 #endif  // DICOW_ABLATIONS
 
+// ---- LayerNorm fold, producer side (DICOW_EPI_LNSTAT): butterfly reductions over the lanes of a row with DPP lane moves.
+// ln_merge<CTRL>(a, b, bit): two values whose partial sums live in lane pairs (l, l ^ k) -- CTRL = the DPP move that reads lane
+// l ^ k -- become ONE: a lane with bit clear ends with a(l) + a(l ^ k), a lane with bit set with b(l) + b(l ^ k); the number of
+// live values halves with every lane bit, and after the last one lane l holds the row total of value number (l & 15).
+template <int CTRL, int BANK = 0xf>
+__device__ __forceinline__ float ln_dpp(float old, float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(x), CTRL, 0xf, BANK, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float ln_merge(float a, float b, bool bit) {
+    const float keep = bit ? b : a, send = bit ? a : b;
+    return keep + ln_dpp<CTRL>(0.f, send);
+}
+// lane l ^ 4 inside a row of 16: banks 0 / 2 read lane l + 4 (row_shl:4), banks 1 / 3 lane l - 4 (row_shr:4)
+__device__ __forceinline__ float ln_xor4(float x) { return ln_dpp<0x114, 0xA>(ln_dpp<0x104, 0x5>(0.f, x), x); }
+__device__ __forceinline__ float ln_merge4(float a, float b, bool bit) {
+    const float keep = bit ? b : a, send = bit ? a : b;
+    return keep + ln_xor4(send);
+}
 #include "gemm_ntr.inc"
 
 #ifdef DICOW_ABLATIONS
@@ -1330,6 +1355,13 @@ extern "C" int dicow_gemm_nt_is_persistent(const dicow_gemm_args* a) {
     return (off32 && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= NT_BIG_TILES) ? 1 : 0;
 }
 
+extern "C" int dicow_gemm_nt_lnstat_ok(const dicow_gemm_args* a) {
+    // (the LNSTAT instantiations are 192 x 320 only and the dispatcher forces that shape for them: what remains to ask is whether
+    // the problem reaches the persistent kernel at all and whether its columns are whole 320-wide tiles that fit the 16 slots)
+    return (dicow_gemm_nt_is_persistent(a) && a->M >= 256 && a->N >= 320 && a->N % 320 == 0 && a->N <= 1280 &&
+            (int64_t)a->M * 128 < (1ll << 31) && (a->batch <= 1)) ? 1 : 0;
+}
+
 extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     DICOW_REQUIRE(a && a->A && a->B && a->C, "gemm_nt: null operand");
     if (!(a->flags & DICOW_EPI_COLSUM)) {
@@ -1379,6 +1411,14 @@ static void gemm_nt_setup() {
     NTR_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
 #undef NTR_ATTR
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FDDT_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_RES_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FDDT_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_QKV_LN_FLAGS, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_QKV_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FC1I_LN_FLAGS, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FC1I_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FC1T_LN_FLAGS, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FC1T_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
 #ifdef DICOW_ABLATIONS
     (void)hipFuncSetAttribute((const void*)gemm_nt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NTS_LDS);
 #define NTW_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntw_kernel<F, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS); \
@@ -1467,6 +1507,8 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     constexpr int big_tiles = NT_BIG_TILES;
 #endif
     const bool big = off32 && a->K >= 2 * BK && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= big_tiles;
+    DICOW_REQUIRE(!(a->flags & (DICOW_EPI_LNSTAT | DICOW_EPI_LNFOLD)) || (variant == 0 && big && a->M >= 256 && a->N >= 320),
+                  "gemm_nt: EPI_LNSTAT / EPI_LNFOLD are implemented by the persistent kernel only (M=%d N=%d K=%d: ask dicow_gemm_nt_is_persistent / dicow_gemm_nt_lnstat_ok)", a->M, a->N, a->K);
     DICOW_REQUIRE(!(a->flags & DICOW_EPI_FDDT) || (variant == 0 && big && a->M >= 256 && a->N >= 320),
                   "gemm_nt: EPI_FDDT is implemented by the persistent kernel only (M=%d N=%d K=%d is below its threshold: ask dicow_gemm_nt_is_persistent)", a->M, a->N, a->K);
     if ((variant >= 4 || (variant == 0 && big)) && a->M >= 256 && a->N >= 256) {
@@ -1482,17 +1524,25 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             const int64_t w44 = dicow_cdiv(t44, ncu) * 256 * 256, w35 = dicow_cdiv(t35, ncu) * 192 * 320;
             // (round 3: with the cheaper GELU the inference fc1 -- bias + GELU, no saved derivative -- gains 8 us per launch from
             // the smaller tiles at N = 5120 too: encoder forward 38.86 -> 38.60 ms in-situ; the training epilogues still lose)
-            const bool wide_ok = a->N <= 2048 || a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU) ||
+            const bool wide_ok = a->N <= 2048 || a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU) || a->flags == NT_FC1I_LN_FLAGS ||
                                  ((NT_WIDE35 & 1) && (a->flags & DICOW_EPI_MUL_AUX)) ||                     // experiments: the dgrad x gelu' epilogue,
                                  ((NT_WIDE35 & 2) && (a->flags & DICOW_EPI_GELU_DAUX)) ||                   // the training fc1,
                                  ((NT_WIDE35 & 4) && a->flags == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N)) ||   // qkv,
                                  ((NT_WIDE35 & 8) && a->flags == 0);                                        // plain dgrad
             const bool fddt = (a->flags & DICOW_EPI_FDDT) != 0;      // (only the 192 x 320 instantiation carries that epilogue)
-            DICOW_REQUIRE(!fddt || (a->flags == NT_FDDT_FLAGS && variant == 0 && a->N >= 320 && batch == 1 && a->fddt_rowmask &&
+            DICOW_REQUIRE(!fddt || ((a->flags == NT_FDDT_FLAGS || a->flags == NT_FDDT_LN_FLAGS) && variant == 0 && a->N >= 320 && batch == 1 && a->fddt_rowmask &&
                                     a->fddt_w[0] && a->fddt_w[1] && a->fddt_w[2] && a->fddt_w[3] && a->fddt_b[0] && a->fddt_b[1] &&
                                     a->fddt_b[2] && a->fddt_b[3]),
                           "gemm_nt: EPI_FDDT needs BIAS | RESIDUAL | OUT_F32, N >= 320, one batch, the eight vectors and the row masks");
-            const bool use35 = fddt || variant == 13 || variant == 22 || (variant != 12 && variant != 21 && a->N >= 320 && wide_ok && w35 < w44);
+            const bool lnstat = (a->flags & DICOW_EPI_LNSTAT) != 0, lnfold = (a->flags & DICOW_EPI_LNFOLD) != 0;
+            DICOW_REQUIRE(!lnstat || ((a->flags == NT_RES_LN_FLAGS || a->flags == NT_FDDT_LN_FLAGS) && variant == 0 && batch == 1 && a->aux &&
+                                      a->lnstat && a->N % 320 == 0 && a->N <= 1280 && (int64_t)a->M * 128 < (1ll << 31)),
+                          "gemm_nt: EPI_LNSTAT needs BIAS | RESIDUAL | OUT_F32 [| FDDT], aux (the bf16 copy), lnstat, N %% 320 == 0, N <= 1280 (N=%d)", a->N);
+            DICOW_REQUIRE(!lnfold || ((a->flags == NT_QKV_LN_FLAGS || a->flags == NT_FC1I_LN_FLAGS || a->flags == NT_FC1T_LN_FLAGS) && variant == 0 &&
+                                      batch == 1 && a->lnstat && a->ln_c && a->bias && a->ln_nslots > 0 && a->ln_nslots <= DICOW_LN_SLOTS &&
+                                      a->ln_nslots % 4 == 0 && a->ln_inv_dim > 0.f && (int64_t)a->M * 128 < (1ll << 31)),
+                          "gemm_nt: EPI_LNFOLD needs BIAS with SCALE_N or GELU [| GELU_DAUX], lnstat, ln_c, ln_nslots (multiple of 4, <= 16), ln_inv_dim");
+            const bool use35 = fddt || lnstat || variant == 13 || variant == 22 || (variant != 12 && variant != 21 && a->N >= 320 && wide_ok && w35 < w44);
             const int total = (int)(use35 ? t35 : t44);
             // balanced grid: with r = ceil(total / ncu) rounds needed anyway, ceil(total / r) workgroups each take r (or
             // r - 1) tiles -- e.g. 470 tiles run on 235 workgroups x 2 instead of 214 x 2 + 42 x 1: same makespan, fewer
@@ -1515,7 +1565,8 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
                 const int f_ = a->flags;
                 const bool ct_ = variant != 11 && (f_ == 0 || f_ == DICOW_EPI_BIAS || f_ == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N) || f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU) ||
                                                    f_ == (DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32) || f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX) ||
-                                                   f_ == DICOW_EPI_MUL_AUX || f_ == (DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM) || f_ == NT_FDDT_FLAGS);
+                                                   f_ == DICOW_EPI_MUL_AUX || f_ == (DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM) || f_ == NT_FDDT_FLAGS ||
+                                                   f_ == NT_RES_LN_FLAGS || f_ == NT_FDDT_LN_FLAGS || f_ == NT_QKV_LN_FLAGS || f_ == NT_FC1I_LN_FLAGS || f_ == NT_FC1T_LN_FLAGS);
                 disp_note("gemm_ntr_kernel<%d, %d, %d>", ct_ ? f_ : -1, use35 ? 3 : 4, use35 ? 5 : 4);
             }
             switch (variant == 11 ? -1 : a->flags) {   // compile-time epilogues for the flag sets the training step uses
@@ -1526,6 +1577,11 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
                 case DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32); break;
                 case DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); break;
                 case NT_FDDT_FLAGS: hipLaunchKernelGGL((gemm_ntr_kernel<NT_FDDT_FLAGS, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); break;
+                case NT_RES_LN_FLAGS: hipLaunchKernelGGL((gemm_ntr_kernel<NT_RES_LN_FLAGS, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); break;
+                case NT_FDDT_LN_FLAGS: hipLaunchKernelGGL((gemm_ntr_kernel<NT_FDDT_LN_FLAGS, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); break;
+                case NT_QKV_LN_FLAGS: NTW_LAUNCH(NT_QKV_LN_FLAGS); break;
+                case NT_FC1I_LN_FLAGS: NTW_LAUNCH(NT_FC1I_LN_FLAGS); break;
+                case NT_FC1T_LN_FLAGS: NTW_LAUNCH(NT_FC1T_LN_FLAGS); break;
                 case DICOW_EPI_MUL_AUX: NTW_LAUNCH(DICOW_EPI_MUL_AUX); break;
                 case DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM: NTW_LAUNCH(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM); break;
                 default: NTW_LAUNCH(-1); break;

@@ -194,6 +194,13 @@ def full_fddt_bwd(fddt, w, hb, g, stno, bstride, G, rows, T, D):
 # (DICOW_QK_LOG2=0 in the environment selects the plain form for A/B runs -- tools used to edit this file in place.)
 QK_LOG2 = os.environ.get("DICOW_QK_LOG2", "1") != "0"
 FUSE_NEXT_FDDT = True         # inference forward: the next layer's diagonal FDDT in the fc2 epilogue (see EncoderEngine.forward)
+# LayerNorm folded into the GEMMs on either side of it (round 4; include/dicow_hip.h, DICOW_EPI_LNSTAT / LNFOLD): out-proj / fc2
+# also store bf16(h) and per-row partial statistics, qkv / fc1 read bf16(h) against gamma-scaled weights and normalise in their
+# epilogues -- no LayerNorm launch between them.  BUILT, PARITY-TESTED (tests/test_gpu_lnfold.py) AND MEASURED SLOWER: the two
+# LayerNorm launches it deletes are worth 63 us per layer, the epilogue work it adds 114 us (profiles/r04_lnfold.txt) -- OFF by
+# default, DICOW_LN_FOLD=1 switches the inference forward to it (A/B runs); shapes that do not reach the persistent 192 x 320
+# kernel keep the LayerNorm kernels either way.
+LN_FOLD = os.environ.get("DICOW_LN_FOLD", "0") == "1"
 Q_SCALE = 0.125 * (ops.LOG2E if QK_LOG2 else 1.0)
 
 
@@ -405,8 +412,33 @@ class EncoderEngine:
                 W.scb.append(s)
         W.full_init = prep_full_fddt(enc.initial_fddt, dev) if (cfg.use_fddt and cfg.use_pre_pos_fddt and fddt_is_full(enc.initial_fddt)) else None
         W.full = [prep_full_fddt(f, dev) if fddt_is_full(f) else None for f in (enc.fddts if cfg.use_fddt else [])]
+        W.fold = None                                     # LayerNorm-folded copies: built on first use (prepare_fold)
         self.W = W
         return W
+
+    def prepare_fold(self):
+        """Folded weights of every encoder layer's q/k/v and fc1 (they follow self_attn_layer_norm / final_layer_norm):
+        bf16(gamma . W), its row sums and beta W^T + b -- one small launch per matrix, cached until the weights change."""
+        W, enc = self.W, self.enc
+        if W.fold is not None:
+            return W.fold
+        dev = enc.conv1.weight.device
+        D, F_ = self.cfg.d_model, self.cfg.encoder_ffn_dim
+        fold = []
+        for lyr in enc.layers:
+            f = NS()
+            att, ln1, ln2 = lyr.self_attn, lyr.self_attn_layer_norm, lyr.final_layer_norm
+            f.qkv_w, f.qkv_c, f.qkv_b = _e((3 * D, D), BF16, dev), _e((3 * D,), F32, dev), _e((3 * D,), F32, dev)
+            for k, (lin, has_b) in enumerate(((att.q_proj, True), (att.k_proj, False), (att.v_proj, True))):
+                sl = slice(k * D, (k + 1) * D)
+                ops.lnfold_prep(lin.weight.detach(), ln1.weight.detach(), ln1.bias.detach(), lin.bias.detach() if has_b else None,
+                                f.qkv_w[sl], f.qkv_c[sl], f.qkv_b[sl])
+            f.fc1_w, f.fc1_c, f.fc1_b = _e((F_, D), BF16, dev), _e((F_,), F32, dev), _e((F_,), F32, dev)
+            ops.lnfold_prep(lyr.fc1.weight.detach(), ln2.weight.detach(), ln2.bias.detach(), lyr.fc1.bias.detach(), f.fc1_w, f.fc1_c, f.fc1_b)
+            f.eps1, f.eps2 = float(ln1.eps), float(ln2.eps)
+            fold.append(f)
+        W.fold = fold
+        return fold
 
     def forward(self, input_features, stno_mask, enrollments=None, need_grad=True):
         enc, cfg, W = self.enc, self.cfg, self.W
@@ -447,6 +479,16 @@ class EncoderEngine:
         if fuse_next:
             rowmask = torch.zeros(_ceil(rows, 192) + 64, 4, dtype=F32, device=dev)
             rowmask[:rows].view(B, T, 4).copy_(stno.permute(0, 2, 1))
+        # LayerNorm fold (inference forward): needs every GEMM of the layer on the persistent kernel and 320-wide column tiles
+        fold = None
+        if (LN_FOLD and not need_grad and not cfg.use_enrollments and all(f is None for f in W.full) and D % 320 == 0 and D <= 1280
+                and ops.gemm_nt(h, W.layers[0].fc2.w, h, rows, D, F_, residual=h, bias=W.layers[0].fc2.b, query_lnstat=True)
+                and ops.gemm_nt(h, W.layers[0].att.o.w, h, rows, D, D, residual=h, bias=W.layers[0].att.o.b, query_lnstat=True)
+                and ops.gemm_nt(h, W.layers[0].att.qkv.w, h, rows, 3 * D, D, query_persistent=True)):
+            fold = self.prepare_fold()
+            stat1 = torch.zeros(rows, L.LN_SLOTS, 2, dtype=F32, device=dev)      # row partials of the LN1 / LN2 inputs
+            stat2 = torch.zeros(rows, L.LN_SLOTS, 2, dtype=F32, device=dev)
+        hb = None                                        # bf16 copy of h + its row partials in stat1: written by the previous fc2
         fddt_done = False                                # h already carries this layer's FDDT (written by the previous fc2)
         for i, lyr in enumerate(enc.layers):
             w = W.layers[i]
@@ -468,7 +510,10 @@ class EncoderEngine:
             xln = _e((rows, D), BF16, dev)
             mean, rstd = _e((rows,), F32, dev), _e((rows,), F32, dev)
             ln = lyr.self_attn_layer_norm
-            if not use_scb:
+            fold1 = fold is not None and hb is not None and mode == ops.MODE_NONE      # LN1 folded: h, hb, stat1 came out of the previous fc2
+            if fold1:
+                hp = h
+            elif not use_scb:
                 hp = _e((rows, D), F32, dev) if mode != ops.MODE_NONE else h
                 ops.fddt_ln_fwd(h, rows, D, mode=mode, stno=stno, stno_bstride=bstride, T=T, w=fw, b=fb,
                                 h_out=hp if mode != ops.MODE_NONE else None, ln_w=ln.weight.detach(),
@@ -493,11 +538,32 @@ class EncoderEngine:
                                 y_bf16=xln, mean=mean, rstd=rstd)
             Ls.rows, Ls.B_after, Ls.hp, Ls.xln, Ls.mean, Ls.rstd = rows, Bc, hp, xln, mean, rstd
             # ---- self-attention (HF WhisperAttention; q pre-scaled in the projection epilogue, in base-2 units: Q_SCALE above)
-            qkv = linear_fwd(xln, w.att.qkv, rows, flags=L.EPI_SCALE_N, scale=Q_SCALE, scale_ncols=D)
+            if fold1:
+                fl = fold[i]
+                qkv = _e((rows, 3 * D), BF16, dev)
+                ops.gemm_nt(hb, fl.qkv_w, qkv, rows, 3 * D, D, bias=fl.qkv_b, flags=L.EPI_SCALE_N, scale=Q_SCALE, scale_ncols=D,
+                            ln_fold=(stat1, fl.qkv_c, D, fl.eps1))
+            else:
+                qkv = linear_fwd(xln, w.att.qkv, rows, flags=L.EPI_SCALE_N, scale=Q_SCALE, scale_ncols=D)
             o = _e((rows, D), BF16, dev)
             lse = _e((Bc, H, T), F32, dev)
             ops.attn_fwd(heads(qkv[:, :D], Bc, T, H), heads(qkv[:, D:2 * D], Bc, T, H), heads(qkv[:, 2 * D:], Bc, T, H),
                          heads(o, Bc, T, H), lse, q_log2=QK_LOG2)
+            if fold is not None:                                  # LN2 folded: out-proj also writes bf16(h2) and its row partials
+                h2, h2b = _e((rows, D), F32, dev), _e((rows, D), BF16, dev)
+                ops.gemm_nt(o, w.att.o.w, h2, rows, D, D, bias=w.att.o.b, residual=hp, ln_stat=(h2b, stat2))
+                fl = fold[i]
+                a = _e((rows, F_), BF16, dev)
+                ops.gemm_nt(h2b, fl.fc1_w, a, rows, F_, D, bias=fl.fc1_b, flags=L.EPI_GELU, ln_fold=(stat2, fl.fc1_c, D, fl.eps2))
+                # the next layer's LN1 can be folded too when fc2 writes its final input: its FDDT fused here, or no FDDT at all
+                nxt_plain = i + 1 < len(enc.layers) and not (cfg.use_fddt and i + 1 < len(enc.fddts))
+                hb = _e((rows, D), BF16, dev) if (i + 1 < len(enc.layers) and (fuse_here or nxt_plain)) else None
+                h = _e((rows, D), F32, dev)
+                ops.gemm_nt(a, w.fc2.w, h, rows, D, F_, bias=w.fc2.b, residual=h2,
+                            fddt=(tuple(t.detach() for t in nfw), tuple(t.detach() for t in nfb), rowmask) if fuse_here else None,
+                            ln_stat=(hb, stat1) if hb is not None else None)
+                fddt_done = fuse_here
+                continue
             h2 = linear_fwd(o, w.att.o, rows, out_dtype=F32, residual=hp)
             # ---- feed-forward
             ln2 = lyr.final_layer_norm

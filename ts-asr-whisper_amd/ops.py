@@ -212,12 +212,28 @@ def fddt_ln_bwd(h_in, rows, D, *, mode=MODE_NONE, stno=None, stno_bstride=None, 
 # ------------------------------------------------------------------------------------------------ GEMM
 def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, residual=None, ldr=None, aux=None,
             ldaux=None, flags=0, scale=1.0, scale_ncols=0, batch=1, strideA=0, strideB=0, strideC=0, strideAux=0, colsum_out=None,
-            fddt=None, query_persistent=False):
+            fddt=None, query_persistent=False, ln_stat=None, ln_fold=None, query_lnstat=False):
     """C[M,N] = epilogue(A[M,K] @ B[N,K]^T).  Pointers + leading dimensions; see include/dicow_hip.h.
     colsum_out [N] fp32: += column sums of the result (a bias gradient), fused into the epilogue.
     fddt = (w[4], b[4], rowmask): DICOW_EPI_FDDT, the next layer's diagonal FDDT applied to the fp32 result (persistent kernel only).
-    query_persistent: launch nothing, return dicow_gemm_nt_is_persistent for this problem."""
+    query_persistent: launch nothing, return dicow_gemm_nt_is_persistent for this problem.
+    LayerNorm fold (include/dicow_hip.h, DICOW_EPI_LNSTAT / LNFOLD):
+      ln_stat = (hb, stats): the PRODUCER of the residual stream also stores the bf16 copy hb [M, N] (through aux) and the row
+                partials stats [M, 16, 2] fp32 (query_lnstat: launch nothing, return dicow_gemm_nt_lnstat_ok);
+      ln_fold = (stats, c, width, eps): the CONSUMER -- A = the producer's hb, B = the folded weight, bias = the folded bias -- scales
+                rows by rstd, subtracts rstd * mean * c[n]."""
     a = L.GemmArgs()
+    if ln_stat is not None:
+        hb, stats = ln_stat
+        assert aux is None and stats.dtype == F32 and stats.numel() >= M * 2 * L.LN_SLOTS
+        aux, ldaux = hb, (hb.stride(0) if ldaux is None else ldaux)
+        a.lnstat = stats.data_ptr()
+        flags |= L.EPI_LNSTAT
+    if ln_fold is not None:
+        stats, lc, width, eps = ln_fold
+        assert stats.dtype == F32 and stats.numel() >= M * 2 * L.LN_SLOTS and lc.dtype == F32 and lc.numel() >= N and width % 320 == 0
+        a.lnstat, a.ln_c, a.ln_inv_dim, a.ln_eps, a.ln_nslots = stats.data_ptr(), lc.data_ptr(), 1.0 / width, eps, 4 * (width // 320)
+        flags |= L.EPI_LNFOLD
     if fddt is not None:
         fw, fb, rowmask = fddt
         a.fddt_w, a.fddt_b, a.fddt_rowmask = _arr4(fw), _arr4(fb), rowmask.data_ptr()
@@ -244,12 +260,23 @@ def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, re
     a.flags, a.scale, a.scale_ncols = flags, scale, scale_ncols
     if query_persistent:
         return bool(L.lib().dicow_gemm_nt_is_persistent(C.byref(a)))
+    if query_lnstat:
+        return bool(L.lib().dicow_gemm_nt_lnstat_ok(C.byref(a)))
     if K >= 8192 and colsum_out is None:             # deep contraction, small output: split ranges + ordered sum (LM-head dgrad)
         need = L.lib().dicow_gemm_nt_splitk_ws_bytes(C.byref(a))
         if need:
             ws = workspace(need, C_out.device)
             a.colsum_ws, a.colsum_ws_bytes = ws.data_ptr(), ws.numel()
     L.call_struct("dicow_gemm_nt", a)
+
+
+def lnfold_prep(W, gamma, beta, bias, out_w, out_c, out_b):
+    """Weights of a Linear behind a LayerNorm, folded: out_w bf16 [N, K] = bf16(gamma * W), out_c [N] = its row sums (fp32),
+    out_b [N] = bias + W_bf16 @ beta.  W fp32 [N, K] contiguous; bias may be None."""
+    N, K = W.shape
+    assert W.is_contiguous() and W.dtype == F32 and out_w.dtype == torch.bfloat16 and out_w.stride(1) == 1
+    L.call("dicow_lnfold_prep", W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(bias), out_w.data_ptr(), out_w.stride(0),
+           out_c.data_ptr(), out_b.data_ptr(), N, K, L.stream())
 
 
 def gemm_tn(A, B, C_out, Mk, N1, N2, *, lda=None, ldb=None, ldc=None, batch=1, strideA=0, strideB=0, accumulate=True,
