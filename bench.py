@@ -488,7 +488,7 @@ def main():
             fe = {"logmel_ms": round(t_mel / NFE, 4), "logmel_gflops": round(mel_flop / (t_mel / NFE) / 1e6, 1),
                   "logmel_algorithmic_mb": round(mel_bytes / 1e6, 1), "logmel_gbps": round(mel_bytes / (t_mel / NFE) / 1e6, 1),
                   "augment_ms": round(t_aug / NFE, 4),
-                  "what": "dicow_logmel (direct fp32 DFT per frame + slaney mel + log / clamp) on B x 30 s of 16 kHz audio resident in HBM; "
+                  "what": "dicow_logmel (the 400-point DFT as an exact-fp32 matrix product on v_mfma_f32_32x32x2_f32 + slaney mel + log / clamp) on B x 30 s of 16 kHz audio resident in HBM; "
                           "BatchAugmenter with the STNO segment augmentation and the joint SpecAug forced on (host planner incl.)",
                   "in_timed_region": bool(a.from_audio)}
         except Exception as ex:

@@ -344,11 +344,12 @@ int dicow_conv2_col2im_gelu_bwd(const void* dA2, const void* pre1, void* d_pre1,
 /* ------------------------------------------------------------------------------------------------ log-mel front end
  * Whisper features on the GPU (reference call site src/data/local_datasets.py:208-214 -> HF feature_extraction_whisper.py
  * :135-165): wave fp32 [B, n_samples] (padded to a multiple of 30 s) -> out fp32 [B, M, n_samples/160].
- * tw_cos/tw_sin: [400, 201] hann-window-folded DFT tables, fb: [201, M] slaney mel filterbank (host-built once,
- * ts-asr-whisper_amd/features.py). */
+ * tw_cos/tw_sin: [400, 224] hann-window-folded DFT tables (201 bins, rows zero-padded to 224 = 7 blocks of 32: ABI 4 -- the
+ * DFT runs as an exact-fp32 matrix product on v_mfma_f32_32x32x2_f32), fb: [201, M] slaney mel filterbank, mel_range: [M][2] int32,
+ * the first and one-past-the-last bin where column m of fb is non-zero (host-built once, ts-asr-whisper_amd/features.py). */
 int64_t dicow_logmel_ws_bytes(int B, int n_samples);
-int dicow_logmel(const float* wave, int B, int n_samples, const float* tw_cos, const float* tw_sin, const float* fb, int M,
-                 float* out, void* ws, int64_t ws_bytes, void* stream);
+int dicow_logmel(const float* wave, int B, int n_samples, const float* tw_cos, const float* tw_sin, const float* fb,
+                 const int* mel_range, int M, float* out, void* ws, int64_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------ batch augmentation
  * The collator's training-time augmentations (reference src/data/collators.py:189-214), applied to the batch where it

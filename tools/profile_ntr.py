@@ -47,14 +47,16 @@ def run(N, K, epi):
     nk = K // 64
     # per workgroup: its tiles in time order
     per = {}
+    clk_of = {}
     for i in range(ntiles):
         per.setdefault(int(d[i, 4]), []).append((int(d[i, 0]), int(d[i, 1]), int(d[i, 2])))
+        clk_of[(int(d[i, 4]), int(d[i, 0]))] = float(d[i, 3])
     gaps = []
     by_order = {}
     for b, ts in per.items():
         ts.sort()
         for k, (a0, a1, a2) in enumerate(ts):
-            by_order.setdefault(k, []).append(((a1 - a0) / 100.0, (a2 - a1) / 100.0))
+            by_order.setdefault(k, []).append(((a1 - a0) / 100.0, (a2 - a1) / 100.0, clk_of[(b, a0)]))
         for (a0, a1, a2), (b0, b1, b2) in zip(ts, ts[1:]):
             gaps.append((b0 - a2) / 100.0)
     print(f"N{N} K{K} {epi:8s}: kernel {s.elapsed_time(e)*1e3:7.1f} us (stamps span {end:7.1f}) | k-loop {kl.mean():6.2f} us/tile "
@@ -62,6 +64,11 @@ def run(N, K, epi):
           f"(min {ep.min():.1f} max {ep.max():.1f}) | inter-tile gap {statistics.mean(gaps) if gaps else 0:.2f} us | {len(per)} WGs x {ntiles/len(per):.1f} tiles", flush=True)
     print("      k-loop / epilogue us by the tile's position in its workgroup's walk: " +
           "  ".join(f"#{k}: {statistics.mean(x[0] for x in v):.1f}/{statistics.mean(x[1] for x in v):.1f}" for k, v in sorted(by_order.items())), flush=True)
+    # the same k-loops in SHADER CLOCKS (s_memtime) and the clock rate they imply: a slow first tile with the same clock count is the
+    # board's clock, not the memory system
+    print("      k-loop shader clocks per step / implied MHz by position: " +
+          "  ".join(f"#{k}: {statistics.mean(x[2] for x in v) / nk:.0f}/{statistics.mean(x[2] for x in v) / statistics.mean(x[0] for x in v):.0f}"
+                    for k, v in sorted(by_order.items())), flush=True)
 for N, K, epi in ((3840, 1280, "plain"), (1280, 1280, "plain"), (1280, 5120, "plain"), (1280, 1280, "res"), (1280, 5120, "res"),
                   (5120, 1280, "gelu"), (5120, 1280, "geluinf"), (5120, 1280, "plain")):
     run(N, K, epi)

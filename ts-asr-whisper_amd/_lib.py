@@ -130,7 +130,7 @@ _SIGS = {
     "dicow_embed_bwd": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_gelu_bwd_bf16": [c_vp, c_vp, c_vp, c_i64, c_vp],
     "dicow_conv2_col2im_gelu_bwd": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
-    "dicow_logmel": [c_vp, c_i, c_i, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp],
+    "dicow_logmel": [c_vp, c_i, c_i, c_vp, c_vp, c_vp, c_vp, c_i, c_vp, c_vp, c_i64, c_vp],
     "dicow_stno_noise_rescale": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_f, c_vp],
     "dicow_stno_segment_augment": [c_vp, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_specaug_joint": [c_vp, c_vp, c_vp, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_vp, c_i, c_vp, c_i, c_i, c_vp],

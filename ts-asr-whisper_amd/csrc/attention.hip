@@ -922,6 +922,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2n_t;
 #ifndef ATTN_BWD_TAIL
 #define ATTN_BWD_TAIL 1
 #endif
+#ifndef ATTN_DKV_CTS
+#define ATTN_DKV_CTS 0     // dkv kernel: the ring slot as a COMPILE-TIME constant (tile loop unrolled by two): every LDS address = lane register + immediate
+#endif
+#ifndef ATTN_DKV_1BAR
+#define ATTN_DKV_1BAR 0    // with ATTN_DKV_CTS: ONE barrier per query tile (the next tile is requested after it, not before)
+#endif
 template <int N> struct attn_ic { static constexpr int value = N; };
 #ifndef ATTN_OCC4_PRIO
 #define ATTN_OCC4_PRIO 0   // experiments: 1 = priority 1 in the S^T segment, 2 = in the softmax + PV segment, 3 / 4 = static by workgroup parity
@@ -1553,6 +1559,100 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
     // 32 keys all lie past Lk keeps only the barriers and its share of the staging)
     const bool tail_half = ATTN_BWD_TAIL && nt * KV_TILE - a.Lq >= 32 && nt - 1 > t0;
     const bool wave_live = !ATTN_BWD_TAIL || kblk0 + wave * 32 < a.Lk;
+#if ATTN_DKV_CTS
+    // Compile-time ring slot ST (the tile loop is unrolled by two): sQ / sdO / statistics / transposed-fragment addresses are a lane
+    // register + an instruction immediate -- the ~28 v_add_u32 and ~50 s_* of address arithmetic per 32-query block are gone.
+    // ATTN_DKV_1BAR: the request for tile t + 1 goes out AFTER tile t's barrier (every wave has then finished reading tile t - 1,
+    // whose slot it overwrites), so the end-of-tile barrier is not needed.
+    auto dkv_tile = [&](int t, auto nqb_tag, auto st_tag) {
+        constexpr int NQB = decltype(nqb_tag)::value, ST = decltype(st_tag)::value;
+        constexpr int SQ = ST * 2 * TILE_BYTES, SDO = SQ + TILE_BYTES, SNQ = (1 - ST) * 2 * TILE_BYTES;
+        auto request_next = [&]() {
+            stage_tile<NI>(srcQ, (t + 1) * KV_TILE, smem + SNQ, wave);
+            stage_tile<NI>(srcdO, (t + 1) * KV_TILE, smem + SNQ + TILE_BYTES, wave);
+            stage_stats64(lse, delta, (t + 1) * KV_TILE, a.Lq, smem + 4 * TILE_BYTES + (1 - ST) * 512, wave, lane);
+        };
+#if ATTN_DKV_1BAR
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this tile: requested a whole tile ago
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (t + 1 < nt) request_next();
+#else
+        if (t + 1 < nt) {
+            request_next();
+            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * NI + 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#endif
+        const int qt0 = t * KV_TILE;
+        const float* sStat = reinterpret_cast<const float*>(smem + 4 * TILE_BYTES + ST * 512);
+        const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + KB > a.Lk) || (a.causal && (kblk0 + wave * 32 + 31 > qt0));
+#define DKV_QBLOCK(QB)                                                                                                  \
+        {                                                                                                               \
+            tr8_t tdo, tq;                                                                                              \
+            tr_issue_u<(QB) * 4096 + SDO>(tdo, qb00, qb01, qb10, qb11);                                                 \
+            tr_issue_u<(QB) * 4096 + SQ>(tq, qb00, qb01, qb10, qb11);                                                   \
+            f32x16_t s, dp;                       /* accumulators seeded with -lse[q], -delta[q] (see attn_bwd_dq_kernel) */ \
+            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                          \
+                const float4 lv = *reinterpret_cast<const float4*>(sStat + (QB) * 32 + 8 * q4 + 4 * hh);                 \
+                const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 64 + (QB) * 32 + 8 * q4 + 4 * hh);          \
+                s[4 * q4] = lv.x; s[4 * q4 + 1] = lv.y; s[4 * q4 + 2] = lv.z; s[4 * q4 + 3] = lv.w;                     \
+                dp[4 * q4] = dv4.x; dp[4 * q4 + 1] = dv4.y; dp[4 * q4 + 2] = dv4.z; dp[4 * q4 + 3] = dv4.w;             \
+            }                                                                                                           \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(smem + SQ + fo[QB][kk]);                          \
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(smem + SDO + fo[QB][kk]);                         \
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);                                    \
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
+            }                                                                                                           \
+            f32x16_t pv, dsv;                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = (LOG2 ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * LOG2E));                 \
+            if (need_mask) {                      /* ONE branch per block: a test inside the score loop becomes 16 */   \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
+                    const int qq = qt0 + (QB) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);                                   \
+                    if (qq >= a.Lq || key >= a.Lk || (a.causal && key > qq)) pv[r] = 0.f;                               \
+                }                                                                                                       \
+            }                                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) dsv[r] = pv[r] * dp[r];                                      \
+            bf16x8_t qtf[2][2], dotf[2][2];                                                                             \
+            tr_wait<0>(tdo);                                                                                            \
+            tr_wait<0>(tq);                                                                                             \
+            tr_pack(dotf, tdo);                                                                                         \
+            tr_pack(qtf, tq);                                                                                           \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                             \
+                const bf16x8_t pf = pack8(pv, 8 * x);                                                                   \
+                const bf16x8_t df = pack8(dsv, 8 * x);                                                                  \
+                _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                         \
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[x][d], pf, dv[d], 0, 0, 0);                    \
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[x][d], df, dk[d], 0, 0, 0);                     \
+                }                                                                                                       \
+            }                                                                                                           \
+        }
+        if (wave_live) {
+            DKV_QBLOCK(0)
+            if constexpr (NQB == 2) DKV_QBLOCK(1)
+        }
+#undef DKV_QBLOCK
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#if !ATTN_DKV_1BAR
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#endif
+    };
+    {
+        const int nfull = tail_half ? nt - 1 : nt;
+        int t = t0;
+        for (; t + 1 < nfull; t += 2) { dkv_tile(t, attn_ic<2>{}, attn_ic<0>{}); dkv_tile(t + 1, attn_ic<2>{}, attn_ic<1>{}); }
+        if (t < nfull) { dkv_tile(t, attn_ic<2>{}, attn_ic<0>{}); ++t; }
+        if (tail_half) { if ((t - t0) & 1) dkv_tile(nt - 1, attn_ic<1>{}, attn_ic<1>{}); else dkv_tile(nt - 1, attn_ic<1>{}, attn_ic<0>{}); }
+#if ATTN_DKV_1BAR
+        __builtin_amdgcn_s_barrier();
+#endif
+    }
+#else
     auto dkv_tile = [&](int t, auto nqb_tag) {
         constexpr int NQB = decltype(nqb_tag)::value;
         char* sQ = smem + ((t - t0) & 1) * 2 * TILE_BYTES;
@@ -1676,6 +1776,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
         for (int t = t0; t < nfull; ++t) dkv_tile(t, attn_ic<2>{});
         if (tail_half) dkv_tile(nt - 1, attn_ic<1>{});
     }
+#endif
     if (a.dv_colsum) {        // v_proj bias gradient, fused: second workspace plane, partial row (b, key block, wave)
         // partial rows are indexed by 128-key block and wave-in-block whatever the workgroup size (the reduction's layout)
         const int nqb = (a.Lq + 127) / 128, nkb = (a.Lk + 127) / 128;

@@ -5,12 +5,19 @@
 // (hann-400 periodic window, hop 160, last frame dropped) -> |.|^2 -> slaney mel projection -> log10(clamp 1e-10)
 // -> max(x, clip_max - 8) -> (x + 4) / 4, output [B, M, n_frames] fp32.
 //
-// Kernel 1 (one workgroup = 32 frames of one clip): the 5360 samples the frames touch are staged in LDS; thread k
-// owns frequency bin k and runs the direct DFT for all 32 frames against window-folded twiddle tables
-// tw_cos/tw_sin [400, 201] (coalesced over k, L2-resident), 64 fp32 accumulators in registers; power spectrum goes
-// to LDS; the mel projection is a [32 x 201] x [201 x M] product from LDS; log10 and the workgroup max are written.
+// Round 4: the 400-point real DFT of a block of frames IS a matrix product -- [frames x 400 samples] . [400 x (201 cos | 201 sin)]
+// against the window-folded twiddle tables -- and runs on the matrix pipe in EXACT fp32 (v_mfma_f32_32x32x2_f32: 64 flop / clock /
+// SIMD = the fp32 vector rate, but one instruction per 64 cycles instead of 32 v_fma per lane, with every frame / bin pair reusing
+// its operands from registers).  logmel_mfma_kernel, one workgroup = 64 frames of one clip, 4 waves = 2 frame blocks x {re, im}:
+//   * the 10480 samples the frames touch are staged in LDS once, one pad word every 160 samples (hop 160 = 0 mod 32 banks: the
+//     A fragment -- lane = frame -- would otherwise be a 32-way bank conflict);
+//   * B fragments (2 samples x 32 bins of the cos or sin table, rows padded to 224 bins) come straight from L2 (the 717 KB table pair
+//     is shared by every workgroup), one k-step ahead in registers; 7 bin blocks x 200 k-steps = 1400 MFMAs per wave;
+//   * re^2 + im^2 meet in LDS ([64][209] fp32 over the sample stage), the slaney projection walks only each filter's non-zero bins
+//     (~400 multiply-adds per frame instead of 201 x M), log10, workgroup maximum.
+// 104 VGPRs + 57 KB of LDS: three workgroups per CU, the 750 workgroups of 16 clips are resident at once.
 // Kernel 2: clip max over the workgroup maxima, then the dynamic-range clamp and affine normalisation.
-// ~15 GFLOP fp32 per 16 clips: far below both rooflines; exact-ish fp32 (no FFT reordering error).
+// logmel_kernel (round 1-3: the direct DFT on the vector pipe, thread = frequency bin) is kept for -DLOGMEL_DIRECT A/B builds.
 #include "common.h"
 
 #define LM_FRAMES 32
@@ -20,7 +27,7 @@
 #define LM_SPAN (LM_HOP * (LM_FRAMES - 1) + LM_NFFT)      // 5360 samples
 
 __global__ void __launch_bounds__(256) logmel_kernel(const float* __restrict__ wave, int n_samples, int n_frames,
-                                                     const float* __restrict__ tw_cos, const float* __restrict__ tw_sin,
+                                                     const float* __restrict__ tw_cos, const float* __restrict__ tw_sin, int ldt,
                                                      const float* __restrict__ fb, int M, float* __restrict__ out,
                                                      float* __restrict__ blockmax) {
     __shared__ __attribute__((aligned(16))) float xs[LM_SPAN];
@@ -43,7 +50,7 @@ __global__ void __launch_bounds__(256) logmel_kernel(const float* __restrict__ w
         for (int n = 0; n < LM_NFFT; n += 4) {
             float c[4], s[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { c[e] = tw_cos[(n + e) * LM_BINS + tid]; s[e] = tw_sin[(n + e) * LM_BINS + tid]; }
+            for (int e = 0; e < 4; ++e) { c[e] = tw_cos[(n + e) * ldt + tid]; s[e] = tw_sin[(n + e) * ldt + tid]; }
 #pragma unroll
             for (int f = 0; f < LM_FRAMES; ++f) {
                 const float4 x = *reinterpret_cast<const float4*>(&xs[f * LM_HOP + n]);
@@ -73,6 +80,118 @@ __global__ void __launch_bounds__(256) logmel_kernel(const float* __restrict__ w
     if (tid == 0) blockmax[(int64_t)b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// ---- round 4: the DFT on the matrix pipe (see the header)
+#define LMM_FRAMES 64
+#define LMM_SPAN (LM_HOP * (LMM_FRAMES - 1) + LM_NFFT)                 // 10480 samples
+#define LMM_XS (LMM_SPAN + LMM_SPAN / LM_HOP + 1)                       // + one pad word per 160 samples
+#define LMM_LD 224                                                      // table row length (bins, zero-padded): 7 blocks of 32
+#define LMM_PW 209                                                      // row stride of the power image (odd: conflict-free columns)
+typedef __attribute__((ext_vector_type(16))) float lm_f32x16_t;
+
+__global__ void __launch_bounds__(256, 3) logmel_mfma_kernel(const float* __restrict__ wave, int n_samples, int n_frames,
+                                                             const float* __restrict__ tw_cos, const float* __restrict__ tw_sin,
+                                                             const float* __restrict__ fb, const int* __restrict__ mel_range, int M,
+                                                             float* __restrict__ out, float* __restrict__ blockmax) {
+    __shared__ __attribute__((aligned(16))) float sm[LMM_FRAMES * LMM_PW > LMM_XS ? LMM_FRAMES * LMM_PW : LMM_XS];
+    __shared__ float red[4];
+    const int b = blockIdx.y, t0 = blockIdx.x * LMM_FRAMES, tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float* w = wave + (int64_t)b * n_samples;
+    const int p0 = t0 * LM_HOP - LM_NFFT / 2;
+    if (p0 >= 0 && p0 + LMM_SPAN <= n_samples) {                      // interior block: 16-byte loads (p0 and the span are multiples of 4)
+        const float4* w4 = reinterpret_cast<const float4*>(w + p0);
+        for (int i4 = tid; i4 < LMM_SPAN / 4; i4 += 256) {
+            const float4 x = w4[i4];
+            float* d = &sm[4 * i4 + (4 * i4) / LM_HOP];               // (a quad never straddles a 160-sample block)
+            d[0] = x.x; d[1] = x.y; d[2] = x.z; d[3] = x.w;
+        }
+    } else {
+        for (int i = tid; i < LMM_SPAN; i += 256) {
+            int p = p0 + i;                                           // centred frames, reflect padding
+            if (p < 0) p = -p;
+            if (p >= n_samples) p = 2 * (n_samples - 1) - p;
+            p = p < 0 ? 0 : (p >= n_samples ? n_samples - 1 : p);    // frames beyond the clip (masked below)
+            sm[i + i / LM_HOP] = w[p];
+        }
+    }
+    __syncthreads();
+    const int rb = wv & 1, half = wv >> 1;                            // frame block, {0: cos -> re, 1: sin -> im}
+    const int f = lane & 31, kk = lane >> 5;
+    const float* tab = (half ? tw_sin : tw_cos) + kk * LMM_LD + f;    // B fragment of k-step n: tab[n * LMM_LD + 32 cb]
+    const float* xa = sm + (rb * 32 + f) * (LM_HOP + 1) + kk;          // A fragment of k-step n: xa[n + n / 160]
+    lm_f32x16_t acc[7];
+#pragma unroll
+    for (int cb = 0; cb < 7; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.f;
+    // B fragments TWO k-steps ahead in registers (L2 latency ~ two k-steps of 7 MFMAs when three waves share the SIMD); the asm
+    // statement pins the order "request step n + 4, then compute step n" -- left alone hipcc sinks the loads next to their use
+    float b0[7], b1[7], bc[7];
+#pragma unroll
+    for (int cb = 0; cb < 7; ++cb) { b0[cb] = tab[cb * 32]; b1[cb] = tab[2 * LMM_LD + cb * 32]; }
+    // three segments: inside one the pad offset n / 160 is a constant (n even, k-step = 2 samples, 160 even)
+#pragma unroll
+    for (int seg = 0; seg < 3; ++seg) {
+        const int n1 = seg == 2 ? LM_NFFT : (seg + 1) * LM_HOP;
+#pragma unroll 2
+        for (int n = seg * LM_HOP; n < n1; n += 4) {
+            const float a0 = xa[n + seg], a1 = xa[n + 2 + seg];
+            const int na = n + 4 < LM_NFFT ? n + 4 : n, nb = n + 6 < LM_NFFT ? n + 6 : n;     // (past the end: re-read, no branch)
+#pragma unroll
+            for (int cb = 0; cb < 7; ++cb) bc[cb] = b0[cb];
+#pragma unroll
+            for (int cb = 0; cb < 7; ++cb) b0[cb] = tab[na * LMM_LD + cb * 32];
+#pragma unroll
+            for (int cb = 0; cb < 7; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bc[cb], acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int cb = 0; cb < 7; ++cb) bc[cb] = b1[cb];
+#pragma unroll
+            for (int cb = 0; cb < 7; ++cb) b1[cb] = tab[nb * LMM_LD + cb * 32];
+#pragma unroll
+            for (int cb = 0; cb < 7; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bc[cb], acc[cb], 0, 0, 0);
+        }
+    }
+    __syncthreads();                                                  // every wave is done with the sample stage
+    // power image pw[frame][bin] over the same LDS: the re waves write re^2, then the im waves add im^2
+    // C layout of the 32 x 32 product: lane -> column (bin) lane & 31, register r -> row (frame) 8 (r / 4) + 4 (lane / 32) + r % 4
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        if (half == ph) {
+#pragma unroll
+            for (int cb = 0; cb < 7; ++cb) {
+                const int bin = cb * 32 + f;
+                if (bin < LM_BINS) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* p = &sm[(rb * 32 + 8 * (r >> 2) + 4 * kk + (r & 3)) * LMM_PW + bin];
+                        const float v = acc[cb][r] * acc[cb][r];
+                        *p = ph ? *p + v : v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // slaney projection over each filter's non-zero bins [lo, hi) only, log10, outputs, workgroup maximum
+    const int fr = tid & 63, mg = tid >> 6;
+    const bool fvalid = t0 + fr < n_frames;
+    float lmax = -INFINITY;
+    for (int m = mg; m < M; m += 4) {
+        const int lo = mel_range[2 * m], hi = mel_range[2 * m + 1];
+        float a = 0.f;
+        for (int k = lo; k < hi; ++k) a += sm[fr * LMM_PW + k] * fb[k * M + m];
+        const float v = __builtin_amdgcn_logf(fmaxf(a, 1e-10f)) * 0.30102999566398120f;      // v_log_f32 (base 2, ~1 ulp) x log10(2)
+        if (fvalid) {
+            out[((int64_t)b * M + m) * n_frames + t0 + fr] = v;
+            lmax = fmaxf(lmax, v);
+        }
+    }
+    lmax = wave_max(lmax);
+    if (lane == 0) red[wv] = lmax;
+    __syncthreads();
+    if (tid == 0) blockmax[(int64_t)b * gridDim.x + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 __global__ void logmel_finalize_kernel(float* __restrict__ out, const float* __restrict__ blockmax, int nblocks, int64_t per_clip) {
     __shared__ float cm;
     const int b = blockIdx.y;
@@ -91,17 +210,27 @@ __global__ void logmel_finalize_kernel(float* __restrict__ out, const float* __r
 
 extern "C" int64_t dicow_logmel_ws_bytes(int B, int n_samples) {
     const int n_frames = n_samples / LM_HOP;
-    return (int64_t)B * dicow_cdiv(n_frames, LM_FRAMES) * 4;
+    return (int64_t)B * dicow_cdiv(n_frames, LM_FRAMES) * 4;          // (sized for the smaller of the two frame blocks: covers both kernels)
 }
 
 extern "C" int dicow_logmel(const float* wave, int B, int n_samples, const float* tw_cos, const float* tw_sin, const float* fb,
-                            int M, float* out, void* ws, int64_t ws_bytes, void* stream) {
-    DICOW_REQUIRE(wave && tw_cos && tw_sin && fb && out && B > 0 && M > 0, "logmel: null/empty argument");
+                            const int* mel_range, int M, float* out, void* ws, int64_t ws_bytes, void* stream) {
+    DICOW_REQUIRE(wave && tw_cos && tw_sin && fb && mel_range && out && B > 0 && M > 0, "logmel: null/empty argument");
     DICOW_REQUIRE(n_samples >= LM_NFFT && n_samples % LM_HOP == 0, "logmel: n_samples=%d must be a multiple of %d (pad to 30 s)", n_samples, LM_HOP);
-    const int n_frames = n_samples / LM_HOP, nb = dicow_cdiv(n_frames, LM_FRAMES);
+    const int n_frames = n_samples / LM_HOP;
+#ifdef LOGMEL_DIRECT
+    const int nb = dicow_cdiv(n_frames, LM_FRAMES);
+#else
+    const int nb = dicow_cdiv(n_frames, LMM_FRAMES);
+#endif
     DICOW_REQUIRE(ws && ws_bytes >= (int64_t)B * nb * 4, "logmel: workspace too small (need %ld bytes)", (long)B * nb * 4);
+#ifdef LOGMEL_DIRECT
     hipLaunchKernelGGL(logmel_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, wave, n_samples, n_frames, tw_cos, tw_sin,
-                       fb, M, out, (float*)ws);
+                       LMM_LD, fb, M, out, (float*)ws);
+#else
+    hipLaunchKernelGGL(logmel_mfma_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, wave, n_samples, n_frames, tw_cos, tw_sin,
+                       fb, mel_range, M, out, (float*)ws);
+#endif
     DICOW_CHECK_LAUNCH("logmel");
     const int64_t per_clip = (int64_t)M * n_frames;
     hipLaunchKernelGGL(logmel_finalize_kernel, dim3(64, B), dim3(256), 0, (hipStream_t)stream, out, (const float*)ws, nb, per_clip);

@@ -12,6 +12,7 @@ from . import _lib as L
 from . import ops
 
 N_FFT, HOP, SR, N_SAMPLES = 400, 160, 16000, 480000
+TABLE_LD = 224                 # row length of the DFT tables (csrc/logmel.hip: LMM_LD)
 _TABLES = {}
 
 
@@ -41,10 +42,18 @@ def _tables(n_mels, device):
         n = np.arange(N_FFT)
         win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / N_FFT)                      # periodic hann
         ang = 2.0 * np.pi * np.outer(n, np.arange(1 + N_FFT // 2)) / N_FFT
-        tw_c = (win[:, None] * np.cos(ang)).astype(np.float32)
-        tw_s = (-win[:, None] * np.sin(ang)).astype(np.float32)
+        # rows zero-padded from 201 to TABLE_LD bins: the kernel's B fragments are 32-bin blocks of a row (7 blocks)
+        tw_c = np.zeros((N_FFT, TABLE_LD), np.float32)
+        tw_s = np.zeros((N_FFT, TABLE_LD), np.float32)
+        tw_c[:, :1 + N_FFT // 2] = (win[:, None] * np.cos(ang)).astype(np.float32)
+        tw_s[:, :1 + N_FFT // 2] = (-win[:, None] * np.sin(ang)).astype(np.float32)
         fb = mel_filter_bank(n_mels).astype(np.float32)
-        _TABLES[key] = tuple(torch.from_numpy(np.ascontiguousarray(t)).to(device) for t in (tw_c, tw_s, fb))
+        # the bins where filter m is non-zero: the projection skips the exact zeros (same sum, in the same order, as the dense loop)
+        rng = np.zeros((n_mels, 2), np.int32)
+        for m in range(n_mels):
+            nz = np.nonzero(fb[:, m])[0]
+            rng[m] = (nz[0], nz[-1] + 1) if nz.size else (0, 0)
+        _TABLES[key] = tuple(torch.from_numpy(np.ascontiguousarray(t)).to(device) for t in (tw_c, tw_s, fb, rng))
     return _TABLES[key]
 
 
@@ -67,9 +76,9 @@ def log_mel(wave: torch.Tensor, n_mels: int) -> torch.Tensor:
         raise L.DicowError("log_mel: the waveform must be on the GPU (no CPU fallback)")
     wave = wave.contiguous().to(torch.float32)
     B, n = wave.shape
-    tw_c, tw_s, fb = _tables(n_mels, wave.device)
+    tw_c, tw_s, fb, rng = _tables(n_mels, wave.device)
     out = torch.empty(B, n_mels, n // HOP, dtype=torch.float32, device=wave.device)
     ws = ops.workspace(L.lib().dicow_logmel_ws_bytes(B, n), wave.device)
-    L.call("dicow_logmel", wave.data_ptr(), B, n, tw_c.data_ptr(), tw_s.data_ptr(), fb.data_ptr(), n_mels, out.data_ptr(),
+    L.call("dicow_logmel", wave.data_ptr(), B, n, tw_c.data_ptr(), tw_s.data_ptr(), fb.data_ptr(), rng.data_ptr(), n_mels, out.data_ptr(),
            ws.data_ptr(), ws.numel(), L.stream())
     return out
