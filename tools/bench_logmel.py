@@ -28,7 +28,7 @@ for name, path in libs:
     outs[name] = o.float().cpu()
     ms = statistics.median(ts)
     mb = (wave.numel() * 4 + o.numel() * 4 * 3) / 1e6          # audio read + features written, re-read and re-written by the finalize pass
-    print(f"{name:20s} {ms:7.4f} ms per call ({B} clips)   {mb / ms / 1e3:7.1f} GB/s algorithmic ({mb:.0f} MB)   "
+    print(f"{name:20s} {ms:7.4f} ms per call ({B} clips)   {mb / ms:7.1f} GB/s algorithmic ({mb:.0f} MB)   "
           f"{2 * B * 3000 * 400 * 402 / ms / 1e9:6.1f} TFLOP/s of the dense DFT", flush=True)
 names = list(outs)
 for n in names[1:]:
