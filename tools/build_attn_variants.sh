@@ -1,5 +1,5 @@
 #!/bin/bash
-# Build A/B variants of the library that differ only in attention.hip's -D flags: tools/build_variants.sh name "flags" [name "flags" ...]
+# Build A/B variants of the library that differ only in attention.hip's -D flags (with the measured-and-rejected kernels of csrc/experiments/ compiled in): tools/build_attn_variants.sh name "flags" [name "flags" ...]
 # -> tools/libv_<name>.so (git-ignored; travels to the GPU box).  Used with DICOW_HIP_LIB=... and tools/ab_*.py.
 set -e
 cd "$(dirname "$0")/../ts-asr-whisper_amd/csrc"
@@ -9,7 +9,7 @@ names=()
 while [ $# -gt 1 ]; do
   n=$1; f=$2; shift 2
   names+=("$n")
-  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c attention.hip -o build/attention_v_$n.o $f ) &
+  ( hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c attention.hip -DDICOW_EXPERIMENTS -o build/attention_v_$n.o $f ) &
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done

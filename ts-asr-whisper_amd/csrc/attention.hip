@@ -200,707 +200,19 @@ __device__ __forceinline__ void attn_block_coords(int nblk, int H, int B, int& b
     h = bh % H; b = bh / H;
 }
 
-#ifndef ATTN_FWD_WGS
-#define ATTN_FWD_WGS 3          // workgroups per CU: 154 VGPRs fit three; equal time at large-v3-turbo (3840 workgroups), one round instead of 1.5 at whisper-base B = 8 (768)
-#endif
 #ifndef ATTN_DKV_JIT
 #define ATTN_DKV_JIT 0
 #endif
 #ifndef ATTN_BWD_DKV_NW8
 #define ATTN_BWD_DKV_NW8 0
 #endif
-#ifndef ATTN_FWD_LATE_DMA
-#define ATTN_FWD_LATE_DMA 0
-#endif
-#ifndef ATTN_FWD_REGSTAGE
-#define ATTN_FWD_REGSTAGE 0
-#endif
-#ifndef ATTN_FWD_NW8
+#ifdef DICOW_EXPERIMENTS
+#include "experiments/attention_fwd_variants.inc"      // the measured-and-rejected forward kernels (see the file)
+#else
 #define ATTN_FWD_NW8 0
-#endif
-#ifndef ATTN_FWD_ILP
-#define ATTN_FWD_ILP 0
-#endif
-#ifndef ATTN_FWD_MSUM
-#define ATTN_FWD_MSUM 0
-#endif
-#ifndef ATTN_FWD_ASMSEED
-#define ATTN_FWD_ASMSEED 0
-#endif
-// LOG2: q carries a factor log2(e) (folded into the q-scale of the projection epilogue), i.e. the scores ARE base-2
-// exponents.  The forward loop is bound by its VALU instruction count (removing the 32 fma of a tile: -6 %, measured), so
-//   * the S accumulators are SEEDED with -m_ref (a 16-register tuple that only changes when the reference moves): the MFMA
-//     chain delivers s - m_ref and the per-score fma disappears -- p = 2^s' straight away;
-//   * the row sum l += sum p runs on the matrix pipe: one more MFMA per P fragment against a constant all-ones operand
-//     (D[i][q] = sum_k P^T[k][q] for every i; 4 MFMAs per tile instead of 32 v_add and the final half-wave exchange).
-template <bool LOG2, int NW = 4>    // NW waves = NW * 32 query rows per workgroup, sharing each K / V tile
-__global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (LOG2 ? 2 : ATTN_FWD_WGS)) attn_fwd_kernel(const dicow_attn_fwd_args a) {
-    constexpr int QB = NW * 32, NI = 8 / NW;
-    constexpr bool LATE = ATTN_FWD_LATE_DMA && !LOG2 && NW == 4 && !ATTN_FWD_REGSTAGE;   // four slots, tile t+3 requested from inside tile t's softmax
-    constexpr int NS = LATE ? 4 : 3;
-    __shared__ __attribute__((aligned(16))) char smem[2 * NS * TILE_BYTES];      // NS (K, V) slots
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = lane >> 5;
-    int qblk, h, b;
-    attn_block_coords((a.Lq + QB - 1) / QB, a.H, a.B, qblk, h, b);
-    const int q0 = qblk * QB;
-    const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
-    const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
-    const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
-
-    // Q fragments (b-operand): column q = lane&31, k-slots d = 16kk + 8hh + e
-    int qrow = q0 + wave * 32 + (lane & 31);
-    const int qrow_c = qrow < a.Lq ? qrow : a.Lq - 1;
-    bf16x8_t qf[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-        qf[kk] = *reinterpret_cast<const bf16x8_t*>(Q + (int64_t)qrow_c * a.q_rs + kk * 16 + hh * 8);
-
-    f32x16_t o[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_ref = -INFINITY, l_run = 0.f;     // reference maximum (raw score units; LOG2: base-2 units) and running sum of 2^((s - m_ref) log2 e)
-    f32x16_t seed, lacc;                      // LOG2: -m_ref in every entry (0 while no score has been seen); row sums on the matrix pipe
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { seed[r] = 0.f; lacc[r] = 0.f; }
-#if defined(DICOW_ABLATIONS) && defined(ATTN_ABL_ZSEED)
-    asm volatile("" : "+v"(seed));              // (opaque zeros: the compiler must keep the tuple in registers)
-#endif
-    bf16x8_t ones;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3F80;
-
-    int kv_end = a.Lk;
-    if (a.causal) { const int lim = q0 + QB < a.Lk ? q0 + QB : a.Lk; kv_end = lim; }   // keys <= last q row of the block
-    const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
-
-    const tile_src_t srcK = make_tile_src<SWZ_K, NI>(K, a.k_rs, a.Lk, wave, lane), srcV = make_tile_src<SWZ_V, NI>(V, a.v_rs, a.Lk, wave, lane);
-    // Three-slot ring, ONE barrier per k-tile: the barrier that publishes tile t also proves every wave has left tile
-    // t-1, whose slot is then refilled with tile t+2 (two tiles of DMA lead instead of one).
-    stage_tile<NI>(srcK, 0, smem, wave);
-    stage_tile<NI>(srcV, 0, smem + TILE_BYTES, wave);
-    if (nt > 1) {
-        stage_tile<NI>(srcK, KV_TILE, smem + 2 * TILE_BYTES, wave);
-        stage_tile<NI>(srcV, KV_TILE, smem + 3 * TILE_BYTES, wave);
-    }
-    if (LATE && nt > 2) {
-        stage_tile<NI>(srcK, 2 * KV_TILE, smem + 4 * TILE_BYTES, wave);
-        stage_tile<NI>(srcV, 2 * KV_TILE, smem + 5 * TILE_BYTES, wave);
-    }
-#ifdef ATTN_PROFILE
-    long long pacc[6] = {0, 0, 0, 0, 0, 0}, pt[7];
-    const long long pstart = clock64();
-#define PT(i) pt[i] = clock64();
-#else
-#define PT(i)
-#endif
-    // K fragments are read one tile AHEAD (during the previous tile's softmax), so the QK^T MFMAs start right behind the
-    // barrier instead of behind an LDS round trip; for that, tile t+1 must already be visible during tile t: the wait
-    // at the top covers everything issued so far (tile t+1 was requested a full iteration earlier).
-    bf16x8_t kfr[2][4];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-            kfr[kb][kk] = *reinterpret_cast<const bf16x8_t*>(smem + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
-    int slot = 0;
-#if ATTN_FWD_REGSTAGE
-    typedef __attribute__((ext_vector_type(4))) unsigned u32x4_rs_t;
-    u32x4_rs_t rgK[NI], rgV[NI];
-    char* rg_dst = smem;
-#endif
-    for (int t = 0; t < nt; ++t) {
-        PT(0)
-        char* sK = smem + slot * 2 * TILE_BYTES;
-        char* sV = sK + TILE_BYTES;
-        const int slot_n = slot == NS - 1 ? 0 : slot + 1;
-        if (t > 0) {
-            // tile t+1 landed (this wave's share).  LATE: tile t+2, requested half a tile ago, may still be in flight --
-            // loads complete in order, so "at most its 2 NI instructions outstanding" covers everything older
-            if (LATE && t + 2 < nt) asm volatile("s_waitcnt vmcnt(%0)" :: "i"(LATE ? 2 * NI : 0) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        }
-#if defined(DICOW_ABLATIONS) && defined(ATTN_ABL_NODMA)
-        if (false) {                                       // (ablation: no DMA after the prologue; results wrong, timing valid)
-#else
-        if (LATE && ATTN_FWD_LATE_DMA == 2) {              // four slots, requests right behind the barrier: two tiles of flight
-            if (t + 3 < nt) {
-                char* nK = smem + (slot == 0 ? NS - 1 : slot - 1) * 2 * TILE_BYTES;
-                stage_tile<NI>(srcK, (t + 3) * KV_TILE, nK, wave);
-                stage_tile<NI>(srcV, (t + 3) * KV_TILE, nK + TILE_BYTES, wave);
-            }
-        } else if (!LATE && t + 2 < nt) {
-#endif
-            char* nK = smem + (slot == 0 ? 2 : slot - 1) * 2 * TILE_BYTES;    // slot of tile t-1 == slot of tile t+2
-#if ATTN_FWD_REGSTAGE
-            // register staging: plain buffer loads now, ds_write at the end of this tile (same LDS image as the DMA form)
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                rgK[i] = __builtin_amdgcn_raw_buffer_load_b128(srcK.rs, srcK.vo[i], (t + 2) * KV_TILE * srcK.row_bytes, 0);
-                rgV[i] = __builtin_amdgcn_raw_buffer_load_b128(srcV.rs, srcV.vo[i], (t + 2) * KV_TILE * srcV.row_bytes, 0);
-            }
-            rg_dst = nK;
-#else
-            stage_tile<NI>(srcK, (t + 2) * KV_TILE, nK, wave);
-            stage_tile<NI>(srcV, (t + 2) * KV_TILE, nK + TILE_BYTES, wave);
-#endif
-        }
-        PT(1)
-
-        // ---- S^T = K . Q^T  (two 32-key blocks)
-        f32x16_t s[2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            if constexpr (LOG2) {
-#if ATTN_FWD_ASMSEED
-                // vdst != srcC spelled out: left to the register allocator, the seed tuple is COPIED into one of the two S
-                // blocks every tile (16 v_mov in front of the MFMA chain)
-                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[kb]) : "v"(kfr[kb][0]), "v"(qf[0]), "v"(seed));
-#else
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][0], qf[0], seed, 0, 0, 0);
-#endif
-#pragma unroll
-                for (int kk = 1; kk < 4; ++kk)
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
-            } else {
-#if defined(DICOW_ABLATIONS) && defined(ATTN_ABL_ZSEED)
-                // diagnostic: the first MFMA takes its C operand from a 16-register tuple of zeros that is NOT its destination
-                // (what the seeded q_log2 form does) -- isolates the price of that operand form
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][0], qf[0], seed, 0, 0, 0);
-#pragma unroll
-                for (int kk = 1; kk < 4; ++kk)
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
-#else
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
-#endif
-            }
-        }
-        // V^T fragments for both 32-key blocks: issued now, consumed after the softmax
-        const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
-        tr8_t tv0, tv1;
-        tr_issue_v<0>(tv0, va0, va1);
-        tr_issue_v<4096>(tv1, va0, va1);
-        PT(2)
-        // ---- mask (tile-uniform test first), online softmax.  The loop is VALU-bound at head_dim 64 (32 scores per lane
-        // and k-tile against 16 MFMAs), so the per-score work is pared down to max3 / fma / exp2 / add / pack:
-        //   * the running maximum is kept in raw score units and log2(e) is folded into one fma per score;
-        //   * the accumulator rescale is LAZY: the reference maximum m_ref only moves when some row's maximum grew by more
-        //     than 2^8 (wave-uniform test), otherwise p = 2^((s - m_ref) log2 e) simply runs up to 256 -- exact in fp32 / bf16
-        //     range, and the final 1/l normalisation is unchanged.  After the first tiles the 32 multiplies on O vanish.
-        const int k0 = t * KV_TILE;
-        const bool need_mask = (k0 + KV_TILE > a.Lk) || (a.causal && (k0 + KV_TILE - 1 > q0 + wave * 32));
-        if (need_mask) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= a.Lk || (a.causal && key > qrow)) s[kb][r] = -INFINITY;
-                }
-        }
-#if ATTN_FWD_ILP
-        // four independent max3 chains (a single chain of 16 dependent v_max3 stalls a wave that has one partner on its SIMD),
-        // and the half-wave exchange through v_permlane32_swap (VALU) instead of ds_bpermute + lgkmcnt(0)
-        float mq[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) mq[c] = fmaxf(s[0][c], s[1][c]);
-#pragma unroll
-        for (int r = 4; r < 16; r += 4)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) mq[c] = fmaxf(fmaxf(mq[c], s[0][r + c]), s[1][r + c]);
-        float mx = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
-        {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-            mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        }
-#else
-        float mx = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);        // -> v_max3_f32
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-#endif
-        float psum = 0.f;
-        if constexpr (LOG2) {
-            // s holds s - m_ref (0 subtracted while the row has no reference yet).  The reference moves when a row maximum has
-            // grown by more than 2^8 -- or when the row sees its first finite score.
-            const bool unset = m_ref == -INFINITY;
-            if (__builtin_amdgcn_ballot_w64(mx > 8.0f || (unset && mx > -INFINITY)) != 0) {
-                float d = unset ? mx : fmaxf(mx, 0.f);
-                const bool none = d == -INFINITY;              // still nothing visible for this row
-                d = none ? 0.f : d;
-                const float alpha = unset ? 1.0f : __builtin_amdgcn_exp2f(-d);
-#if ATTN_FWD_MSUM
-#pragma unroll
-                for (int r = 0; r < 16; ++r) lacc[r] *= alpha;
-#else
-                l_run *= alpha;
-#endif
-#pragma unroll
-                for (int dd = 0; dd < 2; ++dd)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) s[kb][r] -= d;
-                m_ref = none ? m_ref : (unset ? d : m_ref + d);
-                const float ns = none ? 0.f : -m_ref;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) seed[r] = ns;
-            }
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(s[kb][r]);
-                    s[kb][r] = p;
-#if !ATTN_FWD_MSUM
-                    psum += p;               // (one chain of scalar adds: packed f32 adds beside MFMAs cost more than they save)
-#endif
-                }
-        } else {
-        if (__builtin_amdgcn_ballot_w64(mx > m_ref + 8.0f * LN2) != 0) {       // also taken on the first tile (m_ref = -inf)
-            const float m_new = fmaxf(m_ref, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;  // fully masked so far: keep everything at 0
-            const float alpha = __builtin_amdgcn_exp2f((m_ref - m_use) * LOG2E);
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            m_ref = m_new;
-        }
-        const float mL = (m_ref == -INFINITY) ? 0.f : m_ref * LOG2E;
-#if ATTN_FWD_ILP
-        float ps4[4] = {0.f, 0.f, 0.f, 0.f};
-#endif
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-#if defined(DICOW_ABLATIONS) && defined(ATTN_ABL_NOFMA)
-                const float p = __builtin_amdgcn_exp2f(s[kb][r]);
-#elif defined(DICOW_ABLATIONS) && defined(ATTN_ABL_NOEXP)
-                const float p = fmaf(s[kb][r], LOG2E, -mL);
-#else
-                const float p = __builtin_amdgcn_exp2f(fmaf(s[kb][r], LOG2E, -mL));
-#endif
-                s[kb][r] = p;
-#if !(defined(DICOW_ABLATIONS) && defined(ATTN_ABL_NOSUM))
-#if ATTN_FWD_ILP
-                ps4[r & 3] += p;
-#else
-                psum += p;
-#endif
-#endif
-            }
-#if ATTN_FWD_ILP
-        psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
-#endif
-        }
-        if (LATE && ATTN_FWD_LATE_DMA == 1 && t + 3 < nt) {          // slot of tile t-1 (free since this tile's barrier); issued among VALU work, not in front of the MFMAs
-            char* nK = smem + (slot == 0 ? NS - 1 : slot - 1) * 2 * TILE_BYTES;
-            stage_tile<NI>(srcK, (t + 3) * KV_TILE, nK, wave);
-            stage_tile<NI>(srcV, (t + 3) * KV_TILE, nK + TILE_BYTES, wave);
-        }
-        l_run += psum;
-        PT(3)
-        // ---- O^T += V^T . P^T
-        {
-            bf16x8_t vf[2][2];
-            tr_wait<8>(tv0);
-            tr_pack(vf, tv0);
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const bf16x8_t pf = pack8(s[0], 8 * x);
-#pragma unroll
-                for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
-                if (LOG2 && ATTN_FWD_MSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
-            }
-            {   // next tile's K fragments (unconditional: the counted LDS waits below rely on exactly 8 reads here; past the
-                // last tile this reads a stale slot and the values are never used)
-                const char* nKf = smem + slot_n * 2 * TILE_BYTES;
-                asm volatile("" ::: "memory");
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk)
-                        kfr[kb][kk] = *reinterpret_cast<const bf16x8_t*>(nKf + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
-                asm volatile("" ::: "memory");
-            }
-            tr_wait<8>(tv1);      // LDS returns in order: the 8 younger K-fragment reads may stay in flight
-            tr_pack(vf, tv1);
-#pragma unroll
-            for (int x = 0; x < 2; ++x) {
-                const bf16x8_t pf = pack8(s[1], 8 * x);
-#pragma unroll
-                for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
-                if (LOG2 && ATTN_FWD_MSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
-            }
-        }
-        PT(4)
-#if ATTN_FWD_REGSTAGE
-        if (t + 2 < nt) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                *reinterpret_cast<u32x4_rs_t*>(rg_dst + (wave * NI + i) * 1024 + lane * 16) = rgK[i];
-                *reinterpret_cast<u32x4_rs_t*>(rg_dst + TILE_BYTES + (wave * NI + i) * 1024 + lane * 16) = rgV[i];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the tile is in LDS before this wave reaches the barrier
-        }
-#endif
-        slot = slot_n;
-        PT(5)
-#ifdef ATTN_PROFILE
-        for (int i = 0; i < 5; ++i) pacc[i] += pt[i + 1] - pt[i];
-#endif
-    }
-#ifdef ATTN_PROFILE
-    const long long pend = clock64();
-#endif
-
-    // ---- epilogue
-    const float l_tot = (LOG2 && ATTN_FWD_MSUM) ? lacc[0] : l_run + __shfl_xor(l_run, 32, 64);
-    const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (qrow < a.Lq) {
-        unsigned short* O = reinterpret_cast<unsigned short*>(a.o) + (int64_t)b * a.o_bs + (int64_t)qrow * a.o_rs + h * HD;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int col = d * 32 + 8 * q4 + 4 * hh;
-                *reinterpret_cast<uint2*>(O + col) =
-                    make_uint2(pack_bf16x2(o[d][4 * q4] * inv_l, o[d][4 * q4 + 1] * inv_l),
-                               pack_bf16x2(o[d][4 * q4 + 2] * inv_l, o[d][4 * q4 + 3] * inv_l));
-            }
-#ifndef ATTN_PROFILE
-        if (a.lse && hh == 0)
-            a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = LOG2 ? (m_ref + __builtin_amdgcn_logf(l_tot)) * LN2      // (v_log_f32 is log2)
-                                                                : m_ref + __builtin_amdgcn_logf(l_tot) * LN2;
-#endif
-    }
-#ifdef ATTN_PROFILE
-    if (a.lse && tid == 0) {       // diagnostic build: per-workgroup phase cycles of wave 0 overwrite the lse buffer
-        long long* pr = reinterpret_cast<long long*>(a.lse) + 8 * blockIdx.x;
-        for (int i = 0; i < 5; ++i) pr[i] = pacc[i];
-        pr[5] = pend - pstart; pr[6] = nt; pr[7] = clock64() - pend;
-    }
-#endif
-}
-
-
-// ---- software-pipelined forward (round 3).  The loop above is VALU-bound at head_dim 64 (165 VALU against 16 MFMAs per
-// 64-key tile and wave), and each wave runs its phases strictly in sequence -- S^T MFMAs, softmax, PV MFMAs -- so the matrix
-// pipe only works while another wave of the SIMD happens to be in a different phase (SQ counters: VALU-active 66 % + MFMA-busy
-// 40 % of the SIMD cycles, overlapping by 6 %: profiles/r03_attn_fwd_variants.txt).  Here every wave overlaps its OWN phases:
-//   * S^T of tile t+1 is computed while tile t's softmax runs (two score buffers; the K fragments of tile t+2 are read from
-//     LDS during tile t), its row maximum is taken under the PV MFMAs of tile t;
-//   * the softmax of the second 32-key block runs under the PV MFMAs of the first;
-//   * sched_group_barrier pins the interleave (one MFMA, then a handful of VALU instructions, ...).
-// K ring: three slots (tile t+2 read, t+3 landing), V ring: two slots (tile t read, t+1 landing); one barrier per tile.
-#ifndef ATTN_FWD_PIPE
 #define ATTN_FWD_PIPE 0
 #endif
-#ifndef ATTN_PIPE_WGS
-#define ATTN_PIPE_WGS 2
-#endif
-#ifndef ATTN_PIPE_NOSCHED
-#define ATTN_PIPE_NOSCHED 0
-#endif
-#ifndef ATTN_PIPE_LATE_V1
-#define ATTN_PIPE_LATE_V1 1
-#endif
-#ifndef ATTN_PIPE_V1
-#define ATTN_PIPE_V1 3          // trailing VALU instructions (adds, packs) behind each S^T MFMA, after its 2 fma + 2 exp
-#endif
-#ifndef ATTN_PIPE_V2
-#define ATTN_PIPE_V2 6          // ... behind each of the first four PV MFMAs, after 4 fma + 4 exp (softmax of the second key block)
-#endif
-#ifndef ATTN_PIPE_V3
-#define ATTN_PIPE_V3 5          // ... behind each of the last four PV MFMAs (row maximum of the next tile: 16 max3 + exchange)
-#endif
-#if ATTN_PIPE_NOSCHED
-#define PIPE_SGB(m, n, i)
-#else
-#define PIPE_SGB(m, n, i) __builtin_amdgcn_sched_group_barrier(m, n, i)
-#endif
-__global__ void __launch_bounds__(256, ATTN_PIPE_WGS) attn_fwd_pipe_kernel(const dicow_attn_fwd_args a) {
-    __shared__ __attribute__((aligned(16))) char smem[5 * TILE_BYTES];      // K slots 0..2, V slots 3..4
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = lane >> 5;
-    int qblk, h, b;
-    attn_block_coords((a.Lq + 127) / 128, a.H, a.B, qblk, h, b);
-    const int q0 = qblk * 128;
-    const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
-    const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
-    const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
-    int qrow = q0 + wave * 32 + (lane & 31);
-    const int qrow_c = qrow < a.Lq ? qrow : a.Lq - 1;
-    bf16x8_t qf[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-        qf[kk] = *reinterpret_cast<const bf16x8_t*>(Q + (int64_t)qrow_c * a.q_rs + kk * 16 + hh * 8);
-    f32x16_t o[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[d][r] = 0.f;
-    float m_ref = -INFINITY, l_run = 0.f;
-    int kv_end = a.Lk;
-    if (a.causal) { const int lim = q0 + 128 < a.Lk ? q0 + 128 : a.Lk; kv_end = lim; }
-    const int nt = (kv_end + KV_TILE - 1) / KV_TILE;
-    const tile_src_t srcK = make_tile_src<SWZ_K>(K, a.k_rs, a.Lk, wave, lane), srcV = make_tile_src<SWZ_V>(V, a.v_rs, a.Lk, wave, lane);
-    char* const sKr = smem;
-    char* const sVr = smem + 3 * TILE_BYTES;
-    stage_tile(srcK, 0, sKr, wave);
-    if (nt > 1) stage_tile(srcK, KV_TILE, sKr + TILE_BYTES, wave);
-    if (nt > 2) stage_tile(srcK, 2 * KV_TILE, sKr + 2 * TILE_BYTES, wave);
-    stage_tile(srcV, 0, sVr, wave);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
 
-    bf16x8_t kfr[2][4];
-    auto read_k = [&](const char* sK) __attribute__((always_inline)) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                kfr[kb][kk] = *reinterpret_cast<const bf16x8_t*>(sK + kswz(kb * 32 + (lane & 31), kk * 2 + hh));
-    };
-    auto qk = [&](f32x16_t (&s)[2]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[kb][kk], qf[kk], s[kb], 0, 0, 0);
-        }
-    };
-    // mask (tile-uniform test first) + row maximum of one tile's scores; the half-wave exchange is a VALU swap (an LDS
-    // permute here would slip into the counted LDS waits of the V fragments)
-    // (MASKED is a compile-time flag: a run-time branch here would end the scheduling region the row maximum shares with the
-    // PV MFMAs; the tiles that need the mask -- the ragged last one, the diagonal ones of a causal problem -- form a suffix)
-    auto mask_max = [&](auto masked, f32x16_t (&s)[2], int t) __attribute__((always_inline)) -> float {
-        const int k0 = t * KV_TILE;
-        if constexpr (decltype(masked)::value) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (key >= a.Lk || (a.causal && key > qrow)) s[kb][r] = -INFINITY;
-                }
-        }
-        float mx = fmaxf(s[0][0], s[1][0]);
-#pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, s[0][r]), s[1][r]);        // -> v_max3_f32
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    };
-
-    f32x16_t sA[2], sB[2];
-    float mxA, mxB = 0.f;
-    read_k(sKr);
-    qk(sA);
-    read_k(sKr + TILE_BYTES);                         // tile 1 (nt == 1: never staged, the scores it yields are never used)
-    mxA = mask_max(std::true_type{}, sA, 0);
-    int ks2 = 2, ks3 = 0;                             // ring slots of K tiles t+2 and t+3
-
-    // one tile: sc / mxc = scores and row maximum of tile t (ready), sn / mxn = those of tile t+1 (produced here)
-    auto body = [&](f32x16_t (&sc)[2], float mxc, f32x16_t (&sn)[2], float& mxn, int t) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // K(t+2), V(t): requested one tile ago
-        __builtin_amdgcn_s_barrier();                      // ... and every wave has left tile t-1: slots of K(t), V(t-1) are free
-        asm volatile("" ::: "memory");
-        if (t + 3 < nt) stage_tile(srcK, (t + 3) * KV_TILE, sKr + ks3 * TILE_BYTES, wave);
-        if (t + 1 < nt) stage_tile(srcV, (t + 1) * KV_TILE, sVr + ((t + 1) & 1) * TILE_BYTES, wave);
-        const char* sV = sVr + (t & 1) * TILE_BYTES;
-        const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
-        tr8_t tv0, tv1;
-        tr_issue_v<0>(tv0, va0, va1);
-#if !ATTN_PIPE_LATE_V1
-        tr_issue_v<4096>(tv1, va0, va1);
-#endif
-        // lazy rescale (see attn_fwd_kernel)
-        if (__builtin_amdgcn_ballot_w64(mxc > m_ref + 8.0f * LN2) != 0) {
-            const float m_new = fmaxf(m_ref, mxc);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f((m_ref - m_use) * LOG2E);
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            m_ref = m_new;
-        }
-        const float mL = (m_ref == -INFINITY) ? 0.f : m_ref * LOG2E;
-        float psum = 0.f;
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- S^T of tile t+1  ||  softmax of tile t, first key block
-        qk(sn);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(sc[0][r], LOG2E, -mL));
-            sc[0][r] = p;
-            psum += p;
-        }
-        const bf16x8_t pf00 = pack8(sc[0], 0), pf01 = pack8(sc[0], 8);
-#pragma unroll
-        for (int g = 0; g < 8; ++g) {          // per MFMA gap: 2 fma, 2 exp, 3 of the adds / packs that follow them
-            PIPE_SGB(0x008, 1, 0);
-            PIPE_SGB(0x002, 2, 0);
-            PIPE_SGB(0x400, 2, 0);
-            PIPE_SGB(0x002, ATTN_PIPE_V1, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- PV, first key block  ||  softmax of the second
-        bf16x8_t vf[2][2];
-#if ATTN_PIPE_LATE_V1
-        tr_wait<0>(tv0);
-        tr_issue_v<4096>(tv1, va0, va1);          // the second block's V fragments fly under the first block's PV MFMAs
-#else
-        tr_wait<8>(tv0);
-#endif
-        tr_pack(vf, tv0);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][d], pf00, o[d], 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][d], pf01, o[d], 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(sc[1][r], LOG2E, -mL));
-            sc[1][r] = p;
-            psum += p;
-        }
-        const bf16x8_t pf10 = pack8(sc[1], 0), pf11 = pack8(sc[1], 8);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            PIPE_SGB(0x008, 1, 0);
-            PIPE_SGB(0x002, 4, 0);
-            PIPE_SGB(0x400, 4, 0);
-            PIPE_SGB(0x002, ATTN_PIPE_V2, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        l_run += psum;
-        // K fragments of tile t+2 (unconditional: the counted wait below relies on exactly 8 younger reads; past the last
-        // tile this reads a stale slot and the values are never used)
-        asm volatile("" ::: "memory");
-        read_k(sKr + ks2 * TILE_BYTES);
-        asm volatile("" ::: "memory");
-        tr_wait<8>(tv1);
-        tr_pack(vf, tv1);
-        // ---- PV, second key block  ||  mask + row maximum of tile t+1
-#pragma unroll
-        for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0][d], pf10, o[d], 0, 0, 0);
-#pragma unroll
-        for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1][d], pf11, o[d], 0, 0, 0);
-        mxn = mask_max(std::false_type{}, sn, t + 1);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            PIPE_SGB(0x008, 1, 0);
-            PIPE_SGB(0x002, ATTN_PIPE_V3, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        ks2 = ks2 == 2 ? 0 : ks2 + 1;
-        ks3 = ks3 == 2 ? 0 : ks3 + 1;
-    };
-    // tiles 0 .. nt-2 (none of them needs a mask: the kernel serves non-causal problems, only the last tile can be ragged);
-    // two copies of the body so that the two score buffers swap roles without register moves
-    for (int t = 0; t + 1 < nt; t += 2) {
-        body(sA, mxA, sB, mxB, t);
-        if (t + 2 < nt) body(sB, mxB, sA, mxA, t + 1);
-    }
-    // last tile: its scores were produced by the body before it (or the prologue); mask, maximum again, softmax, PV
-    {
-        const int t = nt - 1;
-        if (t & 1) {
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb) sA[kb] = sB[kb];
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const char* sV = sVr + (t & 1) * TILE_BYTES;
-        const unsigned va0 = tr_base(sV, lane, 0), va1 = tr_base(sV, lane, 1);
-        tr8_t tv0, tv1;
-        tr_issue_v<0>(tv0, va0, va1);
-        tr_issue_v<4096>(tv1, va0, va1);
-        const float mxc = mask_max(std::true_type{}, sA, t);
-        if (__builtin_amdgcn_ballot_w64(mxc > m_ref + 8.0f * LN2) != 0) {
-            const float m_new = fmaxf(m_ref, mxc);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f((m_ref - m_use) * LOG2E);
-            l_run *= alpha;
-#pragma unroll
-            for (int d = 0; d < 2; ++d)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[d][r] *= alpha;
-            m_ref = m_new;
-        }
-        const float mL = (m_ref == -INFINITY) ? 0.f : m_ref * LOG2E;
-        float psum = 0.f;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(fmaf(sA[kb][r], LOG2E, -mL));
-                sA[kb][r] = p;
-                psum += p;
-            }
-        l_run += psum;
-        bf16x8_t vf[2][2];
-        tr_wait<8>(tv0);
-        tr_pack(vf, tv0);
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const bf16x8_t pf = pack8(sA[0], 8 * x);
-#pragma unroll
-            for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
-        }
-        tr_wait<0>(tv1);
-        tr_pack(vf, tv1);
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const bf16x8_t pf = pack8(sA[1], 8 * x);
-#pragma unroll
-            for (int d = 0; d < 2; ++d) o[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[x][d], pf, o[d], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv_l = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (qrow < a.Lq) {
-        unsigned short* O = reinterpret_cast<unsigned short*>(a.o) + (int64_t)b * a.o_bs + (int64_t)qrow * a.o_rs + h * HD;
-#pragma unroll
-        for (int d = 0; d < 2; ++d)
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int col = d * 32 + 8 * q4 + 4 * hh;
-                *reinterpret_cast<uint2*>(O + col) =
-                    make_uint2(pack_bf16x2(o[d][4 * q4] * inv_l, o[d][4 * q4 + 1] * inv_l),
-                               pack_bf16x2(o[d][4 * q4 + 2] * inv_l, o[d][4 * q4 + 3] * inv_l));
-            }
-        if (a.lse && hh == 0)
-            a.lse[((int64_t)b * a.H + h) * a.Lq + qrow] = m_ref + __builtin_amdgcn_logf(l_tot) * LN2;
-    }
-}
-
-#undef PIPE_SGB
 
 // ---- four workgroups per CU (round 3).  Every restructuring of the forward loop that costs the third wave per SIMD loses ~12 %
 // (profiles/r03_attn_fwd_variants.txt): the loop lives on the interleave of independent waves.  This form goes the other way:
@@ -1262,8 +574,8 @@ extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
     if (!check_strides(a->q_rs, "q") || !check_strides(a->k_rs, "k") || !check_strides(a->v_rs, "v") ||
         !check_strides(a->o_rs, "o")) return DICOW_ERR_INVALID;
     DICOW_REQUIRE(a->q_bs % 8 == 0 && a->k_bs % 8 == 0 && a->v_bs % 8 == 0 && a->o_bs % 4 == 0, "attn_fwd: batch strides must keep 16-byte alignment");
-    // eight-wave workgroups (256 query rows share each K / V tile: half the LDS-DMA instructions per wave, which cost the
-    // four-wave form 14 % -- profiles/r03_attn_fwd_variants.txt) once they still fill the chip twice over
+    dim3 grid(dicow_cdiv(a->Lq, 128) * a->H * a->B);
+#ifdef DICOW_EXPERIMENTS
     static const int ncu = [] { hipDeviceProp_t pr; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&pr, d) == hipSuccess ? pr.multiProcessorCount : 256; }();
     const int64_t wg8 = (int64_t)dicow_cdiv(a->Lq, 256) * a->H * a->B;
     if (ATTN_FWD_NW8 && !a->q_log2 && wg8 >= 2 * ncu) {
@@ -1271,13 +583,17 @@ extern "C" int dicow_attn_fwd(const dicow_attn_fwd_args* a, void* stream) {
         DICOW_CHECK_LAUNCH("attn_fwd (8 waves)");
         return DICOW_OK;
     }
-    dim3 grid(dicow_cdiv(a->Lq, 128) * a->H * a->B);
-    if (a->q_log2 && ATTN_FWD_OCC4 && ATTN_OCC4_SPEC) hipLaunchKernelGGL((attn_fwd_occ4_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, *a);
-    else if (a->q_log2 && ATTN_FWD_OCC4) hipLaunchKernelGGL((attn_fwd_occ4_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, *a);
-    else if (a->q_log2) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    else if (ATTN_FWD_OCC4) hipLaunchKernelGGL((attn_fwd_occ4_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, *a);
-    else if (ATTN_FWD_PIPE && !a->causal) hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+    if (!ATTN_FWD_OCC4) {
+        if (a->q_log2) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+        else if (ATTN_FWD_PIPE && !a->causal) hipLaunchKernelGGL(attn_fwd_pipe_kernel, grid, dim3(256), 0, (hipStream_t)stream, *a);
+        else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, *a);
+        DICOW_CHECK_LAUNCH("attn_fwd (experiment)");
+        return DICOW_OK;
+    }
+#endif
+    if (a->q_log2 && ATTN_OCC4_SPEC) hipLaunchKernelGGL((attn_fwd_occ4_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else if (a->q_log2) hipLaunchKernelGGL((attn_fwd_occ4_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, *a);
+    else hipLaunchKernelGGL((attn_fwd_occ4_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, *a);
     DICOW_CHECK_LAUNCH("attn_fwd");
     return DICOW_OK;
 }
@@ -1560,98 +876,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
     const bool tail_half = ATTN_BWD_TAIL && nt * KV_TILE - a.Lq >= 32 && nt - 1 > t0;
     const bool wave_live = !ATTN_BWD_TAIL || kblk0 + wave * 32 < a.Lk;
 #if ATTN_DKV_CTS
-    // Compile-time ring slot ST (the tile loop is unrolled by two): sQ / sdO / statistics / transposed-fragment addresses are a lane
-    // register + an instruction immediate -- the ~28 v_add_u32 and ~50 s_* of address arithmetic per 32-query block are gone.
-    // ATTN_DKV_1BAR: the request for tile t + 1 goes out AFTER tile t's barrier (every wave has then finished reading tile t - 1,
-    // whose slot it overwrites), so the end-of-tile barrier is not needed.
-    auto dkv_tile = [&](int t, auto nqb_tag, auto st_tag) {
-        constexpr int NQB = decltype(nqb_tag)::value, ST = decltype(st_tag)::value;
-        constexpr int SQ = ST * 2 * TILE_BYTES, SDO = SQ + TILE_BYTES, SNQ = (1 - ST) * 2 * TILE_BYTES;
-        auto request_next = [&]() {
-            stage_tile<NI>(srcQ, (t + 1) * KV_TILE, smem + SNQ, wave);
-            stage_tile<NI>(srcdO, (t + 1) * KV_TILE, smem + SNQ + TILE_BYTES, wave);
-            stage_stats64(lse, delta, (t + 1) * KV_TILE, a.Lq, smem + 4 * TILE_BYTES + (1 - ST) * 512, wave, lane);
-        };
-#if ATTN_DKV_1BAR
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this tile: requested a whole tile ago
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 1 < nt) request_next();
-#else
-        if (t + 1 < nt) {
-            request_next();
-            asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * NI + 1) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#endif
-        const int qt0 = t * KV_TILE;
-        const float* sStat = reinterpret_cast<const float*>(smem + 4 * TILE_BYTES + ST * 512);
-        const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + KB > a.Lk) || (a.causal && (kblk0 + wave * 32 + 31 > qt0));
-#define DKV_QBLOCK(QB)                                                                                                  \
-        {                                                                                                               \
-            tr8_t tdo, tq;                                                                                              \
-            tr_issue_u<(QB) * 4096 + SDO>(tdo, qb00, qb01, qb10, qb11);                                                 \
-            tr_issue_u<(QB) * 4096 + SQ>(tq, qb00, qb01, qb10, qb11);                                                   \
-            f32x16_t s, dp;                       /* accumulators seeded with -lse[q], -delta[q] (see attn_bwd_dq_kernel) */ \
-            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                          \
-                const float4 lv = *reinterpret_cast<const float4*>(sStat + (QB) * 32 + 8 * q4 + 4 * hh);                 \
-                const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 64 + (QB) * 32 + 8 * q4 + 4 * hh);          \
-                s[4 * q4] = lv.x; s[4 * q4 + 1] = lv.y; s[4 * q4 + 2] = lv.z; s[4 * q4 + 3] = lv.w;                     \
-                dp[4 * q4] = dv4.x; dp[4 * q4 + 1] = dv4.y; dp[4 * q4 + 2] = dv4.z; dp[4 * q4 + 3] = dv4.w;             \
-            }                                                                                                           \
-            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
-                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(smem + SQ + fo[QB][kk]);                          \
-                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(smem + SDO + fo[QB][kk]);                         \
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);                                    \
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
-            }                                                                                                           \
-            f32x16_t pv, dsv;                                                                                           \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = (LOG2 ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * LOG2E));                 \
-            if (need_mask) {                      /* ONE branch per block: a test inside the score loop becomes 16 */   \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
-                    const int qq = qt0 + (QB) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);                                   \
-                    if (qq >= a.Lq || key >= a.Lk || (a.causal && key > qq)) pv[r] = 0.f;                               \
-                }                                                                                                       \
-            }                                                                                                           \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) dsv[r] = pv[r] * dp[r];                                      \
-            bf16x8_t qtf[2][2], dotf[2][2];                                                                             \
-            tr_wait<0>(tdo);                                                                                            \
-            tr_wait<0>(tq);                                                                                             \
-            tr_pack(dotf, tdo);                                                                                         \
-            tr_pack(qtf, tq);                                                                                           \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                             \
-                const bf16x8_t pf = pack8(pv, 8 * x);                                                                   \
-                const bf16x8_t df = pack8(dsv, 8 * x);                                                                  \
-                _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                         \
-                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[x][d], pf, dv[d], 0, 0, 0);                    \
-                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[x][d], df, dk[d], 0, 0, 0);                     \
-                }                                                                                                       \
-            }                                                                                                           \
-        }
-        if (wave_live) {
-            DKV_QBLOCK(0)
-            if constexpr (NQB == 2) DKV_QBLOCK(1)
-        }
-#undef DKV_QBLOCK
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#if !ATTN_DKV_1BAR
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#endif
-    };
-    {
-        const int nfull = tail_half ? nt - 1 : nt;
-        int t = t0;
-        for (; t + 1 < nfull; t += 2) { dkv_tile(t, attn_ic<2>{}, attn_ic<0>{}); dkv_tile(t + 1, attn_ic<2>{}, attn_ic<1>{}); }
-        if (t < nfull) { dkv_tile(t, attn_ic<2>{}, attn_ic<0>{}); ++t; }
-        if (tail_half) { if ((t - t0) & 1) dkv_tile(nt - 1, attn_ic<1>{}, attn_ic<1>{}); else dkv_tile(nt - 1, attn_ic<1>{}, attn_ic<0>{}); }
-#if ATTN_DKV_1BAR
-        __builtin_amdgcn_s_barrier();
-#endif
-    }
+#include "experiments/attention_dkv_cts.inc"       // compile-time ring slot / one barrier per tile: measured equal (profiles/r04_attn_bwd_variants.txt)
 #else
     auto dkv_tile = [&](int t, auto nqb_tag) {
         constexpr int NQB = decltype(nqb_tag)::value;
@@ -1676,49 +901,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
         const unsigned q00 = qb00 + stg, q01 = qb01 + stg, q10 = qb10 + stg, q11 = qb11 + stg;
         const unsigned o00 = q00 + TILE_BYTES, o01 = q01 + TILE_BYTES, o10 = q10 + TILE_BYTES, o11 = q11 + TILE_BYTES;
 #if ATTN_DKV_JIT
-        // the transposed Q / dO fragments (32 registers) are requested AFTER the scores are packed, not before the S^T / dP^T MFMAs:
-        // their LDS latency is no longer hidden behind this wave's own work, but the kernel fits 168 VGPRs = three waves per SIMD
-#define DKV_QBLOCK(QB)                                                                                                  \
-        {                                                                                                               \
-            f32x16_t s, dp;                       /* accumulators seeded with -lse[q], -delta[q] (see attn_bwd_dq_kernel) */ \
-            _Pragma("unroll") for (int q4 = 0; q4 < 4; ++q4) {                                                          \
-                const float4 lv = *reinterpret_cast<const float4*>(sStat + (QB) * 32 + 8 * q4 + 4 * hh);                 \
-                const float4 dv4 = *reinterpret_cast<const float4*>(sStat + 64 + (QB) * 32 + 8 * q4 + 4 * hh);          \
-                s[4 * q4] = lv.x; s[4 * q4 + 1] = lv.y; s[4 * q4 + 2] = lv.z; s[4 * q4 + 3] = lv.w;                     \
-                dp[4 * q4] = dv4.x; dp[4 * q4 + 1] = dv4.y; dp[4 * q4 + 2] = dv4.z; dp[4 * q4 + 3] = dv4.w;             \
-            }                                                                                                           \
-            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
-                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(sQ + fo[QB][kk]);                                 \
-                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(sdO + fo[QB][kk]);                                \
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);                                    \
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
-            }                                                                                                           \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) s[r] = (LOG2 ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * LOG2E));                  \
-            if (need_mask) {                      /* ONE branch per block: a test inside the score loop becomes 16 */   \
-                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
-                    const int qq = qt0 + (QB) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);                                   \
-                    if (qq >= a.Lq || key >= a.Lk || (a.causal && key > qq)) s[r] = 0.f;                                \
-                }                                                                                                       \
-            }                                                                                                           \
-            _Pragma("unroll") for (int r = 0; r < 16; ++r) dp[r] = s[r] * dp[r];                                        \
-            bf16x8_t pf[2], df[2];                                                                                      \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x) { pf[x] = pack8(s, 8 * x); df[x] = pack8(dp, 8 * x); }        \
-            asm volatile("" : "+v"(pf[0]), "+v"(pf[1]), "+v"(df[0]), "+v"(df[1]));   /* packed before the fragments are requested */ \
-            tr8_t tdo, tq;                                                                                              \
-            tr_issue_u<(QB) * 4096>(tdo, o00, o01, o10, o11);                                                           \
-            tr_issue_u<(QB) * 4096>(tq, q00, q01, q10, q11);                                                            \
-            bf16x8_t qtf[2][2], dotf[2][2];                                                                             \
-            tr_wait<8>(tdo);                                                                                            \
-            tr_pack(dotf, tdo);                                                                                         \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                               \
-                _Pragma("unroll") for (int d = 0; d < 2; ++d)                                                           \
-                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[x][d], pf[x], dv[d], 0, 0, 0);                 \
-            tr_wait<0>(tq);                                                                                             \
-            tr_pack(qtf, tq);                                                                                           \
-            _Pragma("unroll") for (int x = 0; x < 2; ++x)                                                               \
-                _Pragma("unroll") for (int d = 0; d < 2; ++d)                                                           \
-                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[x][d], df[x], dk[d], 0, 0, 0);                  \
-        }
+#include "experiments/attention_dkv_jit.inc"       // three waves per SIMD with just-in-time fragments: measured equal (profiles/r03_attn_bwd_variants.txt)
 #else
 #define DKV_QBLOCK(QB)                                                                                                  \
         {                                                                                                               \

@@ -11,7 +11,7 @@ for s in $SRCS; do
   o=build/${s%.hip}.o
   OBJS="$OBJS $o"
   stale=0
-  for dep in "$s" common.h ../../include/dicow_hip.h $(ls *.inc 2>/dev/null); do
+  for dep in "$s" common.h ../../include/dicow_hip.h $(ls *.inc experiments/*.inc 2>/dev/null); do
     if [ ! -f "$o" ] || [ "$dep" -nt "$o" ]; then stale=1; fi
   done
   if [ $stale -eq 1 ]; then

@@ -644,493 +644,7 @@ __global__ void __launch_bounds__(256) gemm_nt_skinny_kernel(const dicow_gemm_ar
 #define NT256_STAGE (2 * 256 * BK * 2)       // A + B = 64 KiB
 #define NT256_LDS (2 * NT256_STAGE)
 #ifdef DICOW_ABLATIONS
-// ------------------------------------------------------------------------------------------------ NT, 256x256 tile
-// 512 threads = 8 waves as 2 (M) x 4 (N); wave tile 128 (M) x 64 (N) = 4x2 MFMA tiles (128 fp32 accumulators/lane).
-// Twice the arithmetic intensity of the 128x128 kernel (128 flop per LDS-staged byte): at ~0.7 PFLOP/s the small
-// tile already pulls ~11 TB/s through L2 -> LDS.  Two 64 KiB stages (128 KiB of the CU's 160 KiB LDS), one workgroup
-// per CU with two waves per SIMD.
-
-template <int ABL>   // ablation: 0 = real kernel, 1 = no DMA after the first tile, 2 = no MFMA, 3 = no LDS fragment reads
-__global__ void __launch_bounds__(512, 2) gemm_nt256_kernel(const dicow_gemm_args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256;
-    int tm, tn;
-    tile_coords(ntm, ntn, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int bz = blockIdx.z;
-    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
-    const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
-    const int wm = wave >> 2, wn = wave & 3;          // wave tile: rows m [wm*128, +128), cols n [wn*64, +64)
-
-    f32x16_t acc[2][4];                               // [n block i][m block j]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = a.K / BK;
-    // stage image: [A 256 rows x 128 B][B 256 rows x 128 B]; the 8 waves x 4 instructions cover 32 x 8 rows each
-    nt_stage(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, 0, smem, smem + 256 * 128, wave, lane);
-    // Software pipeline (one barrier per k-step, MFMA work on both sides of it):
-    //   * fragment reads run one 16-deep k-slice ahead of the MFMAs that consume them (two register sets f0/f1);
-    //   * the LAST slice's MFMAs of tile t are issued AFTER the barrier that opens tile t+1, so the matrix pipe has
-    //     work while the first fragment reads of the new tile are in flight (the barrier only needs those fragments
-    //     to have left LDS, which lgkmcnt(0) guarantees);
-    //   * the DMA of tile t+2 is issued right after that barrier, two instruction pairs per slice, and gets ~3/4 of
-    //     a k-step to land.
-    // sched_group_barrier pins [reads][DMA][8 MFMA] per slice (hipcc otherwise sinks the reads behind the MFMAs).
-    bf16x8_t wf0[2], xf0[4], wf1[2], xf1[4];
-#define LDFRAG(WF, XF, KK)                                                                                   \
-    if (ABL != 3 || t == 0) {                                                                                \
-        const int c_ = (KK) * 2 + (lane >> 5);                                                               \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) WF[i] = lds_frag_nt(sB, wn * 64 + i * 32 + (lane & 31), c_);  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) XF[j] = lds_frag_nt(sA, wm * 128 + j * 32 + (lane & 31), c_); \
-    }
-#define DOMFMA(WF, XF)                                                                                       \
-    if (ABL == 2) { _Pragma("unroll") for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(XF[j]), "v"(WF[j & 1])); } \
-    else { _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < 2; ++i)              \
-               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0); }
-#define DMA2(I0) if (MORE) { nt_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, (t + 1) * BK, nA, nA + 256 * 128, wave, lane, I0); \
-                             nt_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, (t + 1) * BK, nA, nA + 256 * 128, wave, lane, I0 + 1); }
-#define SCHED(NREAD, NDMA, NMFMA)                                                                            \
-    __builtin_amdgcn_sched_group_barrier(0x100, NREAD, 0);                                                   \
-    __builtin_amdgcn_sched_group_barrier(0x020, NDMA, 0);                                                    \
-    __builtin_amdgcn_sched_group_barrier(0x008, NMFMA, 0);
-    // KSTEP(MORE, FIRST): tile t is in stage t&1; on entry (unless FIRST) f1 holds slice 3 of tile t-1
-#define KSTEP(MORE_, FIRST_)                                                                                 \
-    {                                                                                                        \
-        constexpr bool MORE = MORE_;                                                                         \
-        char* sA = smem + (t & 1) * NT256_STAGE;                                                             \
-        char* sB = sA + 256 * 128;                                                                           \
-        char* nA = smem + ((t + 1) & 1) * NT256_STAGE;                                                       \
-        if (ABL == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                     \
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                     \
-        __builtin_amdgcn_s_barrier();                                                                        \
-        asm volatile("" ::: "memory");                                                                       \
-        LDFRAG(wf0, xf0, 0) DMA2(0)                                                                          \
-        if (!(FIRST_)) { DOMFMA(wf1, xf1) }                                                                  \
-        SCHED(6, MORE ? 4 : 0, (FIRST_) ? 0 : 8)                                                             \
-        LDFRAG(wf1, xf1, 1) DMA2(2) DOMFMA(wf0, xf0) SCHED(6, MORE ? 4 : 0, 8)                                \
-        LDFRAG(wf0, xf0, 2) DOMFMA(wf1, xf1) SCHED(6, 0, 8)                                                  \
-        LDFRAG(wf1, xf1, 3) DOMFMA(wf0, xf0) SCHED(6, 0, 8)                                                  \
-    }
-    int t = 0;
-    if (nk == 1) {
-        KSTEP(false, true)
-    } else {
-        if (ABL == 1 || ABL == 3) KSTEP(false, true) else KSTEP(true, true)
-        for (t = 1; t + 1 < nk; ++t) {
-            if (ABL == 1 || ABL == 3) KSTEP(false, false) else KSTEP(true, false)
-        }
-        KSTEP(false, false)
-    }
-    DOMFMA(wf1, xf1)          // slice 3 of the last tile
-#undef KSTEP
-#undef SCHED
-#undef LDFRAG
-#undef DOMFMA
-#undef DMA2
-    const int flags = a.flags;
-    const int hh = lane >> 5;
-    unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)bz * a.strideC;
-    float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
-    unsigned short* aux = a.aux ? reinterpret_cast<unsigned short*>(a.aux) + (int64_t)bz * a.strideAux : nullptr;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 128 + j * 32 + (lane & 31);
-        if (m >= a.M) continue;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * hh;
-                if (n >= a.N) continue;
-                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                nt_epilogue_quad(a, flags, v, m, n, Cb, Cf, aux);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ NT, persistent, 4 waves
-// Same 64 KiB stage budget as gemm_nt256_kernel ((BM + BN) = 512 rows x 128 B), but ONE wave per SIMD (256 threads), each
-// owning a (NJ*32) x (NI*32) quadrant of the BM x BN = (2*NJ*32) x (2*NI*32) output tile; the accumulator blocks
-// (16 for 128x128, 15 for 96x160) live in AGPRs (unified 512-entry file).
-// Why one wave per SIMD: the 8-wave kernel is LDS-bandwidth co-critical -- per 16-deep slice a wave reads 6 fragments for
-// 8 MFMAs, i.e. per k-step the CU moves 192 KiB of fragments + 64 KiB of DMA = 2048 LDS clocks against 2048 MFMA clocks.
-// A 128x128 wave tile reads 8 fragments for 16 MFMAs (128 + 64 KiB = 1536 clocks), leaving the matrix pipe as the only
-// saturated resource.  With a single wave per SIMD nothing hides latency for us, so the instruction stream is laid
-// out by hand: every MFMA is followed by one LDS read (next slice) or one DMA instruction (next k-tile).
-// Why two tile shapes: tail quantisation.  M = 24000 rows are 93.75 tiles of 256 -- 470 / 1410 / 1880 tiles for
-// N = 1280 / 3840 / 5120, i.e. 1.84 / 5.5 / 7.3 rounds of 256 workgroups: 8 % of every big GEMM is a partial last round.
-// 192 x 320 tiles (NJ, NI = 3, 5) cut the same problems into 500 / 1500 / 2000 tiles = 1.95 / 5.86 / 7.81 rounds (2.3 %
-// idle); dicow_gemm_nt picks the shape with the smaller padded work.
-//
-// (Tried and dropped: running only the whole rounds here and cutting the partial last round into 128x128 quarter tiles
-// for gemm_nt_kernel -- the quarter tiles quantise again (two resident per CU, each at half speed): 0.34 -> 0.40 ms.
-// Unrolling the k-loop by two to make the LDS stage an immediate (12 -> 4 VALU adds per step): 2-4 % slower.
-// A dynamic per-XCD tile queue (one returning atomic per tile, fetched three k-steps ahead) against the 5-20 % CU-to-CU
-// spread: 12-25 % slower -- the device-scope atomic's round trip sits in the k-loop's vmcnt(0) wait.
-// A 4-byte-per-lane "L2 warm-up" DMA for the k-slab two steps ahead, with the step barrier waiting on vmcnt(2) instead
-// of 0: 1-4 % slower; the two extra VMEM issues per step cost more than the HBM misses they hide.
-// Stores straight from the MFMA layout (32 rows x 16 B per instruction) instead of the LDS transpose: 10 % slower.)
-//
-// The kernel is PERSISTENT: one workgroup per CU walks the tile list (virtual block id v = blockIdx.x + round *
-// gridDim.x through the same XCD-aware id -> tile map, so the tiles in flight are the same L2-friendly set).  A
-// per-workgroup timeline (tools/profile_ksteps.py) of the one-tile-per-workgroup form showed, for a K=1280 tile,
-// 30 us of k-loop against 10 us of epilogue + 1 us prologue + 2 us workgroup relaunch gap.  Here
-//   * the first-stage DMA of the NEXT tile is issued before the epilogue of the current one;
-//   * the epilogue sends the accumulators through LDS (the stage that was read last) so every store instruction covers
-//     2 rows x 256/512 contiguous bytes instead of 32 rows x 16 B (residual / aux reads likewise).
-#define NTW_LDS (NT256_LDS + 2048)         // two stages + the tile's bias row (up to 320 floats)
-
-template <int FLAGS, int NJ, int NI>
-__global__ void __launch_bounds__(256) gemm_ntw_kernel(const dicow_gemm_args a) {
-    static_assert(NJ + NI == 8 && NI >= 4 && NI <= 5, "stage image is (BM + BN) = 512 rows; the epilogue handles 4 or 5 column blocks");
-    constexpr int BMT = 2 * NJ * 32, BNT = 2 * NI * 32;              // output tile
-    constexpr int WMR = NJ * 32, WNC = NI * 32;                      // wave quadrant
-    constexpr int NDA = 2 * NJ, NDB = 2 * NI;                        // DMA instructions (8 rows x 128 B) per wave and k-step
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntm = (a.M + BMT - 1) / BMT, ntn = (a.N + BNT - 1) / BNT;
-    const int nwg = ntm * ntn, total = nwg * (a.batch > 0 ? a.batch : 1);
-    const int wm = wave >> 1, wn = wave & 1;          // wave quadrant: rows m [wm*WMR, +WMR), cols n [wn*WNC, +WNC)
-    const int nk = a.K / BK;
-    const int flags = a.flags;
-    constexpr bool LDS_BIAS = FLAGS >= 0 && (FLAGS & DICOW_EPI_BIAS) != 0;
-    float* sbias = reinterpret_cast<float*>(smem + NT256_LDS);       // the tile's BNT bias values (compile-time-flag kernels)
-
-    int v = blockIdx.x;
-    int bz = v / nwg, tm, tn;
-    tile_coords_id(ntm, ntn, v - bz * nwg, tm, tn);
-    int m0 = tm * BMT, n0 = tn * BNT;
-    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
-    const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
-    int par = 0;                                      // stage holding k-tile 0 of the current output tile
-    // DMA source = buffer descriptor (operand base) + scalar k offset + per-lane 32-bit byte offset (row * ld + swizzled chunk),
-    // the offsets being computed once per output tile: plain VALU instructions share the SIMD's issue port with the MFMAs
-    // (tools/probe_overlap.hip), and the 16 64-bit address adds per k-step of the pointer form cost ~6 % of the loop.
-    // Instruction d < NDA of a wave moves row group wave*NDA + d of the A image, d >= NDA row group wave*NDB + d - NDA of B.
-    unsigned off[16];
-#define NTW_OFFSETS()                                                                                        \
-    _Pragma("unroll") for (int d = 0; d < 16; ++d) {                                                         \
-        const int q_ = d < NDA ? wave * NDA + d : wave * NDB + d - NDA;                                      \
-        const int row_ = q_ * 8 + (lane >> 3), c_ = (lane & 7) ^ ((row_ >> 1) & 7);                          \
-        if (d < NDA) { int g_ = m0 + row_; g_ = g_ < a.M ? g_ : a.M - 1; off[d] = (unsigned)(((int64_t)g_ * a.lda + c_ * 8) * 2); } \
-        else { int g_ = n0 + row_; g_ = g_ < a.N ? g_ : a.N - 1; off[d] = (unsigned)(((int64_t)g_ * a.ldb + c_ * 8) * 2); } \
-    }
-#define NTW_RSRC()                                                                                           \
-    rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, 0xffffffffu, 0x00020000);      \
-    rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(B), 0, 0xffffffffu, 0x00020000);
-#define NTW_DMA(D, K0, SA)                                                                                   \
-    { if ((D) < NDA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)((SA) + (wave * NDA + (D)) * 1024), 16, off[D], (K0) * 2, 0, 0); \
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)((SA) + BMT * 128 + (wave * NDB + (D) - NDA) * 1024), 16, off[D], (K0) * 2, 0, 0); }
-    __amdgpu_buffer_rsrc_t rsA, rsB;
-    NTW_RSRC()
-    NTW_OFFSETS()
-#pragma unroll
-    for (int d = 0; d < 16; ++d) NTW_DMA(d, 0, smem)
-
-    while (true) {
-        f32x16_t acc[NI][NJ];                         // [n block i][m block j]
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-        bf16x8_t wf0[NI], xf0[NJ], wf1[NI], xf1[NJ];
-#define LDFRAG(WF, XF, KK)                                                                                   \
-    {                                                                                                        \
-        const int c_ = (KK) * 2 + (lane >> 5);                                                               \
-        _Pragma("unroll") for (int i = 0; i < NI; ++i) WF[i] = lds_frag_nt(sB, wn * WNC + i * 32 + (lane & 31), c_); \
-        _Pragma("unroll") for (int j = 0; j < NJ; ++j) XF[j] = lds_frag_nt(sA, wm * WMR + j * 32 + (lane & 31), c_); \
-    }
-#define DOMFMA(WF, XF)                                                                                       \
-    { _Pragma("unroll") for (int j = 0; j < NJ; ++j) _Pragma("unroll") for (int i = 0; i < NI; ++i)          \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0); }
-#define DMA8(D0) if (MORE) { _Pragma("unroll") for (int d_ = 0; d_ < 8; ++d_) NTW_DMA((D0) + d_, (t + 1) * BK, nA) }
-    // one slice: NJ*NI MFMAs with NR LDS reads and ND DMA instructions threaded between them (one per MFMA while they last)
-#define SCHED(NR, ND)                                                                                        \
-    _Pragma("unroll") for (int s_ = 0; s_ < (NR); ++s_) {                                                    \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); } \
-    _Pragma("unroll") for (int s_ = 0; s_ < (ND); ++s_) {                                                    \
-        if ((NR) + s_ < NJ * NI) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           \
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }                                                 \
-    if (NJ * NI - (NR) - (ND) > 0) __builtin_amdgcn_sched_group_barrier(0x008, NJ * NI - (NR) - (ND), 0);
-#define KSTEP(MORE_, FIRST_)                                                                                 \
-    {                                                                                                        \
-        constexpr bool MORE = MORE_;                                                                         \
-        char* sA = smem + ((t + par) & 1) * NT256_STAGE;                                                     \
-        char* sB = sA + BMT * 128;                                                                           \
-        char* nA = smem + ((t + par + 1) & 1) * NT256_STAGE;                                                 \
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                          \
-        __builtin_amdgcn_s_barrier();                                                                        \
-        asm volatile("" ::: "memory");                                                                       \
-        LDFRAG(wf0, xf0, 0) DMA8(0)                                                                          \
-        if (!(FIRST_)) { DOMFMA(wf1, xf1) SCHED(8, MORE ? 8 : 0) }                                           \
-        LDFRAG(wf1, xf1, 1) DMA8(8) DOMFMA(wf0, xf0) SCHED(8, MORE ? 8 : 0)                                  \
-        LDFRAG(wf0, xf0, 2) DOMFMA(wf1, xf1) SCHED(8, 0)                                                     \
-        LDFRAG(wf1, xf1, 3) DOMFMA(wf0, xf0) SCHED(8, 0)                                                     \
-    }
-#ifdef NTW_PROFILE
-        const long long pc0 = clock64(), pw0 = wall_clock64();
-#endif
-        // bias of this tile's BNT columns -> LDS (read back as quads by the epilogue; a global load there would queue
-        // behind the next tile's DMA).  Written after the first k-step's barrier: every wave has left the previous epilogue.
-        float bias_t = 0.f, bias_u = 0.f;
-        if (LDS_BIAS) {
-            const int nb = n0 + tid; bias_t = a.bias[nb < a.N ? nb : a.N - 1];
-            if (BNT > 256 && tid < BNT - 256) { const int nc = n0 + 256 + tid; bias_u = a.bias[nc < a.N ? nc : a.N - 1]; }
-        }
-#define NTW_PUT_BIAS() if (LDS_BIAS) { sbias[tid] = bias_t; if (BNT > 256 && tid < BNT - 256) sbias[256 + tid] = bias_u; }
-        int t = 0;
-        if (nk == 1) {
-            KSTEP(false, true)
-            NTW_PUT_BIAS()
-        } else {
-            KSTEP(true, true)
-            NTW_PUT_BIAS()
-            for (t = 1; t + 1 < nk; ++t) KSTEP(true, false)
-            KSTEP(false, false)
-        }
-        DOMFMA(wf1, xf1)
-#undef NTW_PUT_BIAS
-#undef KSTEP
-#undef SCHED
-#undef LDFRAG
-#undef DOMFMA
-#undef DMA8
-#ifdef NTW_PROFILE
-        const long long pc1 = clock64(), pw1 = wall_clock64();
-        const int pv = v;
-#endif
-        // ---- this tile's output coordinates; then move the staging state on to the next tile and start its DMA
-        const int em0 = m0 + wm * WMR, en0 = n0 + wn * WNC, ebz = bz, etm = tm;
-        char* scr = smem + ((nk - 1 + par) & 1) * NT256_STAGE + wave * 16384;    // stage read last
-        par = (par + nk) & 1;
-        v += gridDim.x;
-        const bool more_tiles = v < total;
-        if (more_tiles) {
-            bz = v / nwg;
-            tile_coords_id(ntm, ntn, v - bz * nwg, tm, tn);
-            m0 = tm * BMT; n0 = tn * BNT;
-            A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
-            B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
-            char* fA = smem + par * NT256_STAGE;      // last read in k-step nk-2: released by the k-step nk-1 barrier
-            NTW_OFFSETS()
-            NTW_RSRC()
-#pragma unroll
-            for (int d = 0; d < 16; ++d) NTW_DMA(d, 0, fA)
-        }
-        unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)ebz * a.strideC;
-        float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)ebz * a.strideC;
-        unsigned short* aux = a.aux ? reinterpret_cast<unsigned short*>(a.aux) + (int64_t)ebz * a.strideAux : nullptr;
-#ifdef NTW_PROFILE
-        aux = nullptr;
-#endif
-        // the epilogue's lane-derived LDS offsets / guards are tile-invariant; hidden behind an opaque copy of the lane id
-        // so that they are not hoisted out of the tile loop into the k-loop's register budget (that spilled 60-90 VGPRs)
-        int le = lane;
-        asm volatile("" : "+v"(le));
-        const int ml = le & 31, hh = le >> 5;
-        const int tr8 = le >> 3, tq = le & 7;         // tail pass (5th column block): 8 rows x 8 column quads per instruction
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                 // every wave has finished its fragment reads of the last stage
-        asm volatile("" ::: "memory");
-#ifdef NTW_PROFILE
-        const long long pj0 = wall_clock64();
-#endif
-        {
-            // Pass (j): [32 rows][128 n] fp32 per wave, row stride 512 B, 16-B chunk c of row r at c ^ (r & 31); each
-            // read-back instruction covers 2 rows x 512 B.  NI == 5 adds a tail pass per j for the 5th column block:
-            // [32 rows][32 n], row stride 128 B, chunk c of row r at c ^ (r & 7), 8 rows x 128 B per instruction.  With
-            // compile-time flags the [m][n]-indexed inputs (saved gelu' / residual) of pass j+1 are requested BEFORE the
-            // stores of pass j are issued (vmcnt retires in order).
-            // (Tried and dropped: doing the math in the MFMA layout and sending packed bf16 rows through LDS -- half
-            // the LDS bytes, but every accumulator then needs a v_accvgpr_read + VALU pack instead of going
-            // AGPR -> LDS directly, and it measured 4-10 % slower on the plain/bias/GELU GEMMs.)
-            constexpr bool TAIL = NI == 5;
-            constexpr int NIT = 16 + (TAIL ? 4 : 0);  // read-back instructions per j: 16 main + 4 tail
-            constexpr bool PRE_AUX = FLAGS >= 0 && (FLAGS & (DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) != 0;
-            constexpr bool PRE_RES = FLAGS >= 0 && (FLAGS & DICOW_EPI_RESIDUAL) != 0;
-            uint2 xa[2][PRE_AUX ? NIT : 1];
-            float4 xr[2][PRE_RES ? NIT : 1];
-            const int nq = en0 + 4 * ml, nqt = en0 + 128 + 4 * tq;
-            float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), bqt = bq;
-            if (FLAGS >= 0 && (FLAGS & DICOW_EPI_BIAS)) {
-                bq = *reinterpret_cast<const float4*>(sbias + wn * WNC + 4 * ml);
-                if (TAIL) bqt = *reinterpret_cast<const float4*>(sbias + wn * WNC + 128 + 4 * tq);
-            }
-            // Global traffic of the compile-time-flag epilogues goes through buffer descriptors: per-lane byte offsets
-            // are tile-invariant, the row of each instruction is a SCALAR offset, rows past M fall outside num_records
-            // (stores dropped, loads return 0) and lanes past N get an out-of-range offset.  The pointer form spent ~12
-            // VALU instructions (64-bit multiply-adds, compares) plus an exec branch on every store -- ~3 us per tile on
-            // the issue port that is otherwise free to run the next tile's MFMAs.
-            constexpr int ESZ = (FLAGS >= 0 && (FLAGS & DICOW_EPI_OUT_F32)) ? 4 : 2;
-            constexpr bool COLSUM = FLAGS >= 0 && (FLAGS & DICOW_EPI_COLSUM) != 0;
-            const bool edge_m = em0 + WMR > a.M;
-            float cs[4] = {0.f, 0.f, 0.f, 0.f}, cst[4] = {0.f, 0.f, 0.f, 0.f};
-            constexpr bool AUX_IO = FLAGS >= 0 && (FLAGS & (DICOW_EPI_GELU | DICOW_EPI_GELU_BWD | DICOW_EPI_MUL_AUX)) != 0;
-            const unsigned OOB = 0x80000000u;
-            const bool nok = nq < a.N, nokt = nqt < a.N;
-            __amdgpu_buffer_rsrc_t rsC, rsX, rsR;
-            unsigned voC = OOB, voX = OOB, voR = OOB, voCt = OOB, voXt = OOB, voRt = OOB;
-            if (FLAGS >= 0) {
-                rsC = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.C) + (int64_t)ebz * a.strideC * ESZ, 0,
-                                                        (unsigned)(((int64_t)(a.M - 1) * a.ldc + a.N) * ESZ), 0x00020000);
-                if (nok) voC = (unsigned)((hh * (int)a.ldc + 4 * ml) * ESZ);
-                if (TAIL && nokt) voCt = (unsigned)((tr8 * (int)a.ldc + 128 + 4 * tq) * ESZ);
-                if (AUX_IO) {
-                    rsX = __builtin_amdgcn_make_buffer_rsrc(aux, 0, (unsigned)(((int64_t)(a.M - 1) * a.ldaux + a.N) * 2), 0x00020000);
-                    if (nok && aux) voX = (unsigned)((hh * (int)a.ldaux + 4 * ml) * 2);          // no aux: stores dropped (no branch per quad)
-                    if (TAIL && nokt && aux) voXt = (unsigned)((tr8 * (int)a.ldaux + 128 + 4 * tq) * 2);
-                }
-                if (PRE_RES) {
-                    rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual), 0,
-                                                            (unsigned)(((int64_t)(a.M - 1) * a.ldr + a.N) * 4), 0x00020000);
-                    if (nok) voR = (unsigned)((hh * (int)a.ldr + 4 * ml) * 4);
-                    if (TAIL && nokt) voRt = (unsigned)((tr8 * (int)a.ldr + 128 + 4 * tq) * 4);
-                }
-            }
-            // scalar byte offset of read-back instruction IT of pass J: main instructions step 2 rows, tail ones 8 rows
-#define NTW_SOFF(J, IT, LD, SZ) ((int)((((int64_t)(em0 + (J) * 32 + ((IT) < 16 ? (IT) * 2 : ((IT) - 16) * 8))) * (LD) + en0) * (SZ)))
-#define NTW_PREFETCH(J, BUF)                                                                                 \
-    if (PRE_AUX || PRE_RES) {                                                                                \
-        _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                                 \
-            if (PRE_AUX) { const auto u_ = __builtin_amdgcn_raw_buffer_load_b64(rsX, it < 16 ? voX : voXt, NTW_SOFF(J, it, a.ldaux, 2), 0); \
-                           xa[BUF][it] = make_uint2(u_[0], u_[1]); }                                         \
-            if (PRE_RES) { const auto r_ = __builtin_amdgcn_raw_buffer_load_b128(rsR, it < 16 ? voR : voRt, NTW_SOFF(J, it, a.ldr, 4), 0);  \
-                           xr[BUF][it] = make_float4(__uint_as_float(r_[0]), __uint_as_float(r_[1]), __uint_as_float(r_[2]), __uint_as_float(r_[3])); } \
-        }                                                                                                    \
-    }
-            typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-            typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-            // math + stores of one read-back quad (compile-time flags): IT = instruction index, TL = tail pass
-#define NTW_EMIT(J, IT, F4, TL)                                                                              \
-    {                                                                                                        \
-        float vv[4] = {(F4).x, (F4).y, (F4).z, (F4).w}, dg[4];                                               \
-        nt_epilogue_math<FLAGS>(a, flags, vv, dg, 0, (TL) ? nqt : nq, aux, (TL) ? &bqt : &bq,                \
-                                PRE_AUX ? &xa[(J) & 1][IT] : nullptr, PRE_RES ? &xr[(J) & 1][IT] : nullptr); \
-        if (COLSUM) {                                 /* bias gradient: column sums of the result, rows past M excluded */ \
-            const int rw_ = (TL) ? ((IT) - 16) * 8 + tr8 : (IT) * 2 + hh;                                    \
-            const float ok_ = (!edge_m || em0 + (J) * 32 + rw_ < a.M) ? 1.f : 0.f;                           \
-            _Pragma("unroll") for (int e = 0; e < 4; ++e) { if (TL) cst[e] = fmaf(vv[e], ok_, cst[e]); else cs[e] = fmaf(vv[e], ok_, cs[e]); } \
-        }                                                                                                    \
-        if ((FLAGS & DICOW_EPI_GELU) != 0) {                                                                 \
-            const u32x2_t xv = {pack_bf16x2(dg[0], dg[1]), pack_bf16x2(dg[2], dg[3])};                       \
-            __builtin_amdgcn_raw_buffer_store_b64(xv, rsX, (TL) ? voXt : voX, NTW_SOFF(J, IT, a.ldaux, 2), 0); \
-        }                                                                                                    \
-        if (ESZ == 4) {                                                                                      \
-            const u32x4_t ov = {__float_as_uint(vv[0]), __float_as_uint(vv[1]), __float_as_uint(vv[2]), __float_as_uint(vv[3])}; \
-            __builtin_amdgcn_raw_buffer_store_b128(ov, rsC, (TL) ? voCt : voC, NTW_SOFF(J, IT, a.ldc, 4), 0); \
-        } else {                                                                                             \
-            const u32x2_t ov = {pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3])};                       \
-            __builtin_amdgcn_raw_buffer_store_b64(ov, rsC, (TL) ? voCt : voC, NTW_SOFF(J, IT, a.ldc, 2), 0); \
-        }                                                                                                    \
-    }
-            NTW_PREFETCH(0, 0)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = i * 8 + 2 * q + hh;
-                        *reinterpret_cast<float4*>(scr + ml * 512 + ((c ^ ml) << 4)) =
-                            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
-                    }
-                __builtin_amdgcn_sched_barrier(0);
-                if (j + 1 < NJ) { NTW_PREFETCH(j + 1, (j + 1) & 1) }
-                if (FLAGS >= 0) {
-#pragma unroll
-                    for (int it = 0; it < 16; ++it) {
-                        const int row = it * 2 + hh;
-                        const float4 f = *reinterpret_cast<const float4*>(scr + row * 512 + ((ml ^ row) << 4));
-                        NTW_EMIT(j, it, f, false)
-                    }
-                } else {
-                    // runtime flags: a real loop keeps the code small (fully unrolled it was ~200 KB of instructions
-                    // and ran at instruction-cache-miss speed)
-#pragma unroll 1
-                    for (int pg = 0; pg < 4; ++pg) {
-#pragma unroll
-                        for (int pp = 0; pp < 4; ++pp) {
-                            const int row = (pg * 4 + pp) * 2 + hh;
-                            const float4 f = *reinterpret_cast<const float4*>(scr + row * 512 + ((ml ^ row) << 4));
-                            const int m = em0 + j * 32 + row;
-                            if (m < a.M && nq < a.N) {
-                                float vv[4] = {f.x, f.y, f.z, f.w};
-                                nt_epilogue_quad<FLAGS>(a, flags, vv, m, nq, Cb, Cf, aux);
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (TAIL) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int c = 2 * q + hh;
-                        *reinterpret_cast<float4*>(scr + ml * 128 + ((c ^ (ml & 7)) << 4)) =
-                            make_float4(acc[NI - 1][j][4 * q], acc[NI - 1][j][4 * q + 1], acc[NI - 1][j][4 * q + 2], acc[NI - 1][j][4 * q + 3]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int it = 16; it < 20; ++it) {
-                        const int row = (it - 16) * 8 + tr8;
-                        const float4 f = *reinterpret_cast<const float4*>(scr + row * 128 + ((tq ^ (row & 7)) << 4));
-                        if (FLAGS >= 0) {
-                            NTW_EMIT(j, it, f, true)
-                        } else {
-                            const int m = em0 + j * 32 + row;
-                            if (m < a.M && nqt < a.N) {
-                                float vv[4] = {f.x, f.y, f.z, f.w};
-                                nt_epilogue_quad<FLAGS>(a, flags, vv, m, nqt, Cb, Cf, aux);
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if (COLSUM) {
-                // partial sums of this wave's WMR rows -> colsum_ws[(tile row * 2 + wm)][N]; every (row, column) of the
-                // workspace is written exactly once per launch, the host adds the 2 * ceil(M/BMT) rows up afterwards
-                float* wsr = reinterpret_cast<float*>(a.colsum_ws) + (int64_t)(etm * 2 + wm) * a.N;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) cs[e] += __shfl_xor(cs[e], 32, 64);
-                if (hh == 0 && nok) *reinterpret_cast<float4*>(wsr + nq) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-                if (TAIL) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        cst[e] += __shfl_xor(cst[e], 8, 64); cst[e] += __shfl_xor(cst[e], 16, 64); cst[e] += __shfl_xor(cst[e], 32, 64);
-                    }
-                    if (tr8 == 0 && nokt) *reinterpret_cast<float4*>(wsr + nqt) = make_float4(cst[0], cst[1], cst[2], cst[3]);
-                }
-            }
-#undef NTW_EMIT
-#undef NTW_PREFETCH
-#undef NTW_SOFF
-        }
-#ifdef NTW_PROFILE
-        if (a.aux && tid == 0) {   // diagnostic build only: per-tile k-loop cycles and wall-clock (100 MHz) timestamps
-            long long* pr = reinterpret_cast<long long*>(a.aux) + 6 * pv;
-            pr[0] = pc1 - pc0; pr[1] = pw1 - pw0; pr[2] = pw0; pr[3] = pw0; pr[4] = pw1; pr[5] = wall_clock64();
-            (void)pj0;
-        }
-#endif
-        if (!more_tiles) break;
-    }
-}
-#undef NTW_OFFSETS
-#undef NTW_RSRC
-#undef NTW_DMA
-
+#include "experiments/gemm_nt_two_stage.inc"      // the two-stage kernels of rounds 1-2 (A/B baselines)
 #endif  // DICOW_ABLATIONS
 
 // ---- LayerNorm fold, producer side (DICOW_EPI_LNSTAT): butterfly reductions over the lanes of a row with DPP lane moves.
@@ -1155,119 +669,7 @@ __device__ __forceinline__ float ln_merge4(float a, float b, bool bit) {
 #include "gemm_ntr.inc"
 
 #ifdef DICOW_ABLATIONS
-// ------------------------------------------------------------------------------------------------ NT, 256x256, staggered
-// Same tile / wave grid as gemm_nt256_kernel, but the contraction advances in 32-deep PHASES through a 4-stage LDS ring
-// (4 x 32 KiB) and the two wave groups (waves 0-3 / 4-7: one wave of each per SIMD) run ONE PHASE APART: in barrier
-// interval I group 0 works on phase I and group 1 on phase I-1.  While one group sits in its LDS-read / barrier
-// bubble the other group's MFMAs keep the SIMD's matrix pipe busy (the lock-step kernel loses ~45 % of the pipe
-// there).  DMA of phase I+2 is issued in interval I (its stage was last read in interval I-1) and has two intervals
-// to land; waits are counted (vmcnt(4) keeps the newest group in flight).
-#define NTS_STAGE (2 * 256 * 64)             // A 16 KiB + B 16 KiB (32-deep)
-#define NTS_LDS (4 * NTS_STAGE)
-
-__device__ __forceinline__ void nts_stage_part(const unsigned short* __restrict__ A, const unsigned short* __restrict__ B,
-                                               int64_t lda, int64_t ldb, int M, int N, int m0, int n0, int k0, char* sA,
-                                               char* sB, int wave, int lane, int i) {
-    const int q = wave * 2 + i;                       // DMA instruction index: 16 rows x 64 B
-    const int row = q * 16 + (lane >> 2), p = lane & 3;
-    const int c = p ^ ((row >> 3) & 3);
-    int gm = m0 + row; gm = gm < M ? gm : M - 1;
-    int gn = n0 + row; gn = gn < N ? gn : N - 1;
-    glds16(A + (int64_t)gm * lda + k0 + c * 8, sA + q * 1024);
-    glds16(B + (int64_t)gn * ldb + k0 + c * 8, sB + q * 1024);
-}
-__device__ __forceinline__ bf16x8_t lds_frag_nts(const char* s, int row, int c) {
-    return *reinterpret_cast<const bf16x8_t*>(s + row * 64 + ((c ^ ((row >> 3) & 3)) << 4));
-}
-
-__global__ void __launch_bounds__(512, 2) gemm_nt256s_kernel(const dicow_gemm_args a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntm = (a.M + 255) / 256, ntn = (a.N + 255) / 256;
-    int tm, tn;
-    tile_coords(ntm, ntn, tm, tn);
-    const int m0 = tm * 256, n0 = tn * 256;
-    const int bz = blockIdx.z;
-    const unsigned short* A = reinterpret_cast<const unsigned short*>(a.A) + (int64_t)bz * a.strideA;
-    const unsigned short* B = reinterpret_cast<const unsigned short*>(a.B) + (int64_t)bz * a.strideB;
-    const int wm = wave >> 2, wn = wave & 3;          // wm doubles as the stagger group
-    const int grp = wm;
-
-    f32x16_t acc[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int P = a.K / 32;
-    bf16x8_t wf0[2], xf0[4], wf1[2], xf1[4];
-#define NTS_LD(WF, XF, SA, SB, KK)                                                                           \
-    {                                                                                                        \
-        const int c_ = (KK) * 2 + (lane >> 5);                                                               \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) WF[i] = lds_frag_nts(SB, wn * 64 + i * 32 + (lane & 31), c_);  \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) XF[j] = lds_frag_nts(SA, wm * 128 + j * 32 + (lane & 31), c_); \
-    }
-#define NTS_MFMA(WF, XF)                                                                                     \
-    { _Pragma("unroll") for (int j = 0; j < 4; ++j) _Pragma("unroll") for (int i = 0; i < 2; ++i)            \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WF[i], XF[j], acc[i][j], 0, 0, 0); }
-    auto dma = [&](int ph) {
-        char* sA = smem + (ph & 3) * NTS_STAGE;
-        nts_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, ph * 32, sA, sA + 256 * 64, wave, lane, 0);
-        nts_stage_part(A, B, a.lda, a.ldb, a.M, a.N, m0, n0, ph * 32, sA, sA + 256 * 64, wave, lane, 1);
-    };
-    dma(0);
-    if (P > 1) dma(1);
-    bool pending = false;                             // f1 holds the second slice of the previous phase
-    for (int I = 0; I <= P; ++I) {
-        if (I + 1 < P) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (I + 2 < P) dma(I + 2);
-        const int ph = I - grp;
-        if (ph >= 0 && ph < P) {
-            const char* sA = smem + (ph & 3) * NTS_STAGE;
-            const char* sB = sA + 256 * 64;
-            NTS_LD(wf0, xf0, sA, sB, 0)
-            if (pending) NTS_MFMA(wf1, xf1)
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            NTS_LD(wf1, xf1, sA, sB, 1)
-            NTS_MFMA(wf0, xf0)
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            pending = true;
-        }
-    }
-    if (pending) NTS_MFMA(wf1, xf1)
-#undef NTS_LD
-#undef NTS_MFMA
-
-    const int flags = a.flags;
-    const int hh = lane >> 5;
-    unsigned short* Cb = reinterpret_cast<unsigned short*>(a.C) + (int64_t)bz * a.strideC;
-    float* Cf = reinterpret_cast<float*>(a.C) + (int64_t)bz * a.strideC;
-    unsigned short* aux = a.aux ? reinterpret_cast<unsigned short*>(a.aux) + (int64_t)bz * a.strideAux : nullptr;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 128 + j * 32 + (lane & 31);
-        if (m >= a.M) continue;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * hh;
-                if (n >= a.N) continue;
-                float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                nt_epilogue_quad(a, flags, v, m, n, Cb, Cf, aux);
-            }
-        }
-    }
-}
-
+#include "experiments/gemm_nt256s.inc"
 #endif  // DICOW_ABLATIONS
 
 #include <atomic>
@@ -1603,16 +1005,16 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
         return DICOW_OK;
     }
     const dim3 grid(ntm * ntn, 1, batch);
+    // (32-bit byte offsets inside one batch slice of A / B, as the persistent kernel needs them)
+    const bool t128 = NT128_THREADED && (int64_t)a->M * a->lda * 2 < (1ll << 31) && (int64_t)a->N * a->ldb * 2 < (1ll << 31) && a->K >= 2 * BK;
+    // few 128 x 128 tiles (the decoder at training time: M = batch x label length): 64 x 64 tiles on a deep ring (gemm_nt64_kernel)
+    const int64_t t64 = (int64_t)dicow_cdiv(a->M, 64) * dicow_cdiv(a->N, 64) * batch;
 #ifdef DICOW_ABLATIONS
     if (variant == 1) hipLaunchKernelGGL((gemm_nt_kernel<1, false>), grid, dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, *a);
     else if (variant == 2) hipLaunchKernelGGL((gemm_nt_kernel<2, true>), grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
     else if (variant == 3) hipLaunchKernelGGL((gemm_nt_kernel<1, true>), grid, dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, *a);
     else
 #endif
-    // (32-bit byte offsets inside one batch slice of A / B, as the persistent kernel needs them)
-    const bool t128 = NT128_THREADED && (int64_t)a->M * a->lda * 2 < (1ll << 31) && (int64_t)a->N * a->ldb * 2 < (1ll << 31) && a->K >= 2 * BK;
-    // few 128 x 128 tiles (the decoder at training time: M = batch x label length): 64 x 64 tiles on a deep ring (gemm_nt64_kernel)
-    const int64_t t64 = (int64_t)dicow_cdiv(a->M, 64) * dicow_cdiv(a->N, 64) * batch;
     if (NT64_MAX_TILES128 > 0 && t128 && variant == 0 &&
         ((int64_t)ntm * ntn * batch <= NT64_MAX_TILES128 || (a->K <= NT64_SMALLK && (int64_t)ntm * ntn * batch <= NT64_SMALLK_TILES128))) {
         const dim3 g64(dicow_cdiv(a->M, 64) * dicow_cdiv(a->N, 64), 1, batch);
