@@ -1535,6 +1535,13 @@ __global__ void __launch_bounds__(512, 2) gemm_tn256g_kernel(const tn_group_karg
     }
 }
 
+#ifndef TN_W4
+#define TN_W4 0               // 1: pooled weight gradients on gemm_tn256wg_kernel (experiments/gemm_tnw.inc: measured equal / slower)
+#endif
+#if TN_W4
+#include "experiments/gemm_tnw.inc"       // the same pooled launch on four-wave workgroups (one wave per SIMD, 128 x 128 wave tiles)
+#endif
+
 // C tile (+)= sum_{split} partial[tile][split]  in split order; one workgroup = 4 rows of a 256 x 256 tile
 __global__ void __launch_bounds__(256) tn_group_fixup_kernel(const tn_group_kargs_t g) {
     const tn_group_plan_t& pl = g.plan;
@@ -1728,6 +1735,9 @@ extern "C" int dicow_gemm_tn_group(const dicow_gemm_tn_group_args* ga, void* str
     DICOW_REQUIRE(need == 0 || (ga->ws && ga->ws_bytes >= need), "gemm_tn_group: workspace too small (need %ld bytes)", (long)need);
     static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)gemm_tn256g_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
+#if TN_W4
+        (void)hipFuncSetAttribute((const void*)gemm_tn256wg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TN256_LDS);
+#endif
         return true;
     }();
     (void)attr_set;
@@ -1735,8 +1745,13 @@ extern "C" int dicow_gemm_tn_group(const dicow_gemm_tn_group_args* ga, void* str
     memset(&k, 0, sizeof(k));
     for (int i = 0; i < ga->n; ++i) k.p[i] = ga->p[i];
     k.plan = pl; k.ws = reinterpret_cast<float*>(ga->ws);
+#if TN_W4
+    hipLaunchKernelGGL(gemm_tn256wg_kernel, dim3(pl.G), dim3(256), TN256_LDS, (hipStream_t)stream, k);
+    disp_note("gemm_tn256wg_kernel");
+#else
     hipLaunchKernelGGL(gemm_tn256g_kernel, dim3(pl.G), dim3(512), TN256_LDS, (hipStream_t)stream, k);
     disp_note("gemm_tn256g_kernel");
+#endif
     DICOW_CHECK_LAUNCH("gemm_tn_group");
     if (pl.rem > 0 && pl.s > 1) {
         hipLaunchKernelGGL(tn_group_fixup_kernel, dim3(pl.rem * 64), dim3(256), 0, (hipStream_t)stream, k);
