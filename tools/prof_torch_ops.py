@@ -1,5 +1,5 @@
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, amd_pkg
 pkg = amd_pkg.load()
 from ts_asr_whisper_amd.trainer import TrainStep

@@ -84,8 +84,13 @@ class LinW:
     __slots__ = ("w", "wt", "b", "N", "K")
 
 
-def prep_linear(weights, biases, dev, need_t=True, n_pad=None, scale_info=None):
-    """Fuse several Linear weights [N_i, K] (same K) into one bf16 [sum N_i, K] (+ transposed copy)."""
+_BIAS_COPIES = None           # inside EncoderEngine.prepare(): (dst slice, src) pairs of fused bias vectors, flushed as ONE multi-tensor copy
+
+
+def prep_linear(weights, biases, dev, need_t=True, n_pad=None, scale_info=None, bias_buf=None):
+    """Fuse several Linear weights [N_i, K] (same K) into one bf16 [sum N_i, K] (+ transposed copy).
+    bias_buf: a persistent fp32 [sum N_i] buffer for the fused bias (parts without a bias stay zero in it): the parts are copied in
+    by the caller's pooled copy (_BIAS_COPIES) instead of a zeros + cat pair of launches per layer and step."""
     K = weights[0].shape[1]
     Ns = [w.shape[0] for w in weights]
     N = sum(Ns)
@@ -102,16 +107,24 @@ def prep_linear(weights, biases, dev, need_t=True, n_pad=None, scale_info=None):
     if biases is None or all(b is None for b in biases):
         lw.b = None
     else:
-        parts = [(b.detach() if b is not None else torch.zeros(n, dtype=F32, device=dev)) for b, n in zip(biases, Ns)]
-        lw.b = parts[0] if len(parts) == 1 else torch.cat(parts)
+        if bias_buf is not None and _BIAS_COPIES is not None and len(Ns) > 1:
+            off = 0
+            for b, n in zip(biases, Ns):
+                if b is not None:
+                    _BIAS_COPIES.append((bias_buf[off:off + n], b.detach()))
+                off += n
+            lw.b = bias_buf
+        else:
+            parts = [(b.detach() if b is not None else torch.zeros(n, dtype=F32, device=dev)) for b, n in zip(biases, Ns)]
+            lw.b = parts[0] if len(parts) == 1 else torch.cat(parts)
     return lw
 
 
-def prep_attention(att, dev, fuse_qkv=True):
+def prep_attention(att, dev, fuse_qkv=True, bias_buf=None):
     a = NS()
     if fuse_qkv:
         a.qkv = prep_linear([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight],
-                            [att.q_proj.bias, None, att.v_proj.bias], dev)
+                            [att.q_proj.bias, None, att.v_proj.bias], dev, bias_buf=bias_buf)
     else:
         a.q = prep_linear([att.q_proj.weight], [att.q_proj.bias], dev)
         a.kv = prep_linear([att.k_proj.weight, att.v_proj.weight], [None, att.v_proj.bias], dev)
@@ -394,13 +407,21 @@ class EncoderEngine:
         W.conv1, W.conv1_t = ops.conv_weight_pack(enc.conv1.weight.detach(), W.k1, want_t=True)
         W.conv2, W.conv2_t = ops.conv_weight_pack(enc.conv2.weight.detach(), 3 * D, want_t=True)
         W.layers = []
-        for lyr in enc.layers:
+        # fused q | k | v bias vectors: persistent buffers (k has no bias: its third stays zero), refreshed by ONE multi-tensor copy
+        global _BIAS_COPIES
+        if getattr(self, "_qkv_bias", None) is None or self._qkv_bias[0].device != dev:
+            self._qkv_bias = [torch.zeros(3 * D, dtype=F32, device=dev) for _ in enc.layers]
+        _BIAS_COPIES = []
+        for li, lyr in enumerate(enc.layers):
             w = NS()
             with ops.cast_group():               # the layer's six matrices: one pooled cast + transpose launch
-                w.att = prep_attention(lyr.self_attn, dev)
+                w.att = prep_attention(lyr.self_attn, dev, bias_buf=self._qkv_bias[li])
                 w.fc1 = prep_linear([lyr.fc1.weight], [lyr.fc1.bias], dev)
                 w.fc2 = prep_linear([lyr.fc2.weight], [lyr.fc2.bias], dev)
             W.layers.append(w)
+        if _BIAS_COPIES:
+            torch._foreach_copy_([d for d, _ in _BIAS_COPIES], [s_ for _, s_ in _BIAS_COPIES])
+        _BIAS_COPIES = None
         W.scb = []
         if cfg.use_enrollments and cfg.scb_layers:
             for blk in enc.ca_enrolls:

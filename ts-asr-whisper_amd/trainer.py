@@ -134,6 +134,7 @@ class FlatStore:
         if cur < self.numel:
             keep.append((cur, self.numel))
         self._zero_ranges = keep                     # the complement of the overwritable matrices: ~one range per layer
+        self._zero_views = None
 
     def fingerprint(self):
         """(parameter name, offset, numel) of every entry, in flat-buffer order: what an optimizer checkpoint must agree with."""
@@ -147,8 +148,10 @@ class FlatStore:
             for p, _, _ in self._over:
                 p._grad_overwrite = False
             return
-        for a, b in self._zero_ranges:
-            self.grads[a:b].zero_()
+        if self._zero_views is None:                  # the ~33 small ranges between the matrices: one multi-tensor fill, not 33 launches
+            self._zero_views = [self.grads[a:b] for a, b in self._zero_ranges if b > a]
+        if self._zero_views:
+            torch._foreach_zero_(self._zero_views)
         for p, o, n in self._over:
             p._grad_overwrite = bool(p.requires_grad)
             if not p.requires_grad:                   # frozen after the store was built: no GEMM will write it, keep it zero
