@@ -228,6 +228,34 @@ def test_gemm_nt64_decoder_shapes(ops, M, N, K):
     assert torch.equal(C4, Cf)
 
 
+@pytest.mark.parametrize("M,N,K", [(12000, 512, 512), (12000, 512, 2048), (12000, 512, 1536), (12100, 500, 128), (16000, 768, 64)])
+def test_gemm_nt_mid_size_shapes(ops, M, N, K):
+    """Mid-size problems (whisper-base B = 8: M = 12000 rows against the model width -- too few 256 x 256 tiles for the persistent
+    kernel; 128 x 128 tiles, or the 128 x 256 ring tiles of a -DNT128W=1 build): the result equals the fp64 product to
+    fp32-accumulation accuracy (ragged rows / columns, a single k-step, the fp32-residual epilogue), and two runs agree exactly."""
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A, B = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g) * K ** -0.5)
+    bias, res = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    ref = A.double() @ B.double().t()
+    Ad, Bd = dev(A, torch.bfloat16), dev(B, torch.bfloat16)
+    before = ops.gemm_dispatch_log()
+    Cf = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_nt(Ad, Bd, Cf, M, N, K)
+    after = ops.gemm_dispatch_log()
+    ran = [k for k in after if after[k] != before.get(k, 0)]
+    assert len(ran) == 1 and ran[0] in ("gemm_nt128t_kernel", "gemm_nt128w_kernel", "gemm_nt_kernel<2, false>"), ran
+    assert maxdiff(Cf.cpu(), ref) < 1e-4 * max(1.0, float(ref.abs().max()))
+    C3 = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm_nt(Ad, Bd, C3, M, N, K, bias=dev(bias), residual=dev(res))
+    assert maxdiff(C3.cpu(), _bf((ref + bias).float()) + res) < 4e-2       # one bf16 step of the rounded Linear output at |x| < 8
+    Cb = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    ops.gemm_nt(Ad, Bd, Cb, M, N, K)
+    assert maxdiff(Cb.float().cpu(), ref) < 1e-2 * max(1.0, float(ref.abs().max()))
+    C4 = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(Ad, Bd, C4, M, N, K)
+    assert torch.equal(C4, Cf)
+
+
 @pytest.mark.parametrize("M,N,K,Tn", [(6100, 2244, 128, 305), (12200, 1284, 192, 1525), (24000, 1280, 128, 1500)])
 def test_gemm_nt_fddt_epilogue_bit_exact(ops, M, N, K, Tn):
     """DICOW_EPI_FDDT: the next layer's diagonal FDDT applied in the fp32-residual epilogue of the persistent GEMM equals, bit for
@@ -272,7 +300,8 @@ def test_cast_transpose(ops, R, C, ld, ld_t):
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 256, 192), (6100, 2244, 128), (12200, 1284, 64),     # 128x128 / persistent 256x256 / 192x320
-                                   (16, 1284, 1280), (5, 260, 192)])                           # skinny (M <= 16)
+                                   (16, 1284, 1280), (5, 260, 192),                            # skinny (M <= 16)
+                                   (12000, 508, 192)])                                         # 128x256 ring tiles (mid-size)
 def test_gemm_nt_epilogues(ops, M, N, K):
     from ts_asr_whisper_amd import _lib as L
     g = torch.Generator().manual_seed(5)

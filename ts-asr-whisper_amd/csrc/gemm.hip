@@ -590,6 +590,13 @@ __global__ void __launch_bounds__(256, S > 4 ? 1 : 2) gemm_nt64_kernel(const dic
     }
 }
 
+#ifndef NT128W
+#define NT128W 0                 // mid-size problems on 128 x 256 ring tiles, one workgroup per CU (experiments/gemm_nt128w.inc): whisper-base
+#endif                           // B = 8 step 7.49 ms against 6.95-7.00 with the 128 x 128 tiles at two workgroups per CU (profiles/r04_nt128w.txt)
+#if NT128W
+#include "experiments/gemm_nt128w.inc"
+#endif
+
 // ------------------------------------------------------------------------------------------------ NT, skinny (M <= 16)
 // One decoder step of a batch of <= 16 hypotheses: C[M, N] = x[M, K] W[N, K]^T streams the whole weight matrix once for a
 // handful of rows -- HBM-bound, and the 128-row tiles above spend 25 us per call on it with N / 128 workgroups.  Here a
@@ -802,6 +809,9 @@ extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
 static void gemm_nt_setup() {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm_nt128t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+#if NT128W
+    (void)hipFuncSetAttribute((const void*)gemm_nt128w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT128W_LDS);
+#endif
     (void)hipFuncSetAttribute((const void*)gemm_nt64_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
     (void)hipFuncSetAttribute((const void*)gemm_nt64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
@@ -864,6 +874,9 @@ static void gemm_nt_setup() {
 #endif
 #ifndef NT_BIG_TILES
 #define NT_BIG_TILES 200
+#endif
+#ifndef NT128W_MIN_TILES
+#define NT128W_MIN_TILES 96
 #endif
 static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_colsum, int* colsum_rows) {
     dicow_gemm_args a_copy = *a_in;
@@ -1009,6 +1022,7 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     const bool t128 = NT128_THREADED && (int64_t)a->M * a->lda * 2 < (1ll << 31) && (int64_t)a->N * a->ldb * 2 < (1ll << 31) && a->K >= 2 * BK;
     // few 128 x 128 tiles (the decoder at training time: M = batch x label length): 64 x 64 tiles on a deep ring (gemm_nt64_kernel)
     const int64_t t64 = (int64_t)dicow_cdiv(a->M, 64) * dicow_cdiv(a->N, 64) * batch;
+    const int64_t tw = (int64_t)dicow_cdiv(a->M, 128) * dicow_cdiv(a->N, 256) * batch;      // 128 x 256 tiles (gemm_nt128w_kernel)
 #ifdef DICOW_ABLATIONS
     if (variant == 1) hipLaunchKernelGGL((gemm_nt_kernel<1, false>), grid, dim3(256), 2 * STAGE_BYTES, (hipStream_t)stream, *a);
     else if (variant == 2) hipLaunchKernelGGL((gemm_nt_kernel<2, true>), grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
@@ -1025,6 +1039,13 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             hipLaunchKernelGGL(gemm_nt64_kernel<4>, g64, dim3(256), 4 * 16384, (hipStream_t)stream, *a);
             disp_note("gemm_nt64_kernel<4>");
         }
+#if NT128W
+    } else if (t128 && variant == 0 && a->N >= 256 && a->M >= 128 && tw >= NT128W_MIN_TILES &&
+               tw * 10 >= dicow_cdiv(tw, g_ncu_all) * g_ncu_all * 7) {    // its (one workgroup per CU) rounds at least 70 % full
+        const dim3 gw(dicow_cdiv(a->M, 128) * dicow_cdiv(a->N, 256), 1, batch);
+        hipLaunchKernelGGL(gemm_nt128w_kernel, gw, dim3(256), NT128W_LDS, (hipStream_t)stream, *a);
+        disp_note("gemm_nt128w_kernel");
+#endif
     } else if (t128) {
         hipLaunchKernelGGL(gemm_nt128t_kernel, grid, dim3(256), NT_LDS_BYTES, (hipStream_t)stream, *a);
         disp_note("gemm_nt128t_kernel");

@@ -13,7 +13,7 @@
 //     A fragment -- lane = frame -- would otherwise be a 32-way bank conflict);
 //   * B fragments (2 samples x 32 bins of the cos or sin table, rows padded to 224 bins) come straight from L2 (the 717 KB table pair
 //     is shared by every workgroup), one k-step ahead in registers; 7 bin blocks x 200 k-steps = 1400 MFMAs per wave;
-//   * re^2 + im^2 meet in LDS ([64][209] fp32 over the sample stage), the slaney projection walks only each filter's non-zero bins
+//   * re^2 + im^2 meet in LDS ([64][201] fp32 over the sample stage), the slaney projection walks only each filter's non-zero bins
 //     (~400 multiply-adds per frame instead of 201 x M), log10, workgroup maximum.
 // 104 VGPRs + 57 KB of LDS: three workgroups per CU, the 750 workgroups of 16 clips are resident at once.
 // Kernel 2: clip max over the workgroup maxima, then the dynamic-range clamp and affine normalisation.
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) logmel_kernel(const float* __restrict__ w
 #define LMM_SPAN (LM_HOP * (LMM_FRAMES - 1) + LM_NFFT)                 // 10480 samples
 #define LMM_XS (LMM_SPAN + LMM_SPAN / LM_HOP + 1)                       // + one pad word per 160 samples
 #define LMM_LD 224                                                      // table row length (bins, zero-padded): 7 blocks of 32
-#define LMM_PW 209                                                      // row stride of the power image (odd: conflict-free columns)
+#define LMM_PW 201                                                      // row stride of the power image (odd: conflict-free columns)
 typedef __attribute__((ext_vector_type(16))) float lm_f32x16_t;
 
 __global__ void __launch_bounds__(256, 3) logmel_mfma_kernel(const float* __restrict__ wave, int n_samples, int n_frames,
