@@ -878,6 +878,15 @@ static void gemm_nt_setup() {
 #ifndef NT128W_MIN_TILES
 #define NT128W_MIN_TILES 96
 #endif
+#ifndef NT_DEFER
+#define NT_DEFER 0                // experiment (tools/build_ntd.sh): bit 0 inference fc1 (bias + GELU), bit 1 training fc1 on gemm_ntd_kernel
+#endif
+#ifndef NT_DEFER_BUILD
+#define NT_DEFER_BUILD 0
+#endif
+#if NT_DEFER_BUILD
+extern "C" int dicow_ntd_launch_(const dicow_gemm_args* a, int grid, void* stream);      // experiments/gemm_ntd.hip (internal)
+#endif
 static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_colsum, int* colsum_rows) {
     dicow_gemm_args a_copy = *a_in;
     dicow_gemm_args* a = &a_copy;
@@ -974,6 +983,22 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
 #else
 #define NTW_LAUNCH(F) { if (use35) hipLaunchKernelGGL((gemm_ntr_kernel<F, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); \
                         else hipLaunchKernelGGL((gemm_ntr_kernel<F, 4, 4>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); }
+#endif
+#if NT_DEFER_BUILD
+            // bias + GELU [+ saved derivative] with the epilogue deferred into the next tile's k-loop (experiments/gemm_ntd.hip; round 4: bit-identical, 1.5-2 x slower -- profiles/r04_ntd_deferred_epilogue.txt): 192 x 320 tiles,
+            // at least two tiles per workgroup (the last one is flushed after the loop, nothing hides it)
+            {
+                static const int defer = getenv("DICOW_NT_DEFER") ? atoi(getenv("DICOW_NT_DEFER")) : NT_DEFER;
+                const bool gelu_i = a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU), gelu_t = a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX);
+                if (variant == 0 && batch == 1 && ((gelu_i && (defer & 1)) || (gelu_t && (defer & 2))) && a->N % 320 == 0 && a->K >= 16 * BK && t35 >= 2 * ncu) {
+                    const int rounds_d = dicow_cdiv((int)t35, ncu);
+                    const int rc = dicow_ntd_launch_(a, dicow_cdiv((int)t35, rounds_d), stream);
+                    DICOW_REQUIRE(rc == 0, "gemm_nt: deferred-epilogue kernel refused flags %d", a->flags);
+                    disp_note("gemm_ntd_kernel<%d>", a->flags);
+                    DICOW_CHECK_LAUNCH("gemm_nt (persistent, deferred epilogue)");
+                    return DICOW_OK;
+                }
+            }
 #endif
             if (want_colsum && variant != 11 && a->flags == DICOW_EPI_MUL_AUX) { a->flags |= DICOW_EPI_COLSUM; *fused_colsum = true; }
             {
