@@ -25,7 +25,7 @@ def insitu(fn, rounds=9):
         s.record(); fn(); e.record(); ev.append((s, e))
     torch.cuda.synchronize()
     return statistics.median(s.elapsed_time(e) for s, e in ev) * 1e3
-for (M, N, K) in ((24000, 5120, 1280), (23900, 1600, 1024), (12100, 3520, 1344), (24000, 5120, 2560)):
+for (M, N, K) in ((24000, 5120, 1280), (23900, 1600, 1024), (12100, 3520, 1344)):
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
     A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(bf); W = (torch.randn(N, K, device="cuda", generator=g) * 0.03).to(bf)
     bias = torch.randn(N, device="cuda", generator=g) * 0.1
@@ -38,17 +38,40 @@ for (M, N, K) in ((24000, 5120, 1280), (23900, 1600, 1024), (12100, 3520, 1344),
     after = ops.gemm_dispatch_log()
     kern = ",".join(k for k in after if after[k] != before.get(k, 0))
     torch.cuda.synchronize()
-    out[(M, N, K)] = (C1.cpu(), C2.cpu(), U2.cpu())
-    line = f"M={M} N={N} K={K}: [{kern}]"
+    out[("gelu", M, N, K)] = (C1.cpu(), C2.cpu(), U2.cpu())
+    line = f"gelu  M={M} N={N} K={K}: [{kern}]"
     if M == 24000:
         line += f"  gelu hot {hot(f1):.1f} in-situ {insitu(f1):.1f} us | gelu+daux hot {hot(f2):.1f} in-situ {insitu(f2):.1f} us"
+    print(line, flush=True)
+# light epilogues: plain / bias / bias + q-scale (bf16 out), bias + fp32 residual (fp32 out)
+for (M, N, K) in ((24000, 1280, 1280), (24000, 1280, 5120), (24000, 3840, 1280), (24000, 1280, 3840), (23900, 1600, 1024), (12100, 3520, 1344)):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K + 1)
+    A = (torch.randn(M, K, device="cuda", generator=g) * 0.5).to(bf); W = (torch.randn(N, K, device="cuda", generator=g) * 0.03).to(bf)
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1; res = torch.randn(M, N, device="cuda", generator=g)
+    Cp = torch.full((M, N), float("nan"), dtype=bf, device="cuda"); Cb = torch.full((M, N), float("nan"), dtype=bf, device="cuda")
+    Cs = torch.full((M, N), float("nan"), dtype=bf, device="cuda"); Cr = torch.full((M, N), float("nan"), device="cuda")
+    nq = (N // 12) * 4
+    before = ops.gemm_dispatch_log()
+    fp = lambda: ops.gemm_nt(A, W, Cp, M, N, K)
+    fb = lambda: ops.gemm_nt(A, W, Cb, M, N, K, bias=bias)
+    fs = lambda: ops.gemm_nt(A, W, Cs, M, N, K, bias=bias, flags=L.EPI_SCALE_N, scale=0.125, scale_ncols=nq)
+    fr = lambda: ops.gemm_nt(A, W, Cr, M, N, K, bias=bias, residual=res)
+    fp(); fb(); fs(); fr()
+    after = ops.gemm_dispatch_log()
+    kern = ",".join(k for k in after if after[k] != before.get(k, 0))
+    torch.cuda.synchronize()
+    out[("light", M, N, K)] = (Cp.cpu(), Cb.cpu(), Cs.cpu(), Cr.cpu())
+    line = f"light M={M} N={N} K={K}: [{kern}]"
+    if M == 24000:
+        line += f"\n      in-situ us: plain {insitu(fp):.1f}  bias {insitu(fb):.1f}  bias+scale {insitu(fs):.1f}  bias+residual {insitu(fr):.1f}   | hot: plain {hot(fp):.1f} scale {hot(fs):.1f} residual {hot(fr):.1f}"
     print(line, flush=True)
 torch.save(out, sys.argv[1])
 '''
 lib = os.path.abspath(sys.argv[1]) if len(sys.argv) > 1 else None
+MODE = sys.argv[2] if len(sys.argv) > 2 else "15"
 files = {}
 for rep in range(2):
-    for mode in ("0", "3"):
+    for mode in ("0", MODE):
         f = tempfile.mktemp(suffix=f"_ntd{mode}.pt")
         env = dict(os.environ, DICOW_NT_DEFER=mode)
         if lib: env["DICOW_HIP_LIB"] = lib
@@ -56,9 +79,10 @@ for rep in range(2):
         print(f"--- DICOW_NT_DEFER={mode}\n" + (r.stdout.strip() if r.returncode == 0 else r.stdout + r.stderr[-1500:]), flush=True)
         files.setdefault(mode, f)
 import torch
-a, b = torch.load(files["0"]), torch.load(files["3"])
+a, b = torch.load(files["0"]), torch.load(files[MODE])
 for k in a:
-    for name, x, y in zip(("gelu C", "gelu+daux C", "gelu+daux aux"), a[k], b[k]):
+    names = ("gelu C", "gelu+daux C", "gelu+daux aux") if k[0] == "gelu" else ("plain", "bias", "bias+scale", "bias+residual")
+    for name, x, y in zip(names, a[k], b[k]):
         same = torch.equal(x, y)
         nan = int(torch.isnan(y.float()).sum())
         d = (x.float() - y.float()).abs()

@@ -24,6 +24,7 @@
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef unsigned u32x32_t __attribute__((ext_vector_type(32)));
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 
 // (same tile walk as gemm.hip: grouped + XCD-aware, each XCD a contiguous chunk of the grouped order)
 __device__ __forceinline__ void ntd_tile_coords(int ntm, int ntn, int bid, int& tm, int& tn) {
@@ -47,6 +48,8 @@ __device__ __forceinline__ bf16x8_t ntd_frag(const char* s, int row, int c) {
 #define NTD_LDS (5 * NTD_SLOT)
 #define NTD_C16_NT 2            // cache policy of the bf16 output stores (nt: touched once), as gemm_ntr.inc
 #define NTD_X_NT 0
+#define NTD_C32_NT 0
+#define NTD_RES_NT 2
 #ifndef NTD_VALU_MASK
 #define NTD_VALU_MASK 0x402     // sched_group_barrier classes of the deferred arithmetic: VALU | transcendental
 #endif
@@ -57,7 +60,13 @@ __device__ __forceinline__ bf16x8_t ntd_frag(const char* s, int row, int c) {
 template <int FLAGS>
 __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) {
     constexpr int NJ = 3, NI = 5, BMT = 192, BNT = 320, WMR = 96, WNC = 160;
+    constexpr bool GELU_K = (FLAGS & DICOW_EPI_GELU) != 0;          // heavy deferred work (GELU per element); else "light": stores [+ residual add]
     constexpr bool DAUX = (FLAGS & DICOW_EPI_GELU_DAUX) != 0;
+    constexpr bool BIAS_K = (FLAGS & DICOW_EPI_BIAS) != 0, SCALE_K = (FLAGS & DICOW_EPI_SCALE_N) != 0;
+    constexpr bool RES_K = (FLAGS & DICOW_EPI_RESIDUAL) != 0;      // C (fp32) = bf16(acc + bias) + residual
+    constexpr int ESZ = (FLAGS & DICOW_EPI_OUT_F32) ? 4 : 2;
+    static_assert(!RES_K || ESZ == 4, "residual epilogue: fp32 output");
+    static_assert(RES_K || ESZ == 2, "bf16 output unless residual");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,19 +146,28 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
     const unsigned OOB = 0x80000000u;
     // (32-bit scalar arithmetic: the host checks that every byte offset fits; a 64-bit product would be computed on the VALU and the
     // descriptor word would live in a VGPR -- every store then becomes a readfirstlane waterfall loop)
-    const unsigned nrecC = (unsigned)__builtin_amdgcn_readfirstlane(((a.M - 1) * (int)a.ldc + a.N) * 2);
+    const unsigned nrecC = (unsigned)__builtin_amdgcn_readfirstlane(((a.M - 1) * (int)a.ldc + a.N) * ESZ);
+    const unsigned nrecR = RES_K ? (unsigned)__builtin_amdgcn_readfirstlane(((a.M - 1) * (int)a.ldr + a.N) * 4) : 0u;
     const unsigned nrecX = DAUX ? (unsigned)__builtin_amdgcn_readfirstlane(((a.M - 1) * (int)a.ldaux + a.N) * 2) : 0u;
     const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.C), 0, nrecC, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.aux), 0, nrecX, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, (unsigned)(a.N * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsBi = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.bias), 0, BIAS_K ? (unsigned)(a.N * 4) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.residual), 0, nrecR, 0x00020000);
     int prow = 0;                                     // row of this lane in block j = 0 of the held tile
-    unsigned pvoC = OOB, pvoX = OOB;                  // lane byte offset of element (row ml, column 4 hh) of the HELD tile's wave quadrant
-    // stores carried from the step that computed them to the first half of the next one
+    unsigned pvoC = OOB, pvoX = OOB, pvoR = OOB;      // lane byte offset of element (row ml, column 4 hh) of the HELD tile's wave quadrant
+    // address state of the block a deferred step works on (cur) and of the one before it (prv): scalar byte offset of the block in
+    // the wave quadrant + the lane offset (out of range when there is nothing to do)
+    unsigned cur_voC = OOB, cur_voX = OOB, cur_voR = OOB, prv_voC = OOB, prv_voX = OOB;
+    int cur_soC = 0, cur_soX = 0, cur_soR = 0, prv_soC = 0, prv_soX = 0;
+    // GELU: outputs carried from the step that computed them to the first half of the next one.  Residual: the block's held
+    // dwords and its residual quads (requested one step ahead)
     u32x2_t cst_o[4], cst_d[4];
-    unsigned cst_voC = OOB, cst_voX = OOB;
-    int cst_soC = 0, cst_soX = 0;
+    unsigned hcar[8];
+    u32x4_t rres[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) { cst_o[g] = u32x2_t{0u, 0u}; cst_d[g] = u32x2_t{0u, 0u}; }
+    for (int g = 0; g < 4; ++g) { cst_o[g] = u32x2_t{0u, 0u}; cst_d[g] = u32x2_t{0u, 0u}; rres[g] = u32x4_t{0u, 0u, 0u, 0u}; }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hcar[e] = 0u;
 
     // quad G of the block at dword DIX_ of held vector HV: GELU of the four bf16 pre-activations -> packed outputs
 #define NTD_QUAD(HV, DIX_, G, OUT_O, OUT_D)                                                                  \
@@ -166,8 +184,30 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
     }
 #define NTD_STORE(G)                                                                                         \
     {                                                                                                        \
-        __builtin_amdgcn_raw_buffer_store_b64(cst_o[G], rsC, cst_voC, cst_soC + (G) * 16, NTD_C16_NT);       \
-        if (DAUX) __builtin_amdgcn_raw_buffer_store_b64(cst_d[G], rsX, cst_voX, cst_soX + (G) * 16, NTD_X_NT); \
+        __builtin_amdgcn_raw_buffer_store_b64(cst_o[G], rsC, prv_voC, prv_soC + (G) * 16, NTD_C16_NT);       \
+        if (DAUX) __builtin_amdgcn_raw_buffer_store_b64(cst_d[G], rsX, prv_voX, prv_soX + (G) * 16, NTD_X_NT); \
+    }
+    // light epilogues.  bf16 output: quad G of block (HV, DIX_) straight from the held registers to its place (cur)
+#define NTD_LSTORE(HV, DIX_, G)                                                                              \
+    {                                                                                                        \
+        const u32x2_t o_ = {(HV)[(DIX_) + 2 * (G)], (HV)[(DIX_) + 2 * (G) + 1]};                             \
+        __builtin_amdgcn_raw_buffer_store_b64(o_, rsC, cur_voC, cur_soC + (G) * 16, NTD_C16_NT);             \
+    }
+    // residual: quad G of the PREVIOUS block = its held bf16 values + the residual quad requested one step ago -> fp32 (prv)
+#define NTD_RSTORE(G)                                                                                        \
+    {                                                                                                        \
+        const unsigned w0_ = hcar[2 * (G)], w1_ = hcar[2 * (G) + 1];                                         \
+        const u32x4_t o_ = {__float_as_uint(__uint_as_float(w0_ << 16) + __uint_as_float(rres[G][0])),       \
+                            __float_as_uint(__uint_as_float(w0_ & 0xffff0000u) + __uint_as_float(rres[G][1])), \
+                            __float_as_uint(__uint_as_float(w1_ << 16) + __uint_as_float(rres[G][2])),       \
+                            __float_as_uint(__uint_as_float(w1_ & 0xffff0000u) + __uint_as_float(rres[G][3]))}; \
+        __builtin_amdgcn_raw_buffer_store_b128(o_, rsC, prv_voC, prv_soC + (G) * 32, NTD_C32_NT);            \
+    }
+    // ... and this step's block: its held dwords and its residual quads (cur) for the next step
+#define NTD_RFETCH(HV, DIX_)                                                                                 \
+    {                                                                                                        \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) hcar[e] = (HV)[(DIX_) + e];                            \
+        _Pragma("unroll") for (int g = 0; g < 4; ++g) rres[g] = __builtin_amdgcn_raw_buffer_load_b128(rsR, cur_voR, cur_soR + g * 32, NTD_RES_NT); \
     }
 
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A0, B0 landed; A1 in flight
@@ -207,8 +247,20 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
         else if (s_ < (NR) + (ND) + (NST)) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);                \
         __builtin_amdgcn_sched_group_barrier(NTD_VALU_MASK, NTD_VALU_PER_GAP, 0);                            \
     }
-    // MODE_: 0 plain step, 1 deferred step (stores carried quads in slices 0 / 1, computes block (HV, DIX_) quad g in slice g),
-    // 2 store-only step
+    // light deferred slices: NST stores beside the first fragment reads, NLD extra loads behind the DMA requests, NV VALU per gap
+#define SCHED_L(NR, ND, NST, NLD, NV)                                                                        \
+    _Pragma("unroll") for (int s_ = 0; s_ < NJ * NI; ++s_) {                                                 \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+        if (s_ < (NR)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                    \
+        else if (s_ < (NR) + (ND)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                        \
+        else if (s_ < (NR) + (ND) + ((NLD) + 1) / 2) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      \
+        if (s_ < (NST)) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);                                   \
+        if ((NV) > 0) __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);                                  \
+    }
+    // MODE_: 0 plain step, 1 deferred step on block (HV, DIX_), 2 the step after the last deferred one.
+    //   GELU: a deferred step stores the quads carried from the step before (slices 0 / 1) and computes quad g of its block in slice g;
+    //   bf16 light: stores its own block, two quads in slice 0, two in slice 1;
+    //   residual: finishes the block before (held dwords + residual quads fetched one step ago), then fetches its own.
 #define KSTEP(FIRST_, WAIT_, MODE_, HV, DIX_)                                                                \
     {                                                                                                        \
         const int sb_ = sa + 1 >= 5 ? sa - 4 : sa + 1;                                                       \
@@ -216,55 +268,66 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
         const int da_ = sa + 4 >= 5 ? sa - 1 : sa + 4;                                                       \
         char* sA = smem + sa * NTD_SLOT;                                                                     \
         char* sB = smem + sb_ * NTD_SLOT;                                                                    \
-        u32x2_t no_[4], nd_[4];                                                                                \
+        u32x2_t no_[4], nd_[4];                                                                              \
         asm volatile(WAIT_ ::: "memory");                                                                    \
         __builtin_amdgcn_s_barrier();                                                                        \
         asm volatile("" ::: "memory");                                                                       \
         LDFRAG(wf0, xf0, 0)                                                                                  \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) NTD_DMA_B(e, db_)                                      \
-        if ((MODE_) >= 1) { NTD_STORE(0) NTD_STORE(1) }                                                      \
-        if ((MODE_) == 1) NTD_QUAD(HV, DIX_, 0, no_[0], nd_[0])                                              \
-        if (!(FIRST_)) { DOMFMA(wf1, xf1) if ((MODE_) >= 1) { SCHED_D(8, 4, (DAUX ? 4 : 2)) } else { SCHED(8, 4) } } \
+        if (GELU_K) { if ((MODE_) >= 1) { NTD_STORE(0) NTD_STORE(1) } if ((MODE_) == 1) NTD_QUAD(HV, DIX_, 0, no_[0], nd_[0]) } \
+        else if (RES_K) { if ((MODE_) >= 1) { NTD_RSTORE(0) NTD_RSTORE(1) } }                                \
+        else { if ((MODE_) == 1) { NTD_LSTORE(HV, DIX_, 0) NTD_LSTORE(HV, DIX_, 1) } }                       \
+        if (!(FIRST_)) { DOMFMA(wf1, xf1)                                                                    \
+            if (GELU_K && (MODE_) >= 1) { SCHED_D(8, 4, (DAUX ? 4 : 2)) }                                    \
+            else if (RES_K && (MODE_) >= 1) { SCHED_L(8, 4, 2, 0, 1) }                                       \
+            else if (!GELU_K && !RES_K && (MODE_) == 1) { SCHED_L(8, 4, 2, 0, 0) }                           \
+            else { SCHED(8, 4) } }                                                                           \
         LDFRAG(wf1, xf1, 1)                                                                                  \
         _Pragma("unroll") for (int e = 4; e < 8; ++e) NTD_DMA_B(e, db_)                                      \
-        if ((MODE_) >= 1) { NTD_STORE(2) NTD_STORE(3) }                                                      \
-        if ((MODE_) == 1) NTD_QUAD(HV, DIX_, 1, no_[1], nd_[1])                                              \
-        DOMFMA(wf0, xf0) if ((MODE_) >= 1) { SCHED_D(8, 4, (DAUX ? 4 : 2)) } else { SCHED(8, 4) }            \
+        if (GELU_K) { if ((MODE_) >= 1) { NTD_STORE(2) NTD_STORE(3) } if ((MODE_) == 1) NTD_QUAD(HV, DIX_, 1, no_[1], nd_[1]) } \
+        else if (RES_K) { if ((MODE_) >= 1) { NTD_RSTORE(2) NTD_RSTORE(3) } if ((MODE_) == 1) NTD_RFETCH(HV, DIX_) } \
+        else { if ((MODE_) == 1) { NTD_LSTORE(HV, DIX_, 2) NTD_LSTORE(HV, DIX_, 3) } }                       \
+        DOMFMA(wf0, xf0)                                                                                     \
+        if (GELU_K && (MODE_) >= 1) { SCHED_D(8, 4, (DAUX ? 4 : 2)) }                                        \
+        else if (RES_K && (MODE_) >= 1) { SCHED_L(8, 4, 2, ((MODE_) == 1 ? 4 : 0), 2) }                      \
+        else if (!GELU_K && !RES_K && (MODE_) == 1) { SCHED_L(8, 4, 2, 0, 0) }                               \
+        else { SCHED(8, 4) }                                                                                 \
         LDFRAG(wf0, xf0, 2)                                                                                  \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) NTD_DMA_A(e, da_)                                      \
-        if ((MODE_) == 1) NTD_QUAD(HV, DIX_, 2, no_[2], nd_[2])                                              \
-        DOMFMA(wf1, xf1) if ((MODE_) == 1) { SCHED_D(8, 4, 0) } else { SCHED(8, 4) }                         \
+        if (GELU_K && (MODE_) == 1) NTD_QUAD(HV, DIX_, 2, no_[2], nd_[2])                                    \
+        DOMFMA(wf1, xf1) if (GELU_K && (MODE_) == 1) { SCHED_D(8, 4, 0) } else { SCHED(8, 4) }               \
         LDFRAG(wf1, xf1, 3)                                                                                  \
         _Pragma("unroll") for (int e = 4; e < 8; ++e) NTD_DMA_A(e, da_)                                      \
-        if ((MODE_) == 1) NTD_QUAD(HV, DIX_, 3, no_[3], nd_[3])                                              \
-        DOMFMA(wf0, xf0) if ((MODE_) == 1) { SCHED_D(8, 4, 0) } else { SCHED(8, 4) }                         \
-        if ((MODE_) == 1) { _Pragma("unroll") for (int g = 0; g < 4; ++g) { cst_o[g] = no_[g]; if (DAUX) cst_d[g] = nd_[g]; } } \
+        if (GELU_K && (MODE_) == 1) NTD_QUAD(HV, DIX_, 3, no_[3], nd_[3])                                    \
+        DOMFMA(wf0, xf0) if (GELU_K && (MODE_) == 1) { SCHED_D(8, 4, 0) } else { SCHED(8, 4) }               \
+        if (GELU_K && (MODE_) == 1) { _Pragma("unroll") for (int g = 0; g < 4; ++g) { cst_o[g] = no_[g]; if (DAUX) cst_d[g] = nd_[g]; } } \
         sa = sa + 2 >= 5 ? sa - 3 : sa + 2;                                                                  \
         ka += BK; kb += BK;                                                                                  \
     }
-        // block (I_, J_) of the held tile -> scalar byte offsets of its stores; without a held tile, past the last block or past
-        // row M: out-of-range lane offsets (the stores are dropped)
-#define NTD_BLOCK_ADDR(I_, J_, LIVE_)                                                                        \
+        // the address state moves on to block (I_, J_) of the held tile (called BEFORE the step that works on it); without a held
+        // tile, past the last block or past row M: out-of-range lane offsets (loads return zeros, stores are dropped)
+#define NTD_ADDR(I_, J_, LIVE_)                                                                              \
     {                                                                                                        \
+        prv_soC = cur_soC; prv_voC = cur_voC; prv_soX = cur_soX; prv_voX = cur_voX;                          \
         const bool ok_ = p_valid && (LIVE_) && prow + 32 * (J_) < a.M;                                       \
-        cst_soC = ((J_) * 32 * (int)a.ldc + (I_) * 32) * 2;                                                  \
-        cst_voC = ok_ ? pvoC : OOB;                                                                          \
-        if (DAUX) { cst_soX = ((J_) * 32 * (int)a.ldaux + (I_) * 32) * 2; cst_voX = ok_ ? pvoX : OOB; }      \
+        cur_soC = ((J_) * 32 * (int)a.ldc + (I_) * 32) * ESZ;                                                \
+        cur_voC = ok_ ? pvoC : OOB;                                                                          \
+        if (DAUX) { cur_soX = ((J_) * 32 * (int)a.ldaux + (I_) * 32) * 2; cur_voX = ok_ ? pvoX : OOB; }      \
+        if (RES_K) { cur_soR = ((J_) * 32 * (int)a.ldr + (I_) * 32) * 4; cur_voR = ok_ ? pvoR : OOB; }       \
     }
 #define NTD_STEP_WAIT "s_waitcnt vmcnt(8) lgkmcnt(0)"
         KSTEP(true, "s_waitcnt lgkmcnt(0)", 0, H0, 0)
-        cst_voC = OOB; cst_voX = OOB;                 // step 1 has nothing to store yet
+        cur_voC = OOB; cur_voX = OOB; cur_voR = OOB;  // nothing is pending when the deferred steps start
 #pragma nounroll
         for (int r = 0; r < 4; ++r) {
             const int ri = __builtin_amdgcn_readfirstlane(r);
             const int dix = ri * 8;
-            // a deferred step first issues the stores of the block computed one step earlier (address state cst_*), then computes
-            // its own block; the address state moves on after the step
-            KSTEP(false, NTD_STEP_WAIT, 1, H0, dix) NTD_BLOCK_ADDR(ri, 0, true)
-            KSTEP(false, NTD_STEP_WAIT, 1, H1, dix) NTD_BLOCK_ADDR(ri, 1, true)
-            KSTEP(false, NTD_STEP_WAIT, 1, H2, dix) NTD_BLOCK_ADDR(ri, 2, true)
+            NTD_ADDR(ri, 0, true) KSTEP(false, NTD_STEP_WAIT, 1, H0, dix)
+            NTD_ADDR(ri, 1, true) KSTEP(false, NTD_STEP_WAIT, 1, H1, dix)
+            NTD_ADDR(ri, 2, true) KSTEP(false, NTD_STEP_WAIT, 1, H2, dix)
         }
-        KSTEP(false, NTD_STEP_WAIT, 2, H0, 0)         // step 13: the last block's stores
+        NTD_ADDR(0, 0, false)
+        KSTEP(false, NTD_STEP_WAIT, 2, H0, 0)         // step 13: what the last deferred step left pending
         for (int t = 14; t < nk - 2; ++t) KSTEP(false, NTD_STEP_WAIT, 0, H0, 0)
         NTD_SWITCH_A()
         KSTEP(false, NTD_STEP_WAIT, 0, H0, 0)
@@ -278,8 +341,12 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
             for (int i = 0; i < NI; ++i)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const auto b_ = __builtin_amdgcn_raw_buffer_load_b128(rsBi, (unsigned)((en0_ + 32 * i + 8 * g + 4 * hh) * 4), 0, 0);
-                    bq[i][g] = make_float4(__uint_as_float(b_[0]), __uint_as_float(b_[1]), __uint_as_float(b_[2]), __uint_as_float(b_[3]));
+                    if (BIAS_K) {
+                        const auto b_ = __builtin_amdgcn_raw_buffer_load_b128(rsBi, (unsigned)((en0_ + 32 * i + 8 * g + 4 * hh) * 4), 0, 0);
+                        bq[i][g] = make_float4(__uint_as_float(b_[0]), __uint_as_float(b_[1]), __uint_as_float(b_[2]), __uint_as_float(b_[3]));
+                    } else {
+                        bq[i][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
         }
         KSTEP(false, NTD_STEP_WAIT, 0, H0, 0)
@@ -294,61 +361,101 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
 #undef SCHED_D
 #undef LDFRAG
 #undef DOMFMA
-        // ---- hold: H <- bf16(acc + bias), the AMP Linear output; lane (ml, hh) of block (i, j): row 32 j + ml, columns 32 i + 8 g + 4 hh + e
+        // ---- hold: H <- bf16(acc + bias [, x scale on the q columns]), the AMP Linear output; lane (ml, hh) of block (i, j): row 32 j + ml,
+        // columns 32 i + 8 g + 4 hh + e
         {
-#define NTD_HOLD(HV, I_, J_)                                                                                 \
-    {                                                                                                        \
-        _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                      \
-            (HV)[8 * (I_) + 2 * g] = pack_bf16x2(acc[I_][J_][4 * g] + bq[I_][g].x, acc[I_][J_][4 * g + 1] + bq[I_][g].y);     \
-            (HV)[8 * (I_) + 2 * g + 1] = pack_bf16x2(acc[I_][J_][4 * g + 2] + bq[I_][g].z, acc[I_][J_][4 * g + 3] + bq[I_][g].w); \
-        }                                                                                                    \
-    }
-            NTD_HOLD(H0, 0, 0) NTD_HOLD(H1, 0, 1) NTD_HOLD(H2, 0, 2) NTD_HOLD(H0, 1, 0) NTD_HOLD(H1, 1, 1) NTD_HOLD(H2, 1, 2)
-            NTD_HOLD(H0, 2, 0) NTD_HOLD(H1, 2, 1) NTD_HOLD(H2, 2, 2) NTD_HOLD(H0, 3, 0) NTD_HOLD(H1, 3, 1) NTD_HOLD(H2, 3, 2)
-#undef NTD_HOLD
             const int em0 = m0 + wm * WMR, en0 = n0 + wn * WNC;
-            // rows past M: beyond the buffer's range only for the LAST rows of C; mask them explicitly
-            pvoC = (unsigned)((((int64_t)(em0 + ml)) * a.ldc + en0 + 4 * hh) * 2);
+            const int nq0 = en0 + 4 * hh;             // (x 1.0f is exact: the same bits as the ring kernel's conditional multiply)
+            // the quad (I_, J_, g) as two packed dwords
+#define NTD_PACKQ(I_, J_, G_, W0, W1)                                                                        \
+    {                                                                                                        \
+        float v0_ = acc[I_][J_][4 * (G_)], v1_ = acc[I_][J_][4 * (G_) + 1], v2_ = acc[I_][J_][4 * (G_) + 2], v3_ = acc[I_][J_][4 * (G_) + 3]; \
+        if (BIAS_K) { v0_ += bq[I_][G_].x; v1_ += bq[I_][G_].y; v2_ += bq[I_][G_].z; v3_ += bq[I_][G_].w; } \
+        if (SCALE_K) { const float sc_ = (nq0 + 32 * (I_) + 8 * (G_) < a.scale_ncols) ? a.scale : 1.0f; v0_ *= sc_; v1_ *= sc_; v2_ *= sc_; v3_ *= sc_; } \
+        (W0) = pack_bf16x2(v0_, v1_); (W1) = pack_bf16x2(v2_, v3_);                                          \
+    }
+#define NTD_HOLD(HV, I_, J_)                                                                                 \
+    { _Pragma("unroll") for (int g = 0; g < 4; ++g) { unsigned w0_, w1_; NTD_PACKQ(I_, J_, g, w0_, w1_) (HV)[8 * (I_) + 2 * g] = w0_; (HV)[8 * (I_) + 2 * g + 1] = w1_; } }
+            pvoC = (unsigned)((((int64_t)(em0 + ml)) * a.ldc + en0 + 4 * hh) * ESZ);
             if (DAUX) pvoX = (unsigned)((((int64_t)(em0 + ml)) * a.ldaux + en0 + 4 * hh) * 2);
+            if (RES_K) pvoR = (unsigned)((((int64_t)(em0 + ml)) * a.ldr + en0 + 4 * hh) * 4);
             prow = em0 + ml;
             p_valid = true;
-            // n block 4 of the three row blocks: finished here (not held)
+            // n block 4 of the three row blocks is finished here (not held); its residual quads are requested first
+            u32x4_t ir[RES_K ? NJ : 1][RES_K ? 4 : 1];
+            if (RES_K) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        ir[j][g] = __builtin_amdgcn_raw_buffer_load_b128(rsR, prow + 32 * j < a.M ? pvoR : OOB, (j * 32 * (int)a.ldr + 128) * 4 + g * 32, NTD_RES_NT);
+            }
+            NTD_HOLD(H0, 0, 0) NTD_HOLD(H1, 0, 1) NTD_HOLD(H2, 0, 2) NTD_HOLD(H0, 1, 0) NTD_HOLD(H1, 1, 1) NTD_HOLD(H2, 1, 2)
+            NTD_HOLD(H0, 2, 0) NTD_HOLD(H1, 2, 1) NTD_HOLD(H2, 2, 2) NTD_HOLD(H0, 3, 0) NTD_HOLD(H1, 3, 1) NTD_HOLD(H2, 3, 2)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const bool rok = prow + 32 * j < a.M;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const unsigned w0 = pack_bf16x2(acc[4][j][4 * g] + bq[4][g].x, acc[4][j][4 * g + 1] + bq[4][g].y);
-                    const unsigned w1 = pack_bf16x2(acc[4][j][4 * g + 2] + bq[4][g].z, acc[4][j][4 * g + 3] + bq[4][g].w);
-                    const float x0 = __uint_as_float(w0 << 16), x1 = __uint_as_float(w0 & 0xffff0000u);
-                    const float x2 = __uint_as_float(w1 << 16), x3 = __uint_as_float(w1 & 0xffff0000u);
-                    float c0, c1, c2, c3, p0, p1, p2, p3;
-                    gelu_cdf_pdf(x0, c0, p0); gelu_cdf_pdf(x1, c1, p1); gelu_cdf_pdf(x2, c2, p2); gelu_cdf_pdf(x3, c3, p3);
-                    const u32x2_t o = {pack_bf16x2(x0 * c0, x1 * c1), pack_bf16x2(x2 * c2, x3 * c3)};
-                    __builtin_amdgcn_raw_buffer_store_b64(o, rsC, rok ? pvoC : OOB, (j * 32 * (int)a.ldc + 128) * 2 + g * 16, NTD_C16_NT);
-                    if (DAUX) {
-                        const u32x2_t d = {pack_bf16x2(fmaf(x0, p0, c0), fmaf(x1, p1, c1)), pack_bf16x2(fmaf(x2, p2, c2), fmaf(x3, p3, c3))};
-                        __builtin_amdgcn_raw_buffer_store_b64(d, rsX, rok ? pvoX : OOB, (j * 32 * (int)a.ldaux + 128) * 2 + g * 16, NTD_X_NT);
+                    unsigned w0, w1;
+                    NTD_PACKQ(4, j, g, w0, w1)
+                    if (GELU_K) {
+                        const float x0 = __uint_as_float(w0 << 16), x1 = __uint_as_float(w0 & 0xffff0000u);
+                        const float x2 = __uint_as_float(w1 << 16), x3 = __uint_as_float(w1 & 0xffff0000u);
+                        float c0, c1, c2, c3, p0, p1, p2, p3;
+                        gelu_cdf_pdf(x0, c0, p0); gelu_cdf_pdf(x1, c1, p1); gelu_cdf_pdf(x2, c2, p2); gelu_cdf_pdf(x3, c3, p3);
+                        const u32x2_t o = {pack_bf16x2(x0 * c0, x1 * c1), pack_bf16x2(x2 * c2, x3 * c3)};
+                        __builtin_amdgcn_raw_buffer_store_b64(o, rsC, rok ? pvoC : OOB, (j * 32 * (int)a.ldc + 128) * 2 + g * 16, NTD_C16_NT);
+                        if (DAUX) {
+                            const u32x2_t d = {pack_bf16x2(fmaf(x0, p0, c0), fmaf(x1, p1, c1)), pack_bf16x2(fmaf(x2, p2, c2), fmaf(x3, p3, c3))};
+                            __builtin_amdgcn_raw_buffer_store_b64(d, rsX, rok ? pvoX : OOB, (j * 32 * (int)a.ldaux + 128) * 2 + g * 16, NTD_X_NT);
+                        }
+                    } else if (RES_K) {
+                        const u32x4_t o = {__float_as_uint(__uint_as_float(w0 << 16) + __uint_as_float(ir[j][g][0])),
+                                           __float_as_uint(__uint_as_float(w0 & 0xffff0000u) + __uint_as_float(ir[j][g][1])),
+                                           __float_as_uint(__uint_as_float(w1 << 16) + __uint_as_float(ir[j][g][2])),
+                                           __float_as_uint(__uint_as_float(w1 & 0xffff0000u) + __uint_as_float(ir[j][g][3]))};
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rsC, rok ? pvoC : OOB, (j * 32 * (int)a.ldc + 128) * 4 + g * 32, NTD_C32_NT);
+                    } else {
+                        const u32x2_t o = {w0, w1};
+                        __builtin_amdgcn_raw_buffer_store_b64(o, rsC, rok ? pvoC : OOB, (j * 32 * (int)a.ldc + 128) * 2 + g * 16, NTD_C16_NT);
                     }
                 }
             }
+#undef NTD_HOLD
+#undef NTD_PACKQ
         }
         const bool more_tiles = have_next;
         v = nv; m0 = nm0; n0 = nn0;
         if (!more_tiles) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (empty-descriptor) DMA instructions
-    // ---- flush: the last tile's epilogue, block by block (static register indices)
+    // ---- flush: the last tile's held blocks (static register indices)
     {
-        const int ldc2 = (int)a.ldc * 2, ldx2 = DAUX ? (int)a.ldaux * 2 : 0;
+        const int ldc2 = (int)a.ldc * ESZ, ldx2 = DAUX ? (int)a.ldaux * 2 : 0, ldr4 = RES_K ? (int)a.ldr * 4 : 0;
 #define NTD_FLUSH(HV, I_, J_)                                                                                \
     {                                                                                                        \
+        const bool rok_ = prow + 32 * (J_) < a.M;                                                            \
+        u32x4_t fr_[RES_K ? 4 : 1];                                                                          \
+        if (RES_K) { _Pragma("unroll") for (int g = 0; g < 4; ++g)                                           \
+            fr_[g] = __builtin_amdgcn_raw_buffer_load_b128(rsR, rok_ ? pvoR : OOB, (J_) * 32 * ldr4 + (I_) * 128 + g * 32, NTD_RES_NT); } \
         _Pragma("unroll") for (int g = 0; g < 4; ++g) {                                                      \
-            u32x2_t o_, dd_ = u32x2_t{0u, 0u};                                                               \
-            NTD_QUAD(HV, 8 * (I_), g, o_, dd_)                                                               \
-            const bool rok_ = prow + 32 * (J_) < a.M;                                                        \
-            __builtin_amdgcn_raw_buffer_store_b64(o_, rsC, rok_ ? pvoC : OOB, (J_) * 32 * ldc2 + (I_) * 64 + g * 16, NTD_C16_NT); \
-            if (DAUX) __builtin_amdgcn_raw_buffer_store_b64(dd_, rsX, rok_ ? pvoX : OOB, (J_) * 32 * ldx2 + (I_) * 64 + g * 16, NTD_X_NT); \
+            if (GELU_K) {                                                                                    \
+                u32x2_t o_, dd_ = u32x2_t{0u, 0u};                                                           \
+                NTD_QUAD(HV, 8 * (I_), g, o_, dd_)                                                           \
+                __builtin_amdgcn_raw_buffer_store_b64(o_, rsC, rok_ ? pvoC : OOB, (J_) * 32 * ldc2 + (I_) * 64 + g * 16, NTD_C16_NT); \
+                if (DAUX) __builtin_amdgcn_raw_buffer_store_b64(dd_, rsX, rok_ ? pvoX : OOB, (J_) * 32 * ldx2 + (I_) * 64 + g * 16, NTD_X_NT); \
+            } else if (RES_K) {                                                                              \
+                const unsigned w0_ = (HV)[8 * (I_) + 2 * g], w1_ = (HV)[8 * (I_) + 2 * g + 1];               \
+                const u32x4_t o_ = {__float_as_uint(__uint_as_float(w0_ << 16) + __uint_as_float(fr_[g][0])), \
+                                    __float_as_uint(__uint_as_float(w0_ & 0xffff0000u) + __uint_as_float(fr_[g][1])), \
+                                    __float_as_uint(__uint_as_float(w1_ << 16) + __uint_as_float(fr_[g][2])), \
+                                    __float_as_uint(__uint_as_float(w1_ & 0xffff0000u) + __uint_as_float(fr_[g][3]))}; \
+                __builtin_amdgcn_raw_buffer_store_b128(o_, rsC, rok_ ? pvoC : OOB, (J_) * 32 * ldc2 + (I_) * 128 + g * 32, NTD_C32_NT); \
+            } else {                                                                                         \
+                const u32x2_t o_ = {(HV)[8 * (I_) + 2 * g], (HV)[8 * (I_) + 2 * g + 1]};                     \
+                __builtin_amdgcn_raw_buffer_store_b64(o_, rsC, rok_ ? pvoC : OOB, (J_) * 32 * ldc2 + (I_) * 64 + g * 16, NTD_C16_NT); \
+            }                                                                                                \
         }                                                                                                    \
     }
         NTD_FLUSH(H0, 0, 0) NTD_FLUSH(H1, 0, 1) NTD_FLUSH(H2, 0, 2) NTD_FLUSH(H0, 1, 0) NTD_FLUSH(H1, 1, 1) NTD_FLUSH(H2, 1, 2)
@@ -358,18 +465,21 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
 }
 
 // ---- host side (called by gemm_nt_impl in gemm.hip; not part of the C ABI)
+#define NTD_FOR_FLAGS(X)                                                                                     \
+    X(DICOW_EPI_BIAS | DICOW_EPI_GELU) X(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX)             \
+    X(0) X(DICOW_EPI_BIAS) X(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N) X(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32)
 extern "C" __attribute__((visibility("hidden"))) int dicow_ntd_launch_(const dicow_gemm_args* a, int grid, void* stream) {
     static bool once = false;
     if (!once) {
-        (void)hipFuncSetAttribute((const void*)gemm_ntd_kernel<DICOW_EPI_BIAS | DICOW_EPI_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, NTD_LDS);
-        (void)hipFuncSetAttribute((const void*)gemm_ntd_kernel<DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX>, hipFuncAttributeMaxDynamicSharedMemorySize, NTD_LDS);
+#define X(F) (void)hipFuncSetAttribute((const void*)gemm_ntd_kernel<(F)>, hipFuncAttributeMaxDynamicSharedMemorySize, NTD_LDS);
+        NTD_FOR_FLAGS(X)
+#undef X
         once = true;
     }
-    if (a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU))
-        hipLaunchKernelGGL((gemm_ntd_kernel<DICOW_EPI_BIAS | DICOW_EPI_GELU>), dim3(grid), dim3(256), NTD_LDS, (hipStream_t)stream, *a);
-    else if (a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX))
-        hipLaunchKernelGGL((gemm_ntd_kernel<DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX>), dim3(grid), dim3(256), NTD_LDS, (hipStream_t)stream, *a);
-    else
-        return -1;
-    return 0;
+    switch (a->flags) {
+#define X(F) case (F): hipLaunchKernelGGL((gemm_ntd_kernel<(F)>), dim3(grid), dim3(256), NTD_LDS, (hipStream_t)stream, *a); return 0;
+        NTD_FOR_FLAGS(X)
+#undef X
+        default: return -1;
+    }
 }

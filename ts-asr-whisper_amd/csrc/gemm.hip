@@ -990,7 +990,10 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             {
                 static const int defer = getenv("DICOW_NT_DEFER") ? atoi(getenv("DICOW_NT_DEFER")) : NT_DEFER;
                 const bool gelu_i = a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU), gelu_t = a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX);
-                if (variant == 0 && batch == 1 && ((gelu_i && (defer & 1)) || (gelu_t && (defer & 2))) && a->N % 320 == 0 && a->K >= 16 * BK && t35 >= 2 * ncu) {
+                const bool light = a->flags == 0 || a->flags == DICOW_EPI_BIAS || a->flags == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N);
+                const bool resid = a->flags == (DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32);
+                if (variant == 0 && batch == 1 && ((gelu_i && (defer & 1)) || (gelu_t && (defer & 2)) || (light && (defer & 4)) || (resid && (defer & 8))) &&
+                    a->N % 320 == 0 && a->K >= 16 * BK && t35 > ncu) {
                     const int rounds_d = dicow_cdiv((int)t35, ncu);
                     const int rc = dicow_ntd_launch_(a, dicow_cdiv((int)t35, rounds_d), stream);
                     DICOW_REQUIRE(rc == 0, "gemm_nt: deferred-epilogue kernel refused flags %d", a->flags);
