@@ -11,8 +11,10 @@
 // its operands from registers).  logmel_mfma_kernel, one workgroup = 64 frames of one clip, 4 waves = 2 frame blocks x {re, im}:
 //   * the 10480 samples the frames touch are staged in LDS once, one pad word every 160 samples (hop 160 = 0 mod 32 banks: the
 //     A fragment -- lane = frame -- would otherwise be a 32-way bank conflict);
-//   * B fragments (2 samples x 32 bins of the cos or sin table, rows padded to 224 bins) come straight from L2 (the 717 KB table pair
-//     is shared by every workgroup), one k-step ahead in registers; 7 bin blocks x 200 k-steps = 1400 MFMAs per wave;
+//   * the product is folded about sample 200 (the periodic Hann window, the cosines and -- with a sign -- the sines are symmetric
+//     there): re = C (x[n] + x[400 - n]), im = S (x[n] - x[400 - n]) over 204 table rows instead of 400;
+//   * B fragments (2 samples x 32 bins of the cos or sin table, rows padded to 224 bins) come straight from L2 (the folded table pair
+//     is 366 KB, shared by every workgroup), two k-steps ahead in registers; 7 bin blocks x 102 k-steps = 714 MFMAs per wave;
 //   * re^2 + im^2 meet in LDS ([64][201] fp32 over the sample stage), the slaney projection walks only each filter's non-zero bins
 //     (~400 multiply-adds per frame instead of 201 x M), log10, workgroup maximum.
 // 104 VGPRs + 57 KB of LDS: three workgroups per CU, the 750 workgroups of 16 clips are resident at once.
@@ -86,6 +88,7 @@ __global__ void __launch_bounds__(256) logmel_kernel(const float* __restrict__ w
 #define LMM_XS (LMM_SPAN + LMM_SPAN / LM_HOP + 1)                       // + one pad word per 160 samples
 #define LMM_LD 224                                                      // table row length (bins, zero-padded): 7 blocks of 32
 #define LMM_PW 201                                                      // row stride of the power image (odd: conflict-free columns)
+#define LMM_NK 204                                                      // rows of the folded tables (201 / 200 live ones, zero-padded to whole pairs of k-steps)
 typedef __attribute__((ext_vector_type(16))) float lm_f32x16_t;
 
 __global__ void __launch_bounds__(256, 3) logmel_mfma_kernel(const float* __restrict__ wave, int n_samples, int n_frames,
@@ -114,11 +117,17 @@ __global__ void __launch_bounds__(256, 3) logmel_mfma_kernel(const float* __rest
             sm[i + i / LM_HOP] = w[p];
         }
     }
+    if (tid == 0) sm[LMM_SPAN + LMM_SPAN / LM_HOP] = 0.f;             // sample 400 of the last frame: meets a zero table row, must be finite
     __syncthreads();
     const int rb = wv & 1, half = wv >> 1;                            // frame block, {0: cos -> re, 1: sin -> im}
     const int f = lane & 31, kk = lane >> 5;
-    const float* tab = (half ? tw_sin : tw_cos) + kk * LMM_LD + f;    // B fragment of k-step n: tab[n * LMM_LD + 32 cb]
-    const float* xa = sm + (rb * 32 + f) * (LM_HOP + 1) + kk;          // A fragment of k-step n: xa[n + n / 160]
+    // The window-folded tables are symmetric (cos) / antisymmetric (sin) about sample 200 (periodic Hann: w[n] = w[400 - n], w[0] = 0):
+    //   re_k = sum_{n=0..200} C[n][k] (x[n] + x[400 - n]),   im_k = sum_{n=0..199} S[n][k] (x[n] - x[400 - n])
+    // (host tables: C[200] holds HALF the centre term -- x[200] is added to itself --, rows >= 201 / >= 200 are zero, LMM_NK rows in
+    // all): half the multiply-adds of the plain product; the A fragment costs a second LDS read and an add per k-step of 7 MFMAs.
+    const float* tab = (half ? tw_sin : tw_cos) + (LM_NFFT + kk) * LMM_LD + f;   // folded rows follow the 400 plain ones; B fragment of k-step n: tab[n * LMM_LD + 32 cb]
+    const float* xf = sm + (rb * 32 + f) * (LM_HOP + 1);               // sample i of this lane's frame: xf[i + i / 160]
+    const float sgn = half ? -1.0f : 1.0f;
     lm_f32x16_t acc[7];
 #pragma unroll
     for (int cb = 0; cb < 7; ++cb)
@@ -129,28 +138,26 @@ __global__ void __launch_bounds__(256, 3) logmel_mfma_kernel(const float* __rest
     float b0[7], b1[7], bc[7];
 #pragma unroll
     for (int cb = 0; cb < 7; ++cb) { b0[cb] = tab[cb * 32]; b1[cb] = tab[2 * LMM_LD + cb * 32]; }
-    // three segments: inside one the pad offset n / 160 is a constant (n even, k-step = 2 samples, 160 even)
-#pragma unroll
-    for (int seg = 0; seg < 3; ++seg) {
-        const int n1 = seg == 2 ? LM_NFFT : (seg + 1) * LM_HOP;
+    // folded sample idx = n + kk of a k-step: x[idx] at pad offset (idx >= 160), x[400 - idx] at pad offset 2 if idx <= 80 else 1
+#define LMM_AFRAG(N_) ({ const int i_ = (N_) + kk; xf[i_ + (i_ >= LM_HOP ? 1 : 0)] + sgn * xf[LM_NFFT - i_ + (i_ <= 80 ? 2 : 1)]; })
 #pragma unroll 2
-        for (int n = seg * LM_HOP; n < n1; n += 4) {
-            const float a0 = xa[n + seg], a1 = xa[n + 2 + seg];
-            const int na = n + 4 < LM_NFFT ? n + 4 : n, nb = n + 6 < LM_NFFT ? n + 6 : n;     // (past the end: re-read, no branch)
+    for (int n = 0; n < LMM_NK; n += 4) {
+        const float a0 = LMM_AFRAG(n), a1 = LMM_AFRAG(n + 2);
+        const int na = n + 4 < LMM_NK ? n + 4 : n, nb = n + 6 < LMM_NK ? n + 6 : n;           // (past the end: re-read, no branch)
 #pragma unroll
-            for (int cb = 0; cb < 7; ++cb) bc[cb] = b0[cb];
+        for (int cb = 0; cb < 7; ++cb) bc[cb] = b0[cb];
 #pragma unroll
-            for (int cb = 0; cb < 7; ++cb) b0[cb] = tab[na * LMM_LD + cb * 32];
+        for (int cb = 0; cb < 7; ++cb) b0[cb] = tab[na * LMM_LD + cb * 32];
 #pragma unroll
-            for (int cb = 0; cb < 7; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bc[cb], acc[cb], 0, 0, 0);
+        for (int cb = 0; cb < 7; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bc[cb], acc[cb], 0, 0, 0);
 #pragma unroll
-            for (int cb = 0; cb < 7; ++cb) bc[cb] = b1[cb];
+        for (int cb = 0; cb < 7; ++cb) bc[cb] = b1[cb];
 #pragma unroll
-            for (int cb = 0; cb < 7; ++cb) b1[cb] = tab[nb * LMM_LD + cb * 32];
+        for (int cb = 0; cb < 7; ++cb) b1[cb] = tab[nb * LMM_LD + cb * 32];
 #pragma unroll
-            for (int cb = 0; cb < 7; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bc[cb], acc[cb], 0, 0, 0);
-        }
+        for (int cb = 0; cb < 7; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bc[cb], acc[cb], 0, 0, 0);
     }
+#undef LMM_AFRAG
     __syncthreads();                                                  // every wave is done with the sample stage
     // power image pw[frame][bin] over the same LDS: the re waves write re^2, then the im waves add im^2
     // C layout of the 32 x 32 product: lane -> column (bin) lane & 31, register r -> row (frame) 8 (r / 4) + 4 (lane / 32) + r % 4

@@ -13,6 +13,7 @@ from . import ops
 
 N_FFT, HOP, SR, N_SAMPLES = 400, 160, 16000, 480000
 TABLE_LD = 224                 # row length of the DFT tables (csrc/logmel.hip: LMM_LD)
+FOLD_ROWS = 204                # rows of the folded tables behind the 400 plain ones (csrc/logmel.hip: LMM_NK)
 _TABLES = {}
 
 
@@ -42,11 +43,19 @@ def _tables(n_mels, device):
         n = np.arange(N_FFT)
         win = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / N_FFT)                      # periodic hann
         ang = 2.0 * np.pi * np.outer(n, np.arange(1 + N_FFT // 2)) / N_FFT
-        # rows zero-padded from 201 to TABLE_LD bins: the kernel's B fragments are 32-bin blocks of a row (7 blocks)
-        tw_c = np.zeros((N_FFT, TABLE_LD), np.float32)
-        tw_s = np.zeros((N_FFT, TABLE_LD), np.float32)
-        tw_c[:, :1 + N_FFT // 2] = (win[:, None] * np.cos(ang)).astype(np.float32)
-        tw_s[:, :1 + N_FFT // 2] = (-win[:, None] * np.sin(ang)).astype(np.float32)
+        # rows zero-padded from 201 to TABLE_LD bins: the kernel's B fragments are 32-bin blocks of a row (7 blocks).  Rows 0..399: the
+        # plain window-folded DFT (the direct kernel of -DLOGMEL_DIRECT builds); rows 400..603: the same product folded about sample
+        # 200 (csrc/logmel.hip: w[n] = w[400 - n], cos symmetric, sin antisymmetric) -- row 400 + n pairs with x[n] +- x[400 - n],
+        # the centre row 600 holds half its value (x[200] meets itself), the rows behind the live ones are zero
+        tw_c = np.zeros((N_FFT + FOLD_ROWS, TABLE_LD), np.float32)
+        tw_s = np.zeros((N_FFT + FOLD_ROWS, TABLE_LD), np.float32)
+        c32 = (win[:, None] * np.cos(ang)).astype(np.float32)
+        s32 = (-win[:, None] * np.sin(ang)).astype(np.float32)
+        tw_c[:N_FFT, :1 + N_FFT // 2] = c32
+        tw_s[:N_FFT, :1 + N_FFT // 2] = s32
+        tw_c[N_FFT:N_FFT + 200, :1 + N_FFT // 2] = c32[:200]
+        tw_c[N_FFT + 200, :1 + N_FFT // 2] = c32[200] * np.float32(0.5)
+        tw_s[N_FFT:N_FFT + 200, :1 + N_FFT // 2] = s32[:200]
         fb = mel_filter_bank(n_mels).astype(np.float32)
         # the bins where filter m is non-zero: the projection skips the exact zeros (same sum, in the same order, as the dense loop)
         rng = np.zeros((n_mels, 2), np.int32)
