@@ -465,6 +465,12 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
 }
 
 // ---- host side (called by gemm_nt_impl in gemm.hip; not part of the C ABI)
+#include <stdlib.h>
+// which epilogues take this kernel (bits: 1 inference fc1, 2 training fc1, 4 plain / bias / q-scale, 8 fp32 residual): DICOW_NT_DEFER
+extern "C" __attribute__((visibility("hidden"))) int dicow_ntd_mode_(int dflt) {
+    const char* e = getenv("DICOW_NT_DEFER");
+    return e ? atoi(e) : dflt;
+}
 #define NTD_FOR_FLAGS(X)                                                                                     \
     X(DICOW_EPI_BIAS | DICOW_EPI_GELU) X(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX)             \
     X(0) X(DICOW_EPI_BIAS) X(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N) X(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32)

@@ -886,6 +886,7 @@ static void gemm_nt_setup() {
 #endif
 #if NT_DEFER_BUILD
 extern "C" int dicow_ntd_launch_(const dicow_gemm_args* a, int grid, void* stream);      // experiments/gemm_ntd.hip (internal)
+extern "C" int dicow_ntd_mode_(int dflt);
 #endif
 static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_colsum, int* colsum_rows) {
     dicow_gemm_args a_copy = *a_in;
@@ -988,7 +989,7 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             // bias + GELU [+ saved derivative] with the epilogue deferred into the next tile's k-loop (experiments/gemm_ntd.hip; round 4: bit-identical, 1.5-2 x slower -- profiles/r04_ntd_deferred_epilogue.txt): 192 x 320 tiles,
             // at least two tiles per workgroup (the last one is flushed after the loop, nothing hides it)
             {
-                static const int defer = getenv("DICOW_NT_DEFER") ? atoi(getenv("DICOW_NT_DEFER")) : NT_DEFER;
+                static const int defer = dicow_ntd_mode_(NT_DEFER);            // (experiment build: the run-time switch lives in gemm_ntd.hip)
                 const bool gelu_i = a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU), gelu_t = a->flags == (DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX);
                 const bool light = a->flags == 0 || a->flags == DICOW_EPI_BIAS || a->flags == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N);
                 const bool resid = a->flags == (DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32);
