@@ -32,7 +32,7 @@ extern "C" {
 #define DICOW_ERR_INVALID (-1)  /* bad argument / unsupported shape */
 #define DICOW_ERR_LAUNCH (-2)   /* HIP launch failure */
 
-#define DICOW_ABI_VERSION 4
+#define DICOW_ABI_VERSION 5
 
 int dicow_abi_version(void);
 /* Number of CUs the persistent NT GEMM may occupy (0 = all, the default).  Its workgroups own a whole CU each for the
@@ -344,9 +344,12 @@ int dicow_conv2_col2im_gelu_bwd(const void* dA2, const void* pre1, void* d_pre1,
 /* ------------------------------------------------------------------------------------------------ log-mel front end
  * Whisper features on the GPU (reference call site src/data/local_datasets.py:208-214 -> HF feature_extraction_whisper.py
  * :135-165): wave fp32 [B, n_samples] (padded to a multiple of 30 s) -> out fp32 [B, M, n_samples/160].
- * tw_cos/tw_sin: [400, 224] hann-window-folded DFT tables (201 bins, rows zero-padded to 224 = 7 blocks of 32: ABI 4 -- the
- * DFT runs as an exact-fp32 matrix product on v_mfma_f32_32x32x2_f32), fb: [201, M] slaney mel filterbank, mel_range: [M][2] int32,
- * the first and one-past-the-last bin where column m of fb is non-zero (host-built once, ts-asr-whisper_amd/features.py). */
+ * tw_cos/tw_sin: [604, 224] hann-window-folded DFT tables (201 bins, rows zero-padded to 224 = 7 blocks of 32; the DFT runs as an
+ * exact-fp32 matrix product on v_mfma_f32_32x32x2_f32).  Rows 0..399: T[n][k] = w[n] cos(2 pi k n / 400) resp. -w[n] sin(..)
+ * (what a direct DFT reads).  Rows 400..603 (ABI 5): the SAME product folded about sample 200 -- the kernel pairs row 400 + n with
+ * x[n] + x[400 - n] (cos) resp. x[n] - x[400 - n] (sin), n = 0..203: rows 400 + n = T[n] for n < 200, row 600 = T[200] / 2 in the cos
+ * table (x[200] meets itself) and zero in the sin table, rows 601..603 zero.  fb: [201, M] slaney mel filterbank, mel_range: [M][2]
+ * int32, the first and one-past-the-last bin where column m of fb is non-zero (host-built once, ts-asr-whisper_amd/features.py). */
 int64_t dicow_logmel_ws_bytes(int B, int n_samples);
 int dicow_logmel(const float* wave, int B, int n_samples, const float* tw_cos, const float* tw_sin, const float* fb,
                  const int* mel_range, int M, float* out, void* ws, int64_t ws_bytes, void* stream);

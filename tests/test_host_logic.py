@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()                       # raises loudly if the .so has not been built
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dicow_abi_version() == 4
+    assert lib.dicow_abi_version() == 5
 
 
 def test_gemm_nt_is_persistent_host_logic():
@@ -357,3 +357,26 @@ def test_no_environment_knobs_on_the_product_dispatch_path():
                 stack.pop()
             if "getenv(" in t and not t.startswith("//"):
                 assert any(stack), f"{os.path.basename(path)}:{n}: getenv outside DICOW_ABLATIONS: {t}"
+
+
+def test_logmel_folded_tables_equal_the_plain_dft():
+    """features._tables: rows 400.. of the DFT tables (the product folded about sample 200 that dicow_logmel reads, ABI 5) give the same
+    spectrum as the plain rows 0..399 -- x[n] + x[400 - n] against the cos rows, x[n] - x[400 - n] against the sin rows -- on random
+    frames, in float64 (the table algebra, independent of the kernel)."""
+    import numpy as np
+    import torch
+    from ts_asr_whisper_amd import features as F
+    tw_c, tw_s, fb, rng = (t.numpy().astype(np.float64) for t in F._tables(80, torch.device("cpu")))
+    assert tw_c.shape == (F.N_FFT + F.FOLD_ROWS, F.TABLE_LD) and tw_s.shape == tw_c.shape
+    x = np.random.default_rng(0).standard_normal((7, F.N_FFT + 1))          # sample 400 belongs to the next hop: meets zero rows
+    n = np.arange(F.FOLD_ROWS)
+    xs, xd = x[:, n] + x[:, F.N_FFT - n], x[:, n] - x[:, F.N_FFT - n]
+    re_f, im_f = xs @ tw_c[F.N_FFT:], xd @ tw_s[F.N_FFT:]
+    re_p, im_p = x[:, :F.N_FFT] @ tw_c[:F.N_FFT], x[:, :F.N_FFT] @ tw_s[:F.N_FFT]
+    scale = np.abs(re_p).max()
+    assert np.abs(re_f - re_p).max() < 2e-6 * scale and np.abs(im_f - im_p).max() < 2e-6 * scale
+    assert not tw_c[F.N_FFT + 201:].any() and not tw_s[F.N_FFT + 200:].any() and not tw_c[:, 201:].any()
+    # ... and the plain rows are the windowed DFT itself
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(F.N_FFT) / F.N_FFT)
+    ref = np.fft.rfft(x[:, :F.N_FFT] * w, axis=1)
+    assert np.abs(re_p[:, :201] - ref.real).max() < 2e-6 * scale and np.abs(im_p[:, :201] - ref.imag).max() < 2e-6 * scale
