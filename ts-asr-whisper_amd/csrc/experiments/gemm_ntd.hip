@@ -50,6 +50,12 @@ __device__ __forceinline__ bf16x8_t ntd_frag(const char* s, int row, int c) {
 #define NTD_X_NT 0
 #define NTD_C32_NT 0
 #define NTD_RES_NT 2
+#ifndef NTD_DROP_DEFERRED
+#define NTD_DROP_DEFERRED 0     // diagnostic: every in-loop load / store of the deferred epilogue goes out of range (dropped): what do THEY cost?
+#endif
+#ifndef NTD_DIAG
+#define NTD_DIAG 0                // diagnostic builds (results WRONG): 1 = the deferred steps run as plain steps, 2 = + no hold / immediate blocks, 3 = + no flush
+#endif
 #ifndef NTD_VALU_MASK
 #define NTD_VALU_MASK 0x402     // sched_group_barrier classes of the deferred arithmetic: VALU | transcendental
 #endif
@@ -144,6 +150,11 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
     bool p_valid = false;                             // a held tile exists
     const int ml = lane & 31, hh = lane >> 5;
     const unsigned OOB = 0x80000000u;
+#if NTD_DIAG == 4 || NTD_DIAG == 5
+#define NTD_ROK(X) false      /* diagnostic: the stores of the immediate blocks and of the flush are dropped (5: deferred steps live) */
+#else
+#define NTD_ROK(X) (X)
+#endif
     // (32-bit scalar arithmetic: the host checks that every byte offset fits; a 64-bit product would be computed on the VALU and the
     // descriptor word would live in a VGPR -- every store then becomes a readfirstlane waterfall loop)
     const unsigned nrecC = (unsigned)__builtin_amdgcn_readfirstlane(((a.M - 1) * (int)a.ldc + a.N) * ESZ);
@@ -309,7 +320,7 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
 #define NTD_ADDR(I_, J_, LIVE_)                                                                              \
     {                                                                                                        \
         prv_soC = cur_soC; prv_voC = cur_voC; prv_soX = cur_soX; prv_voX = cur_voX;                          \
-        const bool ok_ = p_valid && (LIVE_) && prow + 32 * (J_) < a.M;                                       \
+        const bool ok_ = NTD_DROP_DEFERRED ? false : (p_valid && (LIVE_) && prow + 32 * (J_) < a.M);           \
         cur_soC = ((J_) * 32 * (int)a.ldc + (I_) * 32) * ESZ;                                                \
         cur_voC = ok_ ? pvoC : OOB;                                                                          \
         if (DAUX) { cur_soX = ((J_) * 32 * (int)a.ldaux + (I_) * 32) * 2; cur_voX = ok_ ? pvoX : OOB; }      \
@@ -322,12 +333,20 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
         for (int r = 0; r < 4; ++r) {
             const int ri = __builtin_amdgcn_readfirstlane(r);
             const int dix = ri * 8;
+#if NTD_DIAG >= 1 && NTD_DIAG != 5
+            (void)dix; KSTEP(false, NTD_STEP_WAIT, 0, H0, 0) KSTEP(false, NTD_STEP_WAIT, 0, H0, 0) KSTEP(false, NTD_STEP_WAIT, 0, H0, 0)
+#else
             NTD_ADDR(ri, 0, true) KSTEP(false, NTD_STEP_WAIT, 1, H0, dix)
             NTD_ADDR(ri, 1, true) KSTEP(false, NTD_STEP_WAIT, 1, H1, dix)
             NTD_ADDR(ri, 2, true) KSTEP(false, NTD_STEP_WAIT, 1, H2, dix)
+#endif
         }
         NTD_ADDR(0, 0, false)
+#if NTD_DIAG >= 1 && NTD_DIAG != 5
+        KSTEP(false, NTD_STEP_WAIT, 0, H0, 0)
+#else
         KSTEP(false, NTD_STEP_WAIT, 2, H0, 0)         // step 13: what the last deferred step left pending
+#endif
         for (int t = 14; t < nk - 2; ++t) KSTEP(false, NTD_STEP_WAIT, 0, H0, 0)
         NTD_SWITCH_A()
         KSTEP(false, NTD_STEP_WAIT, 0, H0, 0)
@@ -361,6 +380,7 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
 #undef SCHED_D
 #undef LDFRAG
 #undef DOMFMA
+#if NTD_DIAG < 2 || NTD_DIAG >= 4
         // ---- hold: H <- bf16(acc + bias [, x scale on the q columns]), the AMP Linear output; lane (ml, hh) of block (i, j): row 32 j + ml,
         // columns 32 i + 8 g + 4 hh + e
         {
@@ -394,7 +414,7 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
             NTD_HOLD(H0, 2, 0) NTD_HOLD(H1, 2, 1) NTD_HOLD(H2, 2, 2) NTD_HOLD(H0, 3, 0) NTD_HOLD(H1, 3, 1) NTD_HOLD(H2, 3, 2)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const bool rok = prow + 32 * j < a.M;
+                const bool rok = NTD_ROK(prow + 32 * j < a.M);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     unsigned w0, w1;
@@ -425,17 +445,19 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
 #undef NTD_HOLD
 #undef NTD_PACKQ
         }
+#endif
         const bool more_tiles = have_next;
         v = nv; m0 = nm0; n0 = nn0;
         if (!more_tiles) break;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the trailing (empty-descriptor) DMA instructions
+#if NTD_DIAG < 3 || NTD_DIAG >= 4
     // ---- flush: the last tile's held blocks (static register indices)
     {
         const int ldc2 = (int)a.ldc * ESZ, ldx2 = DAUX ? (int)a.ldaux * 2 : 0, ldr4 = RES_K ? (int)a.ldr * 4 : 0;
 #define NTD_FLUSH(HV, I_, J_)                                                                                \
     {                                                                                                        \
-        const bool rok_ = prow + 32 * (J_) < a.M;                                                            \
+        const bool rok_ = NTD_ROK(prow + 32 * (J_) < a.M);                                                   \
         u32x4_t fr_[RES_K ? 4 : 1];                                                                          \
         if (RES_K) { _Pragma("unroll") for (int g = 0; g < 4; ++g)                                           \
             fr_[g] = __builtin_amdgcn_raw_buffer_load_b128(rsR, rok_ ? pvoR : OOB, (J_) * 32 * ldr4 + (I_) * 128 + g * 32, NTD_RES_NT); } \
@@ -462,6 +484,7 @@ __global__ void __launch_bounds__(256) gemm_ntd_kernel(const dicow_gemm_args a) 
         NTD_FLUSH(H0, 2, 0) NTD_FLUSH(H1, 2, 1) NTD_FLUSH(H2, 2, 2) NTD_FLUSH(H0, 3, 0) NTD_FLUSH(H1, 3, 1) NTD_FLUSH(H2, 3, 2)
 #undef NTD_FLUSH
     }
+#endif
 }
 
 // ---- host side (called by gemm_nt_impl in gemm.hip; not part of the C ABI)
