@@ -6,9 +6,10 @@ cd "$(dirname "$0")/../ts-asr-whisper_amd/csrc"
 bash build.sh > /dev/null
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -c gemm.hip -o build/gemm_v_ntd.o -DNT_DEFER=0 -DNT_DEFER_BUILD=1 &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -c experiments/gemm_ntd.hip -o build/gemm_ntd_x.o $NTD_FLAGS &
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -c experiments/gemm_ntl.hip -o build/gemm_ntl_x.o $NTD_FLAGS &
 wait
-objs="build/gemm_ntd_x.o"
+objs="build/gemm_ntd_x.o build/gemm_ntl_x.o"
 for s in $(ls *.hip); do b=${s%.hip}; if [ "$b" = gemm ]; then objs="$objs build/gemm_v_ntd.o"; else objs="$objs build/$b.o"; fi; done
 hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../../tools/libv_${NTD_NAME:-ntd}.so
-rm -f build/gemm_ntd_x.o
+rm -f build/gemm_ntd_x.o build/gemm_ntl_x.o
 echo "built tools/libv_${NTD_NAME:-ntd}.so"

@@ -887,6 +887,7 @@ static void gemm_nt_setup() {
 #if NT_DEFER_BUILD
 extern "C" int dicow_ntd_launch_(const dicow_gemm_args* a, int grid, void* stream);      // experiments/gemm_ntd.hip (internal)
 extern "C" int dicow_ntd_mode_(int dflt);
+extern "C" int dicow_ntl_launch_(const dicow_gemm_args* a, int grid, void* stream);      // experiments/gemm_ntl.hip (internal)
 #endif
 static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_colsum, int* colsum_rows) {
     dicow_gemm_args a_copy = *a_in;
@@ -996,11 +997,20 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
                 if (variant == 0 && batch == 1 && ((gelu_i && (defer & 1)) || (gelu_t && (defer & 2)) || (light && (defer & 4)) || (resid && (defer & 8))) &&
                     a->N % 320 == 0 && a->K >= 16 * BK && t35 > ncu) {
                     const int rounds_d = dicow_cdiv((int)t35, ncu);
-                    const int rc = dicow_ntd_launch_(a, dicow_cdiv((int)t35, rounds_d), stream);
-                    DICOW_REQUIRE(rc == 0, "gemm_nt: deferred-epilogue kernel refused flags %d", a->flags);
-                    disp_note("gemm_ntd_kernel<%d>", a->flags);
-                    DICOW_CHECK_LAUNCH("gemm_nt (persistent, deferred epilogue)");
-                    return DICOW_OK;
+                    // light epilogues: the un-swapped-layout kernel (gemm_ntl.hip) unless bit 16 asks for the first form; it refuses ragged M
+                    int rc = -1;
+                    if ((light || resid) && !(defer & 16)) {
+                        rc = dicow_ntl_launch_(a, dicow_cdiv((int)t35, rounds_d), stream);
+                        if (rc == 0) disp_note("gemm_ntl_kernel<%d>", a->flags);
+                    }
+                    if (rc != 0 && (gelu_i || gelu_t || (defer & 16))) {
+                        rc = dicow_ntd_launch_(a, dicow_cdiv((int)t35, rounds_d), stream);
+                        if (rc == 0) disp_note("gemm_ntd_kernel<%d>", a->flags);
+                    }
+                    if (rc == 0) {
+                        DICOW_CHECK_LAUNCH("gemm_nt (persistent, deferred epilogue)");
+                        return DICOW_OK;
+                    }
                 }
             }
 #endif
