@@ -11,7 +11,7 @@ ea = torch.empty(1 << 28, dtype=torch.uint8, device="cuda"); eb = torch.empty(1 
 def run(N, K, epi):
     A = (torch.randn(M, K, device="cuda") * 0.5).to(bf); W = (torch.randn(N, K, device="cuda") * 0.03).to(bf)
     bias = torch.randn(N, device="cuda") * 0.1
-    ntiles = max(((M + 255) // 256) * ((N + 255) // 256), ((M + 191) // 192) * ((N + 319) // 320))     # whichever tile shape is dispatched
+    ntiles = max(((M + 255) // 256) * ((N + 255) // 256), ((M + 191) // 192) * ((N + 319) // 320), ((M + 127) // 128) * ((N + 255) // 256))     # whichever tile shape is dispatched
     dbg = torch.zeros(ntiles * 6, dtype=torch.int64, device="cuda")
     a = L.GemmArgs()
     a.A, a.B = A.data_ptr(), W.data_ptr()

@@ -674,6 +674,16 @@ __device__ __forceinline__ float ln_merge4(float a, float b, bool bit) {
     return keep + ln_xor4(send);
 }
 #include "gemm_ntr.inc"
+#ifndef NT2_MASK
+#define NT2_MASK 0                // shapes on gemm_nt2_kernel (two workgroups per CU): 1 fp32 residual, 2 training fc1 (GELU + gelu'), 4 inference
+#endif                            // fc1 (GELU), 8 dgrad x gelu' (+ column sums), 16 bias / bias + q scale, 32 plain
+#ifndef NT2_SLOTS
+#define NT2_SLOTS 2               // workgroups per CU the grid is sized for (1: diagnostic, a lone workgroup per CU)
+#endif
+#ifndef NT2_DELAY
+#define NT2_DELAY 0               // second half of the grid starts NT2_DELAY x 64 clocks late
+#endif
+#include "gemm_nt2.inc"
 
 #ifdef DICOW_ABLATIONS
 #include "experiments/gemm_nt256s.inc"
@@ -709,9 +719,10 @@ extern "C" int dicow_gemm_dispatch_log(char* buf, int cap) {
     return n;
 }
 
-// ws for DICOW_EPI_COLSUM: the fused path needs 2 * ceil(M/192) partial rows; the fallback runs dicow_colsum_bf16 on C
+// ws for DICOW_EPI_COLSUM: the fused path needs 2 * ceil(M/128) partial rows (gemm_nt2_kernel; 2 * ceil(M/192) for the ring kernel);
+// the fallback runs dicow_colsum_bf16 on C
 extern "C" int64_t dicow_gemm_nt_colsum_ws_bytes(int M, int N) {
-    const int64_t fused = (int64_t)2 * dicow_cdiv(M, 192) * N * 4, fb = dicow_colsum_ws_bytes(M, N);
+    const int64_t fused = (int64_t)2 * dicow_cdiv(M, 128) * N * 4, fb = dicow_colsum_ws_bytes(M, N);
     return fused > fb ? fused : fb;
 }
 
@@ -822,6 +833,11 @@ static void gemm_nt_setup() {
     NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTR_ATTR(DICOW_EPI_MUL_AUX);
     NTR_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
 #undef NTR_ATTR
+#define NT2_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_nt2_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS)
+    NT2_ATTR(0); NT2_ATTR(DICOW_EPI_BIAS); NT2_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N); NT2_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU);
+    NT2_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32); NT2_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX);
+    NT2_ATTR(DICOW_EPI_MUL_AUX); NT2_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
+#undef NT2_ATTR
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FDDT_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_RES_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FDDT_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
@@ -1015,6 +1031,40 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             }
 #endif
             if (want_colsum && variant != 11 && a->flags == DICOW_EPI_MUL_AUX) { a->flags |= DICOW_EPI_COLSUM; *fused_colsum = true; }
+            {
+                // two workgroups per CU (gemm_nt2_kernel, 128 x 256 tiles): the epilogue-heavy shapes, per NT2_MASK
+#ifdef DICOW_ABLATIONS
+                static const int nt2_mask = getenv("DICOW_NT2_MASK") ? atoi(getenv("DICOW_NT2_MASK")) : NT2_MASK;
+                static const int nt2_delay = getenv("DICOW_NT2_DELAY") ? atoi(getenv("DICOW_NT2_DELAY")) : NT2_DELAY;
+#else
+                constexpr int nt2_mask = NT2_MASK, nt2_delay = NT2_DELAY;
+#endif
+                const int f_ = a->flags;
+                const int cls = f_ == NT_RES_FLAGS ? 1 : f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX) ? 2 : f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU) ? 4 :
+                                (f_ == DICOW_EPI_MUL_AUX || f_ == (DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM)) ? 8 :
+                                (f_ == DICOW_EPI_BIAS || f_ == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N)) ? 16 : f_ == 0 ? 32 : 0;
+                if (variant == 0 && (nt2_mask & cls) && a->M >= 128 && a->N >= 256) {
+                    const int64_t t2 = (int64_t)dicow_cdiv(a->M, 128) * dicow_cdiv(a->N, 256) * batch;
+                    const int rounds2 = dicow_cdiv(t2, NT2_SLOTS * ncu);
+                    const dim3 g2(dicow_cdiv(t2, rounds2));
+                    if (colsum_rows) *colsum_rows = 2 * dicow_cdiv(a->M, 128);
+                    disp_note("gemm_nt2_kernel<%d>", f_);
+#define NT2_LAUNCH(F) hipLaunchKernelGGL((gemm_nt2_kernel<F>), g2, dim3(256), NT2_LDS, (hipStream_t)stream, *a, nt2_delay)
+                    switch (f_) {
+                        case 0: NT2_LAUNCH(0); break;
+                        case DICOW_EPI_BIAS: NT2_LAUNCH(DICOW_EPI_BIAS); break;
+                        case DICOW_EPI_BIAS | DICOW_EPI_SCALE_N: NT2_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N); break;
+                        case DICOW_EPI_BIAS | DICOW_EPI_GELU: NT2_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_GELU); break;
+                        case NT_RES_FLAGS: NT2_LAUNCH(NT_RES_FLAGS); break;
+                        case DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX: NT2_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); break;
+                        case DICOW_EPI_MUL_AUX: NT2_LAUNCH(DICOW_EPI_MUL_AUX); break;
+                        default: NT2_LAUNCH(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM); break;
+                    }
+#undef NT2_LAUNCH
+                    DICOW_CHECK_LAUNCH("gemm_nt2 (persistent, two workgroups per CU)");
+                    return DICOW_OK;
+                }
+            }
             {
                 const int f_ = a->flags;
                 const bool ct_ = variant != 11 && (f_ == 0 || f_ == DICOW_EPI_BIAS || f_ == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N) || f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU) ||
