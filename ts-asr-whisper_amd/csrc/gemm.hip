@@ -41,13 +41,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((gbl_void_t*)gsrc, (lds_void_t*)lds_dst, 16, 0, 0);
 }
 
+#ifndef NT_GM
+#define NT_GM 8           // rows of a super-tile of the grouped order (round 5 sweep: profiles/r05_gm_sweep.txt)
+#endif
 // grouped + XCD-aware tile order: consecutive tile ids share A/B panels; block b lands on XCD b % 8, so give
 // each XCD a contiguous chunk of the grouped order (bijective for any grid size).
 __device__ __forceinline__ void tile_coords_id(int ntm, int ntn, int bid, int& tm, int& tn) {
     const int nwg = ntm * ntn;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, loc = bid >> 3;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    const int GM = 8;
+    const int GM = NT_GM;
     const int per_group = GM * ntn;
     const int group = id / per_group, rem = id - group * per_group;
     const int first_m = group * GM;

@@ -84,6 +84,8 @@ def log_mel(wave: torch.Tensor, n_mels: int) -> torch.Tensor:
     if not wave.is_cuda:
         raise L.DicowError("log_mel: the waveform must be on the GPU (no CPU fallback)")
     wave = wave.contiguous().to(torch.float32)
+    if wave.data_ptr() % 16 != 0:         # a contiguous view with an odd storage offset: the kernel stages rows with 16-byte loads
+        wave = wave.clone()
     B, n = wave.shape
     tw_c, tw_s, fb, rng = _tables(n_mels, wave.device)
     out = torch.empty(B, n_mels, n // HOP, dtype=torch.float32, device=wave.device)

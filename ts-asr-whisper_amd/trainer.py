@@ -262,6 +262,9 @@ def _bit_checksum(t):
     return total
 
 
+_SYNC_COALESCE_BELOW = 64 << 20        # bytes: sync_replicas broadcasts larger tensors in place
+
+
 def sync_replicas(model, store=None, process_group=None, mode="broadcast", src=0, extra=()):
     """Make (or check that) every rank of the data-parallel group holds rank ``src``'s model state -- what
     ``torch.nn.parallel.DistributedDataParallel`` does in its constructor (it broadcasts rank 0's parameters and buffers;
@@ -313,9 +316,16 @@ def sync_replicas(model, store=None, process_group=None, mode="broadcast", src=0
         for t in tensors:
             dist.broadcast(t, src=src_global, group=process_group)
             nbytes += t.numel() * t.element_size()
+        # tensors above the threshold go out in place (the frozen decoder of large-v3 is 3.6 GB of fp32, Adam moments on resume
+        # 5 GB: a torch.cat of those is a full-size temporary on top of model + optimizer state); only the small ones -- biases,
+        # LayerNorm vectors, counters: thousands of launches otherwise -- are coalesced per dtype
         by_dtype = collections.OrderedDict()
         for t in rest:
-            by_dtype.setdefault((t.dtype, t.device), []).append(t)
+            if t.numel() * t.element_size() >= _SYNC_COALESCE_BELOW and t.is_contiguous():
+                dist.broadcast(t, src=src_global, group=process_group)
+                nbytes += t.numel() * t.element_size()
+            else:
+                by_dtype.setdefault((t.dtype, t.device), []).append(t)
         for (dt, dev), ts in by_dtype.items():
             flat = torch.cat([t.reshape(-1) for t in ts]) if len(ts) > 1 else ts[0].reshape(-1).clone()
             dist.broadcast(flat, src=src_global, group=process_group)
@@ -492,10 +502,15 @@ class TrainStep:
 
     def finish_step(self):
         """Gradients are in the flat store: exchange (DP), clip, AdamW, invalidate the bf16 compute copies."""
-        if self.first_writer and not self.warmup_phase:
-            self.store.settle_first_writers()
         with tracing.range("exchange"):               # (the buckets themselves leave during "backward", on the side stream)
             self.reducer.finish()
+        # AFTER the exchange has been waited for: a flagged matrix no GEMM wrote still holds the previous step's values, and its
+        # bucket may be in flight on the side stream (in-place all-reduce) -- a zero fill on the compute stream before
+        # reducer.finish() would race with that collective.  Every rank skips the same matrices, so zeroing the (averaged) stale
+        # values afterwards is consistent across ranks.  A gradient written into a flagged matrix by anything other than the
+        # engine's weight-gradient GEMM must clear ``p._grad_overwrite`` itself, or it is zeroed here.
+        if self.first_writer and not self.warmup_phase:
+            self.store.settle_first_writers()
         with tracing.range("optimizer"):
             self.opt.step(preheat_only=self.warmup_phase)
         # the fused optimizer writes through raw pointers (no torch version bump): invalidate the bf16 weight copies --
@@ -619,15 +634,60 @@ class TrainStep:
                 "exp_avg": self.store.exp_avg.clone(), "exp_avg_sq": self.store.exp_avg_sq.clone(),
                 "layout": [(a, b, pre) for a, b, pre in self.store.runs], "entries": self.store.fingerprint()}
 
-    def load_state_dict(self, sd):
+    def resync(self):
+        """Re-run the start-up replica sync (rank 0's parameters, frozen parameters and buffers broadcast, or verified) -- call it
+        after ``model.load_state_dict(...)`` when that happens AFTER this TrainStep was constructed (the resume order
+        INTEGRATION.md documents): the constructor's sync has seen the pre-load weights only."""
+        if self.replica_sync == "none" or self.reducer.world <= 1:
+            return 0
+        n = sync_replicas(self.model, self.store, self.reducer.pg, mode=self.replica_sync)
+        self.model.model.encoder._sig = None          # the bf16 compute copies follow the (possibly replaced) masters
+        self.model.model.encoder._ctc_sig = None
+        self.model._sig = None
+        return n
+
+    def _sync_host_counters_phase(self, phase):
+        keep = self.warmup_phase
+        self.warmup_phase = phase
+        try:
+            return self._sync_host_counters()
+        finally:
+            self.warmup_phase = keep
+
+    def _sync_host_counters(self):
+        """(t, warmup_phase, run_t...) are host mirrors: ranks that resumed from different files would switch phase / count steps
+        differently and their per-segment collectives would stop matching.  broadcast: rank 0's values; verify: raise on a mismatch."""
+        if self.replica_sync == "none" or self.reducer.world <= 1 or not dist.is_initialized():
+            return
+        dev = self.store.params.device
+        mine = torch.tensor([int(self.opt.t), int(bool(self.warmup_phase))] + [int(x) for x in self.opt.run_t], dtype=torch.int64, device=dev)
+        if self.replica_sync == "verify":
+            got = [torch.zeros_like(mine) for _ in range(self.reducer.world)]
+            dist.all_gather(got, mine, group=self.reducer.pg)
+            bad = [r for r, g in enumerate(got) if not torch.equal(g, got[0])]
+            if bad:
+                raise RuntimeError(f"data-parallel replicas resumed with different step counters: ranks {bad} differ from rank 0 "
+                                   f"(global_step / warmup_phase / per-run steps {[g.tolist()[:3] for g in got]})")
+            return
+        src = dist.get_global_rank(self.reducer.pg, 0) if self.reducer.pg is not None else 0
+        dist.broadcast(mine, src=src, group=self.reducer.pg)
+        vals = mine.tolist()
+        self.opt.t, self.opt.run_t = int(vals[0]), [int(x) for x in vals[2:]]
+        self.opt.sync_counters()
+        return bool(vals[1])
+
+    def load_state_dict(self, sd, allow_legacy_layout=False):
         if [tuple(r) for r in sd["layout"]] != [tuple(r) for r in self.store.runs]:
             raise ValueError("optimizer state was saved for a different set of trainable parameters")
         # the runs only fix the run BOUNDARIES; the order of the parameters inside them is part of the layout too (it changed in
         # round 3: weight matrices before vectors) -- moments saved under another order would land on the wrong parameters
         if "entries" not in sd:
-            raise ValueError("optimizer state has no per-parameter layout fingerprint (saved by an older version): the order of the "
-                             "parameters inside the flat buffers cannot be checked; re-save it with this version")
-        if [tuple(e) for e in sd["entries"]] != self.store.fingerprint():
+            if not allow_legacy_layout:
+                raise ValueError("optimizer state has no per-parameter layout fingerprint (saved by an older version): the order of the "
+                                 "parameters inside the flat buffers cannot be checked; pass allow_legacy_layout=True if it was saved by "
+                                 "a version with today's parameter order (weight matrices before vectors inside a layer), or re-save it")
+            log.warning("optimizer state without a layout fingerprint accepted on request: only the run boundaries were checked")
+        elif [tuple(e) for e in sd["entries"]] != self.store.fingerprint():
             mine = {e[0]: e for e in self.store.fingerprint()}
             diff = [e[0] for e in sd["entries"] if tuple(e) != mine.get(e[0])][:4]
             raise ValueError(f"optimizer state was saved under a different flat-buffer layout (first differing parameters: {diff})")
@@ -635,9 +695,18 @@ class TrainStep:
         self.opt.sync_counters()
         self.store.exp_avg.copy_(sd["exp_avg"])
         self.store.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        if self.replica_sync != "none" and self.reducer.world > 1:        # resume: the moments follow the parameters (rank 0's, or checked)
-            sync_replicas(torch.nn.Module(), None, self.reducer.pg, mode=self.replica_sync,
+        phase = bool(sd["warmup_phase"])
+        if self.replica_sync != "none" and self.reducer.world > 1:
+            # resume: parameters (flat store, frozen ones, buffers), moments and device counters follow rank 0 (or are checked), and
+            # so do the host mirrors of the step counters -- ranks that read different files must not diverge in phase / step
+            sync_replicas(self.model, self.store, self.reducer.pg, mode=self.replica_sync,
                           extra=(self.store.exp_avg, self.store.exp_avg_sq, self.opt.counters))
+            p0 = self._sync_host_counters_phase(phase)
+            phase = p0 if p0 is not None else phase
+            self.model.model.encoder._sig = None
+            self.model.model.encoder._ctc_sig = None
+            self.model._sig = None
+        sd = dict(sd, warmup_phase=phase)
         if bool(sd["warmup_phase"]) != self.warmup_phase:
             self._set_phase(preheat_only=bool(sd["warmup_phase"]))
             self.warmup_phase = bool(sd["warmup_phase"])
