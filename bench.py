@@ -49,6 +49,12 @@ def parse():
                          "augmentation + joint SpecAug, collators.py:189-214) -> training step (reported beside the headline, never AS it)")
     ap.add_argument("--gemm-cus", type=int, default=0,
                     help="limit the persistent GEMM grids to this many CUs (what trainer.GradReducer does for N > 1: CUs left to the RCCL channels)")
+    ap.add_argument("--preflight", action="store_true",
+                    help="multi-GPU dress rehearsal: every rank reports its device / PCI bus id / link types / RCCL version / NCCL_* "
+                         "environment, a 256 MB all-reduce is timed, the gradient bucket schedule is listed; one JSON line, exit 0")
+    ap.add_argument("--max-exposed-frac", type=float, default=None,
+                    help="N > 1: fail (non-zero exit, \"error\" in the JSON line) when a rank waits longer than this share of a step for the "
+                         "gradient exchange (default 0.20 over RCCL; off in the shared-GPU gloo test mode unless given)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher self-test: rendezvous + one all-reduce per rank, no training step (runs without a GPU over gloo)")
     return ap.parse_args()
@@ -102,6 +108,11 @@ def launch_ranks(a):
             tail = f.read()[-1500:]
             if tail.strip() and procs[r].returncode not in (0, -9):
                 sys.stderr.write(f"---- rank {r} stderr (tail)\n{tail}\n")
+        out0.seek(0)
+        for ln in out0.read().splitlines():           # a run that failed its own checks still printed its line (with "error")
+            if ln.startswith("{"):
+                sys.stdout.write(ln + "\n")
+        sys.stdout.flush()
         sys.exit(1)
     for f in errs:                                   # warnings of a clean run: relay rank 0's only
         f.seek(0)
@@ -312,6 +323,122 @@ def pmc_traffic(live):
         return None
 
 
+def _topology_text():
+    """`rocm-smi --showtopo` (link type / hops / weight between every pair of GPUs) -- best effort, rank 0 only."""
+    import shutil
+    import subprocess
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        r = subprocess.run([exe, "--showtopo"], capture_output=True, text=True, timeout=60)
+        return (r.stdout or r.stderr)[-6000:]
+    except Exception as ex:
+        return f"rocm-smi --showtopo failed: {ex!r}"
+
+
+def _link_types(topo_text):
+    """The 'Link Type between two GPUs' table of rocm-smi --showtopo as {"GPU0": ["0", "XGMI", ...], ...} (None if absent)."""
+    out, on = {}, False
+    for ln in topo_text.splitlines():
+        if "Link Type between two GPUs" in ln:
+            on = True
+            continue
+        if on:
+            t = ln.split()
+            if not t or t[0].startswith("="):
+                if out:
+                    break
+                continue
+            if t[0].startswith("GPU") and len(t) > 1 and not t[1].startswith("GPU"):
+                out[t[0]] = t[1:]
+    return out or None
+
+
+def preflight(a, world, rank, local, ts, share):
+    """One-shot rehearsal of everything a multi-GPU run depends on (a SCALE run on an 8-GPU node is a single attempt):
+    who sits where, what fabric links them, which RCCL and which NCCL_* settings are live, what a large all-reduce moves per
+    second, and what the gradient exchange will send.  Every rank contributes; rank 0 prints ONE JSON line; exit code 0."""
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+    info = {"rank": rank, "local_rank": local, "device_ordinal": dev, "pid": os.getpid(), "host": os.uname().nodename}
+    if dev is not None:
+        pr = torch.cuda.get_device_properties(dev)
+        info.update(name=pr.name, cus=pr.multi_processor_count, hbm_gb=round(pr.total_memory / 2 ** 30, 1),
+                    pci_bus_id=":".join(f"{getattr(pr, k):02x}" for k in ("pci_domain_id", "pci_bus_id", "pci_device_id") if hasattr(pr, k)) or None,
+                    uuid=str(getattr(pr, "uuid", "")) or None, gcn_arch=getattr(pr, "gcnArchName", None))
+    info["env"] = {k: v for k, v in sorted(os.environ.items()) if k.startswith(("NCCL_", "RCCL_", "HSA_", "HIP_VISIBLE", "ROCR_VISIBLE", "DICOW_RCCL", "DICOW_FORCE"))}
+    bw = None
+    backend = dist.get_backend() if dist.is_initialized() else None
+    if dist.is_initialized():
+        n = (256 << 20) // 4 if (torch.cuda.is_available() and not os.environ.get("DICOW_PREFLIGHT_SMALL")) else (1 << 20) // 4
+        buf = torch.ones(n, dtype=torch.float32, device="cuda" if (torch.cuda.is_available() and backend == "nccl") else "cpu")
+        for _ in range(3):
+            dist.all_reduce(buf)
+            buf.fill_(1.0)
+        if buf.is_cuda:
+            torch.cuda.synchronize()
+        dist.barrier()
+        reps = 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_reduce(buf)
+        if buf.is_cuda:
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        chk = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=buf.device)
+        dist.all_reduce(chk)
+        ok = bool(float(chk[0]) == world * (world + 1) / 2 and float(chk[-1]) == world * (world + 1) / 2)
+        alg = buf.numel() * 4 / dt / 1e9
+        bw = {"bytes": buf.numel() * 4, "ms": round(dt * 1e3, 3), "algbw_gbps": round(alg, 1),
+              "busbw_gbps": round(alg * 2 * (world - 1) / world, 1) if world > 1 else 0.0, "result_ok": ok}
+    info["allreduce_256mb"] = bw
+    every = [None] * world
+    if dist.is_initialized():
+        dist.all_gather_object(every, info)
+    else:
+        every = [info]
+    if rank == 0:
+        topo = _topology_text()
+        segs = [(nm, int(b_ - a_) * 4) for nm, a_, b_ in ts.store.segments] if ts is not None else []
+        try:
+            rccl = ".".join(str(x) for x in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
+        emit(json.dumps({"preflight": True, "n_gpus": world, "backend": backend, "rccl_version": rccl, "torch": torch.__version__,
+                          "shared_gpu_test_mode": bool(share), "ranks": every, "link_types": _link_types(topo), "topology": topo,
+                          "gradient_exchange": {"buckets": len(segs), "bytes_per_step": sum(b for _, b in segs),
+                                                "schedule_in_backward_order": [{"bucket": nm, "bytes": b} for nm, b in segs],
+                                                "op": "all-reduce, AVG inside the collective on RCCL (sum + divide on gloo), fp32, in place, side stream",
+                                                "gemm_cus_left_to_compute": a.gemm_cus or None,
+                                                "replica_sync_at_startup": ts.replica_sync if ts is not None else None,
+                                                "note": None if ts is not None else "no GPU: the model was not built, the schedule is not listed"},
+                          "config": {"global_batch": a.batch * world, "parallelism": f"dp{world}"}}))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def exposed_guard(rank_exposed_ms, step_ms, max_frac):
+    """None, or why the run must fail: some rank's compute stream waits more than `max_frac` of a step for the gradient exchange."""
+    if max_frac is None or not rank_exposed_ms:
+        return None
+    worst = max(rank_exposed_ms)
+    if worst > max_frac * step_ms:
+        return (f"a rank waits {worst:.2f} ms per step for the gradient exchange: more than {max_frac:.0%} of the {step_ms:.2f} ms step "
+                f"(per rank: {list(rank_exposed_ms)}) -- the all-reduce is not hidden behind the backward pass")
+    return None
+
+
+def _replicas_agree(ts, world):
+    """After an optimizer step every rank must hold bit-identical parameters (same averaged gradient, same update): a 64-bit
+    checksum of the flat parameter store, all-gathered.  Returns (ok, checksums)."""
+    from ts_asr_whisper_amd.trainer import _bit_checksum
+    mine = _bit_checksum(ts.store.params) & 0x7FFFFFFFFFFFFFFF
+    dev = ts.store.params.device if dist.get_backend() == "nccl" else "cpu"
+    got = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(got, torch.tensor([mine], dtype=torch.int64, device=dev))
+    sums = [int(g.item()) for g in got]
+    return len(set(sums)) == 1, sums
+
+
 def dry_launch(a, world, rank, local):
     """Launcher self-test (no training step): every rank joins the process group, checks its size, all-reduces its rank id."""
     use_gpu = torch.cuda.is_available() and torch.cuda.device_count() >= world
@@ -367,6 +494,10 @@ def main():
         sys.exit(3)
     if a.dry_launch:
         return dry_launch(a, world, rank, local)
+    if a.preflight and not torch.cuda.is_available():             # no GPU (tests): the rendezvous / all-reduce / report over gloo, no model
+        if world > 1 or "RANK" in os.environ:
+            dist.init_process_group("gloo")
+        return preflight(a, world, rank, local, None, False)
     # DICOW_BENCH_SHARE_GPU=1 (tests on a one-GPU box): every rank uses device 0 and the exchange runs over gloo
     share = os.environ.get("DICOW_BENCH_SHARE_GPU") == "1"
     torch.cuda.set_device(0 if share else local)
@@ -399,6 +530,8 @@ def main():
     ts = TrainStep(model, lr=2e-6, fddt_lr_multiplier=100.0, max_grad_norm=1.0, warmup_steps=2000, max_steps=40000,
                    preheat_prefixes=prefixes, use_fddt_only_n_steps=10 ** 9 if a.preheat else 0,
                    **({"graph": True} if a.graph else {}))
+    if a.preflight:
+        return preflight(a, world, rank, local, ts, share)
     batches = [synthetic_batch(cfg, a.batch, a.labels, seed=1000 + rank * 17 + i, mixed_length=a.se, enrollments=a.se)
                for i in range(2)]
     if a.gemm_cus:
@@ -427,8 +560,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    errors = []
     for i in range(a.warmup):
         loss = run_step(i)
+        if i == 0 and world > 1:
+            # the replicas saw different minibatches; after the exchange + update they must still be bit-identical
+            ok, sums = _replicas_agree(ts, world)
+            if not ok:
+                errors.append(f"replicas differ after the first optimizer step (parameter checksums per rank {[hex(v) for v in sums]}): the gradient exchange is broken")
     sync()
     # ---- the timed region: exactly K steps, no per-launch instrumentation (one event per step boundary for the median)
     ts.reducer.time_exposed = True
@@ -493,9 +632,19 @@ def main():
                   "in_timed_region": bool(a.from_audio)}
         except Exception as ex:
             fe = {"logmel_ms": None, "note": f"failed: {ex!r}"}
+    if world > 1:
+        ok, sums = _replicas_agree(ts, world)
+        if not ok:
+            errors.append(f"replicas differ at the end of the run (parameter checksums per rank {[hex(v) for v in sums]})")
+        lim = a.max_exposed_frac if a.max_exposed_frac is not None else (0.20 if dist.get_backend() == "nccl" else None)
+        msg = exposed_guard(rank_exposed, dt / a.steps * 1e3, lim)
+        if msg:
+            errors.append(msg)
     if rank != 0:
         if dist.is_initialized():
             dist.destroy_process_group()
+        if errors:
+            sys.exit(4)
         return
     ms = dt / a.steps * 1e3
     utts = a.batch * world * a.steps / dt
@@ -616,7 +765,12 @@ def main():
             out["cpu_baseline"]["config1"] = {"value": None, "sample": f"failed: {ex!r}"}
     if dist.is_initialized():
         dist.destroy_process_group()
+    if errors:
+        out["error"] = "; ".join(errors)
     emit(json.dumps(out))
+    if errors:
+        sys.stderr.write("bench.py: " + out["error"] + "\n")
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -157,3 +157,32 @@ def test_bench_launcher_returns_when_a_rank_dies_before_the_rendezvous():
     assert r.returncode == 1 and time.time() - t0 < 120
     assert "rank exit codes" in r.stderr and "rank 1 failing on request" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_preflight_over_gloo_and_the_exposed_wait_guard():
+    """`bench.py --gpus 2 --preflight`: the dress rehearsal of a multi-GPU run (per-rank device report, environment, a timed
+    all-reduce with a checked result, the bucket schedule) -- here without a GPU, over gloo: two ranks, one JSON line, exit 0.
+    And the rule that fails a run whose gradient exchange is not hidden (bench.exposed_guard)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--preflight"], capture_output=True,
+                       text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["preflight"] is True and d["n_gpus"] == 2 and d["backend"] == "gloo" and len(d["ranks"]) == 2
+    assert [q["rank"] for q in d["ranks"]] == [0, 1]
+    for q in d["ranks"]:
+        assert q["allreduce_256mb"]["result_ok"] is True and q["allreduce_256mb"]["ms"] > 0 and "env" in q
+    assert d["config"]["parallelism"] == "dp2" and "gradient_exchange" in d and "topology" in d
+    sys.path.insert(0, root)
+    import bench
+    assert bench.exposed_guard([0.0, 0.1], 100.0, 0.2) is None and bench.exposed_guard([0.0, 0.1], 100.0, None) is None
+    msg = bench.exposed_guard([1.0, 30.0], 100.0, 0.2)
+    assert msg and "30.00 ms" in msg and "20%" in msg
+    topo = "x\n==== Link Type between two GPUs ====\n       GPU0         GPU1\nGPU0   0            XGMI\nGPU1   XGMI         0\n====\n"
+    assert bench._link_types(topo) == {"GPU0": ["0", "XGMI"], "GPU1": ["XGMI", "0"]}

@@ -65,6 +65,33 @@ def test_bench_gpus_2_launches_two_ranks_by_itself():
     assert "cpu_baseline" not in d                                                      # rank 0 at N = 1 only
 
 
+def test_bench_preflight_lists_the_bucket_schedule_and_a_failed_check_fails_the_run():
+    """`bench.py --preflight` on the GPU box (one rank, no process group): device report + the gradient bucket schedule of the
+    model; and a two-rank run (shared GPU, gloo) with --max-exposed-frac -1 (a bound no run can meet) must exit non-zero with ONE JSON line carrying "error"."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preflight", "--model", "whisper-tiny", "--batch", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    gx = d["gradient_exchange"]
+    assert d["preflight"] is True and d["n_gpus"] == 1 and d["ranks"][0]["device_ordinal"] == 0 and d["ranks"][0]["cus"] >= 64
+    assert gx["buckets"] == len(gx["schedule_in_backward_order"]) >= 6 and gx["bytes_per_step"] == sum(b["bytes"] for b in gx["schedule_in_backward_order"])
+    assert gx["schedule_in_backward_order"][0]["bucket"] == "final_ln" and gx["schedule_in_backward_order"][-1]["bucket"] == "stem"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "whisper-tiny", "--batch", "2",
+                        "--labels", "16", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--max-exposed-frac", "-1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, DICOW_BENCH_SHARE_GPU="1"))
+    assert r.returncode != 0
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (r.stdout, r.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert "error" in d and "gradient exchange" in d["error"] and d["n_gpus"] == 2
+
+
 def test_graft_entry_smoke_runs_and_checks_against_the_oracle():
     """__graft_entry__.smoke(): one small fwd+bwd of the hot path on cuda:0 compared with the oracle (raises on mismatch)."""
     if not torch.cuda.is_available():
