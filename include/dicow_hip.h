@@ -32,7 +32,7 @@ extern "C" {
 #define DICOW_ERR_INVALID (-1)  /* bad argument / unsupported shape */
 #define DICOW_ERR_LAUNCH (-2)   /* HIP launch failure */
 
-#define DICOW_ABI_VERSION 5
+#define DICOW_ABI_VERSION 6
 
 int dicow_abi_version(void);
 /* Number of CUs the persistent NT GEMM may occupy (0 = all, the default).  Its workgroups own a whole CU each for the
@@ -171,16 +171,6 @@ int dicow_fddt_full_combine_bwd(const float* g, const float* stno, int64_t stno_
 #define DICOW_EPI_COLSUM   512   /* colsum_out[n] += sum_m C[m,n] (bias gradient of the layer that produced the GEMM's */
                                  /* input gradient); needs colsum_ws of dicow_gemm_nt_colsum_ws_bytes(M, N) bytes     */
 #define DICOW_EPI_FDDT    1024   /* with BIAS | RESIDUAL | OUT_F32: C = FDDT_next(bf16(acc + bias) + residual); persistent kernel only  */
-/* LayerNorm folded into the GEMMs on either side of it (ABI 4; HF:modeling_whisper.py:392-405 via encoder.py:216-221: the
- * pre-LN encoder layer's self_attn_layer_norm -> q/k/v and final_layer_norm -> fc1).  With W' = bf16(gamma . W) (column scale),
- *   LN(h) W^T + b = rstd_r (bf16(h) W'^T) - rstd_r mean_r colsum(W')_n + (beta W^T + b)_n
- * so the GEMM that PRODUCES the residual stream h (out-proj / fc2 with the fp32 residual epilogue) also stores bf16(h) and per-row
- * partial (sum, sum of squares) of the fp32 h, and the GEMM that CONSUMES LN(h) reads bf16(h) as its A operand and applies the
- * row scale + rank-one correction in its epilogue: the LayerNorm launch between them disappears.  Rounding point: bf16 of the
- * un-normalised h instead of bf16 of LN(h) (one bf16 rounding per operand element either way). */
-#define DICOW_EPI_LNSTAT  2048   /* producer: with BIAS | RESIDUAL | OUT_F32 (| FDDT): aux <- bf16 copy of the fp32 result (ld = ldaux), lnstat[m][slot] <- partial (sum, sum sq) */
-#define DICOW_EPI_LNFOLD  4096   /* consumer: acc -> rstd_m acc - rstd_m mean_m ln_c[n] before bias / scale / GELU; A = the producer's bf16 copy, B = W', bias = beta W^T + b */
-#define DICOW_LN_SLOTS 16        /* partial slots per row of lnstat: [M][16][2] fp32; slot = 4 * (column tile of 320) + 2 * wave column + {0: 128 main columns, 1: 32 tail columns} */
 typedef struct {
     const void* A; const void* B; void* C;
     const float* bias; const float* residual; void* aux;
@@ -194,7 +184,7 @@ typedef struct {
        fddt_w[c] / fddt_b[c] = the [N] fp32 weight / bias vectors of class c (S, T, N, O), fddt_rowmask = [>= M rounded up to the
        tile height + 64 rows][4] fp32, row m = the four STNO class masks of output row m */
     const float* fddt_w[4]; const float* fddt_b[4]; const float* fddt_rowmask;
-    /* DICOW_EPI_LNSTAT / LNFOLD only (ABI 4): lnstat = [M][DICOW_LN_SLOTS][2] fp32 row partials (LNSTAT writes its 4 * N / 320 slots,
+    /* EXPERIMENTAL (see the end of this header; zero in the stable ABI): DICOW_EPI_LNSTAT / LNFOLD only: lnstat = [M][DICOW_LN_SLOTS][2] fp32 row partials (LNSTAT writes its 4 * N / 320 slots,
        LNFOLD sums the first ln_nslots in slot order); ln_c = [N] fp32 column sums of the folded weight; ln_inv_dim = 1 / (normalised
        width), ln_eps = LayerNorm epsilon */
     float* lnstat; const float* ln_c; float ln_inv_dim; float ln_eps; int ln_nslots;
@@ -202,13 +192,6 @@ typedef struct {
 /* 1 when dicow_gemm_nt will run this problem on the persistent ring kernel with a compile-time epilogue (the only path
    that implements DICOW_EPI_FDDT), else 0 */
 int dicow_gemm_nt_is_persistent(const dicow_gemm_args* a);
-/* 1 when dicow_gemm_nt will run this DICOW_EPI_LNSTAT problem (flags BIAS | RESIDUAL | OUT_F32 [| FDDT] | LNSTAT) on the persistent
-   ring kernel's 192 x 320 tiles -- the only producer of the row partials (needs N % 320 == 0, N <= 1280) -- else 0 */
-int dicow_gemm_nt_lnstat_ok(const dicow_gemm_args* a);
-/* Weights of a Linear that follows a LayerNorm, folded (once per optimizer step): W fp32 [N, K], gamma / beta fp32 [K], bias fp32 [N] or
-   NULL -> Wf bf16 [N, ldw] = bf16(gamma_k W_nk), c fp32 [N] = sum_k float(Wf_nk), bf fp32 [N] = bias_n + sum_k beta_k float(bf16(W_nk)) */
-int dicow_lnfold_prep(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, int64_t ldw, float* c, float* bf,
-                      int N, int K, void* stream);
 int dicow_gemm_nt(const dicow_gemm_args* a, void* stream);
 int64_t dicow_gemm_nt_colsum_ws_bytes(int M, int N);
 /* Deep contraction, small output (K >= 8192, fewer 128 x 128 tiles than workgroup slots, no epilogue: the tied LM head's dgrad,
@@ -436,6 +419,32 @@ int dicow_adamw_hyper(int* counters, float* hyper, const int* is_pre, int n_runs
                       int warmup_steps, int max_steps, int cosine, double beta1, double beta2, void* stream);
 int dicow_adamw_f32_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1, float beta2,
                         float eps, float weight_decay, const float* gnorm_sq, float max_norm, void* stream);
+
+
+/* ------------------------------------------------------------------------------------------------ EXPERIMENTAL (not part of the stable ABI)
+ * Declared only under -DDICOW_EXPERIMENTAL_ABI and exported only by a library built with -DDICOW_EXPERIMENTS (build.sh -DDICOW_EXPERIMENTS).
+ * Round 4's LayerNorm fold: built, parity-tested (tests/test_gpu_lnfold.py) and measured 3-4 % SLOWER than the two LayerNorm launches it
+ * deletes (profiles/r04_lnfold.txt) -- kept for A/B builds, out of ABI 6.  The tail fields of dicow_gemm_args (lnstat ... ln_nslots) belong to
+ * it and must be zero for a stable-ABI library, which refuses the two flags. */
+#ifdef DICOW_EXPERIMENTAL_ABI
+/* LayerNorm folded into the GEMMs on either side of it (ABI 4; HF:modeling_whisper.py:392-405 via encoder.py:216-221: the
+ * pre-LN encoder layer's self_attn_layer_norm -> q/k/v and final_layer_norm -> fc1).  With W' = bf16(gamma . W) (column scale),
+ *   LN(h) W^T + b = rstd_r (bf16(h) W'^T) - rstd_r mean_r colsum(W')_n + (beta W^T + b)_n
+ * so the GEMM that PRODUCES the residual stream h (out-proj / fc2 with the fp32 residual epilogue) also stores bf16(h) and per-row
+ * partial (sum, sum of squares) of the fp32 h, and the GEMM that CONSUMES LN(h) reads bf16(h) as its A operand and applies the
+ * row scale + rank-one correction in its epilogue: the LayerNorm launch between them disappears.  Rounding point: bf16 of the
+ * un-normalised h instead of bf16 of LN(h) (one bf16 rounding per operand element either way). */
+#define DICOW_EPI_LNSTAT  2048   /* producer: with BIAS | RESIDUAL | OUT_F32 (| FDDT): aux <- bf16 copy of the fp32 result (ld = ldaux), lnstat[m][slot] <- partial (sum, sum sq) */
+#define DICOW_EPI_LNFOLD  4096   /* consumer: acc -> rstd_m acc - rstd_m mean_m ln_c[n] before bias / scale / GELU; A = the producer's bf16 copy, B = W', bias = beta W^T + b */
+#define DICOW_LN_SLOTS 16        /* partial slots per row of lnstat: [M][16][2] fp32; slot = 4 * (column tile of 320) + 2 * wave column + {0: 128 main columns, 1: 32 tail columns} */
+/* 1 when dicow_gemm_nt will run this DICOW_EPI_LNSTAT problem (flags BIAS | RESIDUAL | OUT_F32 [| FDDT] | LNSTAT) on the persistent
+   ring kernel's 192 x 320 tiles -- the only producer of the row partials (needs N % 320 == 0, N <= 1280) -- else 0 */
+int dicow_gemm_nt_lnstat_ok(const dicow_gemm_args* a);
+/* Weights of a Linear that follows a LayerNorm, folded (once per optimizer step): W fp32 [N, K], gamma / beta fp32 [K], bias fp32 [N] or
+   NULL -> Wf bf16 [N, ldw] = bf16(gamma_k W_nk), c fp32 [N] = sum_k float(Wf_nk), bf fp32 [N] = bias_n + sum_k beta_k float(bf16(W_nk)) */
+int dicow_lnfold_prep(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf, int64_t ldw, float* c, float* bf,
+                      int N, int K, void* stream);
+#endif  /* DICOW_EXPERIMENTAL_ABI */
 
 #ifdef __cplusplus
 }

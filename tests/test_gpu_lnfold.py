@@ -3,7 +3,11 @@
 Replaces HF WhisperEncoderLayer's `self_attn_layer_norm` -> q/k/v and `final_layer_norm` -> fc1 (HF modeling_whisper.py:392-405,
 reached from the reference's encoder.py:216-221) without the LayerNorm launch.  Kernel level: the producer's bf16 copy and row
 partials against torch, the consumer against torch's LayerNorm + Linear (fp32 and with the fold's own rounding points).
+EXPERIMENTAL: the fold measured slower (profiles/r04_lnfold.txt) and is not in the stable ABI; these tests load the experiments
+library (ts-asr-whisper_amd/libdicow_hip_exp.so: csrc/build.sh --exp, built by __graft_entry__.build()).
 Run with `pytest -m gpu`."""
+import os
+
 import pytest
 import torch
 
@@ -17,8 +21,15 @@ amd_pkg.load()
 def ops():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from ts_asr_whisper_amd import ops as _ops
-    return _ops
+    from ts_asr_whisper_amd import ops as _ops, _lib as L
+    exp = os.path.join(os.path.dirname(os.path.abspath(L.__file__)), "libdicow_hip_exp.so")
+    if not os.path.exists(exp):
+        pytest.skip("experiments library missing: ts-asr-whisper_amd/csrc/build.sh --exp")
+    old = (L.LIB_PATH, L._lib)
+    L.LIB_PATH, L._lib = exp, None
+    assert L.has_experimental()
+    yield _ops
+    L.LIB_PATH, L._lib = old
 
 
 def _bf(t):

@@ -31,13 +31,21 @@ def test_library_exports_every_declared_symbol():
     """include/dicow_hip.h is the ABI: every function it declares must be exported by the built library and bound."""
     from ts_asr_whisper_amd import _lib
     hdr = open(os.path.join(ROOT, "include", "dicow_hip.h")).read()
+    stable, experimental = hdr.split("#ifdef DICOW_EXPERIMENTAL_ABI")
+    assert set(re.findall(r"^int\s+(dicow_\w+)\s*\(", experimental, flags=re.M)) == set(_lib._SIGS_EXPERIMENTAL)
+    hdr = stable                           # (the experimental tail is declared only under DICOW_EXPERIMENTAL_ABI and not exported by default)
     declared = set(re.findall(r"^(?:int|int64_t|const char\*)\s+(dicow_\w+)\s*\(", hdr, flags=re.M))
     assert len(declared) >= 25
     assert declared == set(_lib.declared_symbols())
     lib = _lib.lib()                       # raises loudly if the .so has not been built
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dicow_abi_version() == 5
+    assert lib.dicow_abi_version() == 6
+    if not _lib.has_experimental():        # the shipped build: nothing but the stable ABI is exported
+        import subprocess
+        out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+        exported = {ln.split()[-1] for ln in out.splitlines() if " T dicow_" in ln}
+        assert exported == declared, exported ^ declared
 
 
 def test_gemm_nt_is_persistent_host_logic():

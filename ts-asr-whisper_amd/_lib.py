@@ -116,12 +116,10 @@ _SIGS = {
     "dicow_fddt_full_combine_bwd": [c_vp, c_vp, c_i64, c_i, c_vp, c_vp, c_i, c_i, c_i, c_vp],
     "dicow_gemm_nt": [C.POINTER(GemmArgs), c_vp],
     "dicow_gemm_nt_is_persistent": [C.POINTER(GemmArgs)],
-    "dicow_gemm_nt_lnstat_ok": [C.POINTER(GemmArgs)],
     "dicow_gemm_tn": [C.POINTER(GemmTnArgs), c_vp],
     "dicow_gemm_tn_group": [C.POINTER(GemmTnGroupArgs), c_vp],
     "dicow_attn_fwd": [C.POINTER(AttnFwdArgs), c_vp],
     "dicow_attn_bwd": [C.POINTER(AttnBwdArgs), c_vp],
-    "dicow_lnfold_prep": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i, c_i, c_vp],
     "dicow_ce_loss_fwd": [C.POINTER(CeArgs), c_vp],
     "dicow_ce_loss_bwd": [C.POINTER(CeArgs), c_vp, c_vp],
     "dicow_ctc_loss_fwd": [C.POINTER(CtcArgs), c_vp],
@@ -142,6 +140,14 @@ _SIGS = {
     "dicow_adamw_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_f, c_vp],
     "dicow_adamw_hyper": [c_vp, c_vp, c_vp, c_i, c_i, c_d, c_d, c_i, c_i, c_i, c_d, c_d, c_vp],
     "dicow_adamw_f32_dev": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f, c_f, c_f, c_f, c_vp, c_f, c_vp],
+}
+
+
+# EXPERIMENTAL entry points (include/dicow_hip.h, DICOW_EXPERIMENTAL_ABI): only a library built with -DDICOW_EXPERIMENTS exports them
+# (round 4's LayerNorm fold: parity-tested, measured slower); bound when present, `has_experimental()` says whether they are
+_SIGS_EXPERIMENTAL = {
+    "dicow_gemm_nt_lnstat_ok": [C.POINTER(GemmArgs)],
+    "dicow_lnfold_prep": [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_i, c_i, c_vp],
 }
 
 
@@ -167,8 +173,22 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = at
             fn.restype = c_i64
+        l._dicow_experimental = True
+        for name, at in _SIGS_EXPERIMENTAL.items():
+            try:
+                fn = getattr(l, name)
+            except AttributeError:
+                l._dicow_experimental = False
+                continue
+            fn.argtypes = at
+            fn.restype = c_i
         _lib = l
     return _lib
+
+
+def has_experimental():
+    """True when the loaded library was built with -DDICOW_EXPERIMENTS (exports the LayerNorm-fold entry points)."""
+    return bool(lib()._dicow_experimental)
 
 
 _SIGS64 = {   # functions returning int64_t (workspace sizes)

@@ -1,14 +1,18 @@
 #!/bin/bash
-# Build libdicow_hip.so for gfx950 in-tree (cross-compiles without a GPU).  Usage: build.sh [extra hipcc flags]
+# Build libdicow_hip.so for gfx950 in-tree (cross-compiles without a GPU).  Usage: build.sh [--exp] [extra hipcc flags]
+#   --exp : build the EXPERIMENTS library instead (../libdicow_hip_exp.so, objects in build_exp/, -DDICOW_EXPERIMENTS): the stable ABI
+#           plus the experimental entry points of include/dicow_hip.h (tests/test_gpu_lnfold.py and the A/B tools load it explicitly)
 set -e
 cd "$(dirname "$0")"
 OUT=../libdicow_hip.so
+BD=build
+if [ "$1" = "--exp" ]; then shift; OUT=../libdicow_hip_exp.so; BD=build_exp; set -- -DDICOW_EXPERIMENTS "$@"; fi
 SRCS=$(ls *.hip)
-mkdir -p build
+mkdir -p $BD
 OBJS=""
 pids=""
 for s in $SRCS; do
-  o=build/${s%.hip}.o
+  o=$BD/${s%.hip}.o
   OBJS="$OBJS $o"
   stale=0
   for dep in "$s" common.h ../../include/dicow_hip.h $(ls *.inc experiments/*.inc 2>/dev/null); do

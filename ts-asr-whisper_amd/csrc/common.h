@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#define DICOW_EXPERIMENTAL_ABI 1      // the sources name the experimental flags / struct tail; the DEFINITIONS are under DICOW_EXPERIMENTS
 #include "../../include/dicow_hip.h"
 
 typedef __bf16 bf16_t;

@@ -772,6 +772,7 @@ extern "C" int dicow_scb_merge_bwd(const float* g, const float* d_qin, const voi
     return DICOW_OK;
 }
 
+#ifdef DICOW_EXPERIMENTS
 // ------------------------------------------------------------------------------------------------ LayerNorm fold: weight preparation
 // (include/dicow_hip.h: dicow_lnfold_prep).  One workgroup per output row n; fixed-order block sums (bit-reproducible).
 __global__ void __launch_bounds__(256) lnfold_prep_kernel(const float* __restrict__ W, const float* __restrict__ gamma,
@@ -810,3 +811,4 @@ extern "C" int dicow_lnfold_prep(const float* W, const float* gamma, const float
     DICOW_CHECK_LAUNCH("lnfold_prep");
     return DICOW_OK;
 }
+#endif  // DICOW_EXPERIMENTS

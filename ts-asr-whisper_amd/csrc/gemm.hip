@@ -778,12 +778,14 @@ extern "C" int dicow_gemm_nt_is_persistent(const dicow_gemm_args* a) {
     return (off32 && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= NT_BIG_TILES) ? 1 : 0;
 }
 
+#ifdef DICOW_EXPERIMENTS
 extern "C" int dicow_gemm_nt_lnstat_ok(const dicow_gemm_args* a) {
     // (the LNSTAT instantiations are 192 x 320 only and the dispatcher forces that shape for them: what remains to ask is whether
     // the problem reaches the persistent kernel at all and whether its columns are whole 320-wide tiles that fit the 16 slots)
     return (dicow_gemm_nt_is_persistent(a) && a->M >= 256 && a->N >= 320 && a->N % 320 == 0 && a->N <= 1280 &&
             (int64_t)a->M * 128 < (1ll << 31) && (a->batch <= 1)) ? 1 : 0;
 }
+#endif
 
 extern "C" int dicow_gemm_nt(const dicow_gemm_args* a, void* stream) {
     DICOW_REQUIRE(a && a->A && a->B && a->C, "gemm_nt: null operand");
@@ -842,6 +844,7 @@ static void gemm_nt_setup() {
     NT2_ATTR(DICOW_EPI_MUL_AUX); NT2_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
 #undef NT2_ATTR
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FDDT_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
+#ifdef DICOW_EXPERIMENTS
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_RES_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FDDT_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_QKV_LN_FLAGS, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
@@ -850,6 +853,7 @@ static void gemm_nt_setup() {
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FC1I_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FC1T_LN_FLAGS, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FC1T_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
+#endif
 #ifdef DICOW_ABLATIONS
     (void)hipFuncSetAttribute((const void*)gemm_nt256s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NTS_LDS);
 #define NTW_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntw_kernel<F, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, NTW_LDS); \
@@ -952,6 +956,9 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     constexpr int big_tiles = NT_BIG_TILES;
 #endif
     const bool big = off32 && a->K >= 2 * BK && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= big_tiles;
+#ifndef DICOW_EXPERIMENTS
+    DICOW_REQUIRE(!(a->flags & (DICOW_EPI_LNSTAT | DICOW_EPI_LNFOLD)), "gemm_nt: EPI_LNSTAT / EPI_LNFOLD are experimental (the LayerNorm fold measured slower, profiles/r04_lnfold.txt): build the library with -DDICOW_EXPERIMENTS");
+#endif
     DICOW_REQUIRE(!(a->flags & (DICOW_EPI_LNSTAT | DICOW_EPI_LNFOLD)) || (variant == 0 && big && a->M >= 256 && a->N >= 320),
                   "gemm_nt: EPI_LNSTAT / EPI_LNFOLD are implemented by the persistent kernel only (M=%d N=%d K=%d: ask dicow_gemm_nt_is_persistent / dicow_gemm_nt_lnstat_ok)", a->M, a->N, a->K);
     DICOW_REQUIRE(!(a->flags & DICOW_EPI_FDDT) || (variant == 0 && big && a->M >= 256 && a->N >= 320),
@@ -1084,11 +1091,13 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
                 case DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32); break;
                 case DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX: NTW_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); break;
                 case NT_FDDT_FLAGS: hipLaunchKernelGGL((gemm_ntr_kernel<NT_FDDT_FLAGS, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); break;
+#ifdef DICOW_EXPERIMENTS
                 case NT_RES_LN_FLAGS: hipLaunchKernelGGL((gemm_ntr_kernel<NT_RES_LN_FLAGS, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); break;
                 case NT_FDDT_LN_FLAGS: hipLaunchKernelGGL((gemm_ntr_kernel<NT_FDDT_LN_FLAGS, 3, 5>), gp, dim3(256), NTR_LDS, (hipStream_t)stream, *a); break;
                 case NT_QKV_LN_FLAGS: NTW_LAUNCH(NT_QKV_LN_FLAGS); break;
                 case NT_FC1I_LN_FLAGS: NTW_LAUNCH(NT_FC1I_LN_FLAGS); break;
                 case NT_FC1T_LN_FLAGS: NTW_LAUNCH(NT_FC1T_LN_FLAGS); break;
+#endif
                 case DICOW_EPI_MUL_AUX: NTW_LAUNCH(DICOW_EPI_MUL_AUX); break;
                 case DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM: NTW_LAUNCH(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM); break;
                 default: NTW_LAUNCH(-1); break;
