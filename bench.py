@@ -205,8 +205,6 @@ def cpu_baseline(cfg_name, labels):
     cfg = pkg.DiCoWConfig.preset(cfg_name, use_pre_pos_fddt=True, non_target_fddt_value=0.5)
     ocfg = O.OracleConfig(**{k: getattr(cfg, k) for k in O.OracleConfig.__dataclass_fields__ if hasattr(cfg, k)})
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
     p = O.init_state(ocfg, seed=0)
     for n, t in p.items():
         if "decoder" not in n and n != "proj_out.weight" and t.is_floating_point():
@@ -215,20 +213,32 @@ def cpu_baseline(cfg_name, labels):
     x = torch.randn(1, cfg.num_mel_bins, 3000, generator=g).clamp_(-1.5, 1.5)
     st = torch.softmax(torch.randn(1, 4, 1500, generator=g), 1)
     lab = torch.randint(0, 50257, (1, labels), generator=g)
-    times = []
-    for it in range(2):
+    # SURVEY 8(d) asks for torch.set_num_threads(nproc); on this host (256 logical cores) the oracle's fp32 GEMMs do not scale past
+    # ~64 threads, so both settings are timed (one step each, a third at the faster setting if time allows) and the BEST is
+    # reported with the thread count it was measured at -- the other figure is in `sample`
+    per = {}
+    for threads in dict.fromkeys([min(cores, 64), cores]):
+        torch.set_num_threads(threads)
         t0 = time.time()
         out = O.model_forward(p, ocfg, x, st, lab, lab)
         out["loss"].backward()
-        times.append(time.time() - t0)
+        per[threads] = [time.time() - t0]
         for t in p.values():
             t.grad = None
-        if sum(times) > 40:
-            break
-    best = min(times)
-    return {"value": 1.0 / best, "unit": "utt/s", "cores": threads, "kind": "port",
-            "sample": f"oracle (plain PyTorch fp32 restatement) fwd+bwd, {cfg_name} dims, B=1, L={labels}, {len(times)} steps, "
-                      f"best {best:.2f} s, host has {cores} logical cores"}
+    fast = min(per, key=lambda k: per[k][0])
+    if sum(v[0] for v in per.values()) < 45:
+        torch.set_num_threads(fast)
+        t0 = time.time()
+        out = O.model_forward(p, ocfg, x, st, lab, lab)
+        out["loss"].backward()
+        per[fast].append(time.time() - t0)
+        for t in p.values():
+            t.grad = None
+    best = min(per[fast])
+    detail = ", ".join(f"{k} threads: " + " / ".join(f"{v:.2f} s" for v in vs) for k, vs in per.items())
+    return {"value": 1.0 / best, "unit": "utt/s", "cores": fast, "kind": "port",
+            "sample": f"oracle (plain PyTorch fp32 restatement) fwd+bwd, {cfg_name} dims, B=1, L={labels}, one step per thread setting "
+                      f"({detail}), best {best:.2f} s at {fast} threads, host has {cores} logical cores"}
 
 
 def cpu_config1():

@@ -46,7 +46,11 @@ CASES = {
     # nearly equal numbers and the q / k projection gradients are weakly conditioned.  Same model with every attention's
     # q_proj / k_proj (weights and the q bias) scaled by QK_SCALE: scores x QK_SCALE^2 -> peaked attention rows.
     "rd_turbo_peaked": ("whisper-large-v3-turbo", 1, 128, {}, False, False),
+    # ROW 9 of the B = 16 batch of tests/test_gpu_realdims.py::test_configs2_batch16_... -- a row whose labels end in -100 padding --
+    # run by the reference as a B = 1 sample: a second row of that batch pinned to the reference directly (round 5)
+    "rd_turbo_row9": ("whisper-large-v3-turbo", 1, 128, {}, False, False),
 }
+B16_ROW = {"rd_turbo_row9": 9}
 QK_SCALE = {"rd_turbo_peaked": 2.0}
 
 
@@ -87,6 +91,12 @@ def inputs(preset, B, L, mixed, se, tag):
     d = DIMS[preset]
     TS_START = ts_start(preset)
     M, T = d["num_mel_bins"], 1500
+    if tag in B16_ROW:                        # one row of the B = 16 test batch, exactly as the test builds it
+        r = B16_ROW[tag]
+        x = torch.from_numpy(hashed_mel(16, M, 2 * T)).clone()[r:r + 1] * 1.5
+        st = hashed_stno(16, T, "rd_turbo_b16.stno")[r:r + 1].clone()
+        lab = hashed_labels(16, L, 0, 50257, "rd_turbo_b16.labels", pad_rows=(3, 9))[r:r + 1].clone()
+        return x, st, lab, lab.clone(), [T]
     x = torch.from_numpy(hashed_mel(B * (2 if se else 1), M, 2 * T)).clone() * 1.5
     st = hashed_stno(B * (2 if se else 1), T, tag + ".stno")
     lens = [T] * (B * (2 if se else 1))

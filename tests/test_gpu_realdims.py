@@ -202,6 +202,11 @@ def test_configs2_batch16_step_row0_vs_reference_golden_and_loss_is_the_mean_of_
             worst_inv = max(worst_inv, d)
     Row0.loss = torch.tensor(rows_loss[0])
     _check_forward(z, Row0)
+    # row 9 -- a row whose labels end in -100 padding -- is pinned to the reference as well (golden rd_turbo_row9: the reference run
+    # on exactly this row as a B = 1 sample): its encoder output and logits INSIDE the B = 16 batch and its own B = 1 loss
+    z9 = load_golden("rd_turbo_row9")
+    assert np.array_equal(z9["labels"][0], lab[9].numpy()) and int((lab[9] == -100).sum()) == L // 4
+    _check_forward(z9, types.SimpleNamespace(encoder_last_hidden_state=enc[9:10], logits=logits[9:10], loss=torch.tensor(rows_loss[9])))
     # different tile shapes / split factors at 1500 and 24000 rows: fp32 accumulation order differs, bf16 roundings flip
     assert worst_inv < 6e-2, worst_inv
     mean_rows = sum(rows_loss) / B
@@ -211,11 +216,11 @@ def test_configs2_batch16_step_row0_vs_reference_golden_and_loss_is_the_mean_of_
         if p.requires_grad:
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
     print("configs[2] B=16: worst row-vs-B=1 encoder deviation", worst_inv, "loss", float(out.loss), "mean of rows", mean_rows)
-    worst = _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checked=20)
+    worst = _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checked=20, extra_rows={9: z9})
     print("configs[2] B=16: worst watched gradient, B=16 step vs mean of the 16 B=1 steps (rel-L2):", worst)
 
 
-def _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checked, prefix="hard"):
+def _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checked, prefix="hard", extra_rows=None):
     """The B = 16 BACKWARD as a step (24000-row dgrad rings, the pooled weight-gradient launch, the staged row backward, first-writer
     gradients -- variants no B = 1 run reaches), value-checked: the hard loss is the mean over ALL B x L label positions
     (modeling_dicow.py:310-323), i.e. the mean of the rows' own B = 1 losses, so for every watched parameter
@@ -234,6 +239,8 @@ def _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checke
         o1.loss.backward()
         if r == 0:                                          # the golden's own sample: its gradients vs the reference's
             _check_grads(z, model, prefix, names, min_checked=min_checked)
+        if extra_rows and r in extra_rows:                  # further rows the reference ran as B = 1 samples (rd_turbo_row9: padded labels)
+            _check_grads(extra_rows[r], model, prefix, names, min_checked=min_checked)
         for n in names:
             acc[n] += named[n].grad.detach().double()
     worst, checked = (0.0, None), 0
