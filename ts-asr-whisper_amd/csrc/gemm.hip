@@ -687,6 +687,10 @@ __device__ __forceinline__ float ln_merge4(float a, float b, bool bit) {
 #define NT2_DELAY 0               // second half of the grid starts NT2_DELAY x 64 clocks late
 #endif
 #include "gemm_nt2.inc"
+#ifndef NTQ_MASK
+#define NTQ_MASK 0                // shapes on gemm_ntq_kernel (320 x 256 tiles), same class bits as NT2_MASK; only whole tiles (M % 320 == 0,
+#endif                            // N % 256 == 0) whose rounds of workgroups pad the problem no more than the ring kernel's shapes do
+#include "gemm_ntq.inc"
 
 #ifdef DICOW_ABLATIONS
 #include "experiments/gemm_nt256s.inc"
@@ -843,6 +847,11 @@ static void gemm_nt_setup() {
     NT2_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32); NT2_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX);
     NT2_ATTR(DICOW_EPI_MUL_AUX); NT2_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
 #undef NT2_ATTR
+#define NTQ_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_ntq_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, NTQ_LDS)
+    NTQ_ATTR(0); NTQ_ATTR(DICOW_EPI_BIAS); NTQ_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N); NTQ_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU);
+    NTQ_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32); NTQ_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX);
+    NTQ_ATTR(DICOW_EPI_MUL_AUX); NTQ_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
+#undef NTQ_ATTR
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FDDT_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
 #ifdef DICOW_EXPERIMENTS
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_RES_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
@@ -1053,6 +1062,37 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
                 const int cls = f_ == NT_RES_FLAGS ? 1 : f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX) ? 2 : f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU) ? 4 :
                                 (f_ == DICOW_EPI_MUL_AUX || f_ == (DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM)) ? 8 :
                                 (f_ == DICOW_EPI_BIAS || f_ == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N)) ? 16 : f_ == 0 ? 32 : 0;
+#ifdef DICOW_ABLATIONS
+                static const int ntq_mask = getenv("DICOW_NTQ_MASK") ? atoi(getenv("DICOW_NTQ_MASK")) : NTQ_MASK;
+#else
+                constexpr int ntq_mask = NTQ_MASK;
+#endif
+                {
+                    // 320 x 256 tiles (gemm_ntq_kernel): whole tiles only, at least three k-steps, and only where its rounds of `ncu`
+                    // workgroups cover no more padded area than the ring kernel's choice (M = 24000: N = 5120 -> 1500 tiles = 6 rounds)
+                    const int64_t tq = (int64_t)(a->M / 320) * (a->N / 256) * batch;
+                    const int64_t wq = dicow_cdiv(tq, ncu) * 320 * 256, wr = (a->N >= 320 && wide_ok && w35 < w44) ? w35 : w44;
+                    if (variant == 0 && (ntq_mask & cls) && a->M % 320 == 0 && a->N % 256 == 0 && a->K >= 3 * BK && tq > 0 && (wq <= wr || (ntq_mask & 1024))) {
+                        const int roundsq = dicow_cdiv(tq, ncu);
+                        const dim3 gq(dicow_cdiv(tq, roundsq));
+                        if (colsum_rows) *colsum_rows = 2 * (a->M / 320);
+                        disp_note("gemm_ntq_kernel<%d>", f_);
+#define NTQ_LAUNCH(F) hipLaunchKernelGGL((gemm_ntq_kernel<F>), gq, dim3(256), NTQ_LDS, (hipStream_t)stream, *a)
+                        switch (f_) {
+                            case 0: NTQ_LAUNCH(0); break;
+                            case DICOW_EPI_BIAS: NTQ_LAUNCH(DICOW_EPI_BIAS); break;
+                            case DICOW_EPI_BIAS | DICOW_EPI_SCALE_N: NTQ_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N); break;
+                            case DICOW_EPI_BIAS | DICOW_EPI_GELU: NTQ_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_GELU); break;
+                            case NT_RES_FLAGS: NTQ_LAUNCH(NT_RES_FLAGS); break;
+                            case DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX: NTQ_LAUNCH(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); break;
+                            case DICOW_EPI_MUL_AUX: NTQ_LAUNCH(DICOW_EPI_MUL_AUX); break;
+                            default: NTQ_LAUNCH(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM); break;
+                        }
+#undef NTQ_LAUNCH
+                        DICOW_CHECK_LAUNCH("gemm_ntq (persistent, 320 x 256 tiles)");
+                        return DICOW_OK;
+                    }
+                }
                 if (variant == 0 && (nt2_mask & cls) && a->M >= 128 && a->N >= 256) {
                     const int64_t t2 = (int64_t)dicow_cdiv(a->M, 128) * dicow_cdiv(a->N, 256) * batch;
                     const int rounds2 = dicow_cdiv(t2, NT2_SLOTS * ncu);
