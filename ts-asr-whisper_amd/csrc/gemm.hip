@@ -677,20 +677,31 @@ __device__ __forceinline__ float ln_merge4(float a, float b, bool bit) {
     return keep + ln_xor4(send);
 }
 #include "gemm_ntr.inc"
+// Round 5's two structural experiments (csrc/experiments/, compiled only into the experiments library or an A/B build that sets a mask):
+// gemm_nt2_kernel (two workgroups per CU, 128 x 256 tiles) and gemm_ntq_kernel (320 x 256 tiles) -- both parity-green, both measured
+// slower or equal (profiles/r05_nt2_two_workgroups.txt, r05_ntq_320x256.txt).  Class bits of the masks: 1 fp32 residual, 2 training fc1
+// (GELU + gelu'), 4 inference fc1 (GELU), 8 dgrad x gelu' (+ column sums), 16 bias / bias + q scale, 32 plain; NTQ bit 1024: also where
+// its rounds of workgroups pad worse than the ring kernel's.  In the experiments library DICOW_NT2_MASK / DICOW_NTQ_MASK /
+// DICOW_NT2_DELAY select at run time (tests/test_gpu_experiments.py).
 #ifndef NT2_MASK
-#define NT2_MASK 0                // shapes on gemm_nt2_kernel (two workgroups per CU): 1 fp32 residual, 2 training fc1 (GELU + gelu'), 4 inference
-#endif                            // fc1 (GELU), 8 dgrad x gelu' (+ column sums), 16 bias / bias + q scale, 32 plain
+#define NT2_MASK 0
+#endif
 #ifndef NT2_SLOTS
 #define NT2_SLOTS 2               // workgroups per CU the grid is sized for (1: diagnostic, a lone workgroup per CU)
 #endif
 #ifndef NT2_DELAY
 #define NT2_DELAY 0               // second half of the grid starts NT2_DELAY x 64 clocks late
 #endif
-#include "gemm_nt2.inc"
 #ifndef NTQ_MASK
-#define NTQ_MASK 0                // shapes on gemm_ntq_kernel (320 x 256 tiles), same class bits as NT2_MASK; only whole tiles (M % 320 == 0,
-#endif                            // N % 256 == 0) whose rounds of workgroups pad the problem no more than the ring kernel's shapes do
-#include "gemm_ntq.inc"
+#define NTQ_MASK 0
+#endif
+#if defined(DICOW_EXPERIMENTS) || defined(DICOW_ABLATIONS) || NT2_MASK || NTQ_MASK
+#define NT_EXPERIMENT_KERNELS 1
+#include "experiments/gemm_nt2.inc"
+#include "experiments/gemm_ntq.inc"
+#else
+#define NT_EXPERIMENT_KERNELS 0
+#endif
 
 #ifdef DICOW_ABLATIONS
 #include "experiments/gemm_nt256s.inc"
@@ -842,6 +853,7 @@ static void gemm_nt_setup() {
     NTR_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX); NTR_ATTR(DICOW_EPI_MUL_AUX);
     NTR_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
 #undef NTR_ATTR
+#if NT_EXPERIMENT_KERNELS
 #define NT2_ATTR(F) (void)hipFuncSetAttribute((const void*)gemm_nt2_kernel<F>, hipFuncAttributeMaxDynamicSharedMemorySize, NT2_LDS)
     NT2_ATTR(0); NT2_ATTR(DICOW_EPI_BIAS); NT2_ATTR(DICOW_EPI_BIAS | DICOW_EPI_SCALE_N); NT2_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU);
     NT2_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32); NT2_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX);
@@ -852,6 +864,7 @@ static void gemm_nt_setup() {
     NTQ_ATTR(DICOW_EPI_BIAS | DICOW_EPI_RESIDUAL | DICOW_EPI_OUT_F32); NTQ_ATTR(DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX);
     NTQ_ATTR(DICOW_EPI_MUL_AUX); NTQ_ATTR(DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM);
 #undef NTQ_ATTR
+#endif
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_FDDT_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
 #ifdef DICOW_EXPERIMENTS
     (void)hipFuncSetAttribute((const void*)gemm_ntr_kernel<NT_RES_LN_FLAGS, 3, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, NTR_LDS);
@@ -1050,9 +1063,10 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
             }
 #endif
             if (want_colsum && variant != 11 && a->flags == DICOW_EPI_MUL_AUX) { a->flags |= DICOW_EPI_COLSUM; *fused_colsum = true; }
+#if NT_EXPERIMENT_KERNELS
             {
                 // two workgroups per CU (gemm_nt2_kernel, 128 x 256 tiles): the epilogue-heavy shapes, per NT2_MASK
-#ifdef DICOW_ABLATIONS
+#if defined(DICOW_ABLATIONS) || defined(DICOW_EXPERIMENTS)
                 static const int nt2_mask = getenv("DICOW_NT2_MASK") ? atoi(getenv("DICOW_NT2_MASK")) : NT2_MASK;
                 static const int nt2_delay = getenv("DICOW_NT2_DELAY") ? atoi(getenv("DICOW_NT2_DELAY")) : NT2_DELAY;
 #else
@@ -1062,7 +1076,7 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
                 const int cls = f_ == NT_RES_FLAGS ? 1 : f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU | DICOW_EPI_GELU_DAUX) ? 2 : f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU) ? 4 :
                                 (f_ == DICOW_EPI_MUL_AUX || f_ == (DICOW_EPI_MUL_AUX | DICOW_EPI_COLSUM)) ? 8 :
                                 (f_ == DICOW_EPI_BIAS || f_ == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N)) ? 16 : f_ == 0 ? 32 : 0;
-#ifdef DICOW_ABLATIONS
+#if defined(DICOW_ABLATIONS) || defined(DICOW_EXPERIMENTS)
                 static const int ntq_mask = getenv("DICOW_NTQ_MASK") ? atoi(getenv("DICOW_NTQ_MASK")) : NTQ_MASK;
 #else
                 constexpr int ntq_mask = NTQ_MASK;
@@ -1115,6 +1129,7 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
                     return DICOW_OK;
                 }
             }
+#endif
             {
                 const int f_ = a->flags;
                 const bool ct_ = variant != 11 && (f_ == 0 || f_ == DICOW_EPI_BIAS || f_ == (DICOW_EPI_BIAS | DICOW_EPI_SCALE_N) || f_ == (DICOW_EPI_BIAS | DICOW_EPI_GELU) ||
