@@ -65,11 +65,21 @@ def _worker(rank, world, port, q, mode):
             sd = ts.state_dict()
             sd["exp_avg"] = torch.full_like(sd["exp_avg"], float(rank + 1))
             sd["exp_avg_sq"] = torch.full_like(sd["exp_avg_sq"], float(rank + 2))
+            # ... and so do the step counters of the file and (a model loaded from another file) the parameters themselves
+            sd["global_step"] = 5 + rank
+            sd["run_t"] = [5 + rank] * len(sd["run_t"])
+            with torch.no_grad():
+                ts.store.params.add_(float(rank))
             ts.load_state_dict(sd)
             resumed = (float(ts.store.exp_avg.mean()), float(ts.store.exp_avg_sq.mean()))
+            resumed_more = (ts.opt.t, tuple(ts.opt.run_t), ts.opt.counters.tolist(), float(ts.store.params.double().sum()))
+            q.put(("more", rank, resumed_more))
         q.put((rank, {k: v.numpy() for k, v in before.items()}, {k: v.numpy() for k, v in after.items()}, nbytes, err, resumed))
     finally:
         dist.destroy_process_group()
+
+
+LAST_MORE = None
 
 
 def _run(mode):
@@ -79,7 +89,12 @@ def _run(mode):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in range(world)]
+    got = []
+    while len([g for g in got if g[0] != "more"]) < world:
+        got.append(q.get(timeout=300))
+    global LAST_MORE
+    LAST_MORE = sorted([g[1:] for g in got if g[0] == "more"])
+    res = [g for g in got if g[0] != "more"]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -99,6 +114,9 @@ def test_trainstep_broadcasts_rank0_state_like_ddp():
     assert r0[3] == r1[3] and r0[3] >= n_bytes                                               # (the flat store pads entries to 64)
     assert r0[4] is None and r1[4] is None
     assert r0[5] == (1.0, 2.0) and r1[5] == (1.0, 2.0)                                        # resumed moments: rank 0's
+    # ... and the host AND device step counters and the parameters: ranks that read different files continue as one replica
+    (_, m0), (_, m1) = LAST_MORE
+    assert m0 == m1 and m0[0] == 5 and set(m0[1]) == {5} and m0[2][0] == 5
 
 
 def test_trainstep_verify_mode_raises_on_diverged_replicas():
