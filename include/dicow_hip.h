@@ -57,13 +57,6 @@ int dicow_cast_transpose_f32_to_bf16(const float* src, void* dst, int64_t ld, vo
 #define DICOW_CAST_GROUP_MAX 8
 typedef struct { const float* src; void* dst; void* dst_t; int R, C; int64_t ld, ld_t; } dicow_cast_problem;
 int dicow_cast_transpose_group(const dicow_cast_problem* p, int n, void* stream);
-/* Several small fp32 vectors copied device -> device in ONE launch (ABI 6): the fused q | k | v bias vectors of the encoder layers are
- * refreshed from the separate q_proj / v_proj bias parameters after every optimizer step (HF:modeling_whisper.py:279-282 keeps them as
- * separate Linears; k_proj has no bias) -- 64 copies of 5 KB that cost a 3.5-us hipMemcpyAsync launch each as separate tensor copies.
- * items: host array of n <= DICOW_COPY_GROUP_MAX (dst, src, count) triples, count in floats; chunk larger lists. */
-#define DICOW_COPY_GROUP_MAX 96
-typedef struct { float* dst; const float* src; int64_t n; } dicow_copy_item;
-int dicow_copy_f32_group(const dicow_copy_item* items, int n, void* stream);
 /* Conv1d weight [O,C,3] fp32 -> bf16 [O,Kpad] (dst) and its transpose [Kpad,O] (dst_t; either may be NULL),
  * k = tap*C + c (tap-major), zero padded to Kpad >= 3C: the GEMM view of conv1/conv2 (encoder.py:167-168). */
 int dicow_conv_weight_pack(const float* w, void* dst, void* dst_t, int O, int C, int Kpad, void* stream);

@@ -599,21 +599,3 @@ def test_attn_fwd_single_query_row(ops, B, H, Lk):
     s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k)
     ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v)
     assert maxdiff(o.float().cpu(), ref) < 2e-2
-
-
-def test_copy_f32_group_pooled_vector_copies(ops):
-    """dicow_copy_f32_group: the fused q | k | v bias buffers of the encoder layers refreshed from the separate q_proj / v_proj bias
-    parameters (HF modeling_whisper.py:279-282) in one launch -- more items than one launch holds, odd lengths, unaligned slices."""
-    g = torch.Generator(device="cuda").manual_seed(9)
-    src = [torch.randn(n, device="cuda", generator=g) for n in [1280] * 100 + [5, 1, 4096, 33]]
-    big = torch.full((sum(t.numel() for t in src) + 64,), -7.0, device="cuda")
-    dst, off = [], 3                                     # (a 12-byte offset: the unaligned path)
-    for t in src:
-        dst.append(big[off:off + t.numel()])
-        off += t.numel()
-    ops.copy_f32_group(zip(dst, src))
-    for d, t in zip(dst, src):
-        assert torch.equal(d, t)
-    assert float(big[:3].abs().max()) == 7.0 and float(big[off:].abs().max()) == 7.0        # nothing outside the slices was touched
-    with pytest.raises(Exception):
-        ops.copy_f32_group([(big[:4], src[0])])

@@ -50,13 +50,6 @@ class CastProblem(C.Structure):
     _fields_ = [("src", c_vp), ("dst", c_vp), ("dst_t", c_vp), ("R", c_i), ("C", c_i), ("ld", c_i64), ("ld_t", c_i64)]
 
 
-class CopyItem(C.Structure):
-    _fields_ = [("dst", c_vp), ("src", c_vp), ("n", c_i64)]
-
-
-COPY_GROUP_MAX = 96
-
-
 class GemmTnGroupArgs(C.Structure):
     _fields_ = [("n", c_i), ("p", GemmTnArgs * TN_GROUP_MAX), ("ws", c_vp), ("ws_bytes", c_i64)]
 
@@ -105,7 +98,6 @@ EPI_LNSTAT, EPI_LNFOLD, LN_SLOTS = 2048, 4096, 16
 _SIGS = {
     "dicow_set_gemm_cus": [c_i],
     "dicow_cast_transpose_group": [C.POINTER(CastProblem), c_i, c_vp],
-    "dicow_copy_f32_group": [C.POINTER(CopyItem), c_i, c_vp],
     "dicow_gemm_dispatch_log": [c_vp, c_i],
     "dicow_cast_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp],
     "dicow_cast_transpose_f32_to_bf16": [c_vp, c_vp, c_i64, c_vp, c_i64, c_i, c_i, c_vp],

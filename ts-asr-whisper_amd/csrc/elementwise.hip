@@ -149,30 +149,6 @@ __global__ void cast_transpose4_group_kernel(const cast_group_kargs_t g) {
     }
 }
 
-// Several small fp32 vectors in one launch (include/dicow_hip.h: dicow_copy_f32_group): blockIdx.y = item, grid-stride over its floats.
-struct copy_group_kargs_t { dicow_copy_item it[DICOW_COPY_GROUP_MAX]; };
-__global__ void __launch_bounds__(256) copy_f32_group_kernel(const copy_group_kargs_t g) {
-    const dicow_copy_item q = g.it[blockIdx.y];
-    const int64_t n4 = ((reinterpret_cast<uintptr_t>(q.dst) | reinterpret_cast<uintptr_t>(q.src)) & 15) == 0 ? q.n / 4 : 0;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256)
-        reinterpret_cast<float4*>(q.dst)[i] = reinterpret_cast<const float4*>(q.src)[i];
-    for (int64_t i = n4 * 4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < q.n; i += (int64_t)gridDim.x * 256) q.dst[i] = q.src[i];
-}
-extern "C" int dicow_copy_f32_group(const dicow_copy_item* items, int n, void* stream) {
-    DICOW_REQUIRE(items && n >= 1 && n <= DICOW_COPY_GROUP_MAX, "copy_f32_group: 1..%d items", DICOW_COPY_GROUP_MAX);
-    copy_group_kargs_t k;
-    int64_t mx = 0;
-    for (int i = 0; i < n; ++i) {
-        DICOW_REQUIRE(items[i].dst && items[i].src && items[i].n > 0, "copy_f32_group: bad item %d", i);
-        k.it[i] = items[i];
-        mx = items[i].n > mx ? items[i].n : mx;
-    }
-    int gx = (int)((mx / 4 + 255) / 256); gx = gx < 1 ? 1 : gx > 64 ? 64 : gx;
-    hipLaunchKernelGGL(copy_f32_group_kernel, dim3(gx, n), dim3(256), 0, (hipStream_t)stream, k);
-    DICOW_CHECK_LAUNCH("copy_f32_group");
-    return DICOW_OK;
-}
-
 extern "C" int dicow_cast_transpose_group(const dicow_cast_problem* p, int n, void* stream) {
     DICOW_REQUIRE(p && n >= 1 && n <= DICOW_CAST_GROUP_MAX, "cast_transpose_group: 1..%d problems", DICOW_CAST_GROUP_MAX);
     cast_group_kargs_t k;

@@ -420,7 +420,7 @@ class EncoderEngine:
                 w.fc2 = prep_linear([lyr.fc2.weight], [lyr.fc2.bias], dev)
             W.layers.append(w)
         if _BIAS_COPIES:
-            ops.copy_f32_group(_BIAS_COPIES)          # ONE launch (64 vectors for large-v3-turbo; _foreach_copy_ issued 64 memcpys)
+            torch._foreach_copy_([d for d, _ in _BIAS_COPIES], [s_ for _, s_ in _BIAS_COPIES])
         _BIAS_COPIES = None
         W.scb = []
         if cfg.use_enrollments and cfg.scb_layers:

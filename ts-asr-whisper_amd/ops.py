@@ -117,22 +117,6 @@ class cast_group:
         return False
 
 
-def copy_f32_group(pairs):
-    """(dst, src) pairs of contiguous fp32 CUDA vectors of equal length, copied in pooled launches (dicow_copy_f32_group) instead of
-    one hipMemcpyAsync each (torch._foreach_copy_ on views of different storages falls back to per-tensor copies: 3.5 us apiece)."""
-    pairs = list(pairs)
-    for d, s_ in pairs:
-        _req(d, F32, "copy_f32_group.dst"); _req(s_, F32, "copy_f32_group.src")
-        if d.numel() != s_.numel() or not d.is_contiguous() or not s_.is_contiguous():
-            raise L.DicowError("copy_f32_group: contiguous vectors of equal length expected")
-    for a in range(0, len(pairs), L.COPY_GROUP_MAX):
-        chunk = pairs[a:a + L.COPY_GROUP_MAX]
-        arr = (L.CopyItem * len(chunk))()
-        for i, (d, s_) in enumerate(chunk):
-            arr[i].dst, arr[i].src, arr[i].n = d.data_ptr(), s_.data_ptr(), d.numel()
-        L.call("dicow_copy_f32_group", arr, len(chunk), L.stream())
-
-
 def cast_transpose_bf16(src: torch.Tensor, out=None, out_t=None, ld=None, ld_t=None):
     """fp32 [R,C] -> bf16 `out` [R,C] (row stride ld) and/or `out_t` [C,R] (row stride ld_t); either may be None."""
     _req(src, F32, "cast_transpose.src")
