@@ -32,7 +32,7 @@ extern "C" {
 #define DICOW_ERR_INVALID (-1)  /* bad argument / unsupported shape */
 #define DICOW_ERR_LAUNCH (-2)   /* HIP launch failure */
 
-#define DICOW_ABI_VERSION 6
+#define DICOW_ABI_VERSION 7
 
 int dicow_abi_version(void);
 /* Number of CUs the persistent NT GEMM may occupy (0 = all, the default).  Its workgroups own a whole CU each for the
@@ -261,9 +261,20 @@ typedef struct {
     float* dq_colsum; float* dv_colsum; void* cs_ws; int64_t cs_ws_bytes;
     int q_log2;                                     /* as in dicow_attn_fwd_args; dq keeps its meaning (gradient of the projection
                                                        output before ANY scaling when dq_scale = head_dim^-0.5), dk = ln 2 dS^T q */
+    /* ABI 7: optional workspace of the FUSED backward (one kernel, 5 matrix passes instead of 7: dQ is summed over the key-block
+       workgroups of a (batch, head) in a fixed order through the XCD's L2 -- no atomics, bit-reproducible).  NULL = the two-kernel
+       form.  dicow_attn_bwd_fused_ws_bytes() bytes, 4096-byte aligned, contents irrelevant on entry; used for dense problems of
+       at least 1024 key-block workgroups (the encoder's self-attention), ignored otherwise. */
+    void* fused_ws; int64_t fused_ws_bytes;
+    int fused_mode;                                 /* 0: the library decides (above); 1: the fused kernel for EVERY dense problem it can
+                                                       address (B*H <= 1000), whatever its size -- how the tests reach its edge cases */
 } dicow_attn_bwd_args;
 int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream);
 int64_t dicow_attn_bwd_colsum_ws_bytes(int B, int H, int Lq, int Lk);
+int64_t dicow_attn_bwd_fused_ws_bytes(int B, int H, int Lq, int Lk);
+/* error bits the last fused launch left in its workspace (synchronise the stream first): 0 = fine, 1 = a hand-off wait timed
+   out, 2 = a (batch, head) was spread over several XCDs; -1 = the copy failed.  dq is not to be trusted when non-zero. */
+int dicow_attn_bwd_fused_status(const void* fused_ws);
 
 
 /* ------------------------------------------------------------------------------------------------ loss

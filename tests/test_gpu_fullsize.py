@@ -468,9 +468,12 @@ def test_gemm_tn_group_falls_back_and_handles_odd_pools(ops):
 
 
 @pytest.mark.parametrize("q_log2", [False, True])
-def test_attention_at_bench_shape_vs_torch(ops, q_log2):
+@pytest.mark.parametrize("fused", [False, True])
+def test_attention_at_bench_shape_vs_torch(ops, q_log2, fused):
     """B = 16, H = 20, T = 1500 (one encoder layer's attention of the bench batch): forward and backward vs torch fp32 math.
-    q_log2: the encoder's mode -- q carries log2(e), scores are base-2 exponents (reference scores = (q . k) ln 2)."""
+    q_log2: the encoder's mode -- q carries log2(e), scores are base-2 exponents (reference scores = (q . k) ln 2).
+    fused: the one-kernel backward (what the encoder runs) -- also bit-identical from launch to launch (dQ crosses the key-block
+    workgroups in a fixed order) while another stream keeps the chip unevenly busy, and its status word stays clear."""
     B, H, Tq = 16, 20, 1500
     ln2 = 0.6931471805599453 if q_log2 else 1.0
     g = torch.Generator(device="cuda").manual_seed(5)
@@ -481,7 +484,20 @@ def test_attention_at_bench_shape_vs_torch(ops, q_log2):
     ops.attn_fwd(q, k, v, o, lse, q_log2=q_log2)
     dq, dk, dv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
     delta = torch.empty(2, B, H, Tq, device="cuda")
-    ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, q_log2=q_log2)
+    ops.attn_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, q_log2=q_log2, fused=fused)
+    if fused:
+        assert ops.attn_bwd_fused_status() == 0
+        side = torch.cuda.Stream()
+        junk = torch.empty(64 << 20, device="cuda")
+        for rep in range(3):                                  # again, under an uneven load from a second stream
+            dq2, dk2, dv2 = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+            with torch.cuda.stream(side):
+                for i in range(4 + 3 * rep):
+                    junk.mul_(1.0001)
+            ops.attn_bwd(q, k, v, o, do, lse, delta, dq2, dk2, dv2, q_log2=q_log2, fused=True)
+            torch.cuda.synchronize()
+            assert ops.attn_bwd_fused_status() == 0
+            assert torch.equal(dq2, dq) and torch.equal(dk2, dk) and torch.equal(dv2, dv), rep
     worst = 0.0
     for b in (0, 7, 15):                                      # fp32 reference per batch row (2.9 GB of scores otherwise)
         qf, kf, vf = (t[b].float().permute(1, 0, 2).requires_grad_(True) for t in (q, k, v))

@@ -521,9 +521,15 @@ def test_attn_fwd_log2_reference_exponent_moves(ops, causal):
 
 @pytest.mark.parametrize("B,H,Lq,Lk,causal", [(1, 2, 128, 64, False), (2, 3, 100, 100, False), (1, 2, 1500, 1500, False),
                                              (2, 2, 77, 77, True), (1, 2, 300, 300, True), (2, 2, 50, 1500, False),
-                                             (1, 1, 200, 130, False), (3, 4, 140, 140, False)])
+                                             (1, 1, 200, 130, False), (3, 4, 140, 140, False), (2, 3, 300, 260, False),
+                                             (1, 4, 520, 700, False)])
 @pytest.mark.parametrize("q_log2", [False, True])
-def test_attn_bwd(ops, B, H, Lq, Lk, causal, q_log2):
+@pytest.mark.parametrize("fused", [False, "force"])
+def test_attn_bwd(ops, B, H, Lq, Lk, causal, q_log2, fused):
+    """fused = "force": the one-kernel (5-pass) backward on every dense case, whatever its size -- one key block (first = last
+    visitor of the dQ tiles), ragged last key block / query tile, an all-padding second query block, Lq != Lk."""
+    if fused and causal:
+        pytest.skip("the fused backward is dense-only")
     g = torch.Generator().manual_seed(B * 999 + Lq + 3 * Lk)
     D = H * 64
     qkv_q = _bf(torch.randn(B, Lq, 3 * D, generator=g) * 0.6)
@@ -553,7 +559,9 @@ def test_attn_bwd(ops, B, H, Lq, Lk, causal, q_log2):
     csq, csv = torch.full((D,), 0.25, device="cuda"), torch.full((D,), -0.5, device="cuda")
     ops.attn_bwd(qd, kd, vd, o, dev(d_o, torch.bfloat16), lse, delta,
                  gq[:, :, :D].view(B, Lq, H, 64), gk[:, :, D:2 * D].view(B, Lk, H, 64), gk[:, :, 2 * D:].view(B, Lk, H, 64),
-                 causal=causal, dq_scale=0.5, dq_colsum=csq, dv_colsum=csv, q_log2=q_log2)
+                 causal=causal, dq_scale=0.5, dq_colsum=csq, dv_colsum=csv, q_log2=q_log2, fused=fused)
+    if fused:
+        assert ops.attn_bwd_fused_status() == 0
     tol = lambda ref: 2e-2 * max(1.0, float(ref.abs().max()))
     # fused bias gradients: column sums of exactly the values that were stored (accumulated onto the initial contents)
     assert maxdiff(csq.cpu(), 0.25 + gq[:, :, :D].float().cpu().double().sum((0, 1))) < 1e-3 * (1 + B * Lq) ** 0.5

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()                       # raises loudly if the .so has not been built
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.dicow_abi_version() == 6
+    assert lib.dicow_abi_version() == 7
     if not _lib.has_experimental():        # the shipped build: nothing but the stable ABI is exported
         import subprocess
         out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout

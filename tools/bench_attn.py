@@ -32,8 +32,30 @@ fl = 4.0 * B * H * Lq * Lk * 64 * (0.5 if causal else 1.0)
 LOG2 = os.environ.get("ATTN_LOG2") == "1"          # the encoder's mode: q carries log2(e)
 t = timeit(lambda: ops.attn_fwd(q, k, v, o, lse, causal=bool(causal), q_log2=LOG2))
 print(f"attn_fwd B{B} H{H} Lq{Lq} Lk{Lk} causal{causal}: {t*1e3:.1f} us  {fl/t/1e9:.0f} TF")
-t = timeit(lambda: ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=bool(causal), dq_scale=0.125, q_log2=LOG2))
-print(f"attn_bwd (dq+dkv): {t*1e3:.1f} us  {3.5*fl/t/1e9:.0f} TF (7 matmul passes)")
+for rep in range(int(os.environ.get("ATTN_BWD_REPS", "2"))):          # interleaved A/B: two-kernel form | fused form (dense, large problems only)
+    t = timeit(lambda: ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=bool(causal), dq_scale=0.125, q_log2=LOG2, fused=False))
+    print(f"attn_bwd (dq+dkv): {t*1e3:.1f} us  {3.5*fl/t/1e9:.0f} TF executed (7 matmul passes), {2.5*fl/t/1e9:.0f} TF algorithmic")
+    if not causal:
+        t = timeit(lambda: ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=0.125, q_log2=LOG2, fused=True))
+        print(f"attn_bwd (fused, incl. stats kernel): {t*1e3:.1f} us  {2.5*fl/t/1e9:.0f} TF algorithmic (5 matmul passes), status {ops.attn_bwd_fused_status()}")
+if os.environ.get("ATTN_PROFILE_FUSED"):     # only with a -DATTN_FUSED_PROFILE=1 build (tools/libv_fprof.so): per-workgroup cycle accounting of the fused backward
+    ops.attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=0.125, q_log2=LOG2, fused=True); torch.cuda.synchronize()
+    ws = ops.attn_bwd_fused_ws(B, H, Lq, Lk, q.device)
+    nt, nkb = (Lq + 63) // 64, (Lk + 127) // 128
+    nfl = B * H * nt * 4
+    off = 4096 + ((nfl * 4 + 4095) // 4096) * 4096 + nfl * 4096
+    nwg = 8 * ((B * H + 7) // 8) * nkb
+    rec = ws[off:off + nwg * 128].view(torch.int64).view(nwg, 16).double().cpu()
+    names = ["loop top, flag poll issue", "A (middle: publish, flag check, sum request)", "wait + barrier X", "B: DMA issue, dQ product", "wait for the sum (slow path: flag)", "LDS read + add", "stores / final rows", "bookkeeping", "barrier Y"]
+    for sel, lab in ((rec[:, 11] == 0, "key block 0"), ((rec[:, 11] > 0) & (rec[:, 11] < nkb - 1), "middle key blocks"), (rec[:, 11] == nkb - 1, "last key block")):
+        r = rec[sel]
+        print(f"fused bwd, {lab} ({int(sel.sum())} workgroups), cycles per 64-query tile (wave 0): " +
+              ", ".join(f"{n} {r[:, i].mean() / nt:.0f}" for i, n in enumerate(names)) +
+              f"; slow path in {r[:, 13].mean() / nt * 100:.0f} % of the tiles; loop total {r[:, 9].mean() / nt:.0f}/tile, {r[:, 10].mean() / 100:.1f} us per workgroup = {r[:, 9].mean() / r[:, 10].mean() * 0.1:.2f} GHz")
+    t0 = rec[:, 12].min()
+    print("fused bwd: workgroup start times (us after the first), percentiles 10/50/90/100:",
+          [round(float(x) / 100, 1) for x in torch.quantile(rec[:, 12] - t0, torch.tensor([0.1, 0.5, 0.9, 1.0], dtype=torch.float64))],
+          "; end of the last:", round(float((rec[:, 12] + rec[:, 10]).max() - t0) / 100, 1))
 if os.environ.get("ATTN_PROFILE"):
     ops.attn_fwd(q, k, v, o, lse, causal=bool(causal)); torch.cuda.synchronize()
     nblk = B * H * ((Lq + 127) // 128)

@@ -1,0 +1,41 @@
+#!/bin/bash
+# One gpurun call of round 6: tools/r06_call.sh <tag> <step> [<step> ...]   (outputs under gpurun_out/r06<tag>/)
+#   steps: attn_tests | attn_bench | gpu_tests | bench | bench_extra | prof | pmc | encfwd | hf | ...  (see the case below)
+tag=$1; shift
+out=gpurun_out/r06$tag; mkdir -p $out
+export TMPDIR=/tmp
+for step in "$@"; do
+  echo "=== $step" | tee -a $out/log.txt
+  case $step in
+    attn_tests) timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -k "attn" 2>&1 | tail -15 | tee $out/attn_tests.txt
+                timeout 900 python -m pytest tests/test_gpu_fullsize.py -x -q -k "attention_at_bench_shape" -s 2>&1 | tail -15 | tee -a $out/attn_tests.txt ;;
+    attn_bench) ATTN_LOG2=1 timeout 600 python tools/bench_attn.py 2>&1 | tee $out/attn_bench.txt ;;
+    attn_prof)  ATTN_LOG2=1 ATTN_BWD_REPS=1 ATTN_PROFILE_FUSED=1 DICOW_HIP_LIB=$PWD/tools/libv_fprof.so timeout 600 python tools/bench_attn.py 2>&1 | tee $out/attn_prof.txt ;;
+    attn_rot)   for r in 0 1 2 99; do echo "rstride $r" | tee -a $out/attn_rot.txt; DICOW_ATTN_FUSED_RSTRIDE=$r ATTN_LOG2=1 ATTN_BWD_REPS=2 timeout 600 python tools/bench_attn.py 2>&1 | grep attn_bwd | tee -a $out/attn_rot.txt; done ;;
+    attn_rocprof) (cd /tmp && ATTN_LOG2=1 ATTN_BWD_REPS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_attn_$tag -o attn -- python $GRAFT_REPO_ROOT/tools/bench_attn.py > $GRAFT_REPO_ROOT/$out/attn_rocprof_run.txt 2>&1)
+                find /tmp/prof_attn_$tag -name "*kernel_stats.csv" -exec cp {} $out/attn_kernel_stats.csv \; ; head -12 $out/attn_kernel_stats.csv ;;
+    attn_abl)   for rep in 1 2; do for v in base abl1 abl63; do l=$PWD/ts-asr-whisper_amd/libdicow_hip.so; [ $v != base ] && l=$PWD/tools/libv_f$v.so
+                  echo -n "$v: " | tee -a $out/attn_abl.txt; DICOW_HIP_LIB=$l ATTN_LOG2=1 ATTN_BWD_REPS=1 timeout 300 python tools/bench_attn.py 2>&1 | grep "fused" | tee -a $out/attn_abl.txt; done; done ;;
+    attn_pmc)   for r in 1 2 99; do for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+                  (cd /tmp && DICOW_ATTN_FUSED_RSTRIDE=$r ATTN_LOG2=1 ATTN_BWD_REPS=1 timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$tag -- python $GRAFT_REPO_ROOT/tools/bench_attn.py > /tmp/pmc_run.txt 2>&1)
+                  f=$(ls /tmp/pmc_$tag/*/*counter_collection.csv 2>/dev/null | head -1)
+                  python - "$f" "$r" <<'PY' | tee -a $out/attn_pmc.txt
+import csv, sys, collections
+agg = collections.defaultdict(lambda: [0, 0.0])
+for row in csv.DictReader(open(sys.argv[1])):
+    name = (row.get("Kernel_Name") or "").split("(")[0].replace("void ", "")
+    if not name.startswith("attn_"): continue
+    k = (name, row["Counter_Name"]); agg[k][0] += 1; agg[k][1] += float(row["Counter_Value"] or 0)
+for (name, c), (n, v) in sorted(agg.items()): print(f"rstride {sys.argv[2]}  {name:40s} {c:14s} per launch {v / n / 1e6:12.2f} M   ({n} launches)")
+PY
+                  rm -rf /tmp/pmc_$tag; done; done ;;
+    gpu_tests)  timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee $out/gpu_tests.txt ;;
+    bench)      timeout 900 python bench.py 2>&1 | tail -3 | tee $out/bench_default.json ;;
+    bench2)     timeout 900 python bench.py 2>&1 | tail -1 | tee $out/bench_default_again.json ;;
+    ab_step)    for i in 1 2; do DICOW_ATTN_BWD_FUSED=0 timeout 600 python bench.py --no-extra --no-cpu-baseline 2>&1 | tail -1 | tee -a $out/ab_step_unfused.json
+                                 DICOW_ATTN_BWD_FUSED=1 timeout 600 python bench.py --no-extra --no-cpu-baseline 2>&1 | tail -1 | tee -a $out/ab_step_fused.json; done ;;
+    prof)       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -o step -- python $GRAFT_REPO_ROOT/bench.py --no-extra --no-cpu-baseline --steps 10 --warmup 3 > $GRAFT_REPO_ROOT/$out/prof_bench.json 2>$GRAFT_REPO_ROOT/$out/prof_err.txt)
+                find /tmp/prof_$tag -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \; ;;
+    *) echo "unknown step $step" ;;
+  esac
+done

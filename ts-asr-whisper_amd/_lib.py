@@ -68,7 +68,8 @@ class AttnBwdArgs(C.Structure):
                 ("o_bs", c_i64), ("o_rs", c_i64), ("do_bs", c_i64), ("do_rs", c_i64),
                 ("dq_bs", c_i64), ("dq_rs", c_i64), ("dk_bs", c_i64), ("dk_rs", c_i64), ("dv_bs", c_i64), ("dv_rs", c_i64),
                 ("B", c_i), ("H", c_i), ("Lq", c_i), ("Lk", c_i), ("causal", c_i), ("dq_scale", c_f),
-                ("dq_colsum", c_vp), ("dv_colsum", c_vp), ("cs_ws", c_vp), ("cs_ws_bytes", c_i64), ("q_log2", c_i)]
+                ("dq_colsum", c_vp), ("dv_colsum", c_vp), ("cs_ws", c_vp), ("cs_ws_bytes", c_i64), ("q_log2", c_i),
+                ("fused_ws", c_vp), ("fused_ws_bytes", c_i64), ("fused_mode", c_i)]
 
 
 class CeArgs(C.Structure):
@@ -120,6 +121,7 @@ _SIGS = {
     "dicow_gemm_tn_group": [C.POINTER(GemmTnGroupArgs), c_vp],
     "dicow_attn_fwd": [C.POINTER(AttnFwdArgs), c_vp],
     "dicow_attn_bwd": [C.POINTER(AttnBwdArgs), c_vp],
+    "dicow_attn_bwd_fused_status": [c_vp],
     "dicow_ce_loss_fwd": [C.POINTER(CeArgs), c_vp],
     "dicow_ce_loss_bwd": [C.POINTER(CeArgs), c_vp, c_vp],
     "dicow_ctc_loss_fwd": [C.POINTER(CtcArgs), c_vp],
@@ -195,6 +197,7 @@ _SIGS64 = {   # functions returning int64_t (workspace sizes)
     "dicow_colsum_ws_bytes": [c_i, c_i],
     "dicow_gemm_nt_colsum_ws_bytes": [c_i, c_i],
     "dicow_attn_bwd_colsum_ws_bytes": [c_i, c_i, c_i, c_i],
+    "dicow_attn_bwd_fused_ws_bytes": [c_i, c_i, c_i, c_i],
     "dicow_fddt_ln_bwd_ws_bytes": [c_i, c_i],
     "dicow_gemm_tn_ws_bytes": [C.POINTER(GemmTnArgs)],
     "dicow_gemm_nt_splitk_ws_bytes": [C.POINTER(GemmArgs)],

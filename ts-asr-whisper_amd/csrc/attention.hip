@@ -16,6 +16,7 @@
 // the source address (K: ds_read_b128 conflict-free; V: tr-read conflict-free).
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -63,6 +64,28 @@ __device__ __forceinline__ void stage_tile(const tile_src_t& t, int row0, char* 
 #pragma unroll
     for (int i = 0; i < NI; ++i)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(t.rs, (lds_void_t*)(lds + (wave * NI + i) * 1024), 16, t.vo[i], so, 0, 0);
+}
+
+// LDS-DMA the compiler must not see.  hipcc tracks every `buffer_load ... lds` it emits and puts s_waitcnt vmcnt(0) in front of the next
+// LDS load whose address it cannot tell apart from the DMA's destination -- in practice every typed LDS load: the prefetch of the
+// next tile, the flag poll and the incoming dQ sum would be waited for at the first fragment read of every block (attn_bwd_dkv_kernel
+// paid exactly that, ~800 cycles per tile, until round 6).  The backward kernels issue their DMA from inline assembly (m0 = wave-uniform LDS address;
+// nothing else in the kernel uses m0) and orders it by hand: s_waitcnt vmcnt + s_barrier.
+template <int SC>      // SC: 0 = default cache policy, 1 = sc0 sc1 (the hand-off traffic: the reader's L1 is bypassed)
+__device__ __forceinline__ void dma16x(unsigned lds_addr, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    if constexpr (SC) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc0 sc1 lds" :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+template <int SC>
+__device__ __forceinline__ void dma4x(unsigned lds_addr, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    if constexpr (SC) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen sc0 sc1 lds" :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+template <int NI = 2>
+__device__ __forceinline__ void stage_tile_x(const tile_src_t& t, int row0, char* lds, int wave) {
+    const unsigned so = (unsigned)(row0 * t.row_bytes), la = (unsigned)(uintptr_t)lds + (unsigned)(wave * NI) * 1024u;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) dma16x<0>(la + i * 1024u, t.rs, t.vo[i], so);
 }
 
 // 8 transposing reads (one 32-key block x 64 d) + wait, as ONE asm statement (see gemm.hip for the rationale).
@@ -857,10 +880,20 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
     const int t0 = a.causal ? (kblk0 / KV_TILE) : 0;                 // query tiles entirely before the key block see none of it
     const int nt = (a.Lq + KV_TILE - 1) / KV_TILE;
     const tile_src_t srcQ = make_tile_src<SWZ_U, NI>(Q, a.q_rs, a.Lq, wave, lane), srcdO = make_tile_src<SWZ_U, NI>(dO, a.do_rs, a.Lq, wave, lane);
+    // (round 6: the DMA is issued from inline assembly -- see dma16x: the compiler's own LDS-DMA made it wait for the NEXT tile's DMA in
+    // front of the first seed read of every block)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0) as a builtin: the compiler's scoreboard learns that the K / V fragment loads are done
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(delta), 0,
+                                                                         (unsigned)(((int64_t)a.B * a.H * a.Lq + a.Lq) * 4), 0x00020000);
+    const unsigned stat_plane = (wave & 1) ? 0u : (unsigned)((int64_t)a.B * a.H * a.Lq * 4);
+    auto stage_stats_x = [&](int q0, char* dst) {
+        int q = q0 + lane; q = q < a.Lq ? q : a.Lq - 1;
+        dma4x<0>((unsigned)(uintptr_t)dst + (unsigned)(wave & 1) * 256u, rsS, stat_plane + (unsigned)q * 4u, 0u);
+    };
     if (t0 < nt) {
-        stage_tile<NI>(srcQ, t0 * KV_TILE, smem, wave);
-        stage_tile<NI>(srcdO, t0 * KV_TILE, smem + TILE_BYTES, wave);
-        stage_stats64(lse, delta, t0 * KV_TILE, a.Lq, smem + 4 * TILE_BYTES, wave, lane);
+        stage_tile_x<NI>(srcQ, t0 * KV_TILE, smem, wave);
+        stage_tile_x<NI>(srcdO, t0 * KV_TILE, smem + TILE_BYTES, wave);
+        stage_stats_x(t0 * KV_TILE, smem + 4 * TILE_BYTES);
     }
     // lane-derived row-fragment offsets (swizzle XORs) computed once: plain VALU instructions share the SIMD's issue port
     // with the MFMAs, so per-tile address arithmetic is pure loss
@@ -884,9 +917,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
         char* sdO = sQ + TILE_BYTES;
         if (t + 1 < nt) {
             char* nQ = smem + ((t - t0 + 1) & 1) * 2 * TILE_BYTES;
-            stage_tile<NI>(srcQ, (t + 1) * KV_TILE, nQ, wave);
-            stage_tile<NI>(srcdO, (t + 1) * KV_TILE, nQ + TILE_BYTES, wave);
-            stage_stats64(lse, delta, (t + 1) * KV_TILE, a.Lq, smem + 4 * TILE_BYTES + ((t - t0 + 1) & 1) * 512, wave, lane);
+            stage_tile_x<NI>(srcQ, (t + 1) * KV_TILE, nQ, wave);
+            stage_tile_x<NI>(srcdO, (t + 1) * KV_TILE, nQ + TILE_BYTES, wave);
+            stage_stats_x((t + 1) * KV_TILE, smem + 4 * TILE_BYTES + ((t - t0 + 1) & 1) * 512);
             asm volatile("s_waitcnt vmcnt(%0)" :: "i"(2 * NI + 1) : "memory");     // this tile landed; the next one (2 NI tile pieces + 1 statistics piece) may fly
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -984,8 +1017,598 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fused backward (5 matrix passes)
+// One kernel for dQ, dK and dV of a dense (non-causal) problem that fills the chip (the encoder's 1500 x 1500 self-attention and
+// the SE-DiCoW enrollment cross-attention).  The two-kernel form above computes S and dP twice (7 matrix passes per score
+// block); here a workgroup owns 128 keys (wave = 32 keys, as attn_bwd_dkv_kernel), walks the 64-query tiles ONCE and produces
+//   per 32 x 32 block:   S = Q K^T, dP = dO V^T          (A = Q / dO row fragments from LDS, B = K / V held in registers)
+//                        dV^T += dO^T P, dK^T += Q^T dS   (A = transposing reads, B = P / dS straight from the accumulators)
+//   per 64-query tile:   dS^T (bf16) of the whole workgroup -> LDS image [128 keys][64 q]   (the lane owns a KEY column of dS,
+//                        the dQ product contracts over keys: the transpose goes through LDS, 16 KB per tile, double-buffered)
+//                        dQ^T[d][q] = K^T[d][key] . dS^T[key][q] over the workgroup's 128 keys: wave w computes the block
+//                        (q block w >> 1, d block w & 1); its K^T fragments are loop-invariant (32 registers, read once)
+// The dQ tile of a (batch, head) is the sum over its key blocks = over WORKGROUPS.  No atomics (bit-reproducible): the key
+// blocks of a (batch, head) run on ONE XCD (attn_block_coords) in dispatch order, every one walks the query tiles in the same
+// order, and key block j adds its partial to the fp32 tile in the workspace AFTER key block j - 1 did -- a flag per
+// (tile, wave block) counts the contributions; the tile lives in that XCD's L2 between the hand-offs (plain stores keep the line
+// in L2, sc1 loads bypass the reader's L1; tools/probe_handoff.hip: 1.1-1.4 us per hop, bit-exact).  Key block 0 stores without
+// reading, the last key block scales, rounds and writes the bf16 dQ rows (and the q-bias column sums).  Block j never waits for a
+// block dispatched after it, so the chain cannot deadlock while workgroups are dispatched in order; a wait that exceeds its
+// budget (or a (batch, head) found on two XCDs) raises the status word of the workspace instead of hanging
+// (dicow_attn_bwd_fused_status).  The workspace tiles are in FRAGMENT order ([q4][lane][4 floats] per wave block): every
+// hand-off load / store instruction moves 1 KB contiguous.
+// One barrier per tile: [A(t): scores, dV, dK, dS -> LDS] wait DMA(t+1) | barrier | request DMA(t+2) [B(t): dQ product, hand-off].
+#define DS_BYTES (128 * 128)
+#define FUSED_WS_HDR 4096                    // status words (int[0] = error bits, int[1] = abort), then per-pair XCD ids; flags follow
+#define FUSED_ERR_TIMEOUT 1
+#define FUSED_ERR_XCD 2
+#ifndef ATTN_FUSED_SPIN
+#define ATTN_FUSED_SPIN (1 << 15)
+#endif
+
+// -delta[q] = -rowsum(dO * O) and -lse (base-2 units in q_log2 mode) for every (b, h, q): the seeds of the dP / S accumulators
+// (computed in the dq kernel's prologue in the two-kernel form); 8 lanes per row.  Also clears the header and flags of the workspace.
+template <bool LOG2>
+__global__ void __launch_bounds__(256) attn_bwd_stats_kernel(const dicow_attn_bwd_args a, unsigned* zero_words, int n_zero) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid < n_zero) zero_words[gid] = 0u;
+    const int64_t row = gid >> 3, nrows = (int64_t)a.B * a.H * a.Lq;
+    const int p = (int)(gid & 7);
+    if (row >= nrows) return;                                  // (rows are 8-lane groups: a group leaves together)
+    const int q = (int)(row % a.Lq), bh = (int)(row / a.Lq), h = bh % a.H, b = bh / a.H;
+    const unsigned short* Op = reinterpret_cast<const unsigned short*>(a.o) + (int64_t)b * a.o_bs + (int64_t)q * a.o_rs + h * HD + p * 8;
+    const unsigned short* dOp = reinterpret_cast<const unsigned short*>(a.d_o) + (int64_t)b * a.do_bs + (int64_t)q * a.do_rs + h * HD + p * 8;
+    const bf16x8_t of = *reinterpret_cast<const bf16x8_t*>(Op), df = *reinterpret_cast<const bf16x8_t*>(dOp);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(bfbits2f((unsigned short)of[e]), bfbits2f((unsigned short)df[e]), s);
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    if (p == 0) {
+        a.delta[row] = -s;
+        a.delta[nrows + row] = LOG2 ? -a.lse[row] * LOG2E : -a.lse[row];
+    }
+}
+
+// 8 transposing reads of ONE 32-column block (bases a0 / a1 = sections 0 / 1) over two consecutive 32-row blocks at OFF:
+// frag(rb, x) = (r[4 rb + 2 x], r[4 rb + 2 x + 1]),  rb = row block, x = 16-row half
+template <int OFF>
+__device__ __forceinline__ void tr_issue_c(tr8_t& t, unsigned a0, unsigned a1) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %1, %9 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %2, %8 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %3, %9 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %4, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %5, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %6, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %7, %9 offset:%13"
+        : "=&v"(t.r0), "=&v"(t.r1), "=&v"(t.r2), "=&v"(t.r3), "=&v"(t.r4), "=&v"(t.r5), "=&v"(t.r6), "=&v"(t.r7)
+        : "v"(a0), "v"(a1), "i"(OFF), "i"(OFF + 2048), "i"(OFF + 4096), "i"(OFF + 6144)
+        : "memory");
+}
+__device__ __forceinline__ void tr_pack_c(bf16x8_t (&f)[2][2], const tr8_t& t) {     // f[row block][x]
+    f[0][0] = __builtin_shufflevector(t.r0, t.r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[0][1] = __builtin_shufflevector(t.r2, t.r3, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[1][0] = __builtin_shufflevector(t.r4, t.r5, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[1][1] = __builtin_shufflevector(t.r6, t.r7, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4f_t;
+
+// poll one flag word until it reads `expect` (every lane loads the same word, L1 bypassed); false = gave up
+__device__ __forceinline__ bool fused_wait_flag(__amdgpu_buffer_rsrc_t rsF, unsigned fo, unsigned expect, int* status) {
+    for (int spin = 0;; ++spin) {
+        unsigned f;
+        asm volatile("buffer_load_dword %0, %1, %2, 0 offen sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(f) : "v"(fo), "s"(rsF) : "memory");
+        if ((unsigned)__builtin_amdgcn_readfirstlane((int)f) == expect) return true;
+        if ((spin & 63) == 63) {
+            const int ab = __hip_atomic_load(status + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__builtin_amdgcn_readfirstlane(ab) != 0 || spin >= ATTN_FUSED_SPIN) {
+                if ((threadIdx.x & 63) == 0) { atomicOr(status, FUSED_ERR_TIMEOUT); __hip_atomic_store(status + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+#ifndef ATTN_FUSED_PROFILE
+#define ATTN_FUSED_PROFILE 0
+#endif
+#ifndef ATTN_FUSED_ABL
+#define ATTN_FUSED_ABL 0      // ablation builds (results are garbage, only the time matters): 1 no hand-off, 2 no dQ product, 4 no dS^T writes, 8 no exponentials, 16 no DMA after the prologue, 32 no dV / dK MFMAs
+#endif
+#if ATTN_FUSED_PROFILE
+// per-workgroup cycle accounting (wave 0): stamps 0..7 per tile, the deltas to the previous stamp summed over the tiles; record of 16
+// int64 per workgroup behind the tiles of the workspace (tools/bench_attn.py ATTN_PROFILE_FUSED=1)
+#define FPROF_DECL long long fp_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; int fp_slow = 0; long long fp_prev = __builtin_readcyclecounter(); const long long fp_t0 = fp_prev, fp_r0 = wall_clock64();
+#define FPROF(i) { const long long n_ = __builtin_readcyclecounter(); fp_acc[i] += n_ - fp_prev; fp_prev = n_; }
+#define FPROF_DEP(x) asm volatile("" : "+v"(x));
+#define FPROF_SLOW ++fp_slow;
+#define FPROF_END { if (tid == 0) { long long* rec = reinterpret_cast<long long*>(tiles + nflags * 4096) + (long long)blockIdx.x * 16; \
+      for (int i = 0; i < 9; ++i) rec[i] = fp_acc[i]; rec[9] = __builtin_readcyclecounter() - fp_t0; rec[10] = wall_clock64() - fp_r0; rec[11] = kblk; rec[12] = fp_r0; rec[13] = fp_slow; } }
+#else
+#define FPROF_DECL
+#define FPROF(i)
+#define FPROF_DEP(x)
+#define FPROF_SLOW
+#define FPROF_END
+#endif
+
+// LDS reads the compiler must not see.  A typed LDS load that follows an LDS-DMA issue makes hipcc insert s_waitcnt vmcnt(0) in front of
+// it (SIInsertWaitcnts cannot tell the DMA's destination from the load's address): the prefetch of the next tile, the flag poll and
+// the incoming dQ sum would all be waited for at the first seed read of every block.  (attn_bwd_dkv_kernel pays exactly that: its seed
+// reads wait for the next tile's DMA, ~800 cycles per tile.)
+struct seeds_t { f32x4_t l0, l1, l2, l3, d0, d1, d2, d3; };
+template <int OFF>      // -lse[q] / -delta[q] of one 32-query block: addr = statistics base + 16 * half
+__device__ __forceinline__ void seeds_issue(seeds_t& t, unsigned addr) {
+    asm volatile(
+        "ds_read_b128 %0, %8 offset:%9\n\t"
+        "ds_read_b128 %1, %8 offset:%10\n\t"
+        "ds_read_b128 %2, %8 offset:%11\n\t"
+        "ds_read_b128 %3, %8 offset:%12\n\t"
+        "ds_read_b128 %4, %8 offset:%13\n\t"
+        "ds_read_b128 %5, %8 offset:%14\n\t"
+        "ds_read_b128 %6, %8 offset:%15\n\t"
+        "ds_read_b128 %7, %8 offset:%16"
+        : "=&v"(t.l0), "=&v"(t.l1), "=&v"(t.l2), "=&v"(t.l3), "=&v"(t.d0), "=&v"(t.d1), "=&v"(t.d2), "=&v"(t.d3)
+        : "v"(addr), "i"(OFF), "i"(OFF + 32), "i"(OFF + 64), "i"(OFF + 96), "i"(OFF + 256), "i"(OFF + 288), "i"(OFF + 320), "i"(OFF + 352)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void seeds_wait(seeds_t& t) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(t.l0), "+v"(t.l1), "+v"(t.l2), "+v"(t.l3), "+v"(t.d0), "+v"(t.d1), "+v"(t.d2), "+v"(t.d3) : "i"(N) : "memory");
+}
+__device__ __forceinline__ f32x16_t cat16(f32x4_t a, f32x4_t b, f32x4_t c, f32x4_t d) {
+    typedef __attribute__((ext_vector_type(8))) float f32x8_t;
+    const f32x8_t lo = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+}
+__device__ __forceinline__ unsigned lds_read_u32_now(unsigned addr) {
+    unsigned v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+    return v;
+}
+// 4 transposing reads = the fragments of ONE 16-row half of a 32-row block of a U image, both 32-column blocks: f[dblk] = (r[2 dblk], r[2 dblk + 1])
+struct tr4_t { bf16x4_t r0, r1, r2, r3; };
+template <int OFF>
+__device__ __forceinline__ void tr_issue_h(tr4_t& t, unsigned a00, unsigned a01, unsigned a10, unsigned a11) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %4 offset:%8\n\t"
+        "ds_read_b64_tr_b16 %1, %5 offset:%8\n\t"
+        "ds_read_b64_tr_b16 %2, %6 offset:%8\n\t"
+        "ds_read_b64_tr_b16 %3, %7 offset:%8"
+        : "=&v"(t.r0), "=&v"(t.r1), "=&v"(t.r2), "=&v"(t.r3) : "v"(a00), "v"(a01), "v"(a10), "v"(a11), "i"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tr_wait_h2(tr4_t& a, tr4_t& b) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a.r0), "+v"(a.r1), "+v"(a.r2), "+v"(a.r3), "+v"(b.r0), "+v"(b.r1), "+v"(b.r2), "+v"(b.r3) : "i"(N) : "memory");
+}
+__device__ __forceinline__ void tr_pack_h(bf16x8_t (&f)[2], const tr4_t& t) {
+    f[0] = __builtin_shufflevector(t.r0, t.r1, 0, 1, 2, 3, 4, 5, 6, 7);
+    f[1] = __builtin_shufflevector(t.r2, t.r3, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+struct land_t { f32x4_t p0, p1, p2, p3; };
+__device__ __forceinline__ void land_read_now(land_t& t, unsigned addr) {      // 4 x [lane][4 floats] at 1 KB strides
+    asm volatile(
+        "ds_read_b128 %0, %4 offset:0\n\t"
+        "ds_read_b128 %1, %4 offset:1024\n\t"
+        "ds_read_b128 %2, %4 offset:2048\n\t"
+        "ds_read_b128 %3, %4 offset:3072\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(t.p0), "=&v"(t.p1), "=&v"(t.p2), "=&v"(t.p3) : "v"(addr) : "memory");
+}
+
+template <bool LOG2>
+__global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn_bwd_args a, char* fws, int nt, int nkb, int rstride) {
+    constexpr int KB = 128;
+    __shared__ __attribute__((aligned(1024))) char smem[4 * TILE_BYTES + 2 * DS_BYTES + 2048];   // Q0 dO0 Q1 dO1 | dS^T x2 | lse/delta x2 | flag polls
+    char* const sDS = smem + 4 * TILE_BYTES;               // the dS^T image [128 keys][64 q] (ONE buffer: two barriers per tile)
+    char* const sZ = sDS + DS_BYTES;                         // landing zone of the incoming dQ sums: 4 KB per wave
+    char* const sST = sZ + DS_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = lane >> 5;
+    // every key block of a (batch, head) on ONE XCD, in dispatch order (dispatch id L runs on XCD L % 8): pair p lives on XCD p % 8;
+    // the grid is padded to whole groups of 8 pairs and the workgroups of the pairs that do not exist leave at once
+    int kblk, h, b;
+    {
+        const int L = blockIdx.x, xcd = L & 7, idx = L >> 3;
+        const int bh = (idx / nkb) * 8 + xcd;
+        if (bh >= a.H * a.B) return;
+        kblk = idx % nkb; h = bh % a.H; b = bh / a.H;
+    }
+    const int kblk0 = kblk * KB;
+    const unsigned short* Q = reinterpret_cast<const unsigned short*>(a.q) + (int64_t)b * a.q_bs + h * HD;
+    const unsigned short* K = reinterpret_cast<const unsigned short*>(a.k) + (int64_t)b * a.k_bs + h * HD;
+    const unsigned short* V = reinterpret_cast<const unsigned short*>(a.v) + (int64_t)b * a.v_bs + h * HD;
+    const unsigned short* dO = reinterpret_cast<const unsigned short*>(a.d_o) + (int64_t)b * a.do_bs + h * HD;
+    const float* lse = a.delta + (int64_t)a.B * a.H * a.Lq + ((int64_t)b * a.H + h) * a.Lq;     // -lse plane of the workspace
+    const float* delta = a.delta + ((int64_t)b * a.H + h) * a.Lq;                                // -delta plane
+    int* const status = reinterpret_cast<int*>(fws);
+    const int pair = b * a.H + h;
+
+    // this wave's 32 keys as B operands (column = key, k-slots = d)
+    const int key = kblk0 + wave * 32 + (lane & 31);
+    const int key_c = key < a.Lk ? key : a.Lk - 1;
+    bf16x8_t kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = *reinterpret_cast<const bf16x8_t*>(K + (int64_t)key_c * a.k_rs + kk * 16 + hh * 8);
+        vf[kk] = *reinterpret_cast<const bf16x8_t*>(V + (int64_t)key_c * a.v_rs + kk * 16 + hh * 8);
+    }
+    // K^T fragments of the dQ product: M = this wave's 32 d columns (d block wave & 1), k = the workgroup's 128 keys.  The key
+    // block passes through the (still unused) ring slots once, as a U image; rows past Lk read as zero.
+    const int dblk = wave & 1, qsub = wave >> 1;
+    bf16x8_t ktf[4][2];
+    {
+        const tile_src_t srcKb = make_tile_src<SWZ_U>(K + (int64_t)kblk0 * a.k_rs, a.k_rs, a.Lk - kblk0, wave, lane);
+        stage_tile_x(srcKb, 0, smem, wave);
+        stage_tile_x(srcKb, KV_TILE, smem + TILE_BYTES, wave);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned ka0 = tr_base_u(smem, lane, dblk, 0), ka1 = tr_base_u(smem, lane, dblk, 1);
+        tr8_t t0, t1;
+        tr_issue_c<0>(t0, ka0, ka1);
+        tr_issue_c<8192>(t1, ka0, ka1);
+        tr_wait<0>(t0);
+        tr_wait<0>(t1);
+        bf16x8_t f[2][2];
+        tr_pack_c(f, t0); ktf[0][0] = f[0][0]; ktf[0][1] = f[0][1]; ktf[1][0] = f[1][0]; ktf[1][1] = f[1][1];
+        tr_pack_c(f, t1); ktf[2][0] = f[0][0]; ktf[2][1] = f[0][1]; ktf[3][0] = f[1][0]; ktf[3][1] = f[1][1];
+        // a wave whose keys all lie past Lk never writes its rows of the dS^T images: they stay zero
+        const bool live0 = kblk0 + wave * 32 < a.Lk;
+        if (!live0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                *reinterpret_cast<uint4*>(sDS + (wave * 32) * 128 + c * 1024 + lane * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // the ring slots are free again
+        asm volatile("" ::: "memory");
+    }
+    f32x16_t dk[2], dv[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[d][r] = 0.f; dv[d][r] = 0.f; }
+    constexpr float dk_mul = LOG2 ? LN2 : 1.0f;
+
+    // ---- the order of the tiles.  Key block j starts at tile s_j = floor(j nt / nkb) and wraps around (nt >= nkb; otherwise every block
+    // starts at tile 0).  The visitors of a tile then arrive a whole stretch of tiles apart -- key block k = the last one with s_k <= tile
+    // first (rank 0: stores without reading), then k - 1, ..., 0, nkb - 1, ..., k + 1 (rank nkb - 1: writes the bf16 rows) -- so a
+    // hand-off has (nt / nkb) tile times to land before it is needed, and every workgroup is the first visitor of some tiles and the
+    // last of others (balanced).  rank(tile) = (k - j) mod nkb is a fixed function of the shape: the sum order is the same in every run.
+    const int R = rstride > 0 ? rstride : nt / nkb;          // tiles between the starts of consecutive key blocks (0: nt < nkb -- every block starts at tile 0)
+    const bool rot = R > 0 && R * (nkb - 1) < nt;
+    const int s_j = rot ? kblk * R : 0;
+    auto tile_of = [&](int i) { const int x = s_j + i; return x >= nt ? x - nt : x; };
+
+    const tile_src_t srcQ = make_tile_src<SWZ_U>(Q, a.q_rs, a.Lq, wave, lane), srcdO = make_tile_src<SWZ_U>(dO, a.do_rs, a.Lq, wave, lane);
+    // -lse / -delta of a 64-query tile: one 4-byte DMA per lane (waves 0 / 2 fetch lse, waves 1 / 3 delta: the same number of VMEM
+    // instructions in every wave); one descriptor over this (batch, head)'s rows of both planes of the workspace
+    const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(delta), 0,
+                                                                         (unsigned)(((int64_t)a.B * a.H * a.Lq + a.Lq) * 4), 0x00020000);
+    const unsigned stat_plane = (wave & 1) ? 0u : (unsigned)((int64_t)a.B * a.H * a.Lq * 4);
+    auto stage_stats_x = [&](int q0, char* dst) {
+        int q = q0 + lane; q = q < a.Lq ? q : a.Lq - 1;
+        dma4x<0>((unsigned)(uintptr_t)dst + (unsigned)(wave & 1) * 256u, rsS, stat_plane + (unsigned)q * 4u, 0u);
+    };
+    stage_tile_x(srcQ, tile_of(0) * KV_TILE, smem, wave);
+    stage_tile_x(srcdO, tile_of(0) * KV_TILE, smem + TILE_BYTES, wave);
+    stage_stats_x(tile_of(0) * KV_TILE, sST);
+    if (nt > 1) {
+        stage_tile_x(srcQ, tile_of(1) * KV_TILE, smem + 2 * TILE_BYTES, wave);
+        stage_tile_x(srcdO, tile_of(1) * KV_TILE, smem + 3 * TILE_BYTES, wave);
+        stage_stats_x(tile_of(1) * KV_TILE, sST + 512);
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // the first tile landed, the second may fly
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    int fo[4];                                             // row fragment offsets of q block 0 (q block 1: + 4096, the same swizzle)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) fo[kk] = uswz(lane & 31, kk * 2 + hh);
+    const unsigned qb00 = tr_base_u(smem, lane, 0, 0), qb01 = tr_base_u(smem, lane, 0, 1);
+    const unsigned qb10 = tr_base_u(smem, lane, 1, 0), qb11 = tr_base_u(smem, lane, 1, 1);
+    // dS^T image: this lane's key row; chunk c (4 queries = 8 bytes per half) at  dsw ^ (c << 4)
+    const int dsrow = wave * 32 + (lane & 31);
+    const int dsw = (dsrow * 128 + 8 * hh) ^ (rev3((dsrow >> 1) & 7) << 4);      // byte offset inside an image
+    const unsigned dsr0 = tr_base_u(sDS, lane, qsub, 0), dsr1 = tr_base_u(sDS, lane, qsub, 1);
+    const bool tail_half = ATTN_BWD_TAIL && nt * KV_TILE - a.Lq >= 32 && nt > 1;
+    const bool wave_live = kblk0 + wave * 32 < a.Lk;
+
+    // hand-off addressing: flag word and 4 KB fragment tile of (pair, tile, this wave)
+    unsigned* const flags = reinterpret_cast<unsigned*>(fws + FUSED_WS_HDR);
+    const int64_t nflags = (int64_t)a.B * a.H * nt * 4;
+    char* const tiles = fws + FUSED_WS_HDR + ((nflags * 4 + 4095) & ~(int64_t)4095);
+    const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc(flags, 0, (unsigned)(nflags * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(tiles, 0, (unsigned)(nflags * 4096), 0x00020000);
+    bool chain_ok = true;
+    if (nkb > 1 && tid == 0) {                               // every key block of a (batch, head) on ONE XCD?  (the hand-off rests on it)
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const int mine = (int)(xcc & 15u) + 1;
+        const int seen = atomicCAS(status + 16 + pair, 0, mine);        // (the header holds <= 1000 pairs: see the launcher)
+        if (seen != 0 && seen != mine) atomicOr(status, FUSED_ERR_XCD);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0), as a builtin: the compiler's own scoreboard learns that the prologue's loads are done
+    const unsigned voff = (unsigned)lane * 16u;
+    char* const sFL = sST + 1024 + wave * 256;               // landing zone of this wave's flag polls (one dword per lane, all the same)
+    const unsigned stat_addr = (unsigned)(uintptr_t)sST + 16u * (unsigned)hh, fl_addr = (unsigned)(uintptr_t)sFL;
+    // ---- a hand-off (tile i of this wave's (q block, d block) of dQ), pipelined so that none of its steps waits on the one before:
+    //   top of A(i)      the flag of tile i is polled (a 4-byte DMA into LDS: no register, no wait)
+    //   middle of A(i)   the poll has landed; flag up -> the sum so far is requested: DMA into the wave's 4 KB of the landing zone
+    //   end of B(i)      sum + this tile's product -> the workspace tile (or, for the last visitor, the bf16 rows of dQ)
+    //   middle of A(i+1) the s_waitcnt vmcnt(0) there has seen the stores acknowledged: the flag of tile i goes up
+    // A visitor needs the one before it to be about one and a half tile times ahead; the rotation puts nt / nkb tiles between them.
+    int pub_idx = -1, pub_val = 0;                           // stores in flight: the flag to raise at the next vmcnt(0)
+    // rank(t) = (k(t) - j) mod nkb, k(t) = min(nkb - 1, t / R) = the last key block that starts at or before tile t, carried incrementally
+    int rk_k = kblk, rk_rem = 0, cur_t = s_j;
+    const unsigned z_addr = (unsigned)(uintptr_t)sZ + (unsigned)wave * 4096u;
+
+    FPROF_DECL
+    // one tile; SLOT = i & 1 at compile time: every LDS address of the body is a lane register + an immediate
+    auto tile_body = [&](const int i, auto slot_tag) {
+        constexpr int SLOT = decltype(slot_tag)::value;
+        const int t = cur_t;
+        char* const sQ = smem + SLOT * 2 * TILE_BYTES;
+        char* const sdO = sQ + TILE_BYTES;
+        const int qt0 = t * KV_TILE;
+        const bool need_mask = (qt0 + KV_TILE > a.Lq) || (kblk0 + KB > a.Lk);
+        const bool two_blocks = !(tail_half && t == nt - 1);
+        const int q32 = qt0 + qsub * 32;                      // first query of this wave's block of the tile's dQ
+        const bool blk_live = q32 < a.Lq;
+        const int rank = rot ? (rk_k >= kblk ? rk_k - kblk : rk_k + nkb - kblk) : kblk;
+        const bool first = rank == 0, last = rank == nkb - 1;
+        const unsigned fidx = (unsigned)((pair * nt + t) * 4 + wave);
+        const bool handoff = blk_live && !first && !(ATTN_FUSED_ABL & 1);
+        unsigned vflag = 0u;                                  // the poll: a plain load (L1 bypassed) nobody waits for before the middle of the A phase
+        const unsigned fbyte = fidx * 4u;
+        if (handoff) asm volatile("buffer_load_dword %0, %1, %2, 0 offen sc0 sc1" : "=v"(vflag) : "v"(fbyte), "s"(rsF) : "memory");
+        FPROF(0)
+#define FUSED_QBLOCK(QB)                                                                                                \
+        {                                                                                                               \
+            constexpr int TOFF = SLOT * 2 * TILE_BYTES + (QB) * 4096;                                                   \
+            tr4_t tdo, tq;                        /* dO^T / Q^T fragments of ONE 16-query half at a time (registers) */ \
+            seeds_t sd;                                                                                                 \
+            seeds_issue<SLOT * 512 + (QB) * 128>(sd, stat_addr);                                                        \
+            tr_issue_h<TOFF + TILE_BYTES>(tdo, qb00, qb01, qb10, qb11);                                                 \
+            tr_issue_h<TOFF>(tq, qb00, qb01, qb10, qb11);                                                               \
+            seeds_wait<8>(sd);                                                                                          \
+            f32x16_t s = cat16(sd.l0, sd.l1, sd.l2, sd.l3), dp = cat16(sd.d0, sd.d1, sd.d2, sd.d3);                    \
+            _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                          \
+                const bf16x8_t qa = *reinterpret_cast<const bf16x8_t*>(sQ + fo[kk] + (QB) * 4096);                       \
+                const bf16x8_t da = *reinterpret_cast<const bf16x8_t*>(sdO + fo[kk] + (QB) * 4096);                      \
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kf[kk], s, 0, 0, 0);                                    \
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vf[kk], dp, 0, 0, 0);                                  \
+            }                                                                                                           \
+            f32x16_t pv, dsv;                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) pv[r] = (ATTN_FUSED_ABL & 8) ? s[r] : (LOG2 ? __builtin_amdgcn_exp2f(s[r]) : __builtin_amdgcn_exp2f(s[r] * LOG2E)); \
+            if (need_mask) {                                                                                            \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                        \
+                    const int qq = qt0 + (QB) * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);                                   \
+                    if (qq >= a.Lq || key >= a.Lk) pv[r] = 0.f;                                                         \
+                }                                                                                                       \
+            }                                                                                                           \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) dsv[r] = (ATTN_FUSED_ABL & 8) ? dp[r] : pv[r] * dp[r];       \
+            bf16x8_t qtf[2], dotf[2];                                                                                   \
+            _Pragma("unroll") for (int x = 0; x < 2; ++x) {                                                             \
+                tr_wait_h2<0>(tdo, tq);                                                                                 \
+                tr_pack_h(dotf, tdo);                                                                                   \
+                tr_pack_h(qtf, tq);                                                                                     \
+                const bf16x8_t pf = pack8(pv, 8 * x);                                                                   \
+                const bf16x8_t df = pack8(dsv, 8 * x);                                                                  \
+                const uint4 du = __builtin_bit_cast(uint4, df);                                                         \
+                if (!(ATTN_FUSED_ABL & 4)) {                                                                            \
+                *reinterpret_cast<uint2*>(sDS + (dsw ^ ((4 * (QB) + 2 * x) << 4))) = make_uint2(du.x, du.y);            \
+                *reinterpret_cast<uint2*>(sDS + (dsw ^ ((4 * (QB) + 2 * x + 1) << 4))) = make_uint2(du.z, du.w); }      \
+                _Pragma("unroll") for (int d = 0; d < 2; ++d) {                                                         \
+                    if (ATTN_FUSED_ABL & 32) { dv[d][0] += bfbits2f((unsigned short)(dotf[d][0] ^ pf[0])); dk[d][0] += bfbits2f((unsigned short)(qtf[d][0] ^ df[0])); } else { \
+                    dv[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dotf[d], pf, dv[d], 0, 0, 0);                       \
+                    dk[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf[d], df, dk[d], 0, 0, 0); }                      \
+                }                                                                                                       \
+                if (x == 0) {                     /* the second half's fragments: requested once the first half's MFMAs have read theirs */ \
+                    asm volatile("" : "+v"(dv[0]), "+v"(dk[0]), "+v"(dv[1]), "+v"(dk[1]));                               \
+                    tr_issue_h<TOFF + TILE_BYTES + 2048>(tdo, qb00, qb01, qb10, qb11);                                  \
+                    tr_issue_h<TOFF + 2048>(tq, qb00, qb01, qb10, qb11);                                                \
+                }                                                                                                       \
+            }                                                                                                           \
+        }
+        if (wave_live) FUSED_QBLOCK(0)
+        // ---- middle of the A phase: everything requested so far has long landed (the next tile's DMA dates from the B phase before),
+        // so this wait is all but free -- and it has seen the stores of the tile before acknowledged: its flag goes up.  The poll of
+        // this tile's flag is in: flag up -> the sum so far is requested now and has the rest of the tile to land.
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(vflag) :: "memory");
+        if (pub_idx >= 0) {
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32((unsigned)pub_val, rsF, (unsigned)pub_idx * 4u, 0, 0);
+            pub_idx = -1;
+        }
+        bool have = false, again = false;
+        if (handoff) {
+            have = chain_ok && (unsigned)__builtin_amdgcn_readfirstlane((int)vflag) == (unsigned)rank;
+            if (have) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) dma16x<1>(z_addr + q4 * 1024u, rsW, voff + q4 * 1024u, fidx * 4096u);
+            } else if (chain_ok) {                            // not yet: a second poll, looked at in front of the barrier
+                again = true;
+                asm volatile("buffer_load_dword %0, %1, %2, 0 offen sc0 sc1" : "=v"(vflag) : "v"(fbyte), "s"(rsF) : "memory");
+            }
+        }
+        if (wave_live && two_blocks) FUSED_QBLOCK(1)
+#undef FUSED_QBLOCK
+        FPROF(1)
+        // ---- barrier X: dS^T complete, this slot free for the tile after next, the next tile landed (its DMA is older than the
+        // four loads of the sum, which may stay in flight: loads complete in order)
+        if (have) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(vflag) :: "memory");
+        if (again && (unsigned)__builtin_amdgcn_readfirstlane((int)vflag) == (unsigned)rank) {     // second chance: the sum travels under the B phase
+            have = true;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) dma16x<1>(z_addr + q4 * 1024u, rsW, voff + q4 * 1024u, fidx * 4096u);
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        FPROF(2)
+        // ---- B phase: the next-but-one tile's DMA, the dQ product, the hand-off
+        const bool more = i + 2 < nt && !(ATTN_FUSED_ABL & 16);
+        if (more) {
+            int t2 = t + 2; t2 = t2 >= nt ? t2 - nt : t2; t2 *= KV_TILE;
+            stage_tile_x(srcQ, t2, sQ, wave);
+            stage_tile_x(srcdO, t2, sdO, wave);
+            stage_stats_x(t2, sST + SLOT * 512);
+        }
+        if (blk_live && !(ATTN_FUSED_ABL & 2)) {
+            tr8_t u0, u1;
+            tr_issue_c<0>(u0, dsr0, dsr1);
+            tr_issue_c<8192>(u1, dsr0, dsr1);
+            f32x16_t dq;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+            bf16x8_t f[2][2];
+            tr_wait<8>(u0);
+            tr_pack_c(f, u0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][0], f[0][0], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][1], f[0][1], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][0], f[1][0], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][1], f[1][1], dq, 0, 0, 0);
+            tr_wait<0>(u1);
+            tr_pack_c(f, u1);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[2][0], f[0][0], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[2][1], f[0][1], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[3][0], f[1][0], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[3][1], f[1][1], dq, 0, 0, 0);
+            FPROF_DEP(dq[0])
+            FPROF(3)
+            if (handoff) {
+                if (!have) {                                  // the slow path: the visitor before had not published by the middle of the A phase
+                    FPROF_SLOW
+                    if (chain_ok) chain_ok = fused_wait_flag(rsF, fidx * 4u, (unsigned)rank, status);
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) dma16x<1>(z_addr + q4 * 1024u, rsW, voff + q4 * 1024u, fidx * 4096u);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                } else if (more) {
+                    asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // only the 5 DMA instructions of the next-but-one tile are younger than the sum
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                FPROF(4)
+                land_t pr;
+                land_read_now(pr, z_addr + voff);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { dq[e] += pr.p0[e]; dq[4 + e] += pr.p1[e]; dq[8 + e] += pr.p2[e]; dq[12 + e] += pr.p3[e]; }
+            }
+            FPROF_DEP(dq[0])
+            FPROF(5)
+            if (ATTN_FUSED_ABL & 1) {
+            } else if (!last) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const u32x4f_t sv = {__float_as_uint(dq[4 * q4]), __float_as_uint(dq[4 * q4 + 1]), __float_as_uint(dq[4 * q4 + 2]), __float_as_uint(dq[4 * q4 + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(sv, rsW, voff + q4 * 1024u, fidx * 4096u, 0);
+                }
+                pub_idx = (int)fidx; pub_val = rank + 1;      // (raised once the stores have been acknowledged: the next vmcnt(0))
+            } else {
+                const int qrow = q32 + (lane & 31);
+                if (a.dq_colsum) {                            // q_proj bias gradient: partial row (b, 32-query block), columns h*64 + dblk*32 ..
+                    float* wsr = reinterpret_cast<float*>(a.cs_ws) + ((int64_t)(b * 2 * nt + (q32 >> 5)) * a.H + h) * HD + dblk * 32;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = qrow < a.Lq ? bf2f(f2bf(dq[r] * a.dq_scale)) : 0.f;
+                        const float tsum = half_wave_sum_dpp(v);
+                        if ((lane & 31) == 31) wsr[8 * (r >> 2) + 4 * hh + (r & 3)] = tsum;
+                    }
+                }
+                if (qrow < a.Lq) {
+                    unsigned short* DQ = reinterpret_cast<unsigned short*>(a.dq) + (int64_t)b * a.dq_bs + (int64_t)qrow * a.dq_rs + h * HD + dblk * 32;
+                    const float sc = a.dq_scale;
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        *reinterpret_cast<uint2*>(DQ + 8 * q4 + 4 * hh) =
+                            make_uint2(pack_bf16x2(dq[4 * q4] * sc, dq[4 * q4 + 1] * sc), pack_bf16x2(dq[4 * q4 + 2] * sc, dq[4 * q4 + 3] * sc));
+                }
+            }
+        } else if (last && a.dq_colsum) {                     // an all-padding 32-query block of the last tile: its partial row is zero
+            float* wsr = reinterpret_cast<float*>(a.cs_ws) + ((int64_t)(b * 2 * nt + (q32 >> 5)) * a.H + h) * HD + dblk * 32;
+            if (lane < 32) wsr[lane] = 0.f;
+        }
+        FPROF(6)
+        // the next tile and its rank
+        ++cur_t; ++rk_rem;
+        if (rk_rem == R) { rk_rem = 0; rk_k = rk_k + 1 < nkb ? rk_k + 1 : rk_k; }
+        if (cur_t == nt) { cur_t = 0; rk_k = 0; rk_rem = 0; }
+        // ---- barrier Y: every wave has read its columns of dS^T
+        FPROF(7)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        FPROF(8)
+    };
+    {
+        int i = 0;
+        for (; i + 1 < nt; i += 2) { tile_body(i, attn_ic<0>{}); tile_body(i + 1, attn_ic<1>{}); }
+        if (i < nt) tile_body(i, attn_ic<0>{});
+    }
+    if (pub_idx >= 0) {                                      // the last tile's flag
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32((unsigned)pub_val, rsF, (unsigned)pub_idx * 4u, 0, 0);
+    }
+    FPROF_END
+    if (a.dv_colsum) {        // v_proj bias gradient, fused: second workspace plane, partial row (b, key block, wave)
+        const int nqb = (a.Lq + 127) / 128, nkb128 = (a.Lk + 127) / 128;
+        float* wsr = reinterpret_cast<float*>(a.cs_ws) + (int64_t)a.B * nqb * 4 * a.H * HD +
+                     ((int64_t)((b * nkb128 + kblk) * 4 + wave) * a.H + h) * HD;
+        tile_colsum_partial(dv, 1.0f, key < a.Lk, wsr, lane);
+    }
+    if (key < a.Lk) {
+        unsigned short* DK = reinterpret_cast<unsigned short*>(a.dk) + (int64_t)b * a.dk_bs + (int64_t)key * a.dk_rs + h * HD;
+        unsigned short* DV = reinterpret_cast<unsigned short*>(a.dv) + (int64_t)b * a.dv_bs + (int64_t)key * a.dv_rs + h * HD;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int col = d * 32 + 8 * q4 + 4 * hh;
+                *reinterpret_cast<uint2*>(DK + col) = make_uint2(pack_bf16x2(dk[d][4 * q4] * dk_mul, dk[d][4 * q4 + 1] * dk_mul),
+                                                                 pack_bf16x2(dk[d][4 * q4 + 2] * dk_mul, dk[d][4 * q4 + 3] * dk_mul));
+                *reinterpret_cast<uint2*>(DV + col) = make_uint2(pack_bf16x2(dv[d][4 * q4], dv[d][4 * q4 + 1]),
+                                                                 pack_bf16x2(dv[d][4 * q4 + 2], dv[d][4 * q4 + 3]));
+            }
+    }
+}
+
 extern "C" int64_t dicow_attn_bwd_colsum_ws_bytes(int B, int H, int Lq, int Lk) {
     return (int64_t)B * (dicow_cdiv(Lq, 128) + dicow_cdiv(Lk, 128)) * 4 * H * HD * 4;
+}
+
+extern "C" int64_t dicow_attn_bwd_fused_ws_bytes(int B, int H, int Lq, int Lk) {
+    (void)Lk;
+    const int64_t nflags = (int64_t)B * H * dicow_cdiv(Lq, KV_TILE) * 4;
+    return FUSED_WS_HDR + ((nflags * 4 + 4095) & ~(int64_t)4095) + nflags * 4096
+#if ATTN_FUSED_PROFILE
+           + (int64_t)8 * dicow_cdiv((int64_t)B * H, 8) * dicow_cdiv(Lk, 128) * 128
+#endif
+        ;
+}
+// error bits a fused launch left in its workspace (0 = fine; read AFTER the stream has been synchronised): 1 = a hand-off wait
+// ran out of its budget, 2 = the key blocks of one (batch, head) were not all on one XCD.  Either way dq is not to be trusted.
+extern "C" int dicow_attn_bwd_fused_status(const void* fused_ws) {
+    int st[2] = {0, 0};
+    if (!fused_ws) return 0;
+    if (hipMemcpy(st, fused_ws, sizeof(st), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return st[0];
+}
+static bool attn_bwd_use_fused(const dicow_attn_bwd_args* a) {
+    if (!a->fused_ws || a->causal) return false;
+    const int64_t nkb = dicow_cdiv(a->Lk, 128), wgs = nkb * a->H * a->B;
+    if ((int64_t)a->B * a->H > 1000) return false;                                       // (the header's per-pair words)
+    if (a->fused_mode != 1 && (wgs < 1024 || a->Lq < 256)) return false;                // below two rounds of the chip the two-kernel form stays
+    const int64_t nflags = (int64_t)a->B * a->H * dicow_cdiv(a->Lq, KV_TILE) * 4;
+    if (nflags * 4096 >= ((int64_t)1 << 32)) return false;
+    return a->fused_ws_bytes >= dicow_attn_bwd_fused_ws_bytes(a->B, a->H, a->Lq, a->Lk);
 }
 
 extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
@@ -1000,6 +1623,38 @@ extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
     for (int i = 0; i < 16; ++i) DICOW_REQUIRE(rs[i] % 4 == 0, "attn_bwd: strides must keep 8-byte alignment");
     DICOW_REQUIRE(a->q_rs % 8 == 0 && a->k_rs % 8 == 0 && a->v_rs % 8 == 0 && a->do_rs % 8 == 0, "attn_bwd: q/k/v/dO row strides %% 8");
     hipStream_t st = (hipStream_t)stream;
+    DICOW_REQUIRE(!a->fused_ws || (((uintptr_t)a->fused_ws & 4095) == 0), "attn_bwd: fused_ws must be 4096-byte aligned");
+    if (attn_bwd_use_fused(a)) {
+        const int nt = dicow_cdiv(a->Lq, KV_TILE), nkb = dicow_cdiv(a->Lk, 128);
+        const int64_t nflags = (int64_t)a->B * a->H * nt * 4;
+        const int n_zero = (int)((FUSED_WS_HDR + nflags * 4) / 4);
+        const int64_t nthr = (int64_t)a->B * a->H * a->Lq * 8;
+        const unsigned sblocks = (unsigned)dicow_cdiv(nthr > n_zero ? nthr : n_zero, 256);
+        char* fws = reinterpret_cast<char*>(a->fused_ws);
+        if (a->q_log2) hipLaunchKernelGGL(attn_bwd_stats_kernel<true>, dim3(sblocks), dim3(256), 0, st, *a, reinterpret_cast<unsigned*>(fws), n_zero);
+        else hipLaunchKernelGGL(attn_bwd_stats_kernel<false>, dim3(sblocks), dim3(256), 0, st, *a, reinterpret_cast<unsigned*>(fws), n_zero);
+        DICOW_CHECK_LAUNCH("attn_bwd_stats");
+        const dim3 grid((unsigned)(8 * dicow_cdiv((int64_t)a->H * a->B, 8) * nkb));      // whole groups of 8 (batch, head) pairs: one pair per XCD
+        static const int rstride = [] { const char* e = getenv("DICOW_ATTN_FUSED_RSTRIDE"); return e ? atoi(e) : 0; }();      // (experiments: the tile stride of the rotation; 0 = nt / nkb)
+        if (a->q_log2) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, grid, dim3(256), 0, st, *a, fws, nt, nkb, rstride);
+        else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, grid, dim3(256), 0, st, *a, fws, nt, nkb, rstride);
+        DICOW_CHECK_LAUNCH("attn_bwd_fused");
+        if (a->dq_colsum || a->dv_colsum) {
+            const int64_t D = (int64_t)a->H * HD;
+            const int rq = a->B * 2 * nt, rk = a->B * dicow_cdiv(a->Lk, 128) * 4;
+            const float* ws = reinterpret_cast<const float*>(a->cs_ws);
+            const int64_t dv_plane = (int64_t)a->B * dicow_cdiv(a->Lq, 128) * 4 * D;
+            int rc = DICOW_OK;
+            if (a->dq_colsum && a->dv_colsum && rq == rk) {
+                float* outs[2] = {a->dq_colsum, a->dv_colsum};
+                return dicow_launch_reduce_multi(ws, rq, D, dv_plane, outs, 2, D, st);
+            }
+            if (a->dq_colsum) rc = dicow_launch_reduce_parts(ws, rq, D, a->dq_colsum, D, st);
+            if (rc == DICOW_OK && a->dv_colsum) rc = dicow_launch_reduce_parts(ws + dv_plane, rk, D, a->dv_colsum, D, st);
+            return rc;
+        }
+        return DICOW_OK;
+    }
     if (a->q_log2) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(dicow_cdiv(a->Lq, 128) * a->H * a->B), dim3(256), 0, st, *a);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(dicow_cdiv(a->Lq, 128) * a->H * a->B), dim3(256), 0, st, *a);
     DICOW_CHECK_LAUNCH("attn_bwd_dq");

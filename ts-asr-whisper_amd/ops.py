@@ -4,6 +4,7 @@ Every wrapper validates device/dtype/contiguity, allocates outputs with torch (t
 allocates) and enqueues the HIP kernels on the current torch stream.
 """
 import ctypes as C
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -397,8 +398,39 @@ def attn_fwd(q, k, v, o, lse=None, causal=False, q_log2=False):
     L.call_struct("dicow_attn_fwd", a)
 
 
-def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0, dq_colsum=None, dv_colsum=None, q_log2=False):
-    """Backward of attn_fwd.  All [B,L,H,64] bf16 views; lse [B,H,Lq] fp32; delta = workspace [2,B,H,Lq] fp32."""
+_FWS = {}
+ATTN_BWD_FUSED = os.environ.get("DICOW_ATTN_BWD_FUSED", "1") != "0"      # A/B switch of the fused (5-pass) attention backward
+
+
+def attn_bwd_fused_ws(B, H, Lq, Lk, device):
+    """Persistent per-(device, stream) workspace of the fused attention backward (the dQ tiles that travel between the key-block
+    workgroups through L2, their flags, a status header).  Stream-ordered reuse, like `workspace`."""
+    n = L.lib().dicow_attn_bwd_fused_ws_bytes(B, H, Lq, Lk)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _FWS.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(n + 4096, dtype=torch.uint8, device=device)
+        _FWS[key] = t
+    off = (-t.data_ptr()) % 4096
+    return t[off:off + n]
+
+
+def attn_bwd_fused_status(device=None) -> int:
+    """Error bits of the fused attention backward's last launches on this device's workspaces (synchronises).  0 = fine."""
+    torch.cuda.synchronize(device)
+    st = 0
+    for (_, idx, _), t in _FWS.items():
+        if device is None or idx == torch.device(device).index:
+            off = (-t.data_ptr()) % 4096
+            st |= L.lib().dicow_attn_bwd_fused_status(t.data_ptr() + off)
+    return st
+
+
+def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0, dq_colsum=None, dv_colsum=None, q_log2=False,
+             fused=None):
+    """Backward of attn_fwd.  All [B,L,H,64] bf16 views; lse [B,H,Lq] fp32; delta = workspace [2,B,H,Lq] fp32.
+    fused: hand the library the workspace of its one-kernel form (used for dense problems that fill the chip; None = the
+    DICOW_ATTN_BWD_FUSED default; "force" = for every dense problem, whatever its size -- tests)."""
     assert delta.numel() >= 2 * lse.numel(), "attn_bwd: delta workspace must hold 2*B*H*Lq floats"
     a = L.AttnBwdArgs()
     a.q, a.k, a.v, a.o, a.d_o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), d_o.data_ptr()
@@ -417,6 +449,10 @@ def attn_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, causal=False, dq_scale=1.0
     if dq_colsum is not None or dv_colsum is not None:       # fused q / v bias gradients ([H*64] fp32, accumulated)
         ws = workspace(L.lib().dicow_attn_bwd_colsum_ws_bytes(a.B, a.H, a.Lq, a.Lk), q.device)
         a.dq_colsum, a.dv_colsum, a.cs_ws, a.cs_ws_bytes = _p(dq_colsum), _p(dv_colsum), ws.data_ptr(), ws.numel()
+    want = ATTN_BWD_FUSED if fused is None else fused
+    if want and not causal and a.B * a.H <= 1000 and (want == "force" or (a.B * a.H * ((a.Lk + 127) // 128) >= 1024 and a.Lq >= 256)):
+        fws = attn_bwd_fused_ws(a.B, a.H, a.Lq, a.Lk, q.device)
+        a.fused_ws, a.fused_ws_bytes, a.fused_mode = fws.data_ptr(), fws.numel(), int(want == "force")
     L.call_struct("dicow_attn_bwd", a)
 
 
