@@ -1367,9 +1367,10 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
         const bool first = rank == 0, last = rank == nkb - 1;
         const unsigned fidx = (unsigned)((pair * nt + t) * 4 + wave);
         const bool handoff = blk_live && !first && !(ATTN_FUSED_ABL & 1);
-        unsigned vflag = 0u;                                  // the poll: a plain load (L1 bypassed) nobody waits for before the middle of the A phase
-        const unsigned fbyte = fidx * 4u;
-        if (handoff) asm volatile("buffer_load_dword %0, %1, %2, 0 offen sc0 sc1" : "=v"(vflag) : "v"(fbyte), "s"(rsF) : "memory");
+        // the poll: a 4-byte DMA into LDS nobody waits for before the middle of the A phase.  (NOT a load into a register: the compiler
+        // believes an asm output is there at once and is free to copy it -- at the merge of two branches it did, before the load had
+        // landed, and the late arrival then overwrote a register that had been given to a dS value.)
+        if (handoff) dma4x<1>(fl_addr, rsF, 0u, fidx * 4u);
         FPROF(0)
 #define FUSED_QBLOCK(QB)                                                                                                \
         {                                                                                                               \
@@ -1423,20 +1424,20 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
         // ---- middle of the A phase: everything requested so far has long landed (the next tile's DMA dates from the B phase before),
         // so this wait is all but free -- and it has seen the stores of the tile before acknowledged: its flag goes up.  The poll of
         // this tile's flag is in: flag up -> the sum so far is requested now and has the rest of the tile to land.
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(vflag) :: "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (pub_idx >= 0) {
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32((unsigned)pub_val, rsF, (unsigned)pub_idx * 4u, 0, 0);
             pub_idx = -1;
         }
         bool have = false, again = false;
         if (handoff) {
-            have = chain_ok && (unsigned)__builtin_amdgcn_readfirstlane((int)vflag) == (unsigned)rank;
+            have = chain_ok && (unsigned)__builtin_amdgcn_readfirstlane((int)lds_read_u32_now(fl_addr)) == (unsigned)rank;
             if (have) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) dma16x<1>(z_addr + q4 * 1024u, rsW, voff + q4 * 1024u, fidx * 4096u);
             } else if (chain_ok) {                            // not yet: a second poll, looked at in front of the barrier
                 again = true;
-                asm volatile("buffer_load_dword %0, %1, %2, 0 offen sc0 sc1" : "=v"(vflag) : "v"(fbyte), "s"(rsF) : "memory");
+                dma4x<1>(fl_addr, rsF, 0u, fidx * 4u);
             }
         }
         if (wave_live && two_blocks) FUSED_QBLOCK(1)
@@ -1445,8 +1446,8 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
         // ---- barrier X: dS^T complete, this slot free for the tile after next, the next tile landed (its DMA is older than the
         // four loads of the sum, which may stay in flight: loads complete in order)
         if (have) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(vflag) :: "memory");
-        if (again && (unsigned)__builtin_amdgcn_readfirstlane((int)vflag) == (unsigned)rank) {     // second chance: the sum travels under the B phase
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (again && (unsigned)__builtin_amdgcn_readfirstlane((int)lds_read_u32_now(fl_addr)) == (unsigned)rank) {     // second chance: the sum travels under the B phase
             have = true;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) dma16x<1>(z_addr + q4 * 1024u, rsW, voff + q4 * 1024u, fidx * 4096u);
