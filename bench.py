@@ -39,6 +39,9 @@ def parse():
     ap.add_argument("--preheat", action="store_true",
                     help="time the recipe's first phase instead (use_fddt_only_n_steps: only FDDT parameters train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the other BASELINE.json workloads (configs[1] whisper-base B=8 from a hipGraph, configs[4]'s per-rank SE-DiCoW "
+                         "B=16) that the default one-GPU headline run times after its own timed region (`other_workloads` of the line)")
     ap.add_argument("--no-power", action="store_true", help="do not sample rocm-smi (board power / shader clock) during the timed region")
     ap.add_argument("--cpu-sample", default="turbo-b1")
     ap.add_argument("--profile-steps", type=int, default=5,
@@ -195,6 +198,36 @@ class KernelTimer:
         fl = [r[2] for r in rec]
         return {"launches": len(rec), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms), "flops": sum(fl),
                 "tflops": sum(fl) / (sum(ms) * 1e-3) / 1e12 if sum(ms) > 0 else 0.0}
+
+
+OTHER_WORKLOADS = {"whisper_base_b8_graph": ["--model", "whisper-base", "--batch", "8", "--graph", "--steps", "10", "--warmup", "4"],      # BASELINE.json configs[1]
+                   "se_dicow_b16": ["--se", "--steps", "6", "--warmup", "2"]}                                                          # configs[4], one rank's share
+
+
+def other_workloads(legs=None):
+    """BASELINE.json configs[1] and configs[4] (per-rank form) under the same clock as the headline: each is THIS script run again as
+    its own process (<= 10 timed steps, no CPU baseline, no extras), after the headline's timed region and instrumented steps are
+    over.  Returns {name: {ms_per_step, utt_s, step_mfma_frac, loss, wall_s}} -- a failed leg reports why instead of a number."""
+    import subprocess
+    legs = legs or OTHER_WORKLOADS
+    out = {}
+    for name, extra in legs.items():
+        t0 = time.time()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-extra", "--no-cpu-baseline", "--no-power",
+                                "--profile-steps", "1"] + extra, capture_output=True, text=True, timeout=240,
+                               env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "DICOW_BENCH_CHILD")})
+            line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith("{")), None)
+            if line is None:
+                out[name] = {"ms_per_step": None, "note": f"no line (rc {r.returncode}): {r.stderr[-300:]}"}
+                continue
+            d = json.loads(line)
+            out[name] = {"ms_per_step": d["ms_per_step"], "utt_s": d["value"], "step_mfma_frac": d.get("step_mfma_frac"),
+                         "batch": d["config"]["global_batch"], "steps": d["steps"], "loss": d.get("loss"), "workload": d["config"]["workload"],
+                         "encoder_forward_ms": (d.get("encoder_forward") or {}).get("ms"), "wall_s": round(time.time() - t0, 1)}
+        except Exception as ex:
+            out[name] = {"ms_per_step": None, "note": f"failed: {ex!r}", "wall_s": round(time.time() - t0, 1)}
+    return out
 
 
 def cpu_baseline(cfg_name, labels):
@@ -759,6 +792,13 @@ def main():
         out["encoder_forward"] = {"ms": None, "note": f"failed: {ex!r}"}
     out["roofline"]["traffic"] = pmc_traffic(ops.gemm_dispatch_log())
     out["roofline"]["traffic_source"] = TRAFFIC_SOURCE
+    headline = a.model.endswith("large-v3-turbo") and a.batch == 16 and not (a.se or a.ctc or a.preheat or a.graph or a.from_audio)
+    if world == 1 and headline and not a.no_extra and "DICOW_BENCH_CHILD" not in os.environ:
+        del model, ts, batches, waves                             # (the legs are processes of their own: give the memory back first)
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        out["other_workloads"] = other_workloads()
     if not a.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(a.model, a.labels)

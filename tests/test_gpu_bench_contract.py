@@ -44,6 +44,24 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert 50.0 < d["power"]["board_w_mean"] < 2000.0 and 100.0 < d["power"]["sclk_mhz_mean"] <= 2500.0 and d["power"]["samples"] >= 1
 
 
+def test_other_workloads_legs_report_step_time_and_throughput():
+    """`other_workloads` of the default headline line (BASELINE.json configs[1] and configs[4]'s per-rank share, each timed as a process
+    of its own after the headline): the leg runner on a seconds-sized stand-in, and the real legs' command lines."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    sys.path.insert(0, ROOT)
+    import bench
+    legs = bench.OTHER_WORKLOADS
+    assert legs["whisper_base_b8_graph"][:5] == ["--model", "whisper-base", "--batch", "8", "--graph"] and "--se" in legs["se_dicow_b16"]
+    assert all(int(v[v.index("--steps") + 1]) <= 10 for v in legs.values())
+    got = bench.other_workloads({"tiny": ["--model", "whisper-tiny", "--batch", "2", "--labels", "16", "--steps", "2", "--warmup", "1"],
+                                 "broken": ["--model", "no-such-model"]})
+    t = got["tiny"]
+    assert t["ms_per_step"] > 0 and abs(t["utt_s"] - 2 * 1e3 / t["ms_per_step"]) < 1e-2 * t["utt_s"] and t["batch"] == 2 and t["steps"] == 2
+    assert t["loss"] == t["loss"] and "whisper-tiny" in t["workload"] and t["wall_s"] > 0
+    assert got["broken"]["ms_per_step"] is None and "note" in got["broken"]                # a failed leg says why; the line still prints
+
+
 def test_bench_gpus_2_launches_two_ranks_by_itself():
     """`bench.py --gpus 2` with no rendezvous in the environment: the launcher starts both ranks; on this one-GPU box they share
     device 0 and exchange over gloo (DICOW_BENCH_SHARE_GPU=1), on a multi-GPU node the same command runs RCCL."""

@@ -240,7 +240,7 @@ def test_save_and_from_pretrained_round_trip(tmp_path):
     torch.manual_seed(0)
     m = pkg.DiCoWForConditionalGeneration(_tiny_cfg())
     m.save_pretrained(tmp_path / "ckpt")
-    assert sorted(os.listdir(tmp_path / "ckpt")) == ["config.json", "model.safetensors"]
+    assert sorted(os.listdir(tmp_path / "ckpt")) == ["config.json", "generation_config.json", "model.safetensors"]      # (round 6: an HF PreTrainedModel)
     m2 = pkg.DiCoWForConditionalGeneration.from_pretrained(str(tmp_path / "ckpt"))
     assert m2._load_report == {"missing": [], "unexpected": []}
     for (n, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):

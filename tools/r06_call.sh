@@ -29,6 +29,7 @@ for row in csv.DictReader(open(sys.argv[1])):
 for (name, c), (n, v) in sorted(agg.items()): print(f"rstride {sys.argv[2]}  {name:40s} {c:14s} per launch {v / n / 1e6:12.2f} M   ({n} launches)")
 PY
                   rm -rf /tmp/pmc_$tag; done; done ;;
+    hf)         timeout 900 python -m pytest tests/test_gpu_hf_trainer.py tests/test_gpu_bench_contract.py -x -q -s 2>&1 | tail -30 | tee $out/hf_tests.txt ;;
     gpu_tests)  timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee $out/gpu_tests.txt ;;
     bench)      timeout 900 python bench.py 2>&1 | tail -3 | tee $out/bench_default.json ;;
     bench2)     timeout 900 python bench.py 2>&1 | tail -1 | tee $out/bench_default_again.json ;;

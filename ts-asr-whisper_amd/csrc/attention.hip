@@ -1636,7 +1636,11 @@ extern "C" int dicow_attn_bwd(const dicow_attn_bwd_args* a, void* stream) {
         else hipLaunchKernelGGL(attn_bwd_stats_kernel<false>, dim3(sblocks), dim3(256), 0, st, *a, reinterpret_cast<unsigned*>(fws), n_zero);
         DICOW_CHECK_LAUNCH("attn_bwd_stats");
         const dim3 grid((unsigned)(8 * dicow_cdiv((int64_t)a->H * a->B, 8) * nkb));      // whole groups of 8 (batch, head) pairs: one pair per XCD
-        static const int rstride = [] { const char* e = getenv("DICOW_ATTN_FUSED_RSTRIDE"); return e ? atoi(e) : 0; }();      // (experiments: the tile stride of the rotation; 0 = nt / nkb)
+#ifdef DICOW_ABLATIONS
+        static const int rstride = [] { const char* e = getenv("DICOW_ATTN_FUSED_RSTRIDE"); return e ? atoi(e) : 0; }();      // (diagnostic builds: the tile stride of the rotation)
+#else
+        const int rstride = 0;                                // nt / nkb
+#endif
         if (a->q_log2) hipLaunchKernelGGL(attn_bwd_fused_kernel<true>, grid, dim3(256), 0, st, *a, fws, nt, nkb, rstride);
         else hipLaunchKernelGGL(attn_bwd_fused_kernel<false>, grid, dim3(256), 0, st, *a, fws, nt, nkb, rstride);
         DICOW_CHECK_LAUNCH("attn_bwd_fused");

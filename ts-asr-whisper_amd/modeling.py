@@ -18,7 +18,12 @@ from torch import nn
 
 from . import _lib as L
 from . import ops
-from .config import DiCoWConfig
+from .config import DiCoWConfig, _HF
+
+if _HF:                                     # the reference's class is a transformers.PreTrainedModel: the HF Trainer the reference trains with
+    from transformers import PreTrainedModel as _ModelBase, GenerationConfig as _GenerationConfig      # (src/train.py:227-262) asks for
+else:                                       # pragma: no cover                                                       # exactly that type
+    _ModelBase, _GenerationConfig = nn.Module, None
 from .engine import EncoderEngine, DecoderEngine, CtcEngine, GradSink, fddt_ptrs, CLS, prep_full_fddt, full_fddt_fwd, full_fddt_bwd
 
 F32, BF16 = torch.float32, torch.bfloat16
@@ -571,22 +576,43 @@ class _DecoderLossFn(torch.autograd.Function):
 _KEYWORD_ONLY_GENERATE_ARGS = ("temperature",)     # read from generate()'s keywords, never from the generation config
 
 
-class DiCoWForConditionalGeneration(nn.Module):
+class DiCoWForConditionalGeneration(_ModelBase):
+    """``transformers.PreTrainedModel`` (as the reference's class, modeling_dicow.py:224-229) so that the caller the reference really
+    uses -- ``transformers.Seq2SeqTrainer`` through ``CustomTrainer`` (src/utils/trainers.py:106-139) -- finds what it asks its model
+    for: ``config.to_json_string``, ``generation_config``, ``main_input_name``, ``floating_point_ops``, ``save_pretrained(dir,
+    state_dict=...)`` with the tied head, ``can_generate``.  Loading / saving / initialisation / generation are this class's own
+    (below); HF's base supplies the bookkeeping.  ``tests/test_gpu_hf_trainer.py`` runs the installed Seq2SeqTrainer over it."""
     config_class = DiCoWConfig
+    base_model_prefix = "model"
+    main_input_name = "input_features"
+    supports_gradient_checkpointing = False
+    _tied_weights_keys = {"proj_out.weight": "model.decoder.embed_tokens.weight"}
+    _keys_to_ignore_on_save = None
+
+    @classmethod
+    def can_generate(cls) -> bool:            # (HF only looks for GenerationMixin in the bases; generate() below is this class's own)
+        return True
 
     def __init__(self, config: DiCoWConfig):
-        super().__init__()
-        self.config = config
+        if _HF:
+            super().__init__(config)          # .config, .generation_config (GenerationConfig.from_model_config), .loss_type, ...
+        else:
+            super().__init__()
+            self.config = config
+            self.generation_config = None
         self.model = DiCoW(config)
         self.proj_out = nn.Linear(config.d_model, config.vocab_size, bias=False)
         self.tokenizer = None
         self.soft_label_creator = None
         self._ts_tables = None
-        self.generation_config = None
         self._eng = None
         self._sig = None
         self.apply(self._init_weights)
+        for m in self.modules():              # (HF's post_init / from_pretrained re-initialise whatever does not say it has been)
+            m._is_hf_initialized = True
         self.tie_weights()
+        if _HF:
+            self.all_tied_weights_keys = dict(self._tied_weights_keys)
         # reference checkpoints saved after set_tokenizer() carry the dense [n_ts, V] smoothing buffer
         # (modeling_dicow.py:33); this implementation rebuilds compact tables from the tokenizer instead
         self._register_load_state_dict_pre_hook(self._drop_soft_label_buffer)
@@ -616,12 +642,30 @@ class DiCoWForConditionalGeneration(nn.Module):
             with torch.no_grad():
                 m.embed_positions.weight.copy_(sinusoids(*m.embed_positions.weight.shape))
 
-    def tie_weights(self):
+    def tie_weights(self, missing_keys=None, recompute_mapping=True):          # (HF's signature; the tie itself is unconditional)
         self.proj_out.weight = self.model.decoder.embed_tokens.weight
+
+    def estimate_tokens(self, input_dict):
+        x = input_dict.get(self.main_input_name) if isinstance(input_dict, dict) else None
+        return int(x.numel()) if x is not None else 0
+
+    def floating_point_ops(self, input_dict, exclude_embeddings=True):
+        """What HF's Trainer accumulates into ``total_flos`` (transformers 4.55 ModuleUtilsMixin.floating_point_ops, the version the
+        reference pins: 6 x tokens x parameters, tokens = elements of the main input)."""
+        n = sum(p.numel() for name, p in self.named_parameters()
+                if not (exclude_embeddings and ("embed_tokens" in name or "embed_positions" in name)))
+        return 6 * self.estimate_tokens(input_dict) * n
+
+    def get_input_embeddings(self):
+        return self.model.decoder.embed_tokens
+
+    def set_input_embeddings(self, value):
+        self.model.decoder.embed_tokens = value
+        self.tie_weights()
 
     # -- checkpoints: the reference builds the model with ``from_pretrained(name, **overrides)`` (containers.py:47-50)
     @classmethod
-    def from_pretrained(cls, name_or_path, **overrides):
+    def from_pretrained(cls, name_or_path, *model_args, **overrides):
         """Local directory with ``config.json`` + ``model.safetensors`` / ``pytorch_model.bin`` (an HF Whisper or a DiCoW
         checkpoint: identical key names), or a preset name such as ``openai/whisper-large-v3-turbo`` (no network in this
         build: the preset gives the architecture, weights stay randomly initialised).  Keys the checkpoint lacks -- the
@@ -633,6 +677,9 @@ class DiCoWForConditionalGeneration(nn.Module):
             with open(os.path.join(name_or_path, "config.json")) as f:
                 cfg = DiCoWConfig.from_hf(json.load(f), **overrides)
             model = cls(cfg)
+            gc_path = os.path.join(name_or_path, "generation_config.json")
+            if _GenerationConfig is not None and os.path.exists(gc_path):
+                model.generation_config = _GenerationConfig.from_pretrained(name_or_path)
             st_path, bin_path = os.path.join(name_or_path, "model.safetensors"), os.path.join(name_or_path, "pytorch_model.bin")
             if os.path.exists(st_path):
                 from safetensors.torch import load_file
@@ -651,15 +698,25 @@ class DiCoWForConditionalGeneration(nn.Module):
         model._load_report = {"missing": None, "unexpected": None, "note": "preset architecture, random initialisation (offline build)"}
         return model
 
-    def save_pretrained(self, directory):
+    def save_pretrained(self, directory, state_dict=None, safe_serialization=True, **kwargs):
+        """``config.json`` + ``model.safetensors`` (+ ``generation_config.json``): what ``from_pretrained`` above reads.  Signature of
+        ``PreTrainedModel.save_pretrained`` as ``Trainer._save`` calls it (``state_dict=`` an already gathered state dict); the tied
+        head is stored once (safetensors refuses tensors that share storage)."""
         import json
         import os
         from safetensors.torch import save_file
         os.makedirs(directory, exist_ok=True)
         with open(os.path.join(directory, "config.json"), "w") as f:
-            json.dump(dict(self.config.to_dict(), model_type="DiCoW", architectures=["DiCoWForConditionalGeneration"]), f, indent=1)
-        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items() if k != "proj_out.weight"}     # tied
-        save_file(sd, os.path.join(directory, "model.safetensors"))
+            json.dump(dict(self.config.hot_path_dict(), model_type="DiCoW", architectures=["DiCoWForConditionalGeneration"]), f, indent=1)
+        gc = getattr(self, "generation_config", None)
+        if gc is not None and hasattr(gc, "save_pretrained"):
+            gc.save_pretrained(directory)
+        sd = self.state_dict() if state_dict is None else state_dict
+        sd = {k: v.detach().cpu().contiguous() for k, v in sd.items() if k != "proj_out.weight"}     # tied
+        if safe_serialization:
+            save_file(sd, os.path.join(directory, "model.safetensors"), metadata={"format": "pt"})
+        else:
+            torch.save(sd, os.path.join(directory, "pytorch_model.bin"))
 
     def generate(self, input_features=None, stno_mask=None, attention_mask=None, decoder_input_ids=None, max_new_tokens=None,
                  max_length=None, generation_config=None, enrollments=None, num_beams=1, return_timestamps=None, use_graphs=False,
@@ -678,8 +735,13 @@ class DiCoWForConditionalGeneration(nn.Module):
         # the explicit keyword ONLY: a GenerationConfig carries temperature = 1.0 by default under the reference's pinned
         # transformers 4.55 (also when loaded from a Whisper checkpoint's generation_config.json), and greedy / beam decoding
         # never consult it.
-        get = (lambda k, d=None: kwargs[k] if kwargs.get(k) is not None else
-               (d if k in _KEYWORD_ONLY_GENERATE_ARGS else (getattr(gc, k, d) if gc is not None else d)))
+        def get(k, d=None):                                   # (an attribute a GenerationConfig holds as None counts as not set)
+            if kwargs.get(k) is not None:
+                return kwargs[k]
+            if k in _KEYWORD_ONLY_GENERATE_ARGS or gc is None:
+                return d
+            v = getattr(gc, k, None)
+            return d if v is None else v
         beams = max(num_beams or 1, get("num_beams", 1) or 1)
         self.stno_mask = stno_mask                            # reference generate() keeps it for detect_language (generation.py:556)
         cfg = self.config
@@ -864,6 +926,10 @@ class DiCoWForConditionalGeneration(nn.Module):
         return self._decoder.detect_language(input_features, stno_mask, lang_token_ids, start, enrollments)
 
     def post_init(self):
+        """The reference's container calls it after ``from_pretrained`` (containers.py:52).  Nothing is re-initialised here (every module
+        is marked initialised by __init__); HF's version records its per-model bookkeeping and ties."""
+        if _HF:
+            super().post_init()
         self.tie_weights()
 
     def get_encoder(self):
