@@ -6,6 +6,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import amd_pkg
 pkg = amd_pkg.load()
+from ts_asr_whisper_amd import _lib as L
+if "DICOW_HIP_LIB" not in os.environ:      # the fold lives in the experiments library only (csrc/build.sh --exp)
+    L.LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ts-asr-whisper_amd", "libdicow_hip_exp.so")
 from ts_asr_whisper_amd import engine as E
 from ts_asr_whisper_amd.data import synthetic_batch
 

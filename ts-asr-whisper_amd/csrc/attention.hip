@@ -1283,7 +1283,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
     // last of others (balanced).  rank(tile) = (k - j) mod nkb is a fixed function of the shape: the sum order is the same in every run.
     const int R = rstride > 0 ? rstride : nt / nkb;          // tiles between the starts of consecutive key blocks (0: nt < nkb -- every block starts at tile 0)
     const bool rot = R > 0 && R * (nkb - 1) < nt;
-    const int s_j = rot ? kblk * R : 0;
+#ifndef ATTN_FUSED_REVERSE
+#define ATTN_FUSED_REVERSE 0      // (measured: the middle blocks 17 -> 14 % of their tiles on the slow path, block 0 -- which then follows the LAST block -- 69 %: no gain)
+#endif
+    // (the rotation runs on a VIRTUAL index vj = nkb - 1 - j: the visitor before key block j on a tile is then key block j - 1, dispatched
+    // BEFORE it -- its lead is the rotation's R tiles plus the dispatch gap instead of minus it; only block 0 follows the last one)
+    const int vj = (rot && ATTN_FUSED_REVERSE) ? nkb - 1 - kblk : kblk;
+    const int s_j = rot ? vj * R : 0;
     auto tile_of = [&](int i) { const int x = s_j + i; return x >= nt ? x - nt : x; };
 
     const tile_src_t srcQ = make_tile_src<SWZ_U>(Q, a.q_rs, a.Lq, wave, lane), srcdO = make_tile_src<SWZ_U>(dO, a.do_rs, a.Lq, wave, lane);
@@ -1348,7 +1354,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
     // A visitor needs the one before it to be about one and a half tile times ahead; the rotation puts nt / nkb tiles between them.
     int pub_idx = -1, pub_val = 0;                           // stores in flight: the flag to raise at the next vmcnt(0)
     // rank(t) = (k(t) - j) mod nkb, k(t) = min(nkb - 1, t / R) = the last key block that starts at or before tile t, carried incrementally
-    int rk_k = kblk, rk_rem = 0, cur_t = s_j;
+    int rk_k = vj, rk_rem = 0, cur_t = s_j;
     const unsigned z_addr = (unsigned)(uintptr_t)sZ + (unsigned)wave * 4096u;
 
     FPROF_DECL
@@ -1363,7 +1369,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
         const bool two_blocks = !(tail_half && t == nt - 1);
         const int q32 = qt0 + qsub * 32;                      // first query of this wave's block of the tile's dQ
         const bool blk_live = q32 < a.Lq;
-        const int rank = rot ? (rk_k >= kblk ? rk_k - kblk : rk_k + nkb - kblk) : kblk;
+        const int rank = rot ? (rk_k >= vj ? rk_k - vj : rk_k + nkb - vj) : kblk;
         const bool first = rank == 0, last = rank == nkb - 1;
         const unsigned fidx = (unsigned)((pair * nt + t) * 4 + wave);
         const bool handoff = blk_live && !first && !(ATTN_FUSED_ABL & 1);
@@ -1457,27 +1463,35 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
         FPROF(2)
         // ---- B phase: the next-but-one tile's DMA, the dQ product, the hand-off
         const bool more = i + 2 < nt && !(ATTN_FUSED_ABL & 16);
+        const bool prod = blk_live && !(ATTN_FUSED_ABL & 2);
+        // this wave's columns of dS^T: all 16 fragment reads up front, then barrier Y -- once every wave HAS them the image may be
+        // rewritten, and the rest of the B phase (the MFMAs, the wait for the sum, the stores) runs un-synchronised, beside the
+        // other waves' next A phase instead of in a burst with their stores and DMA
+        tr8_t u0, u1;
+        if (prod) {
+            tr_issue_c<0>(u0, dsr0, dsr1);
+            tr_issue_c<8192>(u1, dsr0, dsr1);
+        }
         if (more) {
             int t2 = t + 2; t2 = t2 >= nt ? t2 - nt : t2; t2 *= KV_TILE;
             stage_tile_x(srcQ, t2, sQ, wave);
             stage_tile_x(srcdO, t2, sdO, wave);
             stage_stats_x(t2, sST + SLOT * 512);
         }
-        if (blk_live && !(ATTN_FUSED_ABL & 2)) {
-            tr8_t u0, u1;
-            tr_issue_c<0>(u0, dsr0, dsr1);
-            tr_issue_c<8192>(u1, dsr0, dsr1);
+        if (prod) { tr_wait<0>(u0); tr_wait<0>(u1); }
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                         // ---- barrier Y
+        asm volatile("" ::: "memory");
+        if (prod) {
             f32x16_t dq;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dq[r] = 0.f;
             bf16x8_t f[2][2];
-            tr_wait<8>(u0);
             tr_pack_c(f, u0);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][0], f[0][0], dq, 0, 0, 0);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[0][1], f[0][1], dq, 0, 0, 0);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][0], f[1][0], dq, 0, 0, 0);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[1][1], f[1][1], dq, 0, 0, 0);
-            tr_wait<0>(u1);
             tr_pack_c(f, u1);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[2][0], f[0][0], dq, 0, 0, 0);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[2][1], f[0][1], dq, 0, 0, 0);
@@ -1542,11 +1556,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
         ++cur_t; ++rk_rem;
         if (rk_rem == R) { rk_rem = 0; rk_k = rk_k + 1 < nkb ? rk_k + 1 : rk_k; }
         if (cur_t == nt) { cur_t = 0; rk_k = 0; rk_rem = 0; }
-        // ---- barrier Y: every wave has read its columns of dS^T
         FPROF(7)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
         FPROF(8)
     };
     {

@@ -737,10 +737,14 @@ extern "C" int dicow_gemm_dispatch_log(char* buf, int cap) {
     return n;
 }
 
-// ws for DICOW_EPI_COLSUM: the fused path needs 2 * ceil(M/128) partial rows (gemm_nt2_kernel; 2 * ceil(M/192) for the ring kernel);
-// the fallback runs dicow_colsum_bf16 on C
+// ws for DICOW_EPI_COLSUM: the fused path needs 2 * ceil(M/192) partial rows (the ring kernel; 2 * ceil(M/128) only for gemm_nt2_kernel
+// of the experiments library); the fallback runs dicow_colsum_bf16 on C
 extern "C" int64_t dicow_gemm_nt_colsum_ws_bytes(int M, int N) {
+#ifdef DICOW_EXPERIMENTS
     const int64_t fused = (int64_t)2 * dicow_cdiv(M, 128) * N * 4, fb = dicow_colsum_ws_bytes(M, N);
+#else
+    const int64_t fused = (int64_t)2 * dicow_cdiv(M, 192) * N * 4, fb = dicow_colsum_ws_bytes(M, N);
+#endif
     return fused > fb ? fused : fb;
 }
 
@@ -979,7 +983,7 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
 #endif
     const bool big = off32 && a->K >= 2 * BK && (int64_t)dicow_cdiv(a->M, 256) * dicow_cdiv(a->N, 256) * batch >= big_tiles;
 #ifndef DICOW_EXPERIMENTS
-    DICOW_REQUIRE(!(a->flags & (DICOW_EPI_LNSTAT | DICOW_EPI_LNFOLD)), "gemm_nt: EPI_LNSTAT / EPI_LNFOLD are experimental (the LayerNorm fold measured slower, profiles/r04_lnfold.txt): build the library with -DDICOW_EXPERIMENTS");
+    DICOW_REQUIRE(!(a->flags & (DICOW_EPI_LNSTAT | DICOW_EPI_LNFOLD)), "gemm_nt: EPI_LNSTAT / EPI_LNFOLD are experimental (the LayerNorm fold measured slower, profiles/r04_lnfold.txt): build.sh --exp builds libdicow_hip_exp.so, which has them");
 #endif
     DICOW_REQUIRE(!(a->flags & (DICOW_EPI_LNSTAT | DICOW_EPI_LNFOLD)) || (variant == 0 && big && a->M >= 256 && a->N >= 320),
                   "gemm_nt: EPI_LNSTAT / EPI_LNFOLD are implemented by the persistent kernel only (M=%d N=%d K=%d: ask dicow_gemm_nt_is_persistent / dicow_gemm_nt_lnstat_ok)", a->M, a->N, a->K);

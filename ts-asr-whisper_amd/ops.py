@@ -263,7 +263,7 @@ def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, re
         return bool(L.lib().dicow_gemm_nt_is_persistent(C.byref(a)))
     if query_lnstat:
         if not L.has_experimental():
-            raise L.DicowError("the LayerNorm fold is experimental: build the library with ts-asr-whisper_amd/csrc/build.sh -DDICOW_EXPERIMENTS")
+            raise L.DicowError("the LayerNorm fold is experimental: build ts-asr-whisper_amd/csrc/build.sh --exp and load it with DICOW_HIP_LIB=.../libdicow_hip_exp.so")
         return bool(L.lib().dicow_gemm_nt_lnstat_ok(C.byref(a)))
     if K >= 8192 and colsum_out is None:             # deep contraction, small output: split ranges + ordered sum (LM-head dgrad)
         need = L.lib().dicow_gemm_nt_splitk_ws_bytes(C.byref(a))
@@ -274,10 +274,11 @@ def gemm_nt(A, B, C_out, M, N, K, *, lda=None, ldb=None, ldc=None, bias=None, re
 
 
 def lnfold_prep(W, gamma, beta, bias, out_w, out_c, out_b):
-    if not L.has_experimental():
-        raise L.DicowError("dicow_lnfold_prep is experimental: build the library with ts-asr-whisper_amd/csrc/build.sh -DDICOW_EXPERIMENTS")
     """Weights of a Linear behind a LayerNorm, folded: out_w bf16 [N, K] = bf16(gamma * W), out_c [N] = its row sums (fp32),
     out_b [N] = bias + W_bf16 @ beta.  W fp32 [N, K] contiguous; bias may be None."""
+    if not L.has_experimental():
+        raise L.DicowError("dicow_lnfold_prep is experimental: build ts-asr-whisper_amd/csrc/build.sh --exp and load it with "
+                           "DICOW_HIP_LIB=.../libdicow_hip_exp.so")
     N, K = W.shape
     assert W.is_contiguous() and W.dtype == F32 and out_w.dtype == torch.bfloat16 and out_w.stride(1) == 1
     L.call("dicow_lnfold_prep", W.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _p(bias), out_w.data_ptr(), out_w.stride(0),

@@ -157,6 +157,18 @@ class FlatStore:
             if not p.requires_grad:                   # frozen after the store was built: no GEMM will write it, keep it zero
                 self.grads[o:o + n].zero_()
 
+    def settle_range(self, a, b):
+        """The still-flagged matrices inside grads[a:b] (a bucket about to leave): zeroed and un-flagged ON THE COMPUTE STREAM, before the
+        bucket's event is recorded -- zeros go on the wire, not last step's values, and the result does not depend on every rank
+        having skipped the same matrices."""
+        n_left = 0
+        for p, o, n in self._over:
+            if a <= o < b and getattr(p, "_grad_overwrite", False):
+                self.grads[o:o + n].zero_()
+                p._grad_overwrite = False
+                n_left += 1
+        return n_left
+
     def settle_first_writers(self):
         """After a backward pass under zero_grad(first_writer=True): a flagged matrix whose weight-gradient GEMM did NOT run
         (its flag is still set -- the encoder backward was not reached, or skipped that matrix) holds the PREVIOUS step's
@@ -372,6 +384,7 @@ class GradReducer:
         if (self.world == 1 and not self.force) or name not in self.seg or self.preheat_only or self.hold:
             return
         a, b = self.seg[name]
+        self.s.settle_range(a, b)                     # a matrix of this bucket no weight-gradient GEMM wrote: zero it before it is sent
         if self.stream is None:                       # CPU / gloo tests: synchronous
             buf = self.s.grads[a:b]
             dist.all_reduce(buf, group=self.pg)
@@ -504,11 +517,11 @@ class TrainStep:
         """Gradients are in the flat store: exchange (DP), clip, AdamW, invalidate the bf16 compute copies."""
         with tracing.range("exchange"):               # (the buckets themselves leave during "backward", on the side stream)
             self.reducer.finish()
-        # AFTER the exchange has been waited for: a flagged matrix no GEMM wrote still holds the previous step's values, and its
-        # bucket may be in flight on the side stream (in-place all-reduce) -- a zero fill on the compute stream before
-        # reducer.finish() would race with that collective.  Every rank skips the same matrices, so zeroing the (averaged) stale
-        # values afterwards is consistent across ranks.  A gradient written into a flagged matrix by anything other than the
-        # engine's weight-gradient GEMM must clear ``p._grad_overwrite`` itself, or it is zeroed here.
+        # A flagged matrix no GEMM wrote still holds the previous step's values.  Under data parallelism its bucket settled it before
+        # leaving (GradReducer.segment_ready -> FlatStore.settle_range: zeros on the wire, rank-consistent whatever each rank skipped);
+        # what is left here are the matrices of a single-rank run and of segments that were never announced.  After reducer.finish():
+        # a fill on the compute stream must not race with an in-place all-reduce still in flight.  A gradient written into a flagged
+        # matrix by anything other than the engine's weight-gradient GEMM must clear ``p._grad_overwrite`` itself, or it is zeroed.
         if self.first_writer and not self.warmup_phase:
             self.store.settle_first_writers()
         with tracing.range("optimizer"):
@@ -676,7 +689,14 @@ class TrainStep:
         self.opt.sync_counters()
         return bool(vals[1])
 
-    def load_state_dict(self, sd, allow_legacy_layout=False):
+    def load_state_dict(self, sd, allow_legacy_layout=False, sync_model=True):
+        """Optimizer state (moments, step counters, phase) of ``state_dict()``.  UNDER DATA PARALLELISM THIS IS A COLLECTIVE
+        (``replica_sync`` != "none"): EVERY rank must call it, each after loading its model weights; a call on rank 0 alone hangs in
+        the broadcast.  With ``sync_model=True`` (default) the whole model state then follows rank 0 -- the flat parameter store, the
+        frozen parameters (the 3.6 GB decoder of large-v3) and the buffers -- so a rank that loaded only the optimizer state has
+        its freshly loaded WEIGHTS overwritten by rank 0's; a checksum mismatch before the broadcast is logged as a warning.
+        ``sync_model=False``: only the moments and counters are synchronised (every rank is trusted to have loaded the same
+        weights; ``replica_sync="verify"`` still checks them)."""
         if [tuple(r) for r in sd["layout"]] != [tuple(r) for r in self.store.runs]:
             raise ValueError("optimizer state was saved for a different set of trainable parameters")
         # the runs only fix the run BOUNDARIES; the order of the parameters inside them is part of the layout too (it changed in
@@ -699,8 +719,17 @@ class TrainStep:
         if self.replica_sync != "none" and self.reducer.world > 1:
             # resume: parameters (flat store, frozen ones, buffers), moments and device counters follow rank 0 (or are checked), and
             # so do the host mirrors of the step counters -- ranks that read different files must not diverge in phase / step
-            sync_replicas(self.model, self.store, self.reducer.pg, mode=self.replica_sync,
-                          extra=(self.store.exp_avg, self.store.exp_avg_sq, self.opt.counters))
+            if sync_model or self.replica_sync == "verify":
+                if self.replica_sync == "broadcast":
+                    try:                                  # say so when the broadcast is about to overwrite weights that differ
+                        sync_replicas(self.model, self.store, self.reducer.pg, mode="verify")
+                    except RuntimeError as ex:
+                        log.warning("load_state_dict: the ranks' model weights differ before the resume broadcast -- rank 0's replace the others' (%s)", ex)
+                sync_replicas(self.model, self.store, self.reducer.pg, mode=self.replica_sync,
+                              extra=(self.store.exp_avg, self.store.exp_avg_sq, self.opt.counters))
+            else:
+                sync_replicas(torch.nn.Module(), None, self.reducer.pg, mode=self.replica_sync,
+                              extra=(self.store.exp_avg, self.store.exp_avg_sq, self.opt.counters))
             p0 = self._sync_host_counters_phase(phase)
             phase = p0 if p0 is not None else phase
             self.model.model.encoder._sig = None
