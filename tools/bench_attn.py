@@ -46,7 +46,7 @@ if os.environ.get("ATTN_PROFILE_FUSED"):     # only with a -DATTN_FUSED_PROFILE=
     off = 4096 + ((nfl * 4 + 4095) // 4096) * 4096 + nfl * 4096
     nwg = 8 * ((B * H + 7) // 8) * nkb
     rec = ws[off:off + nwg * 128].view(torch.int64).view(nwg, 16).double().cpu()
-    names = ["loop top, flag poll issue", "A (middle: publish, flag check, sum request)", "wait + barrier X", "B: DMA issue, dQ product", "wait for the sum (slow path: flag)", "LDS read + add", "stores / final rows", "bookkeeping", "barrier Y"]
+    names = ["loop top, flag poll issue", "A: q block 0", "wait in the middle (store acks, poll)", "publish, flag check, sum request, q block 1", "wait + barrier X", "dS fragment reads, DMA issue, barrier Y", "dQ product", "wait for the sum (slow path: flag)", "LDS read + add, stores, bookkeeping"]
     for sel, lab in ((rec[:, 11] == 0, "key block 0"), ((rec[:, 11] > 0) & (rec[:, 11] < nkb - 1), "middle key blocks"), (rec[:, 11] == nkb - 1, "last key block")):
         r = rec[sel]
         print(f"fused bwd, {lab} ({int(sel.sum())} workgroups), cycles per 64-query tile (wave 0): " +

@@ -30,6 +30,7 @@ for (name, c), (n, v) in sorted(agg.items()): print(f"rstride {sys.argv[2]}  {na
 PY
                   rm -rf /tmp/pmc_$tag; done; done ;;
     hf)         timeout 900 python -m pytest tests/test_gpu_hf_trainer.py tests/test_gpu_bench_contract.py -x -q -s 2>&1 | tail -30 | tee $out/hf_tests.txt ;;
+    attn_sq)    ATTN_LOG2=1 ATTN_BWD_REPS=1 bash tools/prof_attn_pmc.sh 2>&1 | tail -120 | tee $out/attn_sq.txt; cp gpurun_out/attn_pmc_summary.json $out/ 2>/dev/null ;;
     gpu_tests)  timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee $out/gpu_tests.txt ;;
     bench)      timeout 900 python bench.py 2>&1 | tail -3 | tee $out/bench_default.json ;;
     bench2)     timeout 900 python bench.py 2>&1 | tail -1 | tee $out/bench_default_again.json ;;

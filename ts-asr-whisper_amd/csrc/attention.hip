@@ -1376,7 +1376,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
         // the poll: a 4-byte DMA into LDS nobody waits for before the middle of the A phase.  (NOT a load into a register: the compiler
         // believes an asm output is there at once and is free to copy it -- at the merge of two branches it did, before the load had
         // landed, and the late arrival then overwrote a register that had been given to a dS value.)
-        if (handoff) dma4x<1>(fl_addr, rsF, 0u, fidx * 4u);
+        if (handoff) dma4x<1>(fl_addr, rsF, 0u, fidx * 4u);      // (a DMA into LDS, not a load into a register: a compiler-issued load made hipcc put s_waitcnt vmcnt(0) -- the store acknowledgements -- at the top of every tile; an asm load's output gets copied before it lands)
         FPROF(0)
 #define FUSED_QBLOCK(QB)                                                                                                \
         {                                                                                                               \
@@ -1427,10 +1427,12 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
             }                                                                                                           \
         }
         if (wave_live) FUSED_QBLOCK(0)
+        FPROF(1)
         // ---- middle of the A phase: everything requested so far has long landed (the next tile's DMA dates from the B phase before),
         // so this wait is all but free -- and it has seen the stores of the tile before acknowledged: its flag goes up.  The poll of
         // this tile's flag is in: flag up -> the sum so far is requested now and has the rest of the tile to land.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        FPROF(2)
         if (pub_idx >= 0) {
             if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32((unsigned)pub_val, rsF, (unsigned)pub_idx * 4u, 0, 0);
             pub_idx = -1;
@@ -1448,7 +1450,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
         }
         if (wave_live && two_blocks) FUSED_QBLOCK(1)
 #undef FUSED_QBLOCK
-        FPROF(1)
+        FPROF(3)
         // ---- barrier X: dS^T complete, this slot free for the tile after next, the next tile landed (its DMA is older than the
         // four loads of the sum, which may stay in flight: loads complete in order)
         if (have) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -1460,7 +1462,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        FPROF(2)
+        FPROF(4)
         // ---- B phase: the next-but-one tile's DMA, the dQ product, the hand-off
         const bool more = i + 2 < nt && !(ATTN_FUSED_ABL & 16);
         const bool prod = blk_live && !(ATTN_FUSED_ABL & 2);
@@ -1482,6 +1484,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                         // ---- barrier Y
         asm volatile("" ::: "memory");
+        FPROF(5)
         if (prod) {
             f32x16_t dq;
 #pragma unroll
@@ -1498,7 +1501,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[3][0], f[1][0], dq, 0, 0, 0);
             dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf[3][1], f[1][1], dq, 0, 0, 0);
             FPROF_DEP(dq[0])
-            FPROF(3)
+            FPROF(6)
             if (handoff) {
                 if (!have) {                                  // the slow path: the visitor before had not published by the middle of the A phase
                     FPROF_SLOW
@@ -1511,14 +1514,13 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
                 } else {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
-                FPROF(4)
+                FPROF(7)
                 land_t pr;
                 land_read_now(pr, z_addr + voff);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { dq[e] += pr.p0[e]; dq[4 + e] += pr.p1[e]; dq[8 + e] += pr.p2[e]; dq[12 + e] += pr.p3[e]; }
             }
             FPROF_DEP(dq[0])
-            FPROF(5)
             if (ATTN_FUSED_ABL & 1) {
             } else if (!last) {
 #pragma unroll
@@ -1551,13 +1553,11 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
             float* wsr = reinterpret_cast<float*>(a.cs_ws) + ((int64_t)(b * 2 * nt + (q32 >> 5)) * a.H + h) * HD + dblk * 32;
             if (lane < 32) wsr[lane] = 0.f;
         }
-        FPROF(6)
+        FPROF(8)
         // the next tile and its rank
         ++cur_t; ++rk_rem;
         if (rk_rem == R) { rk_rem = 0; rk_k = rk_k + 1 < nkb ? rk_k + 1 : rk_k; }
         if (cur_t == nt) { cur_t = 0; rk_k = 0; rk_rem = 0; }
-        FPROF(7)
-        FPROF(8)
     };
     {
         int i = 0;
