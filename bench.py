@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--preheat", action="store_true",
                     help="time the recipe's first phase instead (use_fddt_only_n_steps: only FDDT parameters train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-fabric-gbps", type=float, default=0.0,
+                    help="one-GPU rehearsal of the 8-rank exchange: run as rank 0 of a one-rank RCCL group with the bucketed reducer forced and, "
+                         "behind every bucket's all-reduce, a 16-workgroup side-stream kernel that rewrites the bucket in place twice at this "
+                         "algorithm bandwidth (GB/s) -- the CU, HBM and power load of a real ring all-reduce (dicow_fabric_emulate)")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the other BASELINE.json workloads (configs[1] whisper-base B=8 from a hipGraph, configs[4]'s per-rank SE-DiCoW "
                          "B=16) that the default one-GPU headline run times after its own timed region (`other_workloads` of the line)")
@@ -522,6 +526,11 @@ def main():
     if a.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(a)                       # self-launch: one process per GPU
     _claim_stdout()
+    if a.emulate_fabric_gbps > 0.0 and a.gpus == 1:               # rank 0 of a one-rank group, reducer forced, the emulator behind every bucket
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("LOCAL_RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ["DICOW_FORCE_REDUCE"] = "1"
+        os.environ["DICOW_EMULATE_FABRIC_GBPS"] = str(a.emulate_fabric_gbps)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -547,7 +556,10 @@ def main():
         if share:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            import amd_pkg as _ap
+            _ap.load()
+            from ts_asr_whisper_amd.trainer import nccl_pg_options
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=nccl_pg_options())
         assert dist.get_world_size() == a.gpus, (dist.get_world_size(), a.gpus)
     import amd_pkg
     pkg = amd_pkg.load()
@@ -609,6 +621,7 @@ def main():
     sync()
     # ---- the timed region: exactly K steps, no per-launch instrumentation (one event per step boundary for the median)
     ts.reducer.time_exposed = True
+    ts.reducer.time_buckets = world > 1 or ts.reducer.force
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
     sampler = PowerSampler(local) if rank == 0 and not a.no_power else None
     if sampler:
@@ -625,6 +638,12 @@ def main():
     med_ms = step_ms[len(step_ms) // 2] if a.steps % 2 else 0.5 * (step_ms[a.steps // 2 - 1] + step_ms[a.steps // 2])
     exposed_ms = ts.reducer.exposed_ms()
     ts.reducer.time_exposed = False
+    bucket_rep = ts.reducer.bucket_report(a.steps)
+    ts.reducer.time_buckets = False
+    rank_buckets = [bucket_rep]
+    if world > 1:
+        rank_buckets = [None] * world
+        dist.all_gather_object(rank_buckets, bucket_rep)
     rank_ms = [round(dt / a.steps * 1e3, 3)]
     rank_exposed = [round(exposed_ms, 3)]
     if world > 1:
@@ -725,7 +744,11 @@ def main():
                       "forced_on_one_rank": bool(ts.reducer.force and world == 1),
                       "buckets_per_step": len(ts.reducer.seg) if (world > 1 or ts.reducer.force) else 0,
                       "gemm_cus": a.gemm_cus or None,
-                      "bytes_per_step": 4 * ts.store.n_trainable if (world > 1 or ts.reducer.force) else 0},
+                      "bytes_per_step": 4 * ts.store.n_trainable if (world > 1 or ts.reducer.force) else 0,
+                      # per rank: how long a bucket that was ready on the compute stream queued before its all-reduce started on the
+                      # side stream, and how long the collectives themselves kept that stream busy (GradReducer.bucket_report)
+                      "buckets_per_rank": rank_buckets if any(r is not None for r in rank_buckets) else None,
+                      "emulated_fabric_gbps": ts.reducer.emulate_gbps or None},
         "roofline": {"bound": "mfma", "kernel": "gemm_ntr_kernel (persistent LDS-ring 256x256 / 192x320) / gemm_nt128t_kernel (bf16 MFMA 32x32x16; every forward Linear/conv GEMM and dgrad)",
                      "achieved": round(nt["tflops"], 1), "peak": peak, "unit": "TFLOP/s", "frac": round(nt["tflops"] / peak, 4),
                      "traffic": TRAFFIC, "avg_launch_ms": round(nt["avg_ms"], 4), "launches_per_step": nt["launches"] // nprof,

@@ -416,6 +416,11 @@ int dicow_whisper_timestamp_rules(float* scores, int64_t ld, int B, int V, const
  * dicow_adamw_f32 applies
  *   g' = g * min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6));  decoupled weight decay; bias-corrected moments.   */
 int dicow_sumsq_f32(const float* x, int64_t n, float* out, void* stream);
+/* Measurement aid (ABI 7; no reference counterpart): the load an 8-rank RCCL all-reduce of `bytes` at `gbps` GB/s (algorithm bandwidth)
+ * puts on THIS GPU while it runs beside the backward pass, reproduced on one GPU -- `workgroups` blocks rewrite the buffer in place
+ * with its own values, `passes` times (2 = reduce-scatter + all-gather), pacing themselves so that the call takes bytes / gbps.
+ * The data are unchanged.  trainer.GradReducer (DICOW_EMULATE_FABRIC_GBPS) / bench.py --emulate-fabric-gbps. */
+int dicow_fabric_emulate(void* buf, int64_t bytes, double gbps, int workgroups, int passes, void* stream);
 int dicow_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, const float* gnorm_sq, float max_norm, void* stream);
 /* The same update with the step-dependent scalars read from device memory, hyper = {lr, 1 - beta1^t, 1 - beta2^t}: a training

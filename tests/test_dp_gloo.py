@@ -95,6 +95,60 @@ def test_dp_allreduce_matches_mean_of_ranks():
     assert res[0][3] == ["final_ln", "layer2", "layer1", "layer0", "stem"]
 
 
+def _worker_report(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from ts_asr_whisper_amd.trainer import FlatStore, GradReducer, freeze_by_keyword
+        model = _small_model()
+        freeze_by_keyword(model, ("decoder",))
+        store = FlatStore(model, ("model.encoder.fddts", "model.encoder.initial_fddt", "model.encoder.ca_enrolls"))
+        red = GradReducer(store)
+        red.time_buckets = True
+        STEPS = 3
+        # rank 1 "skipped" one flagged weight matrix (its GEMM did not run: stale values, flag still up); rank 0 wrote it
+        store.zero_grad(first_writer=True)
+        p_, o_, n_ = store._over[0]
+        for step in range(STEPS):
+            store.grads.fill_(1.0 + rank)
+            for p, o, n in store._over:
+                p._grad_overwrite = False
+            if rank == 1:
+                store.grads[o_:o_ + n_] = 123.0                   # last step's leftovers
+                p_._grad_overwrite = True
+            for name, a, b in store.segments:
+                red.segment_ready(name)
+            red.finish()
+        rep = red.bucket_report(STEPS)
+        q.put((rank, rep, len(store.segments), float(store.grads[o_]), float(store.grads[o_ + n_ - 1]), bool(getattr(p_, "_grad_overwrite", False)),
+               red.bucket_report(STEPS)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bucket_report_and_per_bucket_settling_over_gloo():
+    """GradReducer.bucket_report (what `bench.py --gpus N` prints per rank so that a SCALE run explains itself): buckets per step, how
+    long ready buckets queued before their all-reduce started, how long the collectives took -- on the synchronous gloo path the lag
+    is 0 by construction and the busy time is wall time.  And FlatStore.settle_range: a first-writer matrix ONE rank
+    skipped goes on the wire as zeros, so both ranks end with the same average -- (fresh + 0) / 2 -- and the flag is consumed."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_report, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, rep, nseg, first, lastv, still, again in got:
+        assert rep["buckets_per_step"] == nseg and rep["start_lag_ms"] == {"mean": 0.0, "max": 0.0, "sum_per_step": 0.0}
+        assert rep["busy_ms_per_step"] > 0.0 and len(rep["longest_queued"]) == min(3, nseg)
+        assert all(set(r) == {"bucket", "lag_ms", "collective_ms"} for r in rep["longest_queued"])
+        assert again is None                                           # the records are consumed by the report
+        assert first == 0.5 and lastv == 0.5 and not still             # rank 0's 1.0 and rank 1's zeros, averaged; not 62.0
+
+
 def test_flat_store_views_and_groups():
     from ts_asr_whisper_amd.trainer import FlatStore, freeze_by_keyword
     model = _small_model()

@@ -31,6 +31,27 @@ PY
                   rm -rf /tmp/pmc_$tag; done; done ;;
     hf)         timeout 900 python -m pytest tests/test_gpu_hf_trainer.py tests/test_gpu_bench_contract.py -x -q -s 2>&1 | tail -30 | tee $out/hf_tests.txt ;;
     attn_sq)    ATTN_LOG2=1 ATTN_BWD_REPS=1 bash tools/prof_attn_pmc.sh 2>&1 | tail -120 | tee $out/attn_sq.txt; cp gpurun_out/attn_pmc_summary.json $out/ 2>/dev/null ;;
+    dp_emul)    timeout 1500 python tools/dp_emulate.py 100 150 200 2>&1 | tee $out/dp_emulated.txt ;;
+    streams)    timeout 900 python tools/probe_streams.py 2>&1 | grep -v amdgpu.ids | tee $out/probe_streams.txt ;;
+    dp_prof)    for v in base emul; do ex=""; [ $v = emul ] && ex="--emulate-fabric-gbps 100"
+                  (cd /tmp && RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29551 DICOW_FORCE_REDUCE=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dpp_$v -o dp -- python $GRAFT_REPO_ROOT/bench.py --gpus 1 --gemm-cus 240 --no-extra --no-cpu-baseline --no-power --steps 8 --warmup 3 --profile-steps 1 $ex > $GRAFT_REPO_ROOT/$out/dp_prof_$v.json 2>/tmp/dpp_$v.err)
+                  find /tmp/dpp_$v -name "*kernel_stats.csv" -exec cp {} $out/dp_kernel_stats_$v.csv \;
+                  [ $v = emul ] && find /tmp/dpp_$v -name "*kernel_trace.csv" -exec python tools/trace_overlap.py {} \; | tee $out/dp_trace_overlap.txt ; done
+                python - $out <<'PY'
+import csv, sys
+o = sys.argv[1]
+def load(v):
+    d = {}
+    for r in csv.DictReader(open(f"{o}/dp_kernel_stats_{v}.csv")):
+        d[r["Name"].split("(")[0][:70]] = (int(r["Calls"]), float(r["TotalDurationNs"]) / 1e6)
+    return d
+a, b = load("base"), load("emul")
+rows = sorted(((b.get(k, (0, 0))[1] - v[1], k, v, b.get(k, (0, 0))) for k, v in a.items()), reverse=True)
+print("kernel                                                                  calls   base ms   emul ms   delta")
+for dlt, k, va, vb in rows[:14]:
+    print(f"{k:70s} {va[0]:6d} {va[1]:9.2f} {vb[1]:9.2f} {dlt:+8.2f}")
+PY
+                ;;
     gpu_tests)  timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee $out/gpu_tests.txt ;;
     bench)      timeout 900 python bench.py 2>&1 | tail -3 | tee $out/bench_default.json ;;
     bench2)     timeout 900 python bench.py 2>&1 | tail -1 | tee $out/bench_default_again.json ;;

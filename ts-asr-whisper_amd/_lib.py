@@ -139,6 +139,7 @@ _SIGS = {
     "dicow_ctc_prefix_score": [C.POINTER(CtcPrefixArgs), c_vp],
     "dicow_whisper_timestamp_rules": [c_vp, c_i64, c_i, c_i, c_vp, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_vp],
     "dicow_sumsq_f32": [c_vp, c_i64, c_vp, c_vp],
+    "dicow_fabric_emulate": [c_vp, c_i64, c_d, c_i, c_i, c_vp],
     "dicow_adamw_f32": [c_vp, c_vp, c_vp, c_vp, c_i64, c_f, c_f, c_f, c_f, c_f, c_i, c_vp, c_f, c_vp],
     "dicow_adamw_hyper": [c_vp, c_vp, c_vp, c_i, c_i, c_d, c_d, c_i, c_i, c_i, c_d, c_d, c_vp],
     "dicow_adamw_f32_dev": [c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_f, c_f, c_f, c_f, c_vp, c_f, c_vp],

@@ -514,6 +514,42 @@ __global__ void __launch_bounds__(256) sumsq_kernel(const float* __restrict__ x,
     }
 }
 
+// ---- "fabric emulator" (measurement aid, round 6): what an 8-rank RCCL all-reduce of a gradient bucket costs the REST of the GPU
+// while it runs beside the backward pass -- a few workgroups parked on CUs, the bucket read and written through HBM twice
+// (reduce-scatter + all-gather), for as long as the links would take -- reproduced on ONE GPU: `workgroups` blocks stream over the
+// bucket in place (every value rewritten with itself) and pace themselves against the 100 MHz wall clock so that the bucket takes
+// bytes / (gbps GB/s).  trainer.GradReducer runs it on the side stream behind the (one-rank) all-reduce of each bucket
+// (DICOW_EMULATE_FABRIC_GBPS); bench.py --emulate-fabric-gbps reports step time and exposed wait per rate.
+__global__ void __launch_bounds__(256) fabric_emulate_kernel(f32x4_t* buf, int64_t n16, double ticks_per_f4_per_block, int passes) {
+    const int64_t per = (n16 + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
+    const long long t0 = wall_clock64();
+    int64_t done = 0;
+    for (int p = 0; p < passes; ++p)
+        for (int64_t i = lo; i < hi; i += 256 * 16) {           // 64 KB per workgroup in flight (16 workgroups: up to ~250 GB/s of algorithm bandwidth)
+            f32x4_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const int64_t j = i + k * 256 + threadIdx.x; if (j < hi) v[k] = __builtin_nontemporal_load(buf + j); }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const int64_t j = i + k * 256 + threadIdx.x; if (j < hi) __builtin_nontemporal_store(v[k], buf + j); }
+            done += (hi - i < 256 * 16 ? hi - i : 256 * 16);
+            const long long due = t0 + (long long)((double)done * ticks_per_f4_per_block / passes);
+            while (wall_clock64() < due) __builtin_amdgcn_s_sleep(32);
+        }
+}
+
+extern "C" int dicow_fabric_emulate(void* buf, int64_t bytes, double gbps, int workgroups, int passes, void* stream) {
+    DICOW_REQUIRE(buf && bytes > 0 && bytes % 16 == 0 && gbps > 0.0 && workgroups > 0 && workgroups <= 1024 && passes > 0 && passes <= 8,
+                  "fabric_emulate: bad arguments");
+    const int64_t n16 = bytes / 16;
+    // the whole bucket in bytes / (gbps 1e9) seconds = that many 1e8-per-second ticks; each block owns 1 / workgroups of it
+    const double ticks_total = (double)bytes / (gbps * 1e9) * 1e8;
+    const double per_block_f4 = (double)((n16 + workgroups - 1) / workgroups);
+    hipLaunchKernelGGL(fabric_emulate_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<f32x4_t*>(buf), n16,
+                       ticks_total / per_block_f4, passes);
+    DICOW_CHECK_LAUNCH("fabric_emulate");
+    return DICOW_OK;
+}
+
 extern "C" int dicow_sumsq_f32(const float* x, int64_t n, float* out, void* stream) {
     DICOW_REQUIRE(x && out && n > 0, "sumsq_f32: bad args");
     int grid = (int)((n / 4 + 255) / 256); if (grid < 1) grid = 1; if (grid > SUMSQ_MAX_BLOCKS) grid = SUMSQ_MAX_BLOCKS;

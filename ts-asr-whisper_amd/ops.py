@@ -516,6 +516,11 @@ def ctc_loss_bwd(a, grad_scale):
     L.check(L.lib().dicow_ctc_loss_bwd(C.byref(a), grad_scale.data_ptr(), L.stream()), "dicow_ctc_loss_bwd")
 
 
+def fabric_emulate(buf, gbps, workgroups=16, passes=2):
+    """The GPU-side load of an 8-rank all-reduce of `buf` at `gbps` GB/s, on one GPU (dicow_fabric_emulate): in place, values unchanged."""
+    L.call("dicow_fabric_emulate", buf.data_ptr(), buf.numel() * buf.element_size(), float(gbps), int(workgroups), int(passes), L.stream())
+
+
 def sumsq(x, out):
     L.call("dicow_sumsq_f32", x.data_ptr(), x.numel(), out.data_ptr(), L.stream())
 

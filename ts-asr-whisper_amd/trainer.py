@@ -15,6 +15,7 @@ import collections
 import logging
 import math
 import os
+import time
 
 import torch
 import torch.distributed as dist
@@ -351,6 +352,17 @@ def sync_replicas(model, store=None, process_group=None, mode="broadcast", src=0
     return nbytes
 
 
+def nccl_pg_options():
+    """Options for ``dist.init_process_group("nccl", pg_options=...)``: RCCL's own stream at high priority, so that it does not land on
+    the hardware queue of the compute stream (see GradReducer.__init__).  None when the backend class is not available."""
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        return opts
+    except Exception:
+        return None
+
+
 class GradReducer:
     """Bucketed gradient all-reduce on a side stream, one bucket per backward segment of the FlatStore."""
 
@@ -361,7 +373,14 @@ class GradReducer:
         # DICOW_FORCE_REDUCE=1 exercises the bucketed side-stream all-reduce even with a single rank (smoke test of
         # the RCCL code path on a 1-GPU box)
         self.force = os.environ.get("DICOW_FORCE_REDUCE") == "1" and dist.is_initialized()
-        self.stream = torch.cuda.Stream() if ((self.world > 1 or self.force) and torch.cuda.is_available()) else None
+        # HIGH-PRIORITY side stream: ROCm maps HIP streams onto a few hardware queues, and a normal-priority pool stream can share ITS
+        # queue with the compute stream -- kernels of one queue never overlap, and the exchange then lengthens the step by exactly
+        # its own busy time (round 6: rocprofv3 showed the bucket kernels and the GEMMs on the same Queue_Id, 0 % overlap,
+        # profiles/r06_dp_emulated.txt).  Priority streams get queues of their own.  The process group should be created with
+        # ProcessGroupNCCL.Options(is_high_priority_stream=True) for the same reason (bench.py does; see nccl_pg_options()).
+        self.stream = None
+        if (self.world > 1 or self.force) and torch.cuda.is_available():
+            self.stream = torch.cuda.Stream(priority=-1 if os.environ.get("DICOW_REDUCER_STREAM_PRIORITY", "high") == "high" else 0)
         if self.stream is not None and self.world > 1:
             # RCCL runs one workgroup per channel beside the backward pass; the persistent GEMM's workgroups own a whole CU
             # each, so leave the channels their CUs (the all-reduce of 2.5 GB has the whole backward pass to hide in and
@@ -376,6 +395,15 @@ class GradReducer:
         self.pending = []
         self.time_exposed = False     # bench: record how long the compute stream waits for the side-stream buckets
         self._exposed = []
+        # bench / SCALE runs: per bucket, when it became ready on the compute stream, when its all-reduce started on the side stream
+        # (the difference = how long the bucket queued behind the ones before it) and how long the collective took
+        self.time_buckets = False
+        self._bucket_ev = []          # (name, ready, start, end) HIP events
+        self._bucket_cpu = []         # (name, seconds) on the synchronous (gloo / CPU) path
+        # one-GPU rehearsal: behind each bucket's (one-rank) all-reduce, the GPU-side load of an 8-rank one at this algorithm bandwidth
+        g = os.environ.get("DICOW_EMULATE_FABRIC_GBPS")
+        self.emulate_gbps = float(g) if g else 0.0
+        self.emulate_workgroups = int(os.environ.get("DICOW_EMULATE_FABRIC_WGS", "16"))
         self.preheat_only = False     # staged freezing, phase 1: only the preheat runs carry gradients
         self.hold = False             # gradient accumulation: not the last micro-batch yet, nothing to exchange
 
@@ -387,19 +415,33 @@ class GradReducer:
         self.s.settle_range(a, b)                     # a matrix of this bucket no weight-gradient GEMM wrote: zero it before it is sent
         if self.stream is None:                       # CPU / gloo tests: synchronous
             buf = self.s.grads[a:b]
+            t0 = time.perf_counter()
             dist.all_reduce(buf, group=self.pg)
             buf.div_(self.world)
+            if self.time_buckets:
+                self._bucket_cpu.append((name, time.perf_counter() - t0))
             return
-        ev = torch.cuda.Event()
+        ev = torch.cuda.Event(enable_timing=self.time_buckets)
         ev.record()
         with torch.cuda.stream(self.stream):
             self.stream.wait_event(ev)
+            if self.time_buckets:
+                e_start = torch.cuda.Event(enable_timing=True)
+                e_start.record()
             buf = self.s.grads[a:b]
             if self._avg_in_collective:               # RCCL averages inside the collective: no second pass over the 2.5 GB
                 dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.pg)
             else:
                 dist.all_reduce(buf, group=self.pg)
                 buf.div_(self.world)
+            if self.emulate_gbps > 0.0 and buf.is_cuda:
+                n = (b - a) // 4 * 4                  # (16-byte multiples; a tail of < 4 floats does not change the load)
+                if n > 0:
+                    ops.fabric_emulate(buf[:n], self.emulate_gbps, self.emulate_workgroups)
+            if self.time_buckets:
+                e_end = torch.cuda.Event(enable_timing=True)
+                e_end.record()
+                self._bucket_ev.append((name, ev, e_start, e_end))
 
     def _reduce_preheat_runs(self):
         """Phase 1 of the staged freezing: the frozen runs hold zeros, so only the (small) preheat runs are exchanged,
@@ -427,6 +469,31 @@ class GradReducer:
                 self._exposed.append((e0, e1))
             else:
                 torch.cuda.current_stream().wait_stream(self.stream)
+
+    def bucket_report(self, steps=1):
+        """{buckets_per_step, start_lag_ms: {mean, max, sum_per_step}, busy_ms_per_step, slowest: [...]} from the time_buckets records:
+        start lag = bucket ready on the compute stream -> its all-reduce starts on the side stream (it queued behind earlier buckets);
+        busy = the collectives' own time.  On the synchronous (gloo / CPU) path only the collectives' wall time exists (lag 0)."""
+        rows = []
+        if self._bucket_ev:
+            torch.cuda.synchronize()
+            rows = [(n, r.elapsed_time(s_), s_.elapsed_time(e)) for n, r, s_, e in self._bucket_ev]
+        elif self._bucket_cpu:
+            rows = [(n, 0.0, dt * 1e3) for n, dt in self._bucket_cpu]
+        self._bucket_ev, self._bucket_cpu = [], []
+        if not rows:
+            return None
+        steps = max(1, steps)
+        per = {}
+        for n, lag, dur in rows:
+            t = per.setdefault(n, [0, 0.0, 0.0])
+            t[0] += 1; t[1] += lag; t[2] += dur
+        worst = sorted(per.items(), key=lambda kv: -kv[1][1] / kv[1][0])[:3]
+        return {"buckets_per_step": len(rows) // steps,
+                "start_lag_ms": {"mean": round(sum(r[1] for r in rows) / len(rows), 4), "max": round(max(r[1] for r in rows), 4),
+                                 "sum_per_step": round(sum(r[1] for r in rows) / steps, 3)},
+                "busy_ms_per_step": round(sum(r[2] for r in rows) / steps, 3),
+                "longest_queued": [{"bucket": n, "lag_ms": round(v[1] / v[0], 4), "collective_ms": round(v[2] / v[0], 4)} for n, v in worst]}
 
     def exposed_ms(self):
         """Mean per-step time the compute stream spent waiting for the gradient exchange (time_exposed = True steps)."""
