@@ -26,7 +26,10 @@ def timed(fn, n=5):
     return (time.perf_counter() - t0) / n * 1e3
 ref = fwd(x, st)
 print(f"single stream B=16: {timed(lambda: fwd(x, st)):.2f} ms")
-s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+# round 6: two normal-priority pool streams may share ONE hardware queue with each other / the default stream (kernels of a queue never
+# overlap: profiles/r06_dp_emulated.txt) -- STREAM_PRIO=1 makes the second stream a high-priority one (a queue of its own)
+s1, s2 = torch.cuda.Stream(), (torch.cuda.Stream(priority=-1) if os.environ.get("STREAM_PRIO") == "1" else torch.cuda.Stream())
+print("second stream:", "high priority (own hardware queue)" if os.environ.get("STREAM_PRIO") == "1" else "normal priority (pool stream)")
 xs, sts = (x[:8].contiguous(), x[8:].contiguous()), (st[:8].contiguous(), st[8:].contiguous())
 for cus in (118, 128, 0):
     ops.set_gemm_cus(cus)

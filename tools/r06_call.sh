@@ -14,7 +14,7 @@ for step in "$@"; do
     attn_rot)   for r in 0 1 2 99; do echo "rstride $r" | tee -a $out/attn_rot.txt; DICOW_ATTN_FUSED_RSTRIDE=$r ATTN_LOG2=1 ATTN_BWD_REPS=2 timeout 600 python tools/bench_attn.py 2>&1 | grep attn_bwd | tee -a $out/attn_rot.txt; done ;;
     attn_rocprof) (cd /tmp && ATTN_LOG2=1 ATTN_BWD_REPS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_attn_$tag -o attn -- python $GRAFT_REPO_ROOT/tools/bench_attn.py > $GRAFT_REPO_ROOT/$out/attn_rocprof_run.txt 2>&1)
                 find /tmp/prof_attn_$tag -name "*kernel_stats.csv" -exec cp {} $out/attn_kernel_stats.csv \; ; head -12 $out/attn_kernel_stats.csv ;;
-    attn_abl)   for rep in 1 2; do for v in base abl1 abl63; do l=$PWD/ts-asr-whisper_amd/libdicow_hip.so; [ $v != base ] && l=$PWD/tools/libv_f$v.so
+    attn_abl)   for rep in 1 2; do for v in base abl1 abl3 abl67 abl63; do l=$PWD/ts-asr-whisper_amd/libdicow_hip.so; [ $v != base ] && l=$PWD/tools/libv_f$v.so
                   echo -n "$v: " | tee -a $out/attn_abl.txt; DICOW_HIP_LIB=$l ATTN_LOG2=1 ATTN_BWD_REPS=1 timeout 300 python tools/bench_attn.py 2>&1 | grep "fused" | tee -a $out/attn_abl.txt; done; done ;;
     attn_pmc)   for r in 1 2 99; do for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
                   (cd /tmp && DICOW_ATTN_FUSED_RSTRIDE=$r ATTN_LOG2=1 ATTN_BWD_REPS=1 timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_$tag -- python $GRAFT_REPO_ROOT/tools/bench_attn.py > /tmp/pmc_run.txt 2>&1)
@@ -52,6 +52,9 @@ for dlt, k, va, vb in rows[:14]:
     print(f"{k:70s} {va[0]:6d} {va[1]:9.2f} {vb[1]:9.2f} {dlt:+8.2f}")
 PY
                 ;;
+    dual)       for pr in 0 1; do STREAM_PRIO=$pr timeout 600 python tools/dual_stream_probe.py 2>&1 | grep -v amdgpu.ids | tee -a $out/dual_stream_probe.txt; done ;;
+    rows)       timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fullsize.py -x -q -k "fddt or ln or row or layernorm" 2>&1 | tail -5 | tee $out/rows_tests.txt
+                for l in $PWD/tools/libv_rows_old.so $PWD/ts-asr-whisper_amd/libdicow_hip.so $PWD/tools/libv_rows_d2.so $PWD/tools/libv_rows_old.so $PWD/ts-asr-whisper_amd/libdicow_hip.so $PWD/tools/libv_rows_d2.so; do [ -f $l ] && (echo "== $l"; DICOW_HIP_LIB=$l timeout 300 python tools/bench_rows.py 2>&1 | grep -v amdgpu.ids) | tee -a $out/bench_rows.txt; done ;;
     gpu_tests)  timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee $out/gpu_tests.txt ;;
     bench)      timeout 900 python bench.py 2>&1 | tail -3 | tee $out/bench_default.json ;;
     bench2)     timeout 900 python bench.py 2>&1 | tail -1 | tee $out/bench_default_again.json ;;

@@ -1326,7 +1326,7 @@ __global__ void __launch_bounds__(256, 2) attn_bwd_fused_kernel(const dicow_attn
     const int dsw = (dsrow * 128 + 8 * hh) ^ (rev3((dsrow >> 1) & 7) << 4);      // byte offset inside an image
     const unsigned dsr0 = tr_base_u(sDS, lane, qsub, 0), dsr1 = tr_base_u(sDS, lane, qsub, 1);
     const bool tail_half = ATTN_BWD_TAIL && nt * KV_TILE - a.Lq >= 32 && nt > 1;
-    const bool wave_live = kblk0 + wave * 32 < a.Lk;
+    const bool wave_live = kblk0 + wave * 32 < a.Lk && !((ATTN_FUSED_ABL & 64) && wave == 3);      // (ablation 64: three working waves per workgroup)
 
     // hand-off addressing: flag word and 4 KB fragment tile of (pair, tile, this wave)
     unsigned* const flags = reinterpret_cast<unsigned*>(fws + FUSED_WS_HDR);

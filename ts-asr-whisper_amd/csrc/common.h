@@ -43,6 +43,20 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, b);
 }
 
+// ---- LDS-DMA the compiler must not see (round 6).  hipcc tracks every `buffer_load ... lds` IT emits and puts s_waitcnt vmcnt(0) in front of the
+// next typed LDS load it cannot tell apart from the DMA's destination -- in practice every one: a kernel that requests rows / tiles
+// several trips ahead and orders them with its own counted waits then waits for ALL of them, the newest included, at the first LDS
+// read of every trip (seen in the ISA of attn_bwd_dkv_kernel and of both staged row kernels: their prefetch never ran ahead).  Issued
+// from inline assembly the DMA is invisible to that pass; the kernel's own s_waitcnt vmcnt(N) + barriers order it.  m0 = wave-uniform
+// LDS byte address (nothing else in these kernels uses m0).  AUX: the builtin's cache-policy bits (0 default, 2 = nt, 17 = sc0 sc1).
+template <int AUX>
+__device__ __forceinline__ void dicow_dma16(unsigned lds_addr, __amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    static_assert(AUX == 0 || AUX == 2 || AUX == 17, "dicow_dma16: cache policy 0, 2 (nt) or 17 (sc0 sc1)");
+    if constexpr (AUX == 17) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen sc0 sc1 lds" :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    else if constexpr (AUX == 2) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds" :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
 // exact (erf) GELU and its derivative (Whisper activation_function="gelu").  Every kernel evaluates the SAME expression (this
 // scalar form and the packed stage-major gelu_cdf_pdf_p below are operation-for-operation identical), so the training
 // forward, the inference forward and the decoder step produce identical activations.

@@ -516,8 +516,7 @@ __global__ void __launch_bounds__(512) fddt_ln_fwd_staged_kernel(const dicow_fdd
     auto stage_rows = [&](int row0, int s) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (lds_void_f_t*)(stg + (s * R + r) * row_lds + wave * 1024), 16, vo32,
-                                                     (row0 + r) * D * 4, 0, ROWS_FWD_NT);
+            dicow_dma16<ROWS_FWD_NT>((unsigned)(uintptr_t)(stg + (s * R + r) * row_lds + wave * 1024), rsH, vo32, (unsigned)((row0 + r) * D * 4));     // (assembly-issued: common.h)
     };
     float m_n[R][4];
     auto load_masks = [&](int row0) {
@@ -939,10 +938,11 @@ __global__ void __launch_bounds__(512) fddt_ln_bwd_staged_kernel(const dicow_fdd
         for (int r = 0; r < R; ++r) {
             char* base = stg + (s * R + r) * row_lds;
             const int so32 = (row0 + r) * D * 4, so16 = (row0 + r) * D * 2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsH, (lds_void_t*)(base + wave * 1024), 16, vo32, so32, 0, ROWS_BWD_H_NT);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsG, (lds_void_t*)(base + 4 * D + wave * 1024), 16, vo32, so32, 0, ROWS_BWD_G_NT);
+            // (assembly-issued, common.h dicow_dma16: the compiler's own LDS-DMA made it wait for the NEWEST request at every trip's first LDS read)
+            dicow_dma16<ROWS_BWD_H_NT>((unsigned)(uintptr_t)(base + wave * 1024), rsH, vo32, (unsigned)so32);
+            dicow_dma16<ROWS_BWD_G_NT>((unsigned)(uintptr_t)(base + 4 * D + wave * 1024), rsG, vo32, (unsigned)so32);
             if (lane < 32 && (int)voY < 2 * D)       // (a last, partly filled wave: only the lanes inside the row)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void_t*)(base + 8 * D + wave * 512), 16, voY, so16, 0, ROWS_BWD_Y_NT);
+                dicow_dma16<ROWS_BWD_Y_NT>((unsigned)(uintptr_t)(base + 8 * D + wave * 512), rsY, voY, (unsigned)so16);
         }
     };
     // per-row scalars (mean, rstd, 4 STNO masks) of a trip are ordinary loads: they are requested one trip ahead, BEFORE
