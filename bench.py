@@ -332,7 +332,7 @@ class PowerSampler:
                 "note": "rocm-smi samples during the timed region (board power cap 1400 W, peak shader clock 2400 MHz)"}
 
 
-PMC_FILES = ("r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01g_pmc_hbm_traffic.json")      # newest first
+PMC_FILES = ("r06_pmc_hbm_traffic.json", "r05_pmc_hbm_traffic.json", "r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01g_pmc_hbm_traffic.json")      # newest first
 TRAFFIC_SOURCE = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, tools/prof_pmc.sh; fabric-side bytes "
                   "per persistent NT GEMM launch, FETCH_SIZE x2 per the gfx950 correction)")
 

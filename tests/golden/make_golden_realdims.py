@@ -49,8 +49,25 @@ CASES = {
     # ROW 9 of the B = 16 batch of tests/test_gpu_realdims.py::test_configs2_batch16_... -- a row whose labels end in -100 padding --
     # run by the reference as a B = 1 sample: a second row of that batch pinned to the reference directly (round 5)
     "rd_turbo_row9": ("whisper-large-v3-turbo", 1, 128, {}, False, False),
+    # round 6: two more rows of that batch run by the reference -- ROW 5, whose clip ends at 18 s (the collator's padding-as-silence
+    # tail: mel floor, STNO silence = 1 from frame 900 on, collators.py:157-161) and ROW 12, all 128 label positions in use
+    "rd_turbo_row5": ("whisper-large-v3-turbo", 1, 128, {}, False, False),
+    "rd_turbo_row12": ("whisper-large-v3-turbo", 1, 128, {}, False, False),
 }
-B16_ROW = {"rd_turbo_row9": 9}
+B16_ROW = {"rd_turbo_row9": 9, "rd_turbo_row5": 5, "rd_turbo_row12": 12}
+B16_SILENCE_FROM = {5: 900}                  # rows of the B = 16 batch whose clip ends early: first padding frame (of 1500)
+
+
+def b16_batch(M, T, L):
+    """The B = 16 batch of tests/test_gpu_realdims.py::test_configs2_batch16_... (rows 1-15; the test puts golden rd_turbo's sample in row 0)."""
+    x = torch.from_numpy(hashed_mel(16, M, 2 * T)).clone() * 1.5
+    st = hashed_stno(16, T, "rd_turbo_b16.stno").clone()
+    lab = hashed_labels(16, L, 0, 50257, "rd_turbo_b16.labels", pad_rows=(3, 9)).clone()
+    for r, n in B16_SILENCE_FROM.items():
+        x[r, :, 2 * n:] = -1.5
+        st[r, :, n:] = 0.0
+        st[r, 0, n:] = 1.0
+    return x, st, lab
 QK_SCALE = {"rd_turbo_peaked": 2.0}
 
 
@@ -93,10 +110,9 @@ def inputs(preset, B, L, mixed, se, tag):
     M, T = d["num_mel_bins"], 1500
     if tag in B16_ROW:                        # one row of the B = 16 test batch, exactly as the test builds it
         r = B16_ROW[tag]
-        x = torch.from_numpy(hashed_mel(16, M, 2 * T)).clone()[r:r + 1] * 1.5
-        st = hashed_stno(16, T, "rd_turbo_b16.stno")[r:r + 1].clone()
-        lab = hashed_labels(16, L, 0, 50257, "rd_turbo_b16.labels", pad_rows=(3, 9))[r:r + 1].clone()
-        return x, st, lab, lab.clone(), [T]
+        xb, stb, labb = b16_batch(M, T, L)
+        x, st, lab = xb[r:r + 1].clone(), stb[r:r + 1].clone(), labb[r:r + 1].clone()
+        return x, st, lab, lab.clone(), [B16_SILENCE_FROM.get(r, T)]
     x = torch.from_numpy(hashed_mel(B * (2 if se else 1), M, 2 * T)).clone() * 1.5
     st = hashed_stno(B * (2 if se else 1), T, tag + ".stno")
     lens = [T] * (B * (2 if se else 1))

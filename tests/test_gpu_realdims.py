@@ -171,7 +171,9 @@ def test_configs2_batch16_step_row0_vs_reference_golden_and_loss_is_the_mean_of_
         golden run never reaches);
       * the step's loss is the mean over ALL label positions (modeling_dicow.py:310-323) = the mean of the 16 rows' own
         losses, each computed by a separate B = 1 forward;
-      * every row's encoder output equals its B = 1 forward (batch invariance of the whole encoder at the bench shape)."""
+      * every row's encoder output equals its B = 1 forward (batch invariance of the whole encoder at the bench shape);
+      * rows 5 (all-silence STNO tail), 9 (padded labels) and 12 (all label positions used) are pinned to the reference's own runs of
+        exactly those rows (goldens rd_turbo_row5 / _row9 / _row12): encoder output and logits inside the batch, loss and gradients as B = 1."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from tests.util import hashed_stno, hashed_labels
@@ -180,8 +182,12 @@ def test_configs2_batch16_step_row0_vs_reference_golden_and_loss_is_the_mean_of_
     B, L, T = 16, int(z["L"]), cfg.max_source_positions
     b1 = _batch(z, cfg)
     x = torch.from_numpy(hashed_mel(B, cfg.num_mel_bins, 2 * T)).clone() * 1.5
-    st = hashed_stno(B, T, "rd_turbo_b16.stno")
+    st = hashed_stno(B, T, "rd_turbo_b16.stno").clone()
     lab = hashed_labels(B, L, 0, 50257, "rd_turbo_b16.labels", pad_rows=(3, 9))
+    SIL5 = 900                                              # row 5's clip ends at 18 s: the collator's padding-as-silence tail (collators.py:157-161)
+    x[5, :, 2 * SIL5:] = -1.5
+    st[5, :, SIL5:] = 0.0
+    st[5, 0, SIL5:] = 1.0                                   # (tests/golden/make_golden_realdims.py::b16_batch builds the same rows)
     x[0], st[0], lab[0] = b1["input_features"][0].cpu(), b1["stno_mask"][0].cpu(), b1["labels"][0].cpu()
     upp = lab.clone()
     upp[0] = b1["upp_labels"][0].cpu()
@@ -207,6 +213,12 @@ def test_configs2_batch16_step_row0_vs_reference_golden_and_loss_is_the_mean_of_
     z9 = load_golden("rd_turbo_row9")
     assert np.array_equal(z9["labels"][0], lab[9].numpy()) and int((lab[9] == -100).sum()) == L // 4
     _check_forward(z9, types.SimpleNamespace(encoder_last_hidden_state=enc[9:10], logits=logits[9:10], loss=torch.tensor(rows_loss[9])))
+    # round 6: two more rows the reference ran -- row 5 (all-silence STNO tail from frame 900 on) and row 12 (all 128 label positions used)
+    z5, z12 = load_golden("rd_turbo_row5"), load_golden("rd_turbo_row12")
+    assert np.array_equal(z5["stno"][0], st[5].numpy()) and float(st[5, 0, SIL5:].min()) == 1.0 and float(st[5, 1:, SIL5:].abs().max()) == 0.0
+    assert np.array_equal(z12["labels"][0], lab[12].numpy()) and int((lab[12] == -100).sum()) == 0
+    _check_forward(z5, types.SimpleNamespace(encoder_last_hidden_state=enc[5:6], logits=logits[5:6], loss=torch.tensor(rows_loss[5])))
+    _check_forward(z12, types.SimpleNamespace(encoder_last_hidden_state=enc[12:13], logits=logits[12:13], loss=torch.tensor(rows_loss[12])))
     # different tile shapes / split factors at 1500 and 24000 rows: fp32 accumulation order differs, bf16 roundings flip
     assert worst_inv < 6e-2, worst_inv
     mean_rows = sum(rows_loss) / B
@@ -216,7 +228,7 @@ def test_configs2_batch16_step_row0_vs_reference_golden_and_loss_is_the_mean_of_
         if p.requires_grad:
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
     print("configs[2] B=16: worst row-vs-B=1 encoder deviation", worst_inv, "loss", float(out.loss), "mean of rows", mean_rows)
-    worst = _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checked=20, extra_rows={9: z9})
+    worst = _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checked=20, extra_rows={9: z9, 5: z5, 12: z12})
     print("configs[2] B=16: worst watched gradient, B=16 step vs mean of the 16 B=1 steps (rel-L2):", worst)
 
 

@@ -55,6 +55,22 @@ PY
     dual)       for pr in 0 1; do STREAM_PRIO=$pr timeout 600 python tools/dual_stream_probe.py 2>&1 | grep -v amdgpu.ids | tee -a $out/dual_stream_probe.txt; done ;;
     rows)       timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_fullsize.py -x -q -k "fddt or ln or row or layernorm" 2>&1 | tail -5 | tee $out/rows_tests.txt
                 for l in $PWD/tools/libv_rows_old.so $PWD/ts-asr-whisper_amd/libdicow_hip.so $PWD/tools/libv_rows_d2.so $PWD/tools/libv_rows_old.so $PWD/ts-asr-whisper_amd/libdicow_hip.so $PWD/tools/libv_rows_d2.so; do [ -f $l ] && (echo "== $l"; DICOW_HIP_LIB=$l timeout 300 python tools/bench_rows.py 2>&1 | grep -v amdgpu.ids) | tee -a $out/bench_rows.txt; done ;;
+    final)      # the round's evidence on ONE box (what is judged is copied into profiles/ afterwards)
+                (timeout 2700 python -m pytest tests -m gpu -q > $out/gpu_tests.txt 2>&1; tail -3 $out/gpu_tests.txt)
+                python bench.py > $out/bench_default.json 2> $out/bench_default.err
+                bash tools/prof_pmc.sh > /dev/null 2>&1; cp gpurun_out/pmc_summary.json $out/pmc_hbm_traffic.json
+                bash tools/prof_step.sh > $out/prof_step.txt 2>&1; cp gpurun_out/kernel_stats.csv $out/kernel_stats.csv
+                bash tools/prof_encfwd.sh > $out/prof_encfwd.txt 2>&1; cp gpurun_out/encfwd_kernel_stats.csv $out/encfwd_kernel_stats.csv
+                python bench.py --preflight > $out/preflight_1gpu.json 2> $out/preflight.err
+                python bench.py --from-audio --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_from_audio.json 2>/dev/null
+                for v in se ctc preheat; do python bench.py --$v --steps 8 --warmup 3 --no-cpu-baseline > $out/bench_$v.json 2> $out/bench_$v.err; done
+                python bench.py --model whisper-base --batch 8 --no-cpu-baseline > $out/bench_base_b8.json 2> $out/base.err
+                python bench.py --model whisper-base --batch 8 --graph --no-cpu-baseline > $out/bench_base_b8_graph.json 2>> $out/base.err
+                bash tools/prof_pmc_mfma.sh > /dev/null 2>&1; cp gpurun_out/pmc_mfma_summary.json $out/pmc_mfma_lds.json 2>/dev/null
+                bash tools/prof_pmc_l2.sh > /dev/null 2>&1; cp gpurun_out/pmc_l2_summary.json $out/pmc_l2_hit_rate.json 2>/dev/null
+                python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_default_again.json 2>/dev/null
+                for f in $out/bench_*.json; do python -c "
+import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['ms_per_step_median'], d['roofline']['frac'], (d.get('kernels') or {}).get('gemm_tn_kernel',{}).get('tflops'), (d.get('encoder_forward') or {}).get('ms'), (d.get('encoder_forward_train') or {}).get('ms'), d.get('power'))"; done ;;
     gpu_tests)  timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee $out/gpu_tests.txt ;;
     bench)      timeout 900 python bench.py 2>&1 | tail -3 | tee $out/bench_default.json ;;
     bench2)     timeout 900 python bench.py 2>&1 | tail -1 | tee $out/bench_default_again.json ;;
