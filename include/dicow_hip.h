@@ -440,7 +440,7 @@ int dicow_adamw_f32_dev(float* p, const float* g, float* m, float* v, int64_t n,
 /* ------------------------------------------------------------------------------------------------ EXPERIMENTAL (not part of the stable ABI)
  * Declared only under -DDICOW_EXPERIMENTAL_ABI and exported only by a library built with -DDICOW_EXPERIMENTS (build.sh --exp -> libdicow_hip_exp.so).
  * Round 4's LayerNorm fold: built, parity-tested (tests/test_gpu_lnfold.py) and measured 3-4 % SLOWER than the two LayerNorm launches it
- * deletes (profiles/r04_lnfold.txt) -- kept for A/B builds, out of ABI 6.  The tail fields of dicow_gemm_args (lnstat ... ln_nslots) belong to
+ * deletes (profiles/r04_lnfold.txt) -- kept for A/B builds, out of the stable ABI.  The tail fields of dicow_gemm_args (lnstat ... ln_nslots) belong to
  * it and must be zero for a stable-ABI library, which refuses the two flags. */
 #ifdef DICOW_EXPERIMENTAL_ABI
 /* LayerNorm folded into the GEMMs on either side of it (ABI 4; HF:modeling_whisper.py:392-405 via encoder.py:216-221: the
