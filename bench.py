@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=5,
                     help="instrumented steps run AFTER the timed region (per-launch HIP events of the dominant kernel: roofline)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (launch-bound configs)")
+    ap.add_argument("--split-streams", action="store_true",
+                    help="run each batch as two half batches on two HIP streams (trainer.SplitSync; same loss and gradients as the two halves "
+                         "accumulated; measured -0.3...-1.8 ms per step, profiles/r06_split_streams.txt: not the default)")
     ap.add_argument("--from-audio", action="store_true",
                     help="the step starts from 16 kHz waveforms resident in HBM: dicow_logmel -> BatchAugmenter (STNO segment "
                          "augmentation + joint SpecAug, collators.py:189-214) -> training step (reported beside the headline, never AS it)")
@@ -579,7 +582,7 @@ def main():
     prefixes = ("model.encoder.fddts", "model.encoder.initial_fddt") + (("model.encoder.ca_enrolls",) if a.se else ())
     ts = TrainStep(model, lr=2e-6, fddt_lr_multiplier=100.0, max_grad_norm=1.0, warmup_steps=2000, max_steps=40000,
                    preheat_prefixes=prefixes, use_fddt_only_n_steps=10 ** 9 if a.preheat else 0,
-                   **({"graph": True} if a.graph else {}))
+                   split_streams=a.split_streams, **({"graph": True} if a.graph else {}))
     if a.preflight:
         return preflight(a, world, rank, local, ts, share)
     batches = [synthetic_batch(cfg, a.batch, a.labels, seed=1000 + rank * 17 + i, mixed_length=a.se, enrollments=a.se)
@@ -735,7 +738,7 @@ def main():
         "config": {"workload": f"{a.model} DiCoW fine-tune step, per-GPU batch {a.batch}, L={a.labels}, decoder frozen, "
                                f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}{', CTC 0.3' if a.ctc else ''}{', preheat phase (FDDT-only training)' if a.preheat else ''}"
                                f"{', step replayed from a hipGraph' if a.graph else ''}{', from 16 kHz audio (log-mel + augmentation inside the step)' if a.from_audio else ''}",
-                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "trainable_params": sum(n for q, _, n, _ in ts.store.entries if q.requires_grad)},
+                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "split_streams": bool(a.split_streams), "trainable_params": sum(n for q, _, n, _ in ts.store.entries if q.requires_grad)},
         "loss": float(loss),
         "per_rank_ms_per_step": rank_ms,
         "allreduce": {"exposed_ms_per_step": rank_exposed,

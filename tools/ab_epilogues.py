@@ -1,6 +1,6 @@
 """The encoder layer's NT GEMMs (large-v3-turbo, B = 16: M = 24000) per EPILOGUE KIND, each on the ring kernel's two tile shapes, and the
 two ways to get the next layer's FDDT + LayerNorm behind fc2 (tables b and c).
-   DICOW_HIP_LIB=tools/libv_ntabl.so DICOW_NT_VARIANT={0,21,22} python tools/ab_epilogues.py
+   DICOW_HIP_LIB=tools/libv_ntabl.so python tools/ab_epilogues.py
 (libv_ntabl.so = `tools/build_var.sh ntabl "-DDICOW_ABLATIONS" "" "" ""`; variant 0 = the shipped choice, 21 = 256 x 256 forced, 22 = 192 x 320
 forced.)  A 256 MB copy runs between launches (operands arrive from HBM / MALL, not from a warm L2); median of 12."""
 import os
@@ -15,7 +15,6 @@ from ts_asr_whisper_amd import ops, _lib as L
 
 bf = torch.bfloat16
 M, D, F = 24000, 1280, 5120
-variant = os.environ.get("DICOW_NT_VARIANT", "0")
 
 
 def rnd(*s):
@@ -38,7 +37,7 @@ def timeit(fn, iters=12):
     return t[len(t) // 2] * 1e3
 
 
-rows = []
+cases = []
 for name, n, k, epi in [("out-proj + bias + fp32 residual", D, D, "res"), ("fc2 + bias + fp32 residual", D, F, "res"),
                         ("qkv + bias + q scale", 3 * D, D, "qkv"), ("fc1 + GELU (inference)", F, D, "gelu"),
                         ("fc1 + GELU + saved gelu' (training)", F, D, "gelu_t"), ("fc2 dgrad x gelu' + column sums", F, D, "mulaux"),
@@ -47,28 +46,35 @@ for name, n, k, epi in [("out-proj + bias + fp32 residual", D, D, "res"), ("fc2 
     bias = torch.randn(n, device="cuda")
     if epi == "res":
         C = torch.empty(M, n, device="cuda"); R = torch.randn(M, n, device="cuda")
-        fn = lambda: ops.gemm_nt(A, W, C, M, n, k, bias=bias, residual=R)
+        fn = lambda A=A, W=W, C=C, R=R, n=n, k=k, bias=bias: ops.gemm_nt(A, W, C, M, n, k, bias=bias, residual=R)
     elif epi == "gelu":
         C = torch.empty(M, n, dtype=bf, device="cuda")
-        fn = lambda: ops.gemm_nt(A, W, C, M, n, k, bias=bias, flags=L.EPI_GELU)
+        fn = lambda A=A, W=W, C=C, n=n, k=k, bias=bias: ops.gemm_nt(A, W, C, M, n, k, bias=bias, flags=L.EPI_GELU)
     elif epi == "gelu_t":
         C = torch.empty(M, n, dtype=bf, device="cuda"); X = torch.empty(M, n, dtype=bf, device="cuda")
-        fn = lambda: ops.gemm_nt(A, W, C, M, n, k, bias=bias, aux=X, flags=L.EPI_GELU | L.EPI_GELU_DAUX)
+        fn = lambda A=A, W=W, C=C, X=X, n=n, k=k, bias=bias: ops.gemm_nt(A, W, C, M, n, k, bias=bias, aux=X, flags=L.EPI_GELU | L.EPI_GELU_DAUX)
     elif epi == "mulaux":
         C = torch.empty(M, n, dtype=bf, device="cuda"); X = rnd(M, n); cs = torch.zeros(n, device="cuda")
-        fn = lambda: ops.gemm_nt(A, W, C, M, n, k, aux=X, flags=L.EPI_MUL_AUX, colsum_out=cs)
+        fn = lambda A=A, W=W, C=C, X=X, cs=cs, n=n, k=k: ops.gemm_nt(A, W, C, M, n, k, aux=X, flags=L.EPI_MUL_AUX, colsum_out=cs)
     elif epi == "qkv":
         C = torch.empty(M, n, dtype=bf, device="cuda")
-        fn = lambda: ops.gemm_nt(A, W, C, M, n, k, bias=bias, flags=L.EPI_SCALE_N, scale=0.18, scale_ncols=D)
+        fn = lambda A=A, W=W, C=C, n=n, k=k, bias=bias: ops.gemm_nt(A, W, C, M, n, k, bias=bias, flags=L.EPI_SCALE_N, scale=0.18, scale_ncols=D)
     else:
         C = torch.empty(M, n, dtype=bf, device="cuda")
-        fn = lambda: ops.gemm_nt(A, W, C, M, n, k)
-    t = timeit(fn)
-    rows.append((name, t, 2.0 * M * n * k / t / 1e6))
-for name, t, tf in rows:
-    print(f"variant {variant:>2s}  {name:40s} {t:7.1f} us  {tf:6.0f} TF", flush=True)
+        fn = lambda A=A, W=W, C=C, n=n, k=k: ops.gemm_nt(A, W, C, M, n, k)
+    # the three tile choices INTERLEAVED, three rounds (the ablation build reads DICOW_NT_VARIANT per call)
+    res = {v: [] for v in ("0", "21", "22")}
+    for rnd_ in range(3):
+        for v in res:
+            os.environ["DICOW_NT_VARIANT"] = v
+            res[v].append(timeit(fn))
+    os.environ["DICOW_NT_VARIANT"] = "0"
+    fl = 2.0 * M * n * k
+    print(f"{name:40s} shipped " + " ".join(f"{t:6.1f}" for t in res["0"]) + "   256x256 " + " ".join(f"{t:6.1f}" for t in res["21"]) +
+          "   192x320 " + " ".join(f"{t:6.1f}" for t in res["22"]) + f"   us   ({fl / min(res['0']) / 1e6:5.0f} TF shipped, best round)", flush=True)
+    del A, W, C
 
-if variant == "0":
+if True:
     # table b: FDDT(next layer) + LayerNorm behind fc2 -- (1) separate staged row kernel on h (training form), (2) FDDT in the fc2 epilogue, the
     # LayerNorm-only wave kernel on h' (inference form; the training form would ALSO have to store h: + M * D * 4 bytes in that epilogue)
     A, W = rnd(M, F), rnd(D, F)

@@ -71,9 +71,13 @@ PY
                 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_default_again.json 2>/dev/null
                 for f in $out/bench_*.json; do python -c "
 import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['ms_per_step_median'], d['roofline']['frac'], (d.get('kernels') or {}).get('gemm_tn_kernel',{}).get('tflops'), (d.get('encoder_forward') or {}).get('ms'), (d.get('encoder_forward_train') or {}).get('ms'), d.get('power'))"; done ;;
-    epi)        for v in 0 21 22; do DICOW_HIP_LIB=$PWD/tools/libv_ntabl.so DICOW_NT_VARIANT=$v timeout 600 python tools/ab_epilogues.py 2>&1 | grep -v amdgpu.ids | tee -a $out/ab_epilogues.txt; done ;;
+    epi)        DICOW_HIP_LIB=$PWD/tools/libv_ntabl.so timeout 900 python tools/ab_epilogues.py 2>&1 | grep -v amdgpu.ids | tee -a $out/ab_epilogues.txt ;;
     base_prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_base_$tag -o base -- python $GRAFT_REPO_ROOT/bench.py --model whisper-base --batch 8 --graph --no-extra --no-cpu-baseline --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$out/base_prof_bench.json 2>$GRAFT_REPO_ROOT/$out/base_prof_err.txt)
                 find /tmp/prof_base_$tag -name "*kernel_stats.csv" -exec cp {} $out/base_kernel_stats.csv \; ; head -30 $out/base_kernel_stats.csv | cut -c1-170 ;;
+    dual_step)  timeout 900 python tools/dual_stream_step_probe.py 2>&1 | grep -v amdgpu.ids | tee $out/dual_stream_step.txt ;;
+    split)      timeout 900 python tools/ab_split.py 6 3 2>&1 | grep -v amdgpu.ids | tee $out/ab_split.txt ;;
+    split_var)  for e in "DICOW_SPLIT_GROUP=1" "DICOW_SPLIT_GROUP=2" "DICOW_SPLIT_GROUP=4" "DICOW_SPLIT_LEAD_FIRST=0 DICOW_SPLIT_GROUP=2" "DICOW_SPLIT_NOWAIT=1"; do echo "== $e" | tee -a $out/ab_split_var.txt
+                  env $e timeout 900 python tools/ab_split.py 6 2 2>&1 | grep -v amdgpu.ids | tee -a $out/ab_split_var.txt; done ;;
     gpu_tests)  timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee $out/gpu_tests.txt ;;
     bench)      timeout 900 python bench.py 2>&1 | tail -3 | tee $out/bench_default.json ;;
     bench2)     timeout 900 python bench.py 2>&1 | tail -1 | tee $out/bench_default_again.json ;;

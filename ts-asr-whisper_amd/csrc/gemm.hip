@@ -961,7 +961,8 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
     static std::once_flag once;
     std::call_once(once, gemm_nt_setup);
 #ifdef DICOW_ABLATIONS
-    static const int variant = getenv("DICOW_NT_VARIANT") ? atoi(getenv("DICOW_NT_VARIANT")) : 0;     // diagnostic builds only
+    const char* variant_ev = getenv("DICOW_NT_VARIANT");                   // diagnostic builds only; read per call so that a tool can
+    const int variant = variant_ev ? atoi(variant_ev) : 0;                 // interleave tile shapes in one process (tools/ab_epilogues.py)
 #else
     constexpr int variant = 0;
 #endif
@@ -1020,7 +1021,10 @@ static int gemm_nt_impl(const dicow_gemm_args* a_in, void* stream, bool* fused_c
                                       batch == 1 && a->lnstat && a->ln_c && a->bias && a->ln_nslots > 0 && a->ln_nslots <= DICOW_LN_SLOTS &&
                                       a->ln_nslots % 4 == 0 && a->ln_inv_dim > 0.f && (int64_t)a->M * 128 < (1ll << 31)),
                           "gemm_nt: EPI_LNFOLD needs BIAS with SCALE_N or GELU [| GELU_DAUX], lnstat, ln_c, ln_nslots (multiple of 4, <= 16), ln_inv_dim");
-            const bool use35 = fddt || lnstat || variant == 13 || variant == 22 || (variant != 12 && variant != 21 && a->N >= 320 && wide_ok && w35 < w44);
+            // (round 6, interleaved A/B of the tile choice per epilogue kind -- profiles/r06_epilogues.txt: the choices above hold, except that a
+            // PLAIN product (no epilogue work at all: the dgrads of out-proj / qkv / fc1) is 1.7-2.1 % faster on 256 x 256 at N = 1280 too)
+            const bool plain256 = a->flags == 0 && !(NT_WIDE35 & 8);
+            const bool use35 = fddt || lnstat || variant == 13 || variant == 22 || (variant != 12 && variant != 21 && a->N >= 320 && wide_ok && !plain256 && w35 < w44);
             const int total = (int)(use35 ? t35 : t44);
             // balanced grid: with r = ceil(total / ncu) rounds needed anyway, ceil(total / r) workgroups each take r (or
             // r - 1) tiles -- e.g. 470 tiles run on 235 workgroups x 2 instead of 214 x 2 + 42 x 1: same makespan, fewer

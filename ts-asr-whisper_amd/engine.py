@@ -695,10 +695,20 @@ class EncoderEngine:
         g = _e((rows, D), F32, dev)
         gb = _e((rows, D), BF16, dev)
         last = enc.layers[nl - 1]
+        # trainer.SplitSync (the step as two half batches on two streams): the FOLLOWER half waits, segment by segment, until the leader
+        # half has enqueued that segment's parameter-gradient writes -- the two halves' sums then land in a fixed order
+        sync = getattr(enc, "_split_sync", None)
+        enter = sync.enter if sync is not None else (lambda name: None)
+        enter("final_ln")
         ops.fddt_ln_bwd(S.h_last, rows, D, mode=ops.MODE_NONE, ln_w=enc.layer_norm.weight.detach(), mean=S.meanf, rstd=S.rstdf,
                         d_y=d_enc.contiguous(), g_out=g, g_out_bf16=gb, dln_w=G.get(enc.layer_norm.weight),
                         dln_b=G.get(enc.layer_norm.bias), colsum_out=G.get(last.fc2.bias))
-        hook = getattr(enc, "_segment_hook", None) or (lambda name: None)
+        seg_hook = getattr(enc, "_segment_hook", None) or (lambda name: None)
+
+        def hook(name):
+            seg_hook(name)
+            if sync is not None:
+                sync.done(name)
         hook("final_ln")
         # Weight gradients are recorded per layer and run as ONE pooled launch (ops.TnGroup / dicow_gemm_tn_group) as soon as
         # the pool holds a tile for every CU: large-v3-turbo has 300 tiles per layer (one launch per layer), whisper-base 48
@@ -706,6 +716,7 @@ class EncoderEngine:
         tng, pend, ncu, per_layer = ops.TnGroup(), [], ops.num_cus(dev), 0
         for i in range(nl - 1, -1, -1):
             n_before = len(tng.items)
+            enter(f"layer{i}")
             lyr, w, Ls = enc.layers[i], W.layers[i], S.layers[i]
             rows, Bc = Ls.rows, Ls.B_after
             # ---- FFN backward (the weight-gradient operands gb, d_u, g2b, d_qkv and the saved activations live on until tng.run())
@@ -783,6 +794,7 @@ class EncoderEngine:
                 for name in pend:
                     hook(name)
                 pend = []
+        enter("stem")
         self._stem_backward(S, g, G)
         hook("stem")
 

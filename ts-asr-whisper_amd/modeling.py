@@ -564,12 +564,17 @@ class _DecoderLossFn(torch.autograd.Function):
         p_emb = model.model.decoder.embed_tokens.weight
         extra = {id(p_emb): (Wv.vpad - model.config.vocab_size) * model.config.d_model}
         G = GradSink(ctx.params, dev, extra_rows=extra)
+        sync = getattr(model, "_split_sync", None)       # trainer.SplitSync: the follower half's decoder gradients after the leader's
+        if sync is not None:
+            sync.enter("decoder")
         d_enc = model._engine(prepare=False).backward(S, g_loss, G, need_d_enc=ctx.need_enc)
         if d_enc is not None:
             d_enc = d_enc.view(S.B, S.T, -1)
         hook = getattr(model, "_segment_hook", None)
         if hook is not None:
             hook("decoder")
+        if sync is not None:
+            sync.done("decoder")
         return (None, d_enc, None, None, None) + tuple(G.result(p) for p in ctx.params)
 
 

@@ -505,14 +505,69 @@ class GradReducer:
         return ms
 
 
+_SPLIT_NOWAIT = os.environ.get("DICOW_SPLIT_NOWAIT") == "1"       # timing experiments only: the halves' gradient sums race
+_SPLIT_LEAD_FIRST = os.environ.get("DICOW_SPLIT_LEAD_FIRST", "1") == "1"
+_SPLIT_GROUP = int(os.environ.get("DICOW_SPLIT_GROUP", "2"))     # encoder layers per cross-stream wait
+
+
+class SplitSync:
+    """Order of the parameter-gradient writes when ONE batch runs as two half batches on two HIP streams (TrainStep(split_streams=True)).
+
+    Both halves add into the same gradient buffers.  The LEADER half's backward is enqueued first (host order), it consumes the
+    first-writer flags and records an event behind every segment of its backward pass (final LayerNorm, each encoder layer with its
+    pooled weight-gradient launch, stem, decoder); the FOLLOWER half waits for the segment's event before it enqueues the same segment,
+    so every gradient is `leader's share, then + follower's share` -- a fixed order, bit-reproducible run to run -- while the two
+    streams otherwise run side by side, one encoder layer apart.  engine.EncoderEngine.backward / modeling._DecoderLossFn call
+    ``enter(name)`` / ``done(name)``; outside a split step ``role`` is None and both are no-ops."""
+
+    def __init__(self, group=_SPLIT_GROUP):
+        self.role, self.ev, self.group, self.free_until = None, {}, max(1, int(group)), None
+
+    def reset(self):
+        self.role, self.ev, self.free_until = None, {}, None
+
+    def _gate(self, name):
+        """Encoder layers are gated in groups of ``group``: one cross-stream wait per group (a wait costs the follower ~40 us of
+        queue latency whether or not it has to block).  Backward walks the layers downwards, so "the leader is through layer j"
+        covers every layer above j: entering layer i the follower waits for the group's LOWEST layer and then runs down to it."""
+        if not name.startswith("layer") or self.group == 1:
+            return name
+        i = int(name[5:])
+        return f"layer{i - i % self.group}"
+
+    def enter(self, name):
+        if self.role == "follow" and not _SPLIT_NOWAIT:
+            gate = self._gate(name)
+            if gate == self.free_until:                 # already waited for this group's lowest layer
+                return
+            ev = self.ev.get(gate)
+            if ev is None:
+                raise RuntimeError(f"SplitSync: the leader half never finished segment {gate!r} -- the two halves' backward passes differ")
+            torch.cuda.current_stream().wait_event(ev)
+            self.free_until = gate
+
+    def done(self, name):
+        if self.role == "lead" and self._gate(name) == name:
+            ev = torch.cuda.Event()
+            ev.record()
+            self.ev[name] = ev
+
+
 class TrainStep:
     """model + FlatStore + FusedAdamW (+ GradReducer): ``loss = step(batch)``."""
 
     def __init__(self, model, lr=2e-6, fddt_lr_multiplier=100.0, weight_decay=0.0, max_grad_norm=1.0, warmup_steps=0,
                  max_steps=0, frozen_keywords=("decoder",), preheat_prefixes=None,
                  process_group=None, augmenter=None, use_fddt_only_n_steps=0, graph=False, use_fddt_only_n_epochs=0,
-                 steps_per_epoch=None, replica_sync="broadcast"):
+                 steps_per_epoch=None, replica_sync="broadcast", split_streams=False):
         self.model = model
+        # split_streams=True: a batch of even size B >= 2 runs as two half batches on two HIP streams (same loss and gradients: the
+        # halves' losses are weighted by their label counts, their gradients add in a fixed order -- SplitSync).  The HBM-bound row
+        # kernels, the attention tails and the partial last rounds of one half fill under the other half's matrix kernels
+        # (profiles/r06_streams.txt).  Sums of two M/2-row products are not bit-equal to one M-row product: opt-in.
+        self.split_streams = bool(split_streams)
+        self._split_sync = SplitSync()
+        self._split_side = None
         # preheat_prefixes=None: the reference's model.prefixes_to_preheat (REFERENCE_PREHEAT_PREFIXES).
         # use_fddt_only_n_epochs (base.yaml:59) is the reference's second phase condition (trainers.py:122: epoch >= n_epochs
         # AND global_step >= n_steps); without a data loader an epoch is `steps_per_epoch` optimizer steps.
@@ -603,6 +658,8 @@ class TrainStep:
             self.model._sig = None
 
     def _micro(self, batch, scale):
+        if self.split_streams and self._can_split(batch):
+            return self._micro_split(batch, scale)
         if self.augmenter is not None:      # enrollments are collated "nested" and stay clean (collators.py:189,216-220)
             batch = self.augmenter(dict(batch))
         with tracing.range("forward"):
@@ -610,6 +667,61 @@ class TrainStep:
         with tracing.range("backward"):
             (out.loss if scale == 1.0 else out.loss * scale).backward()
         return out.loss.detach()
+
+    # ---- one batch as two half batches on two streams
+    def _can_split(self, batch):
+        cfg = self.model.config
+        lab = batch.get("labels")
+        return (self.split_streams and self.augmenter is None and cfg.ctc_weight == 0.0 and batch.get("enrollments") is None and
+                lab is not None and lab.is_cuda and lab.shape[0] >= 2 and lab.shape[0] % 2 == 0 and
+                all(not torch.is_tensor(v) or v.dim() == 0 or v.shape[0] == lab.shape[0] for v in batch.values()))
+
+    def _micro_split(self, batch, scale):
+        model, enc, sync = self.model, self.model.model.encoder, self._split_sync
+        cur = torch.cuda.current_stream()
+        if self._split_side is None:                    # (priority streams get hardware queues of their own: profiles/r06_streams.txt)
+            pf, pl = (int(x) for x in os.environ.get("DICOW_SPLIT_PRIO", "-1,-1").split(","))
+            self._split_side = (torch.cuda.Stream(priority=pf), torch.cuda.Stream(priority=pl))
+        s_f, s_l = self._split_side
+        hb = batch["labels"].shape[0] // 2
+        halves = [{k: (v[i * hb:(i + 1) * hb] if torch.is_tensor(v) and v.dim() > 0 else v) for k, v in batch.items()} for i in (0, 1)]
+        # the loss is the mean over ALL label positions of the batch (modeling_dicow.py:310-323) = the halves' means weighted by their counts
+        # -- and the reference normalises in two ways: the hard-label loss is `.mean()` over ALL positions, padding included
+        # (modeling_dicow.py:312-321), the soft-label loss divides by the number of non-padding positions (modeling_dicow.py:135-145)
+        if getattr(model, "_ts_tables", None) is not None:
+            cnt = torch.stack([(h["labels"] != -100).sum() for h in halves]).to(torch.float32)
+            wts = cnt / cnt.sum().clamp_min(1.0) * scale
+        else:
+            wts = torch.full((2,), 0.5 * scale, dtype=torch.float32, device=batch["labels"].device)
+        enc._engine()                                   # stale bf16 weight copies are re-cast HERE, on the current stream, before the fork
+        model._engine()
+        sync.reset()
+        enc._split_sync = model._split_sync = sync
+        try:
+            with tracing.range("forward"):
+                outs = [None, None]
+                for i, st in (((1, s_l), (0, s_f)) if _SPLIT_LEAD_FIRST else ((0, s_f), (1, s_l))):     # the leader's forward is enqueued first: it stays ahead
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        outs[i] = model(**halves[i])
+            with tracing.range("backward"):
+                hold = self.reducer.hold
+                self.reducer.hold = True                # the leader's segments are half the gradient: nothing leaves yet
+                sync.role = "lead"
+                with torch.cuda.stream(s_l):
+                    (outs[1].loss * wts[1]).backward()
+                self.reducer.hold = hold
+                sync.role = "follow"
+                with torch.cuda.stream(s_f):
+                    (outs[0].loss * wts[0]).backward()
+        finally:
+            sync.role = None
+            enc._split_sync = model._split_sync = None
+        cur.wait_stream(s_l)
+        cur.wait_stream(s_f)
+        for o in outs:
+            o.loss.record_stream(cur)
+        return (outs[0].loss.detach() * wts[0] + outs[1].loss.detach() * wts[1]) / scale
 
     # ---- whole-step hipGraph
     @staticmethod
