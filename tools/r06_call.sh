@@ -68,6 +68,8 @@ PY
                 python bench.py --model whisper-base --batch 8 --graph --no-cpu-baseline > $out/bench_base_b8_graph.json 2>> $out/base.err
                 bash tools/prof_pmc_mfma.sh > /dev/null 2>&1; cp gpurun_out/pmc_mfma_summary.json $out/pmc_mfma_lds.json 2>/dev/null
                 bash tools/prof_pmc_l2.sh > /dev/null 2>&1; cp gpurun_out/pmc_l2_summary.json $out/pmc_l2_hit_rate.json 2>/dev/null
+                python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra --split-streams > $out/bench_split_streams.json 2>/dev/null
+                timeout 900 python tools/ab_split.py 6 3 2>&1 | grep -v amdgpu.ids > $out/ab_split.txt
                 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_default_again.json 2>/dev/null
                 for f in $out/bench_*.json; do python -c "
 import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['ms_per_step_median'], d['roofline']['frac'], (d.get('kernels') or {}).get('gemm_tn_kernel',{}).get('tflops'), (d.get('encoder_forward') or {}).get('ms'), (d.get('encoder_forward_train') or {}).get('ms'), d.get('power'))"; done ;;

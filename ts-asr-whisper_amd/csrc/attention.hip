@@ -1028,16 +1028,28 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
 //                        dQ^T[d][q] = K^T[d][key] . dS^T[key][q] over the workgroup's 128 keys: wave w computes the block
 //                        (q block w >> 1, d block w & 1); its K^T fragments are loop-invariant (32 registers, read once)
 // The dQ tile of a (batch, head) is the sum over its key blocks = over WORKGROUPS.  No atomics (bit-reproducible): the key
-// blocks of a (batch, head) run on ONE XCD (attn_block_coords) in dispatch order, every one walks the query tiles in the same
-// order, and key block j adds its partial to the fp32 tile in the workspace AFTER key block j - 1 did -- a flag per
-// (tile, wave block) counts the contributions; the tile lives in that XCD's L2 between the hand-offs (plain stores keep the line
-// in L2, sc1 loads bypass the reader's L1; tools/probe_handoff.hip: 1.1-1.4 us per hop, bit-exact).  Key block 0 stores without
-// reading, the last key block scales, rounds and writes the bf16 dQ rows (and the q-bias column sums).  Block j never waits for a
-// block dispatched after it, so the chain cannot deadlock while workgroups are dispatched in order; a wait that exceeds its
-// budget (or a (batch, head) found on two XCDs) raises the status word of the workspace instead of hanging
-// (dicow_attn_bwd_fused_status).  The workspace tiles are in FRAGMENT order ([q4][lane][4 floats] per wave block): every
-// hand-off load / store instruction moves 1 KB contiguous.
-// One barrier per tile: [A(t): scores, dV, dK, dS -> LDS] wait DMA(t+1) | barrier | request DMA(t+2) [B(t): dQ product, hand-off].
+// blocks of a (batch, head) -- a "pair" -- run on ONE XCD (pair p -> XCD p % 8: the grid is padded to 8 x ceil(BH / 8) x nkb and
+// mapped inside the kernel; XCC_ID is checked) and pass the running fp32 sum of a tile along a CHAIN through that XCD's L2:
+// the workgroup of rank r for a tile reads what rank r - 1 left in the workspace, adds its share, stores it back and bumps the
+// tile's counter (one u32 per (pair, tile, wave block)); rank 0 stores without reading, the last rank scales, rounds and writes
+// the bf16 dQ rows (and the q-bias column sums).  Plain stores keep the lines in L2, the consumer's loads are `sc0 sc1`
+// (tools/probe_handoff.hip: 1.1-1.4 us per hop, bit-exact).  ROTATION: workgroup j starts at tile j * R (R = nt / nkb) and walks
+// the tiles cyclically; its rank for a tile = the number of workgroups whose walk reached that tile earlier (`rank` in the loop below) -- the workgroups of a pair sit on different
+// tiles and nobody waits for a workgroup dispatched after it: the chain cannot deadlock while workgroups are dispatched in order.
+// A wait that exceeds its budget (or a pair found on two XCDs) raises the status word of the workspace instead of hanging
+// (dicow_attn_bwd_fused_status) and sets the abort word every spinner looks at.  The workspace tiles are in FRAGMENT order
+// ([q4][lane][4 floats] per wave block): every hand-off load / store instruction moves 1 KB contiguous.
+// The hand-off is PIPELINED around the next tile's A phase (profiles/r06_attn_fused.txt):
+//   top of A(t+1)   : the counter of tile t+1 is polled by a 4-byte LDS-DMA (asynchronous; a register poll from inline assembly is
+//                     copied by the compiler before it lands, a builtin load makes the compiler drain every DMA of the tile)
+//   middle of A(t+1): vmcnt(0) -- the stores of tile t have been acknowledged -> publish tile t (counter store); look at the poll:
+//                     if the predecessor is through, request the 4 KB sum by LDS-DMA into this wave's landing zone (sZ)
+//   end of A(t+1)   : second-chance poll in front of barrier X; barrier X (dS^T image complete); dS fragment reads; barrier Y
+//                     (the image may be overwritten by A(t+2)); DMA of the Q / dO tile t+3
+//   B(t+1)          : dQ product; if the sum has not been requested yet: bounded spin on the counter (slow path, ~17 % of the tiles),
+//                     then read the landing zone, add, 16 stores in fragment order.
+// All tile / landing / poll DMA is issued from inline assembly (dma16x / dma4x): behind a BUILTIN LDS-DMA hipcc puts
+// `s_waitcnt vmcnt(0)` in front of the next typed LDS read, which would serialise every prefetch (common.h dicow_dma16).
 #define DS_BYTES (128 * 128)
 #define FUSED_WS_HDR 4096                    // status words (int[0] = error bits, int[1] = abort), then per-pair XCD ids; flags follow
 #define FUSED_ERR_TIMEOUT 1
