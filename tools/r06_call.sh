@@ -80,6 +80,8 @@ import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f
     split)      timeout 900 python tools/ab_split.py 6 3 2>&1 | grep -v amdgpu.ids | tee $out/ab_split.txt ;;
     split_var)  for e in "DICOW_SPLIT_GROUP=1" "DICOW_SPLIT_GROUP=2" "DICOW_SPLIT_GROUP=4" "DICOW_SPLIT_LEAD_FIRST=0 DICOW_SPLIT_GROUP=2" "DICOW_SPLIT_NOWAIT=1"; do echo "== $e" | tee -a $out/ab_split_var.txt
                   env $e timeout 900 python tools/ab_split.py 6 2 2>&1 | grep -v amdgpu.ids | tee -a $out/ab_split_var.txt; done ;;
+    wgs)        for e in "DICOW_WGRAD_STREAM_PRIORITY=-1" "DICOW_WGRAD_STREAM_PRIORITY=0"; do echo "== $e" | tee -a $out/ab_wgrad_stream.txt
+                  env $e timeout 900 python tools/ab_wgrad_stream.py 6 3 2>&1 | grep -v amdgpu.ids | tee -a $out/ab_wgrad_stream.txt; done ;;
     gpu_tests)  timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee $out/gpu_tests.txt ;;
     bench)      timeout 900 python bench.py 2>&1 | tail -3 | tee $out/bench_default.json ;;
     bench2)     timeout 900 python bench.py 2>&1 | tail -1 | tee $out/bench_default_again.json ;;

@@ -32,6 +32,26 @@ def _ceil(a, b):
     return (a + b - 1) // b * b
 
 
+# Weight gradients beside the gradient chain (round 6).  The pooled weight-gradient launch of a layer (ops.TnGroup.run) is off the critical
+# path: nothing in the backward pass reads a dW.  With WGRAD_SIDE_STREAM it is enqueued on a second HIP stream behind an event that says
+# "this layer's operands are written", and the next layer's dgrad chain starts at once: the HBM-bound row kernels, the attention kernel's
+# half-empty last round and the GEMM tails of the chain run beside a matrix-bound kernel instead of after it.  Same kernels, same operands,
+# one writer per dW: bit-identical to the one-stream order.  The side stream is a PRIORITY stream (a queue of its own: a normal-priority pool
+# stream may share the compute stream's hardware queue, profiles/r06_streams.txt); the backward pass joins it before it returns.
+WGRAD_SIDE_STREAM = os.environ.get("DICOW_WGRAD_STREAM", "0") == "1"
+WGRAD_STREAM_PRIORITY = int(os.environ.get("DICOW_WGRAD_STREAM_PRIORITY", "-1"))
+_WGRAD_STREAMS = {}
+
+
+def wgrad_stream(dev):
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index, cur.cuda_stream)
+    st = _WGRAD_STREAMS.get(key)
+    if st is None:
+        st = _WGRAD_STREAMS[key] = torch.cuda.Stream(device=dev, priority=WGRAD_STREAM_PRIORITY)
+    return st
+
+
 class GradSink:
     """fp32 gradient buffers for a set of parameters.  Parameters that carry a persistent ``_direct_grad`` view (set
     by trainer.FlatStore) are accumulated into directly; the others get ONE zeroed flat buffer whose views are
@@ -714,6 +734,25 @@ class EncoderEngine:
         # the pool holds a tile for every CU: large-v3-turbo has 300 tiles per layer (one launch per layer), whisper-base 48
         # (all six layers in one launch at the end).  A layer's DP bucket is only handed over once its gradients have run.
         tng, pend, ncu, per_layer = ops.TnGroup(), [], ops.num_cus(dev), 0
+        side = wgrad_stream(dev) if (WGRAD_SIDE_STREAM and d_enc.is_cuda and not torch.cuda.is_current_stream_capturing()) else None
+
+        def run_wgrads(names):
+            if side is None or not tng.items:
+                tng.run()
+                for name in names:
+                    hook(name)
+                return
+            ready = torch.cuda.Event()
+            ready.record()                                    # every operand of the recorded problems has been enqueued
+            held = [t for it in tng.items for t in (it[0], it[1], it[2])] + ([G.flat] if G.flat.numel() > 1 else [])
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                for t in held:                                # allocated on the compute stream, read here: no reuse before this stream is through
+                    if t is not None and t.is_cuda:
+                        t.record_stream(side)
+                tng.run()
+                for name in names:                            # (the DP bucket / the split-step event are recorded behind the launch, on this stream)
+                    hook(name)
         for i in range(nl - 1, -1, -1):
             n_before = len(tng.items)
             enter(f"layer{i}")
@@ -790,12 +829,12 @@ class EncoderEngine:
             pend.append(f"layer{i}")
             per_layer = max(per_layer, len(tng.items) - n_before)      # problems a layer records (4 with fused q/k/v, else 6)
             if i == 0 or tng.tiles() >= ncu or len(tng.items) + per_layer > L.TN_GROUP_MAX:
-                tng.run()
-                for name in pend:
-                    hook(name)
+                run_wgrads(pend)
                 pend = []
         enter("stem")
         self._stem_backward(S, g, G)
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)  # every dW is written before autograd / the optimizer / the "stem" bucket go on
         hook("stem")
 
     def _stem_backward(self, S, g, G):
