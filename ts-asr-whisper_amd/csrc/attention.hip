@@ -1054,6 +1054,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 8 ? 1 : (ATTN_DKV_JIT ? 3 : 2))
 #define FUSED_WS_HDR 4096                    // status words (int[0] = error bits, int[1] = abort), then per-pair XCD ids; flags follow
 #define FUSED_ERR_TIMEOUT 1
 #define FUSED_ERR_XCD 2
+#ifndef ATTN_FUSED_MIN_WGS
+#define ATTN_FUSED_MIN_WGS 1024              // (512: whisper-base B = 8 -- 768 workgroups -- measured in profiles/r06_base_kernel_table.txt)
+#endif
 #ifndef ATTN_FUSED_SPIN
 #define ATTN_FUSED_SPIN (1 << 15)
 #endif
@@ -1628,7 +1631,7 @@ static bool attn_bwd_use_fused(const dicow_attn_bwd_args* a) {
     if (!a->fused_ws || a->causal) return false;
     const int64_t nkb = dicow_cdiv(a->Lk, 128), wgs = nkb * a->H * a->B;
     if ((int64_t)a->B * a->H > 1000) return false;                                       // (the header's per-pair words)
-    if (a->fused_mode != 1 && (wgs < 1024 || a->Lq < 256)) return false;                // below two rounds of the chip the two-kernel form stays
+    if (a->fused_mode != 1 && (wgs < ATTN_FUSED_MIN_WGS || a->Lq < 256)) return false;  // below two rounds of the chip the two-kernel form stays
     const int64_t nflags = (int64_t)a->B * a->H * dicow_cdiv(a->Lq, KV_TILE) * 4;
     if (nflags * 4096 >= ((int64_t)1 << 32)) return false;
     return a->fused_ws_bytes >= dicow_attn_bwd_fused_ws_bytes(a->B, a->H, a->Lq, a->Lk);
