@@ -84,6 +84,8 @@ import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f
                   env $e timeout 900 python tools/ab_wgrad_stream.py 6 3 2>&1 | grep -v amdgpu.ids | tee -a $out/ab_wgrad_stream.txt; done ;;
     base_fused) for rep in 1 2; do for l in ts-asr-whisper_amd/libdicow_hip.so tools/libv_fmin512.so; do echo -n "$l: " | tee -a $out/base_fused.txt
                   DICOW_HIP_LIB=$PWD/$l python bench.py --model whisper-base --batch 8 --graph --no-extra --no-cpu-baseline --no-power --steps 30 --warmup 5 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" | tee -a $out/base_fused.txt; done; done ;;
+    gaps)       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/gaps_$tag -o g -- python $GRAFT_REPO_ROOT/bench.py --no-extra --no-cpu-baseline --no-power --steps 12 --warmup 3 --profile-steps 1 > $GRAFT_REPO_ROOT/$out/gaps_bench.json 2>/dev/null)
+                find /tmp/gaps_$tag -name "*kernel_trace.csv" -exec python tools/trace_gaps.py {} \; | tee $out/trace_gaps.txt ;;
     gpu_tests)  timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | tail -25 | tee $out/gpu_tests.txt ;;
     bench)      timeout 900 python bench.py 2>&1 | tail -3 | tee $out/bench_default.json ;;
     bench2)     timeout 900 python bench.py 2>&1 | tail -1 | tee $out/bench_default_again.json ;;
