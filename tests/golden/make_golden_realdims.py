@@ -54,7 +54,11 @@ CASES = {
     "rd_turbo_row5": ("whisper-large-v3-turbo", 1, 128, {}, False, False),
     "rd_turbo_row12": ("whisper-large-v3-turbo", 1, 128, {}, False, False),
 }
-B16_ROW = {"rd_turbo_row9": 9, "rd_turbo_row5": 5, "rd_turbo_row12": 12}
+# (round 6, last session) EVERY remaining row of that batch -- 1-4, 6-8, 10, 11, 13-15 -- the same way: the whole headline batch is then
+# pinned to the reference's own runs, row by row (row 0 carries golden rd_turbo's sample)
+for _r in (1, 2, 3, 4, 6, 7, 8, 10, 11, 13, 14, 15):
+    CASES[f"rd_turbo_row{_r}"] = ("whisper-large-v3-turbo", 1, 128, {}, False, False)
+B16_ROW = {f"rd_turbo_row{_r}": _r for _r in range(1, 16)}
 B16_SILENCE_FROM = {5: 900}                  # rows of the B = 16 batch whose clip ends early: first padding frame (of 1500)
 
 

@@ -172,8 +172,9 @@ def test_configs2_batch16_step_row0_vs_reference_golden_and_loss_is_the_mean_of_
       * the step's loss is the mean over ALL label positions (modeling_dicow.py:310-323) = the mean of the 16 rows' own
         losses, each computed by a separate B = 1 forward;
       * every row's encoder output equals its B = 1 forward (batch invariance of the whole encoder at the bench shape);
-      * rows 5 (all-silence STNO tail), 9 (padded labels) and 12 (all label positions used) are pinned to the reference's own runs of
-        exactly those rows (goldens rd_turbo_row5 / _row9 / _row12): encoder output and logits inside the batch, loss and gradients as B = 1."""
+      * ALL of rows 1-15 -- among them 5 (all-silence STNO tail), 3 and 9 (padded labels), 12 (all label positions used) -- are pinned to the
+        reference's own runs of exactly those rows (goldens rd_turbo_row1 .. _row15): encoder output and logits inside the batch, loss and
+        gradients as B = 1.  With row 0 = golden rd_turbo the WHOLE headline batch is reference-pinned, row by row."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from tests.util import hashed_stno, hashed_labels
@@ -208,17 +209,17 @@ def test_configs2_batch16_step_row0_vs_reference_golden_and_loss_is_the_mean_of_
             worst_inv = max(worst_inv, d)
     Row0.loss = torch.tensor(rows_loss[0])
     _check_forward(z, Row0)
-    # row 9 -- a row whose labels end in -100 padding -- is pinned to the reference as well (golden rd_turbo_row9: the reference run
-    # on exactly this row as a B = 1 sample): its encoder output and logits INSIDE the B = 16 batch and its own B = 1 loss
-    z9 = load_golden("rd_turbo_row9")
-    assert np.array_equal(z9["labels"][0], lab[9].numpy()) and int((lab[9] == -100).sum()) == L // 4
-    _check_forward(z9, types.SimpleNamespace(encoder_last_hidden_state=enc[9:10], logits=logits[9:10], loss=torch.tensor(rows_loss[9])))
-    # round 6: two more rows the reference ran -- row 5 (all-silence STNO tail from frame 900 on) and row 12 (all 128 label positions used)
-    z5, z12 = load_golden("rd_turbo_row5"), load_golden("rd_turbo_row12")
-    assert np.array_equal(z5["stno"][0], st[5].numpy()) and float(st[5, 0, SIL5:].min()) == 1.0 and float(st[5, 1:, SIL5:].abs().max()) == 0.0
-    assert np.array_equal(z12["labels"][0], lab[12].numpy()) and int((lab[12] == -100).sum()) == 0
-    _check_forward(z5, types.SimpleNamespace(encoder_last_hidden_state=enc[5:6], logits=logits[5:6], loss=torch.tensor(rows_loss[5])))
-    _check_forward(z12, types.SimpleNamespace(encoder_last_hidden_state=enc[12:13], logits=logits[12:13], loss=torch.tensor(rows_loss[12])))
+    # EVERY other row of the batch is pinned to the reference as well: goldens rd_turbo_row1 .. rd_turbo_row15 are the reference's own runs
+    # on exactly these rows as B = 1 samples (rounds 5-6: rows 9, 5, 12; the rest in round 6's last session) -- the row's encoder output
+    # and logits INSIDE the B = 16 batch, its own B = 1 loss here, its B = 1 gradients in the loop below
+    zrow = {r: load_golden(f"rd_turbo_row{r}") for r in range(1, B)}
+    for r, zr in zrow.items():
+        assert np.array_equal(zr["labels"][0], lab[r].numpy()) and np.array_equal(zr["stno"][0], st[r].numpy()), r
+        _check_forward(zr, types.SimpleNamespace(encoder_last_hidden_state=enc[r:r + 1], logits=logits[r:r + 1], loss=torch.tensor(rows_loss[r])))
+    # the three special rows are what they are meant to be: 9 ends in -100 padding, 5 has the all-silence STNO tail, 12 uses all 128 label positions
+    assert int((lab[9] == -100).sum()) == L // 4 and int((lab[3] == -100).sum()) == L // 4
+    assert float(st[5, 0, SIL5:].min()) == 1.0 and float(st[5, 1:, SIL5:].abs().max()) == 0.0
+    assert int((lab[12] == -100).sum()) == 0
     # different tile shapes / split factors at 1500 and 24000 rows: fp32 accumulation order differs, bf16 roundings flip
     assert worst_inv < 6e-2, worst_inv
     mean_rows = sum(rows_loss) / B
@@ -228,7 +229,7 @@ def test_configs2_batch16_step_row0_vs_reference_golden_and_loss_is_the_mean_of_
         if p.requires_grad:
             assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
     print("configs[2] B=16: worst row-vs-B=1 encoder deviation", worst_inv, "loss", float(out.loss), "mean of rows", mean_rows)
-    worst = _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checked=20, extra_rows={9: z9, 5: z5, 12: z12})
+    worst = _check_b16_gradients_are_the_mean_of_the_rows(z, model, batch, B, min_checked=20, extra_rows=zrow)
     print("configs[2] B=16: worst watched gradient, B=16 step vs mean of the 16 B=1 steps (rel-L2):", worst)
 
 
