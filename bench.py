@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--split-streams", action="store_true",
                     help="run each batch as two half batches on two HIP streams (trainer.SplitSync; same loss and gradients as the two halves "
                          "accumulated; measured -0.3...-1.8 ms per step, profiles/r06_split_streams.txt: not the default)")
+    ap.add_argument("--no-split-fwd", action="store_true",
+                    help="encoder training forward on ONE stream (default: a large even batch runs as two half batches on two HIP streams into the "
+                         "same activation buffers, bit-identical, backward unchanged: engine.SPLIT_FWD)")
     ap.add_argument("--from-audio", action="store_true",
                     help="the step starts from 16 kHz waveforms resident in HBM: dicow_logmel -> BatchAugmenter (STNO segment "
                          "augmentation + joint SpecAug, collators.py:189-214) -> training step (reported beside the headline, never AS it)")
@@ -567,7 +570,10 @@ def main():
     import amd_pkg
     pkg = amd_pkg.load()
     from ts_asr_whisper_amd import ops
+    from ts_asr_whisper_amd import engine as _engine
     from ts_asr_whisper_amd.trainer import TrainStep
+    if a.no_split_fwd:
+        _engine.SPLIT_FWD = False
     from ts_asr_whisper_amd.data import synthetic_batch
 
     over = dict(use_fddt=True, fddt_is_diagonal=True, use_pre_pos_fddt=True, fddt_init="suppressive", non_target_fddt_value=0.5)
@@ -660,10 +666,12 @@ def main():
     nprof = max(1, min(a.profile_steps, a.steps))
     timer.on = True
     split_was, ts.split_streams = ts.split_streams, False   # per-launch events of two overlapping streams would time the overlap, not the kernels
+    fwd_split_was, _engine.SPLIT_FWD = _engine.SPLIT_FWD, False      # (the same for the encoder forward's two half-batch streams)
     for i in range(nprof):
         run_step(i, **({"eager": True} if a.graph else {}))
     sync()
     ts.split_streams = split_was
+    _engine.SPLIT_FWD = fwd_split_was
     timer.on = False
     # ---- the front end by itself (HIP events on the launch stream, after the timed region): log-mel, augmentation
     fe = None
@@ -740,7 +748,7 @@ def main():
         "config": {"workload": f"{a.model} DiCoW fine-tune step, per-GPU batch {a.batch}, L={a.labels}, decoder frozen, "
                                f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}{', CTC 0.3' if a.ctc else ''}{', preheat phase (FDDT-only training)' if a.preheat else ''}"
                                f"{', step replayed from a hipGraph' if a.graph else ''}{', from 16 kHz audio (log-mel + augmentation inside the step)' if a.from_audio else ''}",
-                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "split_streams": bool(a.split_streams), "trainable_params": sum(n for q, _, n, _ in ts.store.entries if q.requires_grad)},
+                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "split_streams": bool(a.split_streams), "encoder_forward_two_streams": bool(_engine.SPLIT_FWD and a.batch % 2 == 0 and a.batch * cfg.max_source_positions >= _engine.SPLIT_FWD_MIN_ROWS and not a.se and not a.graph), "trainable_params": sum(n for q, _, n, _ in ts.store.entries if q.requires_grad)},
         "loss": float(loss),
         "per_rank_ms_per_step": rank_ms,
         "allreduce": {"exposed_ms_per_step": rank_exposed,

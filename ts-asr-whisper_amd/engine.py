@@ -52,6 +52,41 @@ def wgrad_stream(dev):
     return st
 
 
+# The encoder FORWARD of a large even batch as two half batches on two HIP streams, into the halves of the SAME full-batch activation
+# buffers (rows are batch-major: a half batch is a contiguous row range of every buffer).  Every forward kernel is row-parallel, so
+# the results are bit-identical to the one-stream forward; the HBM-bound row kernels, the attention tails and the partial last rounds
+# of one half fill under the other half's matrix kernels (tools/dual_stream_probe.py: -3.4 %, profiles/r06_streams.txt item 3).  The
+# BACKWARD then runs as ONE full batch on one stream, exactly as before -- no gradient is summed in two pieces, nothing to order
+# (what trainer.SplitSync has to do for the whole-step split).  Half 0 stays on the caller's stream, half 1 runs on a high-priority
+# stream of its own hardware queue (a normal-priority pool stream may share the caller's queue: profiles/r06_streams.txt item 1).
+SPLIT_FWD = os.environ.get("DICOW_SPLIT_FWD", "1") != "0"
+SPLIT_FWD_MIN_ROWS = int(os.environ.get("DICOW_SPLIT_FWD_MIN_ROWS", "16000"))      # whisper-base B = 8 (12000 rows, one hipGraph) stays on one stream
+SPLIT_FWD_PARTS = int(os.environ.get("DICOW_SPLIT_FWD_PARTS", "2"))          # (4 measured against 2: profiles/r06_split_fwd.txt)
+_FWD_STREAMS = {}
+
+
+def fwd_side_stream(dev, k=0):
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index, cur.cuda_stream, k)
+    st = _FWD_STREAMS.get(key)
+    if st is None:
+        st = _FWD_STREAMS[key] = torch.cuda.Stream(device=dev, priority=-1)
+    return st
+
+
+def _fwd_parts(B, T, dev):
+    """[(stream, row slice, batch slice)] of the forward's parts: part 0 on the caller's stream, the others on side streams (forked here)."""
+    n = SPLIT_FWD_PARTS if (SPLIT_FWD_PARTS > 2 and B % SPLIT_FWD_PARTS == 0) else 2
+    main_st, Bp = torch.cuda.current_stream(dev), B // n
+    parts = []
+    for k in range(n):
+        st = main_st if k == 0 else fwd_side_stream(dev, k - 1)
+        if k:
+            st.wait_stream(main_st)
+        parts.append((st, slice(k * Bp * T, (k + 1) * Bp * T), slice(k * Bp, (k + 1) * Bp)))
+    return main_st, parts, Bp
+
+
 class GradSink:
     """fp32 gradient buffers for a set of parameters.  Parameters that carry a persistent ``_direct_grad`` view (set
     by trainer.FlatStore) are accumulated into directly; the others get ONE zeroed flat buffer whose views are
@@ -482,6 +517,31 @@ class EncoderEngine:
         return fold
 
     def forward(self, input_features, stno_mask, enrollments=None, need_grad=True):
+        """Encoder forward.  Inference (need_grad False) of a large even batch: the two half batches run the WHOLE forward side by side on
+        two streams (SPLIT_FWD above; each half allocates its temporaries under its own stream, the halves of the output are written in
+        place) -- rows never mix in a forward kernel, so the output is bit-identical.  The training forward splits inside _forward_impl."""
+        cfg = self.cfg
+        B, T = input_features.shape[0], cfg.max_source_positions
+        if (SPLIT_FWD and not need_grad and enrollments is None and not cfg.use_enrollments and input_features.is_cuda and B % 2 == 0
+                and B * T >= SPLIT_FWD_MIN_ROWS and input_features.dim() == 3 and input_features.shape[2] == 2 * T
+                and not torch.cuda.is_current_stream_capturing()):
+            dev, D = input_features.device, cfg.d_model
+            enc_out, enc_bf = _e((B * T, D), F32, dev), _e((B * T, D), BF16, dev)
+            stno_mask = stno_mask.to(device=dev)
+            main_st, parts, _ = _fwd_parts(B, T, dev)
+            S = None
+            for st_, r, bsl in parts:
+                with torch.cuda.stream(st_):
+                    _, Sh = self._forward_impl(input_features[bsl], stno_mask[bsl], None, False, out=(enc_out[r], enc_bf[r]))
+                    del Sh.layers                        # (a side half's temporaries return to ITS stream's pool here, behind its own kernels)
+                S = S or Sh
+            for st_, _, _ in parts[1:]:
+                main_st.wait_stream(st_)
+            S.B0, S.B_out, S.enc_bf, S.h_last = B, B, enc_bf, None
+            return enc_out.view(B, T, D), S
+        return self._forward_impl(input_features, stno_mask, enrollments, need_grad)
+
+    def _forward_impl(self, input_features, stno_mask, enrollments=None, need_grad=True, out=None):
         enc, cfg, W = self.enc, self.cfg, self.W
         dev = input_features.device
         if enrollments is not None:                      # encoder.py:152-154: interleave mixture / enrollment rows
@@ -531,10 +591,44 @@ class EncoderEngine:
             stat2 = torch.zeros(rows, L.LN_SLOTS, 2, dtype=F32, device=dev)
         hb = None                                        # bf16 copy of h + its row partials in stat1: written by the previous fc2
         fddt_done = False                                # h already carries this layer's FDDT (written by the previous fc2)
+        # training forward of a large even batch: two half batches on two streams into shared full-batch buffers (SPLIT_FWD above)
+        split = (SPLIT_FWD and need_grad and fold is None and not fuse_next and not cfg.use_enrollments and all(f is None for f in W.full)
+                 and B % 2 == 0 and rows >= SPLIT_FWD_MIN_ROWS and not torch.cuda.is_current_stream_capturing())
+        if split:
+            main_st, halves, Bh = _fwd_parts(B, T, dev)  # fork: h (stem + initial FDDT) is complete
+            rh = Bh * T
         for i, lyr in enumerate(enc.layers):
             w = W.layers[i]
             Ls = NS(h_in=h, B=Bc, bstride=bstride)
             rows = Bc * T
+            if split:
+                fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None
+                mode, fw, fb = fddt_ptrs(fd, cfg)
+                ln, ln2 = lyr.self_attn_layer_norm, lyr.final_layer_norm
+                xln, mean, rstd = _e((rows, D), BF16, dev), _e((rows,), F32, dev), _e((rows,), F32, dev)
+                hp = _e((rows, D), F32, dev) if mode != ops.MODE_NONE else h
+                qkv, o, lse = _e((rows, 3 * D), BF16, dev), _e((rows, D), BF16, dev), _e((Bc, H, T), F32, dev)
+                h2, xln2 = _e((rows, D), F32, dev), _e((rows, D), BF16, dev)
+                mean2, rstd2 = _e((rows,), F32, dev), _e((rows,), F32, dev)
+                u, a, hn = _e((rows, F_), BF16, dev), _e((rows, F_), BF16, dev), _e((rows, D), F32, dev)
+                for st_, r, bsl in halves:
+                    with torch.cuda.stream(st_):
+                        ops.fddt_ln_fwd(h[r], rh, D, mode=mode, stno=stno[bsl], stno_bstride=bstride, T=T, w=fw, b=fb,
+                                        h_out=hp[r] if mode != ops.MODE_NONE else None, ln_w=ln.weight.detach(),
+                                        ln_b=ln.bias.detach(), y_bf16=xln[r], mean=mean[r], rstd=rstd[r])
+                        linear_fwd(xln[r], w.att.qkv, rh, flags=L.EPI_SCALE_N, scale=Q_SCALE, scale_ncols=D, out=qkv[r])
+                        ops.attn_fwd(heads(qkv[r][:, :D], Bh, T, H), heads(qkv[r][:, D:2 * D], Bh, T, H), heads(qkv[r][:, 2 * D:], Bh, T, H),
+                                     heads(o[r], Bh, T, H), lse[bsl], q_log2=QK_LOG2)
+                        linear_fwd(o[r], w.att.o, rh, out_dtype=F32, residual=hp[r], out=h2[r])
+                        ops.fddt_ln_fwd(h2[r], rh, D, mode=ops.MODE_NONE, ln_w=ln2.weight.detach(), ln_b=ln2.bias.detach(), y_bf16=xln2[r],
+                                        mean=mean2[r], rstd=rstd2[r])
+                        linear_fwd(xln2[r], w.fc1, rh, gelu_aux=u[r], out=a[r])
+                        linear_fwd(a[r], w.fc2, rh, out_dtype=F32, residual=h2[r], out=hn[r])
+                h = hn
+                Ls.rows, Ls.B_after, Ls.hp, Ls.xln, Ls.mean, Ls.rstd = rows, Bc, hp, xln, mean, rstd
+                Ls.qkv, Ls.o, Ls.lse, Ls.h2, Ls.xln2, Ls.mean2, Ls.rstd2, Ls.u, Ls.a = qkv, o, lse, h2, xln2, mean2, rstd2, u, a
+                S.layers.append(Ls)
+                continue
             fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None
             mode, fw, fb = fddt_ptrs(fd, cfg)
             if fddt_done:
@@ -625,11 +719,18 @@ class EncoderEngine:
                 S.layers.append(Ls)
         rows = Bc * T
         S.h_last, S.B_out, S.bstride_out = h, Bc, bstride
-        enc_out = _e((rows, D), F32, dev)
-        enc_bf = _e((rows, D), BF16, dev)
+        enc_out, enc_bf = out if out is not None else (_e((rows, D), F32, dev), _e((rows, D), BF16, dev))
         S.meanf, S.rstdf = _e((rows,), F32, dev), _e((rows,), F32, dev)
-        ops.fddt_ln_fwd(h, rows, D, mode=ops.MODE_NONE, ln_w=enc.layer_norm.weight.detach(), ln_b=enc.layer_norm.bias.detach(),
-                        y_bf16=enc_bf, y_f32=enc_out, mean=S.meanf, rstd=S.rstdf)
+        if split:                                        # the final LayerNorm per half too, then the join
+            for st_, r, bsl in halves:
+                with torch.cuda.stream(st_):
+                    ops.fddt_ln_fwd(h[r], rh, D, mode=ops.MODE_NONE, ln_w=enc.layer_norm.weight.detach(), ln_b=enc.layer_norm.bias.detach(),
+                                    y_bf16=enc_bf[r], y_f32=enc_out[r], mean=S.meanf[r], rstd=S.rstdf[r])
+            for st_, _, _ in halves[1:]:
+                main_st.wait_stream(st_)
+        else:
+            ops.fddt_ln_fwd(h, rows, D, mode=ops.MODE_NONE, ln_w=enc.layer_norm.weight.detach(), ln_b=enc.layer_norm.bias.detach(),
+                            y_bf16=enc_bf, y_f32=enc_out, mean=S.meanf, rstd=S.rstdf)
         S.enc_bf = enc_bf
         return enc_out.view(Bc, T, D), S
 
