@@ -73,6 +73,24 @@ PY
                 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_default_again.json 2>/dev/null
                 for f in $out/bench_*.json; do python -c "
 import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['ms_per_step_median'], d['roofline']['frac'], (d.get('kernels') or {}).get('gemm_tn_kernel',{}).get('tflops'), (d.get('encoder_forward') or {}).get('ms'), (d.get('encoder_forward_train') or {}).get('ms'), d.get('power'))"; done ;;
+    final2)     # the last session's evidence (encoder forward on two streams by default): one-stream runs beside the default ones; per-kernel profiles
+                # and counter passes with DICOW_SPLIT_FWD=0 so that a kernel's duration is its own and not that of two overlapping launches
+                (timeout 2700 python -m pytest tests -m gpu -q > $out/gpu_tests.txt 2>&1; tail -3 $out/gpu_tests.txt)
+                python bench.py > $out/bench_default.json 2> $out/bench_default.err
+                python bench.py --no-split-fwd --no-extra --no-cpu-baseline > $out/bench_one_stream.json 2>/dev/null
+                DICOW_SPLIT_FWD=0 bash tools/prof_pmc.sh > /dev/null 2>&1; cp gpurun_out/pmc_summary.json $out/pmc_hbm_traffic.json
+                DICOW_SPLIT_FWD=0 bash tools/prof_step.sh > $out/prof_step.txt 2>&1; cp gpurun_out/kernel_stats.csv $out/kernel_stats.csv
+                bash tools/prof_step.sh > $out/prof_step_two_streams.txt 2>&1; cp gpurun_out/kernel_stats.csv $out/kernel_stats_two_streams.csv
+                DICOW_SPLIT_FWD=0 bash tools/prof_encfwd.sh > $out/prof_encfwd.txt 2>&1; cp gpurun_out/encfwd_kernel_stats.csv $out/encfwd_kernel_stats.csv
+                timeout 900 python tools/ab_split_fwd.py 2 2>&1 | grep -v amdgpu.ids > $out/ab_split_fwd.txt
+                python bench.py --preflight > $out/preflight_1gpu.json 2> $out/preflight.err
+                python bench.py --from-audio --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_from_audio.json 2>/dev/null
+                for v in se ctc preheat; do python bench.py --$v --steps 8 --warmup 3 --no-cpu-baseline > $out/bench_$v.json 2> $out/bench_$v.err; done
+                python bench.py --model whisper-base --batch 8 --graph --no-cpu-baseline > $out/bench_base_b8_graph.json 2> $out/base.err
+                DICOW_SPLIT_FWD=0 bash tools/prof_pmc_mfma.sh > /dev/null 2>&1; cp gpurun_out/pmc_mfma_summary.json $out/pmc_mfma_lds.json 2>/dev/null
+                python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_default_again.json 2>/dev/null
+                for f in $out/bench_*.json; do python -c "
+import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['ms_per_step_median'], d['roofline']['frac'], (d.get('kernels') or {}).get('gemm_tn_kernel',{}).get('tflops'), (d.get('encoder_forward') or {}).get('ms'), (d.get('encoder_forward') or {}).get('mfma_frac'), (d.get('encoder_forward_train') or {}).get('ms'), (d.get('encoder_forward_train') or {}).get('mfma_frac'), d.get('power'))"; done ;;
     epi)        DICOW_HIP_LIB=$PWD/tools/libv_ntabl.so timeout 900 python tools/ab_epilogues.py 2>&1 | grep -v amdgpu.ids | tee -a $out/ab_epilogues.txt ;;
     base_prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_base_$tag -o base -- python $GRAFT_REPO_ROOT/bench.py --model whisper-base --batch 8 --graph --no-extra --no-cpu-baseline --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$out/base_prof_bench.json 2>$GRAFT_REPO_ROOT/$out/base_prof_err.txt)
                 find /tmp/prof_base_$tag -name "*kernel_stats.csv" -exec cp {} $out/base_kernel_stats.csv \; ; head -30 $out/base_kernel_stats.csv | cut -c1-170 ;;
