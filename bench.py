@@ -748,7 +748,7 @@ def main():
         "config": {"workload": f"{a.model} DiCoW fine-tune step, per-GPU batch {a.batch}, L={a.labels}, decoder frozen, "
                                f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}{', CTC 0.3' if a.ctc else ''}{', preheat phase (FDDT-only training)' if a.preheat else ''}"
                                f"{', step replayed from a hipGraph' if a.graph else ''}{', from 16 kHz audio (log-mel + augmentation inside the step)' if a.from_audio else ''}",
-                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "split_streams": bool(a.split_streams), "encoder_forward_two_streams": bool(_engine.SPLIT_FWD and a.batch % 2 == 0 and a.batch * cfg.max_source_positions >= _engine.SPLIT_FWD_MIN_ROWS and not a.se and not a.graph), "trainable_params": sum(n for q, _, n, _ in ts.store.entries if q.requires_grad)},
+                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "split_streams": bool(a.split_streams), "encoder_forward_two_streams": bool(_engine.SPLIT_FWD and a.batch % 2 == 0 and a.batch * cfg.max_source_positions >= _engine.SPLIT_FWD_MIN_ROWS and not a.graph) and ("behind the speaker-communication layers" if a.se else True), "trainable_params": sum(n for q, _, n, _ in ts.store.entries if q.requires_grad)},
         "loss": float(loss),
         "per_rank_ms_per_step": rank_ms,
         "allreduce": {"exposed_ms_per_step": rank_exposed,

@@ -32,12 +32,14 @@ def _step(model, batch):
     return out.encoder_last_hidden_state.detach().clone(), out.logits.detach().clone(), out.loss.detach().clone(), grads
 
 
-@pytest.mark.parametrize("B", [2, 4, 6])
-def test_split_forward_is_bit_equal_to_the_one_stream_forward(B, monkeypatch):
+@pytest.mark.parametrize("B,se", [(2, False), (4, False), (6, False), (2, True), (4, True)])
+def test_split_forward_is_bit_equal_to_the_one_stream_forward(B, se, monkeypatch):
+    """se: SE-DiCoW (B mixture + enrollment pairs, two speaker-communication layers): the fork comes behind the last of them, where the
+    enrollment rows are dropped, over the plain layers that follow."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from ts_asr_whisper_amd import engine
-    model, batch = _model_and_batch(B)
+    model, batch = _model_and_batch(B, se=se)
     monkeypatch.setattr(engine, "SPLIT_FWD_MIN_ROWS", 0)
     monkeypatch.setattr(engine, "SPLIT_FWD", False)
     enc0, lg0, loss0, g0 = _step(model, batch)
@@ -61,6 +63,40 @@ def test_split_forward_is_bit_equal_to_the_one_stream_forward(B, monkeypatch):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("B", [2, 4])
+def test_frozen_decoder_runs_as_two_halves_too_and_nothing_moves(B, monkeypatch):
+    """The reference's default recipe freezes the decoder (keyword "decoder"): then neither direction of the decoder reduces anything
+    over rows, and engine.SPLIT_DEC runs its layers -- forward and backward -- as two half batches on two streams; the LM head and the
+    loss stay on the full batch.  Logits, loss and every (encoder) gradient are bit-equal to the one-stream step."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ts_asr_whisper_amd import engine
+    from ts_asr_whisper_amd.trainer import freeze_by_keyword
+    model, batch = _model_and_batch(B)
+    model.tie_weights()
+    freeze_by_keyword(model, ("decoder",))
+    assert not any(p.requires_grad for p in model.model.decoder.parameters()) and not model.proj_out.weight.requires_grad
+    batch["labels"][B - 1, 10:] = -100
+    monkeypatch.setattr(engine, "SPLIT_FWD_MIN_ROWS", 0)
+    monkeypatch.setattr(engine, "SPLIT_FWD", False)
+    enc0, lg0, loss0, g0 = _step(model, batch)
+    assert len(g0) > 20 and all(n.startswith("model.encoder.") for n in g0)
+    seen = []
+    real = engine.DecoderEngine._layers_fwd
+    monkeypatch.setattr(engine.DecoderEngine, "_layers_fwd", lambda self, enc_bf, Bp, *a: (seen.append(Bp), real(self, enc_bf, Bp, *a))[1])
+    monkeypatch.setattr(engine, "SPLIT_FWD", True)
+    for dec_on in (True, False, True):
+        monkeypatch.setattr(engine, "SPLIT_DEC", dec_on)
+        del seen[:]
+        enc1, lg1, loss1, g1 = _step(model, batch)
+        assert seen == ([B // 2, B // 2] if dec_on else [B]), seen
+        assert torch.equal(enc1, enc0) and torch.equal(lg1, lg0) and torch.equal(loss1, loss0), dec_on
+        assert g1.keys() == g0.keys()
+        for n in g0:
+            assert torch.equal(g1[n], g0[n]), (dec_on, n)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("B", [2, 6])
 def test_split_inference_forward_is_bit_equal_to_the_one_stream_forward(B, monkeypatch):
     if not torch.cuda.is_available():
@@ -80,7 +116,7 @@ def test_split_inference_forward_is_bit_equal_to_the_one_stream_forward(B, monke
     torch.cuda.synchronize()
 
 
-def test_split_forward_leaves_odd_batches_and_enrollments_alone(monkeypatch):
+def test_split_forward_leaves_odd_batches_small_batches_and_se_inference_alone(monkeypatch):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from ts_asr_whisper_amd import engine
@@ -94,8 +130,10 @@ def test_split_forward_leaves_odd_batches_and_enrollments_alone(monkeypatch):
     with torch.no_grad():
         model(**batch)
     assert not calls
-    model, batch = _model_and_batch(2, se=True)                 # SE-DiCoW (interleaved enrollment rows, rows dropped mid-encoder): one stream
+    model, batch = _model_and_batch(3, se=True)                 # SE-DiCoW with an odd number of pairs: one stream
     _step(model, batch)
+    assert not calls
+    model, batch = _model_and_batch(2, se=True)                 # SE-DiCoW inference: one stream (only the training forward forks behind the SCB layers)
     with torch.no_grad():
         model(**batch)
     assert not calls

@@ -12,6 +12,7 @@ per-layer FDDT + optional speaker-communication block + WhisperEncoderLayer, fin
 layers.py:145-193 (SCB), HF modeling_whisper.py WhisperEncoderLayer / WhisperDecoderLayer / WhisperAttention,
 modeling_dicow.py:248-338 (shift, tied LM head, losses).
 """
+import contextlib
 import os
 from types import SimpleNamespace as NS
 
@@ -61,6 +62,7 @@ def wgrad_stream(dev):
 # stream of its own hardware queue (a normal-priority pool stream may share the caller's queue: profiles/r06_streams.txt item 1).
 SPLIT_FWD = os.environ.get("DICOW_SPLIT_FWD", "1") != "0"
 SPLIT_FWD_MIN_ROWS = int(os.environ.get("DICOW_SPLIT_FWD_MIN_ROWS", "16000"))      # whisper-base B = 8 (12000 rows, one hipGraph) stays on one stream
+SPLIT_DEC = os.environ.get("DICOW_SPLIT_DEC", "1") != "0"                     # the FROZEN decoder's layers too (forward and backward: DecoderEngine)
 SPLIT_FWD_PARTS = int(os.environ.get("DICOW_SPLIT_FWD_PARTS", "2"))          # (4 measured against 2: profiles/r06_split_fwd.txt)
 _FWD_STREAMS = {}
 
@@ -592,16 +594,20 @@ class EncoderEngine:
         hb = None                                        # bf16 copy of h + its row partials in stat1: written by the previous fc2
         fddt_done = False                                # h already carries this layer's FDDT (written by the previous fc2)
         # training forward of a large even batch: two half batches on two streams into shared full-batch buffers (SPLIT_FWD above)
-        split = (SPLIT_FWD and need_grad and fold is None and not fuse_next and not cfg.use_enrollments and all(f is None for f in W.full)
-                 and B % 2 == 0 and rows >= SPLIT_FWD_MIN_ROWS and not torch.cuda.is_current_stream_capturing())
-        if split:
-            main_st, halves, Bh = _fwd_parts(B, T, dev)  # fork: h (stem + initial FDDT) is complete
-            rh = Bh * T
+        # (SE-DiCoW: the speaker-communication layers pair mixture and enrollment rows and the enrollment rows are dropped behind the last
+        # of them -- the fork comes behind that layer, over the 24 plain layers that follow)
+        split_ok = (SPLIT_FWD and need_grad and fold is None and not fuse_next and all(f is None for f in W.full)
+                    and not torch.cuda.is_current_stream_capturing())
+        split_from = cfg.scb_layers if (cfg.use_enrollments and cfg.scb_layers) else 0
+        halves = None
         for i, lyr in enumerate(enc.layers):
             w = W.layers[i]
             Ls = NS(h_in=h, B=Bc, bstride=bstride)
             rows = Bc * T
-            if split:
+            if split_ok and halves is None and i == split_from and Bc % 2 == 0 and rows >= SPLIT_FWD_MIN_ROWS:
+                main_st, halves, Bh = _fwd_parts(Bc, T, dev)      # fork: h (stem + initial FDDT, or the last speaker-communication layer) is complete
+                rh, sstep = Bh * T, bstride // (4 * T)             # (sstep: STNO rows per encoder row -- 2 once the enrollment rows are gone)
+            if halves is not None:
                 fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None
                 mode, fw, fb = fddt_ptrs(fd, cfg)
                 ln, ln2 = lyr.self_attn_layer_norm, lyr.final_layer_norm
@@ -613,7 +619,7 @@ class EncoderEngine:
                 u, a, hn = _e((rows, F_), BF16, dev), _e((rows, F_), BF16, dev), _e((rows, D), F32, dev)
                 for st_, r, bsl in halves:
                     with torch.cuda.stream(st_):
-                        ops.fddt_ln_fwd(h[r], rh, D, mode=mode, stno=stno[bsl], stno_bstride=bstride, T=T, w=fw, b=fb,
+                        ops.fddt_ln_fwd(h[r], rh, D, mode=mode, stno=stno[bsl.start * sstep:], stno_bstride=bstride, T=T, w=fw, b=fb,
                                         h_out=hp[r] if mode != ops.MODE_NONE else None, ln_w=ln.weight.detach(),
                                         ln_b=ln.bias.detach(), y_bf16=xln[r], mean=mean[r], rstd=rstd[r])
                         linear_fwd(xln[r], w.att.qkv, rh, flags=L.EPI_SCALE_N, scale=Q_SCALE, scale_ncols=D, out=qkv[r])
@@ -721,7 +727,7 @@ class EncoderEngine:
         S.h_last, S.B_out, S.bstride_out = h, Bc, bstride
         enc_out, enc_bf = out if out is not None else (_e((rows, D), F32, dev), _e((rows, D), BF16, dev))
         S.meanf, S.rstdf = _e((rows,), F32, dev), _e((rows,), F32, dev)
-        if split:                                        # the final LayerNorm per half too, then the join
+        if halves is not None:                           # the final LayerNorm per half too, then the join
             for st_, r, bsl in halves:
                 with torch.cuda.stream(st_):
                     ops.fddt_ln_fwd(h[r], rh, D, mode=ops.MODE_NONE, ln_w=enc.layer_norm.weight.detach(), ln_b=enc.layer_norm.bias.detach(),
@@ -987,18 +993,14 @@ class DecoderEngine:
         self.W = W
         return W
 
-    def forward(self, enc_bf, B, T, decoder_input_ids, labels, upp_labels, ts=None):
+    def _layers_fwd(self, enc_bf, B, T, Lq, h):
+        """The decoder layers on B sequences: h fp32 [B*Lq, D] (embeddings) -> (last hidden state, per-layer saved activations)."""
         model, cfg, W = self.model, self.cfg, self.W
         dec = model.model.decoder
         dev = enc_bf.device
         D, H, F_ = cfg.d_model, cfg.decoder_attention_heads, cfg.decoder_ffn_dim
-        Lq = decoder_input_ids.shape[1]
-        if Lq > cfg.max_target_positions:
-            raise ValueError(f"decoder length {Lq} exceeds max_target_positions {cfg.max_target_positions}")
         rows = B * Lq
-        S = NS(B=B, T=T, Lq=Lq, ids=decoder_input_ids.contiguous(), layers=[], enc_bf=enc_bf)
-        h = _e((rows, D), F32, dev)
-        ops.embed_fwd(S.ids, dec.embed_tokens.weight.detach(), dec.embed_positions.weight.detach(), h)
+        out = []
         for i, lyr in enumerate(dec.layers):
             w = W.layers[i]
             Ls = NS(h_in=h)
@@ -1028,11 +1030,43 @@ class DecoderEngine:
             Ls.u = _e((rows, F_), BF16, dev)
             Ls.a = linear_fwd(Ls.x3, w.fc1, rows, gelu_aux=Ls.u)
             h = linear_fwd(Ls.a, w.fc2, rows, out_dtype=F32, residual=Ls.h3)
-            S.layers.append(Ls)
-        S.h_last = h
+            out.append(Ls)
+        return h, out
+
+    def forward(self, enc_bf, B, T, decoder_input_ids, labels, upp_labels, ts=None):
+        model, cfg, W = self.model, self.cfg, self.W
+        dec = model.model.decoder
+        dev = enc_bf.device
+        D, H, F_ = cfg.d_model, cfg.decoder_attention_heads, cfg.decoder_ffn_dim
+        Lq = decoder_input_ids.shape[1]
+        if Lq > cfg.max_target_positions:
+            raise ValueError(f"decoder length {Lq} exceeds max_target_positions {cfg.max_target_positions}")
+        rows = B * Lq
+        S = NS(B=B, T=T, Lq=Lq, ids=decoder_input_ids.contiguous(), enc_bf=enc_bf)
+        h = _e((rows, D), F32, dev)
+        ops.embed_fwd(S.ids, dec.embed_tokens.weight.detach(), dec.embed_positions.weight.detach(), h)
         S.xf, S.mf, S.rf = _e((rows, D), BF16, dev), _e((rows,), F32, dev), _e((rows,), F32, dev)
-        ops.fddt_ln_fwd(h, rows, D, ln_w=dec.layer_norm.weight.detach(), ln_b=dec.layer_norm.bias.detach(), y_bf16=S.xf,
-                        mean=S.mf, rstd=S.rf)
+        # A FROZEN decoder (the reference's default: frozen keyword "decoder") is row-parallel in both directions -- no parameter gradient
+        # is reduced over rows -- so a large even batch runs its decoder layers as two half batches on two streams (SPLIT_FWD above):
+        # the decoder's kernels at B x 128 rows fill a third of the chip each, two of them side by side fill two thirds.  The LM head
+        # and the loss stay on the full batch behind the join; everything is bit-identical.
+        split = (SPLIT_FWD and SPLIT_DEC and B % 2 == 0 and B * T >= SPLIT_FWD_MIN_ROWS and enc_bf.is_cuda
+                 and not torch.cuda.is_current_stream_capturing() and not model.proj_out.weight.requires_grad
+                 and not any(p.requires_grad for p in dec.parameters()))
+        if split:
+            main_st, parts, Bh = _fwd_parts(B, 1, dev)       # (row slices in units of sequences)
+        else:
+            main_st, parts, Bh = None, ((None, slice(0, B), slice(0, B)),), B
+        S.parts = []
+        for st_, _, bsl in parts:
+            rq, re = slice(bsl.start * Lq, bsl.stop * Lq), slice(bsl.start * T, bsl.stop * T)
+            with (torch.cuda.stream(st_) if st_ is not None else contextlib.nullcontext()):
+                hl, layers = self._layers_fwd(enc_bf[re], Bh, T, Lq, h[rq])
+                ops.fddt_ln_fwd(hl, Bh * Lq, D, ln_w=dec.layer_norm.weight.detach(), ln_b=dec.layer_norm.bias.detach(), y_bf16=S.xf[rq],
+                                mean=S.mf[rq], rstd=S.rf[rq])
+            S.parts.append(NS(st=st_, rq=rq, re=re, B=Bh, h_last=hl, layers=layers))
+        for st_, _, _ in parts[1:]:
+            main_st.wait_stream(st_)
         logits = _e((rows, W.vpad), BF16, dev)
         ops.gemm_nt(S.xf, W.head.w, logits, rows, W.vpad, D)
         S.logits = logits
@@ -1054,40 +1088,17 @@ class DecoderEngine:
             loss = S.acc[0] / S.denom
         return loss, logits.view(B, Lq, W.vpad)[:, :, :cfg.vocab_size], S
 
-    def backward(self, S, grad_loss, G, need_d_enc=True, d_logits_ext=None):
-        """Returns d_enc fp32 [B*T, D] (or None)."""
+    def _layers_bwd(self, layers, enc_bf, B, T, Lq, g, gb, G, d_enc):
+        """Backward of _layers_fwd on B sequences: g / gb = gradient wrt the last hidden state (fp32 / bf16); accumulates the
+        cross-attention's share into d_enc [B*T, D] (when given) and returns the gradient wrt the embeddings."""
         model, cfg, W = self.model, self.cfg, self.W
         dec = model.model.decoder
-        dev = S.logits.device
+        dev = g.device
         D, H, F_ = cfg.d_model, cfg.decoder_attention_heads, cfg.decoder_ffn_dim
-        B, T, Lq = S.B, S.T, S.Lq
         rows = B * Lq
-        d_logits = _e((rows, W.vpad), BF16, dev)
-        scale = (grad_loss.to(F32) / S.denom).reshape(1)
-        S.ce.d_logits = d_logits.data_ptr()
-        ops.ce_loss_bwd(S.ce, scale)
-        # tied LM head (modeling_dicow.py:302): d_x = d_logits @ E ; dE += d_logits^T @ x
-        ge = G.get(model.proj_out.weight)
-        if ge is not None:
-            if G.is_direct(model.proj_out.weight) and W.vpad != cfg.vocab_size:
-                # flat-store gradient (trainer.FlatStore) of a vocabulary that is not a multiple of 128: the padded rows go
-                # through a temporary so that the tied weight's gradient is COMPLETE in the flat store before the "decoder"
-                # segment is handed to the data-parallel all-reduce (it used to reach p.grad only after autograd returned)
-                tmp = torch.zeros(W.vpad, D, dtype=F32, device=dev)
-                ops.gemm_tn(d_logits, S.xf, tmp, rows, W.vpad, D)
-                ge.add_(tmp[:cfg.vocab_size])
-            else:
-                ops.gemm_tn(d_logits, S.xf, G.raw(model.proj_out.weight, W.vpad * D).view(W.vpad, D), rows, W.vpad, D)
-        d_xf = linear_dgrad(d_logits, W.head, rows)
-        g = _e((rows, D), F32, dev)
-        gb = _e((rows, D), BF16, dev)
         nl = len(dec.layers)
-        ops.fddt_ln_bwd(S.h_last, rows, D, ln_w=dec.layer_norm.weight.detach(), mean=S.mf, rstd=S.rf, d_y=d_xf, g_out=g,
-                        g_out_bf16=gb, dln_w=G.get(dec.layer_norm.weight), dln_b=G.get(dec.layer_norm.bias),
-                        colsum_out=G.get(dec.layers[nl - 1].fc2.bias))
-        d_enc = torch.zeros(B * T, D, dtype=F32, device=dev) if need_d_enc else None
         for i in range(nl - 1, -1, -1):
-            lyr, w, Ls = dec.layers[i], W.layers[i], S.layers[i]
+            lyr, w, Ls = dec.layers[i], W.layers[i], layers[i]
             # FFN
             linear_wgrad(gb, Ls.a, G.get(lyr.fc2.weight), rows)
             d_u = linear_dgrad(gb, w.fc2, rows, aux=Ls.u)
@@ -1112,9 +1123,9 @@ class DecoderEngine:
             bias_grad(dq, G.get(att.q_proj.bias))
             bias_grad(dkv[:, D:], G.get(att.v_proj.bias))
             linear_wgrad(dq, Ls.x2, G.get(att.q_proj.weight), rows)
-            linear_wgrad(dkv[:, :D], S.enc_bf, G.get(att.k_proj.weight), B * T)
-            linear_wgrad(dkv[:, D:], S.enc_bf, G.get(att.v_proj.weight), B * T)
-            if need_d_enc:
+            linear_wgrad(dkv[:, :D], enc_bf, G.get(att.k_proj.weight), B * T)
+            linear_wgrad(dkv[:, D:], enc_bf, G.get(att.v_proj.weight), B * T)
+            if d_enc is not None:
                 linear_dgrad(dkv, w.ca.kv, B * T, out=d_enc, accumulate=True)
             d_x2 = linear_dgrad(dq, w.ca.q, rows)
             g2, g2b = _e((rows, D), F32, dev), _e((rows, D), BF16, dev)
@@ -1143,9 +1154,56 @@ class DecoderEngine:
                             g_out_bf16=g1b, dln_w=G.get(ln.weight), dln_b=G.get(ln.bias),
                             colsum_out=G.get(dec.layers[i - 1].fc2.bias) if i > 0 else None)
             g, gb = g1, g1b
+        return g
+
+    def backward(self, S, grad_loss, G, need_d_enc=True, d_logits_ext=None):
+        """Returns d_enc fp32 [B*T, D] (or None)."""
+        model, cfg, W = self.model, self.cfg, self.W
+        dec = model.model.decoder
+        dev = S.logits.device
+        D, H, F_ = cfg.d_model, cfg.decoder_attention_heads, cfg.decoder_ffn_dim
+        B, T, Lq = S.B, S.T, S.Lq
+        rows = B * Lq
+        d_logits = _e((rows, W.vpad), BF16, dev)
+        scale = (grad_loss.to(F32) / S.denom).reshape(1)
+        S.ce.d_logits = d_logits.data_ptr()
+        ops.ce_loss_bwd(S.ce, scale)
+        # tied LM head (modeling_dicow.py:302): d_x = d_logits @ E ; dE += d_logits^T @ x
+        ge = G.get(model.proj_out.weight)
+        if ge is not None:
+            if G.is_direct(model.proj_out.weight) and W.vpad != cfg.vocab_size:
+                # flat-store gradient (trainer.FlatStore) of a vocabulary that is not a multiple of 128: the padded rows go
+                # through a temporary so that the tied weight's gradient is COMPLETE in the flat store before the "decoder"
+                # segment is handed to the data-parallel all-reduce (it used to reach p.grad only after autograd returned)
+                tmp = torch.zeros(W.vpad, D, dtype=F32, device=dev)
+                ops.gemm_tn(d_logits, S.xf, tmp, rows, W.vpad, D)
+                ge.add_(tmp[:cfg.vocab_size])
+            else:
+                ops.gemm_tn(d_logits, S.xf, G.raw(model.proj_out.weight, W.vpad * D).view(W.vpad, D), rows, W.vpad, D)
+        d_xf = linear_dgrad(d_logits, W.head, rows)
+        g = _e((rows, D), F32, dev)
+        nl = len(dec.layers)
+        d_enc = torch.zeros(B * T, D, dtype=F32, device=dev) if need_d_enc else None
+        split = len(S.parts) > 1                         # (only a frozen decoder was split: no gradient below is reduced over rows)
+        if split:
+            main_st = torch.cuda.current_stream(dev)
+            for P in S.parts[1:]:
+                P.st.wait_stream(main_st)                # fork: d_xf and the zeroed d_enc are complete
+        for P in S.parts:
+            rq, re, rows_p = P.rq, P.re, P.B * Lq
+            with (torch.cuda.stream(P.st) if split else contextlib.nullcontext()):
+                gb = _e((rows_p, D), BF16, dev)
+                ops.fddt_ln_bwd(P.h_last, rows_p, D, ln_w=dec.layer_norm.weight.detach(), mean=S.mf[rq], rstd=S.rf[rq], d_y=d_xf[rq], g_out=g[rq],
+                                g_out_bf16=gb, dln_w=G.get(dec.layer_norm.weight), dln_b=G.get(dec.layer_norm.bias),
+                                colsum_out=G.get(dec.layers[nl - 1].fc2.bias))
+                g_emb = self._layers_bwd(P.layers, S.enc_bf[re], P.B, T, Lq, g[rq], gb, G, d_enc[re] if need_d_enc else None)
+        if split:
+            for P in S.parts[1:]:
+                main_st.wait_stream(P.st)
         gt, gp = G.get(dec.embed_tokens.weight), G.get(dec.embed_positions.weight)
-        if gt is not None or gp is not None:
-            ops.embed_bwd(S.ids, g, gt, gp, D)
+        if gt is not None or gp is not None:             # (a trainable decoder is never split: one part, g_emb covers every row)
+            assert not split
+            ops.embed_bwd(S.ids, g_emb, gt, gp, D)
         return d_enc
 
 
