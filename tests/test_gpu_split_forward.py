@@ -41,6 +41,7 @@ def test_split_forward_is_bit_equal_to_the_one_stream_forward(B, se, monkeypatch
     from ts_asr_whisper_amd import engine
     model, batch = _model_and_batch(B, se=se)
     monkeypatch.setattr(engine, "SPLIT_FWD_MIN_ROWS", 0)
+    monkeypatch.setattr(engine, "SPLIT_BWD", False)             # (this test: the forward alone; the split backward has its own below)
     monkeypatch.setattr(engine, "SPLIT_FWD", False)
     enc0, lg0, loss0, g0 = _step(model, batch)
     # the decoder's gradients pass through atomically accumulated sums (embedding scatter-add, column sums: the order of the additions
@@ -78,6 +79,7 @@ def test_frozen_decoder_runs_as_two_halves_too_and_nothing_moves(B, monkeypatch)
     assert not any(p.requires_grad for p in model.model.decoder.parameters()) and not model.proj_out.weight.requires_grad
     batch["labels"][B - 1, 10:] = -100
     monkeypatch.setattr(engine, "SPLIT_FWD_MIN_ROWS", 0)
+    monkeypatch.setattr(engine, "SPLIT_BWD", False)
     monkeypatch.setattr(engine, "SPLIT_FWD", False)
     enc0, lg0, loss0, g0 = _step(model, batch)
     assert len(g0) > 20 and all(n.startswith("model.encoder.") for n in g0)
@@ -94,6 +96,45 @@ def test_frozen_decoder_runs_as_two_halves_too_and_nothing_moves(B, monkeypatch)
         assert g1.keys() == g0.keys()
         for n in g0:
             assert torch.equal(g1[n], g0[n]), (dec_on, n)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,wgrad", [(2, "main"), (4, "main"), (6, "main"), (4, "alt")])
+def test_split_backward_matrices_bit_equal_vectors_to_rounding_and_bit_reproducible(B, wgrad, monkeypatch):
+    """engine.SPLIT_BWD: the layers' backward chain as two half batches on two streams.  Weight MATRICES come from the same pooled
+    full-batch launch as before (bit-equal), the gradient that flows on to the stem is row-parallel (bit-equal: conv weights, initial
+    FDDT), the layers' VECTOR gradients are sums in two pieces added in a fixed order (equal to rounding, bit-reproducible run to run)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ts_asr_whisper_amd import engine
+    model, batch = _model_and_batch(B)
+    monkeypatch.setattr(engine, "SPLIT_FWD_MIN_ROWS", 0)
+    monkeypatch.setattr(engine, "SPLIT_FWD", True)
+    monkeypatch.setattr(engine, "SPLIT_BWD_WGRAD", wgrad)
+    monkeypatch.setattr(engine, "SPLIT_BWD", False)
+    enc0, lg0, loss0, g0 = _step(model, batch)
+    monkeypatch.setattr(engine, "SPLIT_BWD", True)
+    ran = []
+    real = engine.EncoderEngine._backward_split
+    monkeypatch.setattr(engine.EncoderEngine, "_backward_split", lambda self, *a: (ran.append(1), real(self, *a))[1])
+    runs = [_step(model, batch) for _ in range(3)]
+    assert len(ran) == 3
+    named = dict(model.named_parameters())
+    n_vec = n_mat = 0
+    for enc1, lg1, loss1, g1 in runs:
+        assert torch.equal(enc1, enc0) and torch.equal(lg1, lg0) and torch.equal(loss1, loss0)
+        for n in g0:
+            if not n.startswith("model.encoder."):
+                assert torch.allclose(g1[n], g0[n], rtol=1e-3, atol=1e-6), n            # (decoder: atomically accumulated sums)
+            elif n.startswith(("model.encoder.layers.", "model.encoder.fddts.")) and named[n].dim() == 1:
+                ref = g0[n].double()
+                assert float((g1[n].double() - ref).norm()) <= 2e-4 * float(ref.norm()) + 1e-12, (n, float((g1[n].double() - ref).norm()), float(ref.norm()))
+                assert torch.equal(g1[n], runs[0][3][n]), n                               # run to run: not a bit moves
+                n_vec += 1
+            else:                                                                        # matrices, stem, initial FDDT, final LayerNorm
+                assert torch.equal(g1[n], g0[n]), n
+                n_mat += 1
+    assert n_vec >= 3 * 20 and n_mat >= 3 * 20, (n_vec, n_mat)
     torch.cuda.synchronize()
 
 
@@ -122,6 +163,7 @@ def test_split_forward_leaves_odd_batches_small_batches_and_se_inference_alone(m
     from ts_asr_whisper_amd import engine
     monkeypatch.setattr(engine, "SPLIT_FWD_MIN_ROWS", 0)
     monkeypatch.setattr(engine, "SPLIT_FWD", True)
+    monkeypatch.setattr(engine, "SPLIT_BWD", False)             # (count the forward's forks only)
     calls = []
     real = engine.fwd_side_stream
     monkeypatch.setattr(engine, "fwd_side_stream", lambda dev, k=0: (calls.append(1), real(dev, k))[1])

@@ -63,6 +63,8 @@ def wgrad_stream(dev):
 SPLIT_FWD = os.environ.get("DICOW_SPLIT_FWD", "1") != "0"
 SPLIT_FWD_MIN_ROWS = int(os.environ.get("DICOW_SPLIT_FWD_MIN_ROWS", "16000"))      # whisper-base B = 8 (12000 rows, one hipGraph) stays on one stream
 SPLIT_DEC = os.environ.get("DICOW_SPLIT_DEC", "1") != "0"                     # the FROZEN decoder's layers too (forward and backward: DecoderEngine)
+SPLIT_BWD = os.environ.get("DICOW_SPLIT_BWD", "1") != "0"                     # the encoder BACKWARD's row-parallel chain as two halves too (EncoderEngine._backward_split)
+SPLIT_BWD_WGRAD = os.environ.get("DICOW_SPLIT_BWD_WGRAD", "alt")               # which stream launches a layer's pooled weight gradients: "alt" = odd layers on the side stream (the streams carry equal work: 124.5-124.6 ms per step) | "main" (124.7-124.9; one stream 126.3: profiles/r06_split_fwd.txt)
 SPLIT_FWD_PARTS = int(os.environ.get("DICOW_SPLIT_FWD_PARTS", "2"))          # (4 measured against 2: profiles/r06_split_fwd.txt)
 _FWD_STREAMS = {}
 
@@ -605,6 +607,7 @@ class EncoderEngine:
             Ls = NS(h_in=h, B=Bc, bstride=bstride)
             rows = Bc * T
             if split_ok and halves is None and i == split_from and Bc % 2 == 0 and rows >= SPLIT_FWD_MIN_ROWS:
+                S.split_from0 = i == 0                            # (what the split backward needs: every layer's buffers are full-batch, no SCB)
                 main_st, halves, Bh = _fwd_parts(Bc, T, dev)      # fork: h (stem + initial FDDT, or the last speaker-communication layer) is complete
                 rh, sstep = Bh * T, bstride // (4 * T)             # (sstep: STNO rows per encoder row -- 2 once the enrollment rows are gone)
             if halves is not None:
@@ -837,6 +840,13 @@ class EncoderEngine:
             if sync is not None:
                 sync.done(name)
         hook("final_ln")
+        if (SPLIT_BWD and SPLIT_FWD and getattr(S, "split_from0", False) and (sync is None or sync.role is None) and not WGRAD_SIDE_STREAM
+                and S.B_out % 2 == 0 and not torch.cuda.is_current_stream_capturing()):
+            g = self._backward_split(S, g, gb, G, hook)
+            enter("stem")
+            self._stem_backward(S, g, G)
+            hook("stem")
+            return
         # Weight gradients are recorded per layer and run as ONE pooled launch (ops.TnGroup / dicow_gemm_tn_group) as soon as
         # the pool holds a tile for every CU: large-v3-turbo has 300 tiles per layer (one launch per layer), whisper-base 48
         # (all six layers in one launch at the end).  A layer's DP bucket is only handed over once its gradients have run.
@@ -943,6 +953,127 @@ class EncoderEngine:
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)  # every dW is written before autograd / the optimizer / the "stem" bucket go on
         hook("stem")
+
+    # -- the layers' backward as two half batches on two streams (the forward forked the same way: every saved buffer is full-batch)
+    def _shadow(self, G, dev):
+        """Zeroed fp32 stand-ins for the VECTOR gradients of the layers (LayerNorm affine, biases, diagonal FDDT): the second half's
+        row reductions land here and are added to the real gradients layer by layer, behind the first half's -- a fixed order."""
+        enc, cfg = self.enc, self.cfg
+        sh = getattr(self, "_sh", None)
+        if sh is None or sh.flat.device != dev:
+            per, off = [], 0
+            for i, lyr in enumerate(enc.layers):
+                ps = [p for p in lyr.parameters() if p.dim() == 1]
+                fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None
+                if fd is not None:
+                    ps += [p for p in fd.parameters() if p.dim() == 1]
+                per.append(ps)
+                off += sum(_ceil(p.numel(), 64) for p in ps)
+            sh = NS(flat=torch.zeros(max(off, 1), dtype=F32, device=dev), view={}, per=per)
+            off = 0
+            for ps in per:
+                for p in ps:
+                    sh.view[id(p)] = sh.flat[off:off + p.numel()].view(p.shape)
+                    off += _ceil(p.numel(), 64)
+            self._sh = sh
+        sh.flat.zero_()
+
+        def get(p):
+            if p is None or G.get(p) is None:
+                return None
+            return sh.view[id(p)]                         # (KeyError = a reduction target this scheme does not know: fail loudly)
+        return sh, get
+
+    def _backward_split(self, S, g, gb, G, hook):
+        """Layers nl-1 .. 0 with the row-parallel chain (dgrads, attention backward, row kernels) of the two half batches on two streams.
+        What is NOT row-parallel keeps one owner and one order:
+          * weight matrices: the layer's pooled TN launch over the FULL batch (both halves write the halves of the same operand buffers),
+            launched one layer late -- behind an event of the other half -- so that no stream ever waits for work not yet enqueued;
+            same kernel, same operands as the one-stream backward: bit-equal;
+          * vectors (biases, LayerNorm affine, diagonal FDDT: the fused column / row reductions of the chain's kernels): half 0 adds into
+            the gradient itself, half 1 into zeroed stand-ins (_shadow) that are added behind it, layer by layer, before the layer's
+            DP bucket leaves: a fixed order, bit-reproducible; equal to the one-stream sums to rounding (a sum in two pieces).
+        Every buffer of the pass lives until its end (no block freed here is handed to the other stream mid-pass).  Returns g of layer 0."""
+        enc, cfg, W = self.enc, self.cfg, self.W
+        dev = g.device
+        T, D, H, F_ = S.T, cfg.d_model, cfg.encoder_attention_heads, cfg.encoder_ffn_dim
+        nl = len(enc.layers)
+        Bc = S.B_out
+        rows = Bc * T
+        main_st, parts, Bh = _fwd_parts(Bc, T, dev)             # fork: g / gb (final LayerNorm backward) are complete
+        side_st = parts[1][0]
+        rh = Bh * T
+        sh, shget = self._shadow(G, dev)
+        side_st.wait_stream(main_st)                             # (the zero fill of the stand-ins was enqueued behind the fork above)
+        keep, pending = [], None                                 # pending = (layer, its TnGroup, its stream's partner event)
+
+        def finish(item):                                        # a layer whose chain is enqueued on both streams: weight gradients, stand-in sums, DP bucket
+            i, tg, ev_main, ev_side = item
+            if SPLIT_BWD_WGRAD == "alt" and (i & 1):             # (experiment: odd layers' pooled launch on the side stream, to balance the streams)
+                with torch.cuda.stream(side_st):
+                    side_st.wait_event(ev_main)
+                    tg.run()
+                    ev_side = side_st.record_event()
+                main_st.wait_event(ev_side)
+            else:
+                main_st.wait_event(ev_side)
+                tg.run()
+            dst = [G.get(p) for p in sh.per[i]]
+            src = [sh.view[id(p)] for p, d in zip(sh.per[i], dst) if d is not None]
+            dst = [d for d in dst if d is not None]
+            if dst:
+                torch._foreach_add_(dst, src)
+            hook(f"layer{i}")
+
+        for i in range(nl - 1, -1, -1):
+            lyr, w, Ls = enc.layers[i], W.layers[i], S.layers[i]
+            att, ln, ln2 = lyr.self_attn, lyr.self_attn_layer_norm, lyr.final_layer_norm
+            fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None
+            mode, fw, fb = fddt_ptrs(fd, cfg)
+            prev_b2 = enc.layers[i - 1].fc2.bias if i > 0 else None
+            d_u, d_xln2 = _e((rows, F_), BF16, dev), _e((rows, D), BF16, dev)
+            g2, g2b, d_o = _e((rows, D), F32, dev), _e((rows, D), BF16, dev), _e((rows, D), BF16, dev)
+            d_qkv, d_xln = _e((rows, 3 * D), BF16, dev), _e((rows, D), BF16, dev)
+            g0, g0b = _e((rows, D), F32, dev), (_e((rows, D), BF16, dev) if i > 0 else None)
+            keep += [d_u, d_xln2, g2, g2b, d_o, d_qkv, d_xln, g0, g0b, g, gb]
+            qkv = Ls.qkv
+            evs = []
+            for k, (st_, r, bsl) in enumerate(parts):
+                gg = G.get if k == 0 else shget
+                with torch.cuda.stream(st_):
+                    linear_dgrad(gb[r], w.fc2, rh, aux=Ls.u[r], colsum_out=gg(lyr.fc1.bias), out=d_u[r])
+                    linear_dgrad(d_u[r], w.fc1, rh, out=d_xln2[r])
+                    ops.fddt_ln_bwd(Ls.h2[r], rh, D, mode=ops.MODE_NONE, ln_w=ln2.weight.detach(), mean=Ls.mean2[r], rstd=Ls.rstd2[r],
+                                    d_y=d_xln2[r], g_res=g[r], g_out=g2[r], g_out_bf16=g2b[r], dln_w=gg(ln2.weight), dln_b=gg(ln2.bias),
+                                    colsum_out=gg(att.out_proj.bias))
+                    linear_dgrad(g2b[r], w.att.o, rh, out=d_o[r])
+                    delta = _e((2, Bh, H, T), F32, dev)
+                    ops.attn_bwd(heads(qkv[r][:, :D], Bh, T, H), heads(qkv[r][:, D:2 * D], Bh, T, H), heads(qkv[r][:, 2 * D:], Bh, T, H),
+                                 heads(Ls.o[r], Bh, T, H), heads(d_o[r], Bh, T, H), Ls.lse[bsl], delta, heads(d_qkv[r][:, :D], Bh, T, H),
+                                 heads(d_qkv[r][:, D:2 * D], Bh, T, H), heads(d_qkv[r][:, 2 * D:], Bh, T, H), dq_scale=0.125, q_log2=QK_LOG2,
+                                 dq_colsum=gg(att.q_proj.bias), dv_colsum=gg(att.v_proj.bias))
+                    linear_dgrad(d_qkv[r], w.att.qkv, rh, out=d_xln[r])
+                    ops.fddt_ln_bwd(Ls.h_in[r], rh, D, mode=mode, stno=S.stno[bsl.start:], stno_bstride=Ls.bstride, T=T, w=fw, b=fb,
+                                    ln_w=ln.weight.detach(), mean=Ls.mean[r], rstd=Ls.rstd[r], d_y=d_xln[r], g_res=g2[r], g_out=g0[r],
+                                    g_out_bf16=g0b[r] if g0b is not None else None, dln_w=gg(ln.weight), dln_b=gg(ln.bias),
+                                    dw=tuple(gg(x) for x in fw), db=tuple(gg(x) for x in fb), colsum_out=gg(prev_b2))
+                    keep.append(delta)
+                    evs.append(st_.record_event())
+            # the layer's weight gradients: recorded now (first-writer flags consumed in layer order), launched one layer late
+            tg = ops.TnGroup()
+            linear_wgrad(gb, Ls.a, G.get(lyr.fc2.weight), rows, group=tg, param=lyr.fc2.weight)
+            linear_wgrad(d_u, Ls.xln2, G.get(lyr.fc1.weight), rows, group=tg, param=lyr.fc1.weight)
+            linear_wgrad(g2b, Ls.o, G.get(att.out_proj.weight), rows, group=tg, param=att.out_proj.weight)
+            qkv_wgrad(d_qkv, Ls.xln, G.get(att.q_proj.weight), G.get(att.k_proj.weight), G.get(att.v_proj.weight), rows, D, group=tg,
+                      params=(att.q_proj.weight, att.k_proj.weight, att.v_proj.weight))
+            if pending is not None:
+                finish(pending)
+            pending = (i, tg, evs[0], evs[1])
+            g, gb = g0, g0b
+        finish(pending)
+        main_st.wait_stream(side_st)
+        del keep
+        return g
 
     def _stem_backward(self, S, g, G):
         enc, cfg, W = self.enc, self.cfg, self.W
