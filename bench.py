@@ -54,9 +54,10 @@ def parse():
     ap.add_argument("--split-streams", action="store_true",
                     help="run each batch as two half batches on two HIP streams (trainer.SplitSync; same loss and gradients as the two halves "
                          "accumulated; measured -0.3...-1.8 ms per step, profiles/r06_split_streams.txt: not the default)")
-    ap.add_argument("--no-split-fwd", action="store_true",
-                    help="encoder training forward on ONE stream (default: a large even batch runs as two half batches on two HIP streams into the "
-                         "same activation buffers, bit-identical, backward unchanged: engine.SPLIT_FWD)")
+    ap.add_argument("--no-split-fwd", "--one-stream", dest="no_split_fwd", action="store_true",
+                    help="the whole step on ONE stream (default: the row-parallel work of a large even batch -- encoder forward, the frozen decoder's "
+                         "layers, the encoder backward's dgrad / attention / row-kernel chain -- runs as two half batches on two HIP streams into the "
+                         "halves of the same full-batch buffers; weight gradients stay one full-batch launch per layer: engine.SPLIT_FWD / SPLIT_DEC / SPLIT_BWD)")
     ap.add_argument("--from-audio", action="store_true",
                     help="the step starts from 16 kHz waveforms resident in HBM: dicow_logmel -> BatchAugmenter (STNO segment "
                          "augmentation + joint SpecAug, collators.py:189-214) -> training step (reported beside the headline, never AS it)")
@@ -748,7 +749,7 @@ def main():
         "config": {"workload": f"{a.model} DiCoW fine-tune step, per-GPU batch {a.batch}, L={a.labels}, decoder frozen, "
                                f"bf16 AMP{', SE-DiCoW scb_layers=8 mixed-length' if a.se else ''}{', CTC 0.3' if a.ctc else ''}{', preheat phase (FDDT-only training)' if a.preheat else ''}"
                                f"{', step replayed from a hipGraph' if a.graph else ''}{', from 16 kHz audio (log-mel + augmentation inside the step)' if a.from_audio else ''}",
-                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "split_streams": bool(a.split_streams), "encoder_forward_two_streams": bool(_engine.SPLIT_FWD and a.batch % 2 == 0 and a.batch * cfg.max_source_positions >= _engine.SPLIT_FWD_MIN_ROWS and not a.graph) and ("behind the speaker-communication layers" if a.se else True), "trainable_params": sum(n for q, _, n, _ in ts.store.entries if q.requires_grad)},
+                   "global_batch": a.batch * world, "parallelism": f"dp{world}", "split_streams": bool(a.split_streams), "two_half_batch_streams": bool(_engine.SPLIT_FWD and a.batch % 2 == 0 and a.batch * cfg.max_source_positions >= _engine.SPLIT_FWD_MIN_ROWS and not a.graph) and {"encoder_forward": "behind the speaker-communication layers" if a.se else True, "frozen_decoder_layers": bool(_engine.SPLIT_DEC), "encoder_backward_chain": bool(_engine.SPLIT_BWD) and ("above the speaker-communication layers" if a.se else True), "weight_gradients": "one full-batch pooled launch per layer"}, "trainable_params": sum(n for q, _, n, _ in ts.store.entries if q.requires_grad)},
         "loss": float(loss),
         "per_rank_ms_per_step": rank_ms,
         "allreduce": {"exposed_ms_per_step": rank_exposed,

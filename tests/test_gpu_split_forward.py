@@ -99,15 +99,18 @@ def test_frozen_decoder_runs_as_two_halves_too_and_nothing_moves(B, monkeypatch)
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("B,wgrad", [(2, "main"), (4, "main"), (6, "main"), (4, "alt")])
-def test_split_backward_matrices_bit_equal_vectors_to_rounding_and_bit_reproducible(B, wgrad, monkeypatch):
+@pytest.mark.parametrize("B,wgrad,variant", [(2, "main", ""), (4, "main", ""), (6, "alt", ""), (4, "alt", ""), (4, "alt", "preheat"), (4, "alt", "se"), (2, "main", "se")])
+def test_split_backward_matrices_bit_equal_vectors_to_rounding_and_bit_reproducible(B, wgrad, variant, monkeypatch):
     """engine.SPLIT_BWD: the layers' backward chain as two half batches on two streams.  Weight MATRICES come from the same pooled
     full-batch launch as before (bit-equal), the gradient that flows on to the stem is row-parallel (bit-equal: conv weights, initial
     FDDT), the layers' VECTOR gradients are sums in two pieces added in a fixed order (equal to rounding, bit-reproducible run to run)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from ts_asr_whisper_amd import engine
-    model, batch = _model_and_batch(B)
+    model, batch = _model_and_batch(B, se=variant == "se")      # se: SE-DiCoW -- the split covers the layers above the speaker-communication blocks
+    if variant == "preheat":                                    # the recipe's first phase: only the FDDT parameters train (no weight-gradient GEMM runs)
+        for n, p in model.named_parameters():
+            p.requires_grad_("fddt" in n)
     monkeypatch.setattr(engine, "SPLIT_FWD_MIN_ROWS", 0)
     monkeypatch.setattr(engine, "SPLIT_FWD", True)
     monkeypatch.setattr(engine, "SPLIT_BWD_WGRAD", wgrad)
@@ -134,7 +137,7 @@ def test_split_backward_matrices_bit_equal_vectors_to_rounding_and_bit_reproduci
             else:                                                                        # matrices, stem, initial FDDT, final LayerNorm
                 assert torch.equal(g1[n], g0[n]), n
                 n_mat += 1
-    assert n_vec >= 3 * 20 and n_mat >= 3 * 20, (n_vec, n_mat)
+    assert n_vec >= 3 * (8 if variant else 20) and n_mat >= 3 * (2 if variant == "preheat" else 20), (n_vec, n_mat)
     torch.cuda.synchronize()
 
 

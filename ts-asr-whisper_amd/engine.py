@@ -607,7 +607,7 @@ class EncoderEngine:
             Ls = NS(h_in=h, B=Bc, bstride=bstride)
             rows = Bc * T
             if split_ok and halves is None and i == split_from and Bc % 2 == 0 and rows >= SPLIT_FWD_MIN_ROWS:
-                S.split_from0 = i == 0                            # (what the split backward needs: every layer's buffers are full-batch, no SCB)
+                S.split_from, S.split_sstep = i, bstride // (4 * T)   # (the split backward covers the same layers: their saved buffers are full-batch, no SCB)
                 main_st, halves, Bh = _fwd_parts(Bc, T, dev)      # fork: h (stem + initial FDDT, or the last speaker-communication layer) is complete
                 rh, sstep = Bh * T, bstride // (4 * T)             # (sstep: STNO rows per encoder row -- 2 once the enrollment rows are gone)
             if halves is not None:
@@ -840,13 +840,16 @@ class EncoderEngine:
             if sync is not None:
                 sync.done(name)
         hook("final_ln")
-        if (SPLIT_BWD and SPLIT_FWD and getattr(S, "split_from0", False) and (sync is None or sync.role is None) and not WGRAD_SIDE_STREAM
+        start = nl - 1
+        if (SPLIT_BWD and SPLIT_FWD and getattr(S, "split_from", None) is not None and (sync is None or sync.role is None) and not WGRAD_SIDE_STREAM
                 and S.B_out % 2 == 0 and not torch.cuda.is_current_stream_capturing()):
-            g = self._backward_split(S, g, gb, G, hook)
-            enter("stem")
-            self._stem_backward(S, g, G)
-            hook("stem")
-            return
+            g, gb = self._backward_split(S, g, gb, G, hook)      # layers nl-1 .. split_from on two streams
+            start = S.split_from - 1                             # (SE-DiCoW: the speaker-communication layers below follow on one stream)
+            if start < 0:
+                enter("stem")
+                self._stem_backward(S, g, G)
+                hook("stem")
+                return
         # Weight gradients are recorded per layer and run as ONE pooled launch (ops.TnGroup / dicow_gemm_tn_group) as soon as
         # the pool holds a tile for every CU: large-v3-turbo has 300 tiles per layer (one launch per layer), whisper-base 48
         # (all six layers in one launch at the end).  A layer's DP bucket is only handed over once its gradients have run.
@@ -870,7 +873,7 @@ class EncoderEngine:
                 tng.run()
                 for name in names:                            # (the DP bucket / the split-step event are recorded behind the launch, on this stream)
                     hook(name)
-        for i in range(nl - 1, -1, -1):
+        for i in range(start, -1, -1):
             n_before = len(tng.items)
             enter(f"layer{i}")
             lyr, w, Ls = enc.layers[i], W.layers[i], S.layers[i]
@@ -993,7 +996,8 @@ class EncoderEngine:
           * vectors (biases, LayerNorm affine, diagonal FDDT: the fused column / row reductions of the chain's kernels): half 0 adds into
             the gradient itself, half 1 into zeroed stand-ins (_shadow) that are added behind it, layer by layer, before the layer's
             DP bucket leaves: a fixed order, bit-reproducible; equal to the one-stream sums to rounding (a sum in two pieces).
-        Every buffer of the pass lives until its end (no block freed here is handed to the other stream mid-pass).  Returns g of layer 0."""
+        Every buffer of the pass lives until its end (no block freed here is handed to the other stream mid-pass).  Covers layers nl-1 .. S.split_from
+        (0 for a plain encoder); returns (g, gb) of the lowest one."""
         enc, cfg, W = self.enc, self.cfg, self.W
         dev = g.device
         T, D, H, F_ = S.T, cfg.d_model, cfg.encoder_attention_heads, cfg.encoder_ffn_dim
@@ -1025,7 +1029,8 @@ class EncoderEngine:
                 torch._foreach_add_(dst, src)
             hook(f"layer{i}")
 
-        for i in range(nl - 1, -1, -1):
+        lo, sstep = S.split_from, S.split_sstep
+        for i in range(nl - 1, lo - 1, -1):
             lyr, w, Ls = enc.layers[i], W.layers[i], S.layers[i]
             att, ln, ln2 = lyr.self_attn, lyr.self_attn_layer_norm, lyr.final_layer_norm
             fd = enc.fddts[i] if (cfg.use_fddt and i < len(enc.fddts)) else None
@@ -1053,7 +1058,7 @@ class EncoderEngine:
                                  heads(d_qkv[r][:, D:2 * D], Bh, T, H), heads(d_qkv[r][:, 2 * D:], Bh, T, H), dq_scale=0.125, q_log2=QK_LOG2,
                                  dq_colsum=gg(att.q_proj.bias), dv_colsum=gg(att.v_proj.bias))
                     linear_dgrad(d_qkv[r], w.att.qkv, rh, out=d_xln[r])
-                    ops.fddt_ln_bwd(Ls.h_in[r], rh, D, mode=mode, stno=S.stno[bsl.start:], stno_bstride=Ls.bstride, T=T, w=fw, b=fb,
+                    ops.fddt_ln_bwd(Ls.h_in[r], rh, D, mode=mode, stno=S.stno[bsl.start * sstep:], stno_bstride=Ls.bstride, T=T, w=fw, b=fb,
                                     ln_w=ln.weight.detach(), mean=Ls.mean[r], rstd=Ls.rstd[r], d_y=d_xln[r], g_res=g2[r], g_out=g0[r],
                                     g_out_bf16=g0b[r] if g0b is not None else None, dln_w=gg(ln.weight), dln_b=gg(ln.bias),
                                     dw=tuple(gg(x) for x in fw), db=tuple(gg(x) for x in fb), colsum_out=gg(prev_b2))
@@ -1072,8 +1077,12 @@ class EncoderEngine:
             g, gb = g0, g0b
         finish(pending)
         main_st.wait_stream(side_st)
+        if lo > 0:                                               # layer lo's row kernel reduced into layer lo-1's fc2 bias: half 1's share joins it here
+            pb = enc.layers[lo - 1].fc2.bias
+            if G.get(pb) is not None:
+                G.get(pb).add_(sh.view[id(pb)])
         del keep
-        return g
+        return g, gb
 
     def _stem_backward(self, S, g, G):
         enc, cfg, W = self.enc, self.cfg, self.W
