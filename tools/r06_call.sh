@@ -91,6 +91,18 @@ import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f
                 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_default_again.json 2>/dev/null
                 for f in $out/bench_*.json; do python -c "
 import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['ms_per_step_median'], d['roofline']['frac'], (d.get('kernels') or {}).get('gemm_tn_kernel',{}).get('tflops'), (d.get('encoder_forward') or {}).get('ms'), (d.get('encoder_forward') or {}).get('mfma_frac'), (d.get('encoder_forward_train') or {}).get('ms'), (d.get('encoder_forward_train') or {}).get('mfma_frac'), d.get('power'))"; done ;;
+    final3)     # evidence on the final tree (encoder forward + backward chain + frozen decoder as two half batches on two streams by default):
+                # suite, default line, one-stream line, interleaved A/B of the three switches, kernel stats of the default and of the one-stream step
+                (timeout 2700 python -m pytest tests -m gpu -q > $out/gpu_tests.txt 2>&1; tail -n 3 $out/gpu_tests.txt)
+                python bench.py > $out/bench_default.json 2> $out/bench_default.err
+                for rep in 1 2; do for v in all bwd_off dec_off one_stream; do e="DICOW_SPLIT_FWD=1"; [ $v = bwd_off ] && e="DICOW_SPLIT_BWD=0"; [ $v = dec_off ] && e="DICOW_SPLIT_BWD=0 DICOW_SPLIT_DEC=0"; [ $v = one_stream ] && e="DICOW_SPLIT_FWD=0"
+                  env $e python bench.py --steps 15 --warmup 4 --no-extra --no-cpu-baseline 2>/dev/null | tail -n 1 > $out/bench_ab_${v}_$rep.json; done; done
+                DICOW_SPLIT_FWD=0 bash tools/prof_step.sh --no-extra > $out/prof_step.txt 2>&1; cp gpurun_out/kernel_stats.csv $out/kernel_stats.csv
+                bash tools/prof_step.sh --no-extra > $out/prof_step_two_streams.txt 2>&1; cp gpurun_out/kernel_stats.csv $out/kernel_stats_two_streams.csv
+                for v in se ctc preheat; do python bench.py --$v --steps 8 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_$v.json 2> $out/bench_$v.err; done
+                python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_default_again.json 2>/dev/null
+                for f in $out/bench_*.json; do python -c "
+import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['ms_per_step_median'], d['roofline']['frac'], (d.get('encoder_forward') or {}).get('ms'), (d.get('encoder_forward') or {}).get('mfma_frac'), (d.get('encoder_forward_train') or {}).get('ms'), (d.get('encoder_forward_train') or {}).get('mfma_frac'), (d.get('power') or {}).get('sclk_mhz_mean'))" | tee -a $out/summary.txt; done ;;
     epi)        DICOW_HIP_LIB=$PWD/tools/libv_ntabl.so timeout 900 python tools/ab_epilogues.py 2>&1 | grep -v amdgpu.ids | tee -a $out/ab_epilogues.txt ;;
     base_prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_base_$tag -o base -- python $GRAFT_REPO_ROOT/bench.py --model whisper-base --batch 8 --graph --no-extra --no-cpu-baseline --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$out/base_prof_bench.json 2>$GRAFT_REPO_ROOT/$out/base_prof_err.txt)
                 find /tmp/prof_base_$tag -name "*kernel_stats.csv" -exec cp {} $out/base_kernel_stats.csv \; ; head -30 $out/base_kernel_stats.csv | cut -c1-170 ;;

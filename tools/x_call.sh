@@ -1,10 +1,13 @@
-out=gpurun_out/r06x11; mkdir -p $out
+# scratch call: whisper-base B = 8 hipGraph step with the two half-batch streams forked INSIDE the capture (parallel graph branches)
+out=gpurun_out/r06x12; mkdir -p $out
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_split_forward.py -x -q 2>&1 | tail -25 | tee $out/split_tests.txt
-timeout 900 python -m pytest tests/test_gpu_realdims.py -x -q -k "configs4" 2>&1 | tail -5 | tee -a $out/split_tests.txt
 pr() { python -c "
-import json,sys; d=json.loads(open('$1').read().strip().splitlines()[-1]); print('$2', d['value'], d['ms_per_step'], d['ms_per_step_median'], 'roof', d['roofline']['frac'], 'train-fwd', (d.get('encoder_forward_train') or {}).get('ms'), (d.get('power') or {}).get('sclk_mhz_mean'))"; }
-for rep in 1 2; do for v in se_on se_bwd_off se_off; do e="DICOW_SPLIT_BWD=1"; [ $v = se_bwd_off ] && e="DICOW_SPLIT_BWD=0"; [ $v = se_off ] && e="DICOW_SPLIT_FWD=0"
-  env $e timeout 600 python bench.py --se --steps 8 --warmup 3 --no-extra --no-cpu-baseline 2>$out/bench_$v.err | tail -1 > $out/bench_${v}_$rep.json; pr $out/bench_${v}_$rep.json $v | tee -a $out/ab.txt
+import json,sys; d=json.loads(open('$1').read().strip().splitlines()[-1]); print('$2', d.get('value'), d.get('ms_per_step'), d.get('ms_per_step_median'), 'loss', d.get('loss'), d.get('error'))"; }
+for rep in 1 2 3; do for v in none fwd fwd_dec all; do
+  e="DICOW_SPLIT_IN_CAPTURE=0"
+  [ $v = fwd ] && e="DICOW_SPLIT_IN_CAPTURE=1 DICOW_SPLIT_FWD_MIN_ROWS=6000 DICOW_SPLIT_DEC=0 DICOW_SPLIT_BWD=0"
+  [ $v = fwd_dec ] && e="DICOW_SPLIT_IN_CAPTURE=1 DICOW_SPLIT_FWD_MIN_ROWS=6000 DICOW_SPLIT_BWD=0"
+  [ $v = all ] && e="DICOW_SPLIT_IN_CAPTURE=1 DICOW_SPLIT_FWD_MIN_ROWS=6000"
+  env $e timeout 300 python bench.py --model whisper-base --batch 8 --graph --no-extra --no-cpu-baseline --no-power --steps 30 --warmup 5 2>$out/err_${v}.txt | tail -n 1 > $out/b_${v}_$rep.json
+  pr $out/b_${v}_$rep.json $v | tee -a $out/ab.txt; tail -n 3 $out/err_${v}.txt | cut -c1-300 >> $out/errs.txt
 done; done
-for v in preheat ctc; do for e in 1 0; do DICOW_SPLIT_FWD=$e timeout 600 python bench.py --$v --steps 8 --warmup 3 --no-extra --no-cpu-baseline 2>$out/bench_$v.err | tail -1 > $out/bench_${v}_$e.json; pr $out/bench_${v}_$e.json ${v}_split$e | tee -a $out/ab.txt; done; done

@@ -65,8 +65,13 @@ SPLIT_FWD_MIN_ROWS = int(os.environ.get("DICOW_SPLIT_FWD_MIN_ROWS", "16000"))   
 SPLIT_DEC = os.environ.get("DICOW_SPLIT_DEC", "1") != "0"                     # the FROZEN decoder's layers too (forward and backward: DecoderEngine)
 SPLIT_BWD = os.environ.get("DICOW_SPLIT_BWD", "1") != "0"                     # the encoder BACKWARD's row-parallel chain as two halves too (EncoderEngine._backward_split)
 SPLIT_BWD_WGRAD = os.environ.get("DICOW_SPLIT_BWD_WGRAD", "alt")               # which stream launches a layer's pooled weight gradients: "alt" = odd layers on the side stream (the streams carry equal work: 124.5-124.6 ms per step) | "main" (124.7-124.9; one stream 126.3: profiles/r06_split_fwd.txt)
+SPLIT_IN_CAPTURE = os.environ.get("DICOW_SPLIT_IN_CAPTURE", "0") == "1"      # experiment: fork the two half-batch streams inside a hipGraph capture too (parallel branches of the graph)
 SPLIT_FWD_PARTS = int(os.environ.get("DICOW_SPLIT_FWD_PARTS", "2"))          # (4 measured against 2: profiles/r06_split_fwd.txt)
 _FWD_STREAMS = {}
+
+
+def _split_allowed():
+    return SPLIT_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()
 
 
 def fwd_side_stream(dev, k=0):
@@ -528,7 +533,7 @@ class EncoderEngine:
         B, T = input_features.shape[0], cfg.max_source_positions
         if (SPLIT_FWD and not need_grad and enrollments is None and not cfg.use_enrollments and input_features.is_cuda and B % 2 == 0
                 and B * T >= SPLIT_FWD_MIN_ROWS and input_features.dim() == 3 and input_features.shape[2] == 2 * T
-                and not torch.cuda.is_current_stream_capturing()):
+                and _split_allowed()):
             dev, D = input_features.device, cfg.d_model
             enc_out, enc_bf = _e((B * T, D), F32, dev), _e((B * T, D), BF16, dev)
             stno_mask = stno_mask.to(device=dev)
@@ -599,7 +604,7 @@ class EncoderEngine:
         # (SE-DiCoW: the speaker-communication layers pair mixture and enrollment rows and the enrollment rows are dropped behind the last
         # of them -- the fork comes behind that layer, over the 24 plain layers that follow)
         split_ok = (SPLIT_FWD and need_grad and fold is None and not fuse_next and all(f is None for f in W.full)
-                    and not torch.cuda.is_current_stream_capturing())
+                    and _split_allowed())
         split_from = cfg.scb_layers if (cfg.use_enrollments and cfg.scb_layers) else 0
         halves = None
         for i, lyr in enumerate(enc.layers):
@@ -842,7 +847,7 @@ class EncoderEngine:
         hook("final_ln")
         start = nl - 1
         if (SPLIT_BWD and SPLIT_FWD and getattr(S, "split_from", None) is not None and (sync is None or sync.role is None) and not WGRAD_SIDE_STREAM
-                and S.B_out % 2 == 0 and not torch.cuda.is_current_stream_capturing()):
+                and S.B_out % 2 == 0 and _split_allowed()):
             g, gb = self._backward_split(S, g, gb, G, hook)      # layers nl-1 .. split_from on two streams
             start = S.split_from - 1                             # (SE-DiCoW: the speaker-communication layers below follow on one stream)
             if start < 0:
@@ -1191,7 +1196,7 @@ class DecoderEngine:
         # the decoder's kernels at B x 128 rows fill a third of the chip each, two of them side by side fill two thirds.  The LM head
         # and the loss stay on the full batch behind the join; everything is bit-identical.
         split = (SPLIT_FWD and SPLIT_DEC and B % 2 == 0 and B * T >= SPLIT_FWD_MIN_ROWS and enc_bf.is_cuda
-                 and not torch.cuda.is_current_stream_capturing() and not model.proj_out.weight.requires_grad
+                 and _split_allowed() and not model.proj_out.weight.requires_grad
                  and not any(p.requires_grad for p in dec.parameters()))
         if split:
             main_st, parts, Bh = _fwd_parts(B, 1, dev)       # (row slices in units of sequences)
