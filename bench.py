@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--split-streams", action="store_true",
                     help="run each batch as two half batches on two HIP streams (trainer.SplitSync; same loss and gradients as the two halves "
                          "accumulated; measured -0.3...-1.8 ms per step, profiles/r06_split_streams.txt: not the default)")
+    ap.add_argument("--no-one-stream-ref", action="store_true", help="skip the short one-stream reference run behind the timed region")
     ap.add_argument("--no-split-fwd", "--one-stream", dest="no_split_fwd", action="store_true",
                     help="the whole step on ONE stream (default: the row-parallel work of a large even batch -- encoder forward, the frozen decoder's "
                          "layers, the encoder backward's dgrad / attention / row-kernel chain -- runs as two half batches on two HIP streams into the "
@@ -671,9 +672,24 @@ def main():
     for i in range(nprof):
         run_step(i, **({"eager": True} if a.graph else {}))
     sync()
+    timer.on = False
+    # ---- the same step on ONE stream, un-instrumented, right behind the timed region (same box, same clock state): what the two half-batch streams are worth
+    one_stream = None
+    if (fwd_split_was and not a.graph and not a.no_one_stream_ref and a.batch % 2 == 0
+            and a.batch * cfg.max_source_positions >= _engine.SPLIT_FWD_MIN_ROWS):        # (only where the two streams were in use)
+        n1 = max(2, min(6, a.steps))
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(n1 + 1)]
+        run_step(0)
+        sync()
+        ev1[0].record()
+        for i in range(n1):
+            run_step(i)
+            ev1[i + 1].record()
+        sync()
+        one_stream = {"ms_per_step": round(ev1[0].elapsed_time(ev1[n1]) / n1, 3), "steps": n1,
+                      "what": "the same step with engine.SPLIT_FWD off (forward, frozen decoder and backward chain on one stream), timed after the timed region"}
     ts.split_streams = split_was
     _engine.SPLIT_FWD = fwd_split_was
-    timer.on = False
     # ---- the front end by itself (HIP events on the launch stream, after the timed region): log-mel, augmentation
     fe = None
     if rank == 0:
@@ -752,6 +768,7 @@ def main():
                    "global_batch": a.batch * world, "parallelism": f"dp{world}", "split_streams": bool(a.split_streams), "two_half_batch_streams": bool(_engine.SPLIT_FWD and a.batch % 2 == 0 and a.batch * cfg.max_source_positions >= _engine.SPLIT_FWD_MIN_ROWS and not a.graph) and {"encoder_forward": "behind the speaker-communication layers" if a.se else True, "frozen_decoder_layers": bool(_engine.SPLIT_DEC), "encoder_backward_chain": bool(_engine.SPLIT_BWD) and ("above the speaker-communication layers" if a.se else True), "weight_gradients": "one full-batch pooled launch per layer"}, "trainable_params": sum(n for q, _, n, _ in ts.store.entries if q.requires_grad)},
         "loss": float(loss),
         "per_rank_ms_per_step": rank_ms,
+        "one_stream_reference": one_stream,
         "allreduce": {"exposed_ms_per_step": rank_exposed,
                       "note": "time the compute stream waits for the side-stream RCCL buckets before the optimizer (0 at one rank)",
                       "backend": dist.get_backend() if dist.is_initialized() else None,

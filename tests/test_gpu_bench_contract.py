@@ -39,6 +39,7 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert d["loss"] == d["loss"]                                                        # finite
     sm = rf["sustained_mfma_only"]                                                      # the matrix pipe's ceiling under the power cap
     assert 1000.0 < sm["tflops"] < rf["peak"] and abs(sm["frac_of_it"] - rf["achieved"] / sm["tflops"]) < 1e-3
+    assert d["one_stream_reference"] is None and d["config"]["two_half_batch_streams"] is False   # (a 2 x 1500-row batch runs on one stream)
     assert "power" in d                                                                 # rocm-smi samples of the timed region, or None
     if d["power"] is not None:
         assert 50.0 < d["power"]["board_w_mean"] < 2000.0 and 100.0 < d["power"]["sclk_mhz_mean"] <= 2500.0 and d["power"]["samples"] >= 1

@@ -1,13 +1,11 @@
-# scratch call: whisper-base B = 8 hipGraph step with the two half-batch streams forked INSIDE the capture (parallel graph branches)
-out=gpurun_out/r06x12; mkdir -p $out
+# scratch call: the DP rehearsal (one-rank RCCL reducer forced, emulated 8-rank fabric load) with the two half-batch streams (default) and on one stream
+out=gpurun_out/r06x13; mkdir -p $out
 export TMPDIR=/tmp
-pr() { python -c "
-import json,sys; d=json.loads(open('$1').read().strip().splitlines()[-1]); print('$2', d.get('value'), d.get('ms_per_step'), d.get('ms_per_step_median'), 'loss', d.get('loss'), d.get('error'))"; }
-for rep in 1 2 3; do for v in none fwd fwd_dec all; do
-  e="DICOW_SPLIT_IN_CAPTURE=0"
-  [ $v = fwd ] && e="DICOW_SPLIT_IN_CAPTURE=1 DICOW_SPLIT_FWD_MIN_ROWS=6000 DICOW_SPLIT_DEC=0 DICOW_SPLIT_BWD=0"
-  [ $v = fwd_dec ] && e="DICOW_SPLIT_IN_CAPTURE=1 DICOW_SPLIT_FWD_MIN_ROWS=6000 DICOW_SPLIT_BWD=0"
-  [ $v = all ] && e="DICOW_SPLIT_IN_CAPTURE=1 DICOW_SPLIT_FWD_MIN_ROWS=6000"
-  env $e timeout 300 python bench.py --model whisper-base --batch 8 --graph --no-extra --no-cpu-baseline --no-power --steps 30 --warmup 5 2>$out/err_${v}.txt | tail -n 1 > $out/b_${v}_$rep.json
-  pr $out/b_${v}_$rep.json $v | tee -a $out/ab.txt; tail -n 3 $out/err_${v}.txt | cut -c1-300 >> $out/errs.txt
-done; done
+timeout 1200 python -m pytest tests/test_gpu_bench_contract.py tests/test_gpu_rccl.py tests/test_gpu_dp.py -x -q 2>&1 | tail -n 6 | tee $out/tests.txt
+python bench.py --steps 10 --warmup 3 --no-extra --no-cpu-baseline 2>/dev/null | tail -n 1 > $out/bench_one_stream_ref.json
+python -c "
+import json; d=json.loads(open('$out/bench_one_stream_ref.json').read()); print(d['ms_per_step'], d['one_stream_reference'])" | tee -a $out/tests.txt
+echo "== two half-batch streams (default)" | tee $out/dp_emulated.txt
+DP_EMUL_REPS=2 timeout 1200 python tools/dp_emulate.py 100 2>&1 | grep -v amdgpu.ids | tee -a $out/dp_emulated.txt
+echo "== one stream (DICOW_SPLIT_FWD=0)" | tee -a $out/dp_emulated.txt
+DICOW_SPLIT_FWD=0 DP_EMUL_REPS=1 timeout 1200 python tools/dp_emulate.py 100 2>&1 | grep -v amdgpu.ids | tee -a $out/dp_emulated.txt
