@@ -99,7 +99,7 @@ def test_frozen_decoder_runs_as_two_halves_too_and_nothing_moves(B, monkeypatch)
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("B,wgrad,variant", [(2, "main", ""), (4, "main", ""), (6, "alt", ""), (4, "alt", ""), (4, "alt", "preheat"), (4, "alt", "se"), (2, "main", "se")])
+@pytest.mark.parametrize("B,wgrad,variant", [(2, "main", ""), (4, "main", ""), (6, "alt", ""), (4, "alt", ""), (4, "alt", "preheat"), (4, "alt", "se"), (2, "main", "se"), (4, "third", ""), (6, "third", "se")])
 def test_split_backward_matrices_bit_equal_vectors_to_rounding_and_bit_reproducible(B, wgrad, variant, monkeypatch):
     """engine.SPLIT_BWD: the layers' backward chain as two half batches on two streams.  Weight MATRICES come from the same pooled
     full-batch launch as before (bit-equal), the gradient that flows on to the stem is row-parallel (bit-equal: conv weights, initial

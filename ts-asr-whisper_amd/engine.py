@@ -64,7 +64,7 @@ SPLIT_FWD = os.environ.get("DICOW_SPLIT_FWD", "1") != "0"
 SPLIT_FWD_MIN_ROWS = int(os.environ.get("DICOW_SPLIT_FWD_MIN_ROWS", "16000"))      # whisper-base B = 8 (12000 rows, one hipGraph) stays on one stream
 SPLIT_DEC = os.environ.get("DICOW_SPLIT_DEC", "1") != "0"                     # the FROZEN decoder's layers too (forward and backward: DecoderEngine)
 SPLIT_BWD = os.environ.get("DICOW_SPLIT_BWD", "1") != "0"                     # the encoder BACKWARD's row-parallel chain as two halves too (EncoderEngine._backward_split)
-SPLIT_BWD_WGRAD = os.environ.get("DICOW_SPLIT_BWD_WGRAD", "alt")               # which stream launches a layer's pooled weight gradients: "alt" = odd layers on the side stream (the streams carry equal work: 124.5-124.6 ms per step) | "main" (124.7-124.9; one stream 126.3: profiles/r06_split_fwd.txt)
+SPLIT_BWD_WGRAD = os.environ.get("DICOW_SPLIT_BWD_WGRAD", "alt")               # which stream launches a layer's pooled weight gradients: "alt" = odd layers on the side stream (the streams carry equal work: 124.5-124.6 ms per step) | "main" (124.7-124.9; one stream 126.3) | "third" = every pooled launch on a third queue, settled one layer later still (measured +1.5 ms: 129.5 against 127.9-128.1, profiles/r06_split_bwd.txt)
 SPLIT_IN_CAPTURE = os.environ.get("DICOW_SPLIT_IN_CAPTURE", "0") == "1"      # experiment: fork the two half-batch streams inside a hipGraph capture too (parallel branches of the graph)
 SPLIT_FWD_PARTS = int(os.environ.get("DICOW_SPLIT_FWD_PARTS", "2"))          # (4 measured against 2: profiles/r06_split_fwd.txt)
 _FWD_STREAMS = {}
@@ -1016,8 +1016,32 @@ class EncoderEngine:
         side_st.wait_stream(main_st)                             # (the zero fill of the stand-ins was enqueued behind the fork above)
         keep, pending = [], None                                 # pending = (layer, its TnGroup, its stream's partner event)
 
+        third_st = wgrad_stream(dev) if SPLIT_BWD_WGRAD == "third" else None
+        deferred = []                                            # ("third": layers whose weight gradients run on the third stream, not yet settled)
+
+        def settle(item):                                        # ("third") one layer later still: the stand-in sums and the DP bucket behind the third stream's launch
+            i, ev_side, ev3 = item
+            main_st.wait_event(ev_side)
+            main_st.wait_event(ev3)
+            dst = [G.get(p) for p in sh.per[i]]
+            src = [sh.view[id(p)] for p, d in zip(sh.per[i], dst) if d is not None]
+            dst = [d for d in dst if d is not None]
+            if dst:
+                torch._foreach_add_(dst, src)
+            hook(f"layer{i}")
+
         def finish(item):                                        # a layer whose chain is enqueued on both streams: weight gradients, stand-in sums, DP bucket
             i, tg, ev_main, ev_side = item
+            if third_st is not None:                             # (experiment: every pooled launch on a third queue, neither chain ever carries one)
+                with torch.cuda.stream(third_st):
+                    third_st.wait_event(ev_main)
+                    third_st.wait_event(ev_side)
+                    tg.run()
+                    ev3 = third_st.record_event()
+                deferred.append((i, ev_side, ev3))
+                if len(deferred) > 1:
+                    settle(deferred.pop(0))
+                return
             if SPLIT_BWD_WGRAD == "alt" and (i & 1):             # (experiment: odd layers' pooled launch on the side stream, to balance the streams)
                 with torch.cuda.stream(side_st):
                     side_st.wait_event(ev_main)
@@ -1081,7 +1105,11 @@ class EncoderEngine:
             pending = (i, tg, evs[0], evs[1])
             g, gb = g0, g0b
         finish(pending)
+        while deferred:
+            settle(deferred.pop(0))
         main_st.wait_stream(side_st)
+        if third_st is not None:
+            main_st.wait_stream(third_st)
         if lo > 0:                                               # layer lo's row kernel reduced into layer lo-1's fc2 bias: half 1's share joins it here
             pb = enc.layers[lo - 1].fc2.bias
             if G.get(pb) is not None:
