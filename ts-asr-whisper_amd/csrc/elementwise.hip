@@ -297,6 +297,9 @@ __global__ void reduce_parts_tall_kernel(const float* __restrict__ part, int npa
 
 int dicow_launch_reduce_multi(const float* part, int nparts, int64_t stride, int64_t kstride, float* const* outs, int nout,
                               int64_t n, hipStream_t st) {
+#ifdef DICOW_SKIP_REDUCE_MULTI      // ablation builds only (tools/build_var.sh): timing without the small reduction launches -- results are WRONG
+    return DICOW_OK;
+#endif
     reduce_multi_args ra;
     for (int k = 0; k < 11; ++k) ra.out[k] = k < nout ? outs[k] : nullptr;
     hipLaunchKernelGGL(reduce_parts_tall_kernel, dim3((unsigned)((n + 15) / 16), nout), dim3(256), 0, st, part, nparts, stride,
