@@ -103,6 +103,23 @@ import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f
                 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_default_again.json 2>/dev/null
                 for f in $out/bench_*.json; do python -c "
 import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); print('$f', d['value'], d['ms_per_step'], d['ms_per_step_median'], d['roofline']['frac'], (d.get('encoder_forward') or {}).get('ms'), (d.get('encoder_forward') or {}).get('mfma_frac'), (d.get('encoder_forward_train') or {}).get('ms'), (d.get('encoder_forward_train') or {}).get('mfma_frac'), (d.get('power') or {}).get('sclk_mhz_mean'))" | tee -a $out/summary.txt; done ;;
+    # ---- last sessions: scheduling experiments around the two half-batch streams (profiles/r06_split_bwd.txt, r06_base_kernel_table.txt, r06_dp_emulated.txt)
+    ab_env)     # tools/r06_call.sh <tag> ab_env    with AB_ENVS="name1:VAR=val,VAR2=val name2:..." AB_ARGS="bench.py args" AB_REPS=2   -> interleaved bench lines
+                for rep in $(seq 1 ${AB_REPS:-2}); do for spec in $AB_ENVS; do n=${spec%%:*}; e=$(echo "${spec#*:}" | tr ',' ' ')
+                  env $e timeout 300 python bench.py ${AB_ARGS:---steps 15 --warmup 4 --no-extra --no-cpu-baseline --no-one-stream-ref --profile-steps 1} 2>$out/err_$n.txt | tail -n 1 > $out/b_${n}_$rep.json
+                  python -c "
+import json; d=json.loads(open('$out/b_${n}_$rep.json').read().strip().splitlines()[-1]); print('$n', d.get('value'), d.get('ms_per_step'), d.get('ms_per_step_median'), 'loss', d.get('loss'), (d.get('power') or {}).get('sclk_mhz_mean'), (d.get('encoder_forward_train') or {}).get('ms'))" | tee -a $out/ab.txt; done; done ;;
+                # used as:  basecap  AB_ARGS="--model whisper-base --batch 8 --graph --no-extra --no-cpu-baseline --no-power --steps 30 --warmup 5"
+                #                    AB_ENVS="none:DICOW_SPLIT_IN_CAPTURE=0 fwd:DICOW_SPLIT_IN_CAPTURE=1,DICOW_SPLIT_FWD_MIN_ROWS=6000,DICOW_SPLIT_DEC=0,DICOW_SPLIT_BWD=0 all:DICOW_SPLIT_IN_CAPTURE=1,DICOW_SPLIT_FWD_MIN_ROWS=6000"
+                #           wgrad3   AB_ENVS="alt:DICOW_SPLIT_BWD_WGRAD=alt third:DICOW_SPLIT_BWD_WGRAD=third main:DICOW_SPLIT_BWD_WGRAD=main"
+                #           noreduce AB_ENVS="base1:DICOW_SPLIT_FWD=1 base0:DICOW_SPLIT_FWD=0 nored1:DICOW_HIP_LIB=$PWD/tools/libv_noreduce.so nored0:DICOW_HIP_LIB=$PWD/tools/libv_noreduce.so,DICOW_SPLIT_FWD=0"
+                #                    (tools/build_var.sh noreduce "" "" "" "-DDICOW_SKIP_REDUCE_MULTI" first)
+    cus)        for rep in 1 2; do for c in 0 128 160 192 224; do timeout 300 python bench.py --gemm-cus $c --steps 12 --warmup 4 --no-extra --no-cpu-baseline --no-one-stream-ref 2>/dev/null | tail -n 1 > $out/b_${c}_$rep.json
+                  python -c "
+import json; d=json.loads(open('$out/b_${c}_$rep.json').read().strip().splitlines()[-1]); print('cus$c', d['ms_per_step'], (d.get('encoder_forward_train') or {}).get('ms'))" | tee -a $out/ab.txt; done; done ;;
+    dp_split)   timeout 1200 python -m pytest tests/test_gpu_bench_contract.py tests/test_gpu_rccl.py tests/test_gpu_dp.py -x -q 2>&1 | tail -n 6 | tee $out/tests.txt
+                echo "== two half-batch streams (default)" | tee $out/dp_emulated.txt; DP_EMUL_REPS=2 timeout 1200 python tools/dp_emulate.py 100 2>&1 | grep -v amdgpu.ids | tee -a $out/dp_emulated.txt
+                echo "== one stream (DICOW_SPLIT_FWD=0)" | tee -a $out/dp_emulated.txt; DICOW_SPLIT_FWD=0 DP_EMUL_REPS=1 timeout 1200 python tools/dp_emulate.py 100 2>&1 | grep -v amdgpu.ids | tee -a $out/dp_emulated.txt ;;
     epi)        DICOW_HIP_LIB=$PWD/tools/libv_ntabl.so timeout 900 python tools/ab_epilogues.py 2>&1 | grep -v amdgpu.ids | tee -a $out/ab_epilogues.txt ;;
     base_prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_base_$tag -o base -- python $GRAFT_REPO_ROOT/bench.py --model whisper-base --batch 8 --graph --no-extra --no-cpu-baseline --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$out/base_prof_bench.json 2>$GRAFT_REPO_ROOT/$out/base_prof_err.txt)
                 find /tmp/prof_base_$tag -name "*kernel_stats.csv" -exec cp {} $out/base_kernel_stats.csv \; ; head -30 $out/base_kernel_stats.csv | cut -c1-170 ;;
