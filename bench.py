@@ -639,8 +639,11 @@ def main():
         sampler.start()
     t0 = time.perf_counter()
     marks[0].record()
+    host_s = 0.0
     for i in range(a.steps):
+        h0 = time.perf_counter()
         loss = run_step(i)
+        host_s += time.perf_counter() - h0                       # host time to ENQUEUE the step (no synchronisation inside): the lead it has over the GPU
         marks[i + 1].record()
     sync()
     dt = time.perf_counter() - t0
@@ -769,6 +772,7 @@ def main():
         "loss": float(loss),
         "per_rank_ms_per_step": rank_ms,
         "one_stream_reference": one_stream,
+        "host_enqueue_ms_per_step": round(host_s / a.steps * 1e3, 3),
         "allreduce": {"exposed_ms_per_step": rank_exposed,
                       "note": "time the compute stream waits for the side-stream RCCL buckets before the optimizer (0 at one rank)",
                       "backend": dist.get_backend() if dist.is_initialized() else None,

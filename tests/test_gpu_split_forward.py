@@ -192,3 +192,29 @@ def test_split_forward_leaves_odd_batches_small_batches_and_se_inference_alone(m
     with torch.no_grad():
         model(**batch)
     assert len(calls) == 2
+
+
+def test_split_backward_falls_back_to_one_stream_when_its_buffers_would_not_fit(monkeypatch):
+    """The split backward keeps every layer's gradient buffers until the pass ends; a batch whose buffers exceed the allowed share of the free
+    memory (engine.SPLIT_BWD_MEM_FRACTION) takes the one-stream backward -- bit-equal to SPLIT_BWD off."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from ts_asr_whisper_amd import engine
+    model, batch = _model_and_batch(4)
+    monkeypatch.setattr(engine, "SPLIT_FWD_MIN_ROWS", 0)
+    monkeypatch.setattr(engine, "SPLIT_FWD", True)
+    monkeypatch.setattr(engine, "SPLIT_BWD", False)
+    enc0, lg0, loss0, g0 = _step(model, batch)
+    monkeypatch.setattr(engine, "SPLIT_BWD", True)
+    ran = []
+    real = engine.EncoderEngine._backward_split
+    monkeypatch.setattr(engine.EncoderEngine, "_backward_split", lambda self, *a: (ran.append(1), real(self, *a))[1])
+    monkeypatch.setattr(engine, "SPLIT_BWD_MEM_FRACTION", 0.0)
+    enc1, lg1, loss1, g1 = _step(model, batch)
+    assert not ran
+    for n in g0:
+        if n.startswith("model.encoder."):
+            assert torch.equal(g1[n], g0[n]), n
+    monkeypatch.setattr(engine, "SPLIT_BWD_MEM_FRACTION", 0.6)
+    _step(model, batch)
+    assert len(ran) == 1

@@ -120,6 +120,9 @@ import json; d=json.loads(open('$out/b_${c}_$rep.json').read().strip().splitline
     dp_split)   timeout 1200 python -m pytest tests/test_gpu_bench_contract.py tests/test_gpu_rccl.py tests/test_gpu_dp.py -x -q 2>&1 | tail -n 6 | tee $out/tests.txt
                 echo "== two half-batch streams (default)" | tee $out/dp_emulated.txt; DP_EMUL_REPS=2 timeout 1200 python tools/dp_emulate.py 100 2>&1 | grep -v amdgpu.ids | tee -a $out/dp_emulated.txt
                 echo "== one stream (DICOW_SPLIT_FWD=0)" | tee -a $out/dp_emulated.txt; DICOW_SPLIT_FWD=0 DP_EMUL_REPS=1 timeout 1200 python tools/dp_emulate.py 100 2>&1 | grep -v amdgpu.ids | tee -a $out/dp_emulated.txt ;;
+    conc)       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/conc_$tag -o g -- python $GRAFT_REPO_ROOT/bench.py --no-extra --no-cpu-baseline --no-power --no-one-stream-ref --steps 10 --warmup 3 --profile-steps 1 > $GRAFT_REPO_ROOT/$out/conc_bench.json 2>/dev/null)
+                find /tmp/conc_$tag -name "*kernel_trace.csv" -exec python tools/trace_concurrency.py {} \; | tee $out/trace_concurrency.txt ;;
+    split_tests) timeout 900 python -m pytest tests/test_gpu_split_forward.py -x -q 2>&1 | tail -n 5 | tee $out/split_tests.txt ;;
     epi)        DICOW_HIP_LIB=$PWD/tools/libv_ntabl.so timeout 900 python tools/ab_epilogues.py 2>&1 | grep -v amdgpu.ids | tee -a $out/ab_epilogues.txt ;;
     base_prof)  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_base_$tag -o base -- python $GRAFT_REPO_ROOT/bench.py --model whisper-base --batch 8 --graph --no-extra --no-cpu-baseline --steps 20 --warmup 5 > $GRAFT_REPO_ROOT/$out/base_prof_bench.json 2>$GRAFT_REPO_ROOT/$out/base_prof_err.txt)
                 find /tmp/prof_base_$tag -name "*kernel_stats.csv" -exec cp {} $out/base_kernel_stats.csv \; ; head -30 $out/base_kernel_stats.csv | cut -c1-170 ;;

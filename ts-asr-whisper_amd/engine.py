@@ -65,6 +65,7 @@ SPLIT_FWD_MIN_ROWS = int(os.environ.get("DICOW_SPLIT_FWD_MIN_ROWS", "16000"))   
 SPLIT_DEC = os.environ.get("DICOW_SPLIT_DEC", "1") != "0"                     # the FROZEN decoder's layers too (forward and backward: DecoderEngine)
 SPLIT_BWD = os.environ.get("DICOW_SPLIT_BWD", "1") != "0"                     # the encoder BACKWARD's row-parallel chain as two halves too (EncoderEngine._backward_split)
 SPLIT_BWD_WGRAD = os.environ.get("DICOW_SPLIT_BWD_WGRAD", "alt")               # which stream launches a layer's pooled weight gradients: "alt" = odd layers on the side stream (the streams carry equal work: 124.5-124.6 ms per step) | "main" (124.7-124.9; one stream 126.3) | "third" = every pooled launch on a third queue, settled one layer later still (measured +1.5 ms: 129.5 against 127.9-128.1, profiles/r06_split_bwd.txt)
+SPLIT_BWD_MEM_FRACTION = float(os.environ.get("DICOW_SPLIT_BWD_MEM_FRACTION", "0.6"))   # the split backward only if its buffers fit into this share of the free memory
 SPLIT_IN_CAPTURE = os.environ.get("DICOW_SPLIT_IN_CAPTURE", "0") == "1"      # experiment: fork the two half-batch streams inside a hipGraph capture too (parallel branches of the graph)
 SPLIT_FWD_PARTS = int(os.environ.get("DICOW_SPLIT_FWD_PARTS", "2"))          # (4 measured against 2: profiles/r06_split_fwd.txt)
 _FWD_STREAMS = {}
@@ -847,7 +848,7 @@ class EncoderEngine:
         hook("final_ln")
         start = nl - 1
         if (SPLIT_BWD and SPLIT_FWD and getattr(S, "split_from", None) is not None and (sync is None or sync.role is None) and not WGRAD_SIDE_STREAM
-                and S.B_out % 2 == 0 and _split_allowed()):
+                and S.B_out % 2 == 0 and _split_allowed() and self._split_bwd_fits(S, d_enc.device)):
             g, gb = self._backward_split(S, g, gb, G, hook)      # layers nl-1 .. split_from on two streams
             start = S.split_from - 1                             # (SE-DiCoW: the speaker-communication layers below follow on one stream)
             if start < 0:
@@ -963,6 +964,21 @@ class EncoderEngine:
         hook("stem")
 
     # -- the layers' backward as two half batches on two streams (the forward forked the same way: every saved buffer is full-batch)
+    def _split_bwd_fits(self, S, dev):
+        """The split backward keeps every layer's gradient buffers until the pass ends (no block is handed from one stream to the other mid-pass):
+        ~40 bytes per row and model column per layer (31 GB at B = 16 for large-v3-turbo).  A batch too large for that falls back to the one-stream
+        backward, which frees a layer's buffers as it goes."""
+        cfg = self.cfg
+        nl = len(self.enc.layers) - S.split_from
+        need = nl * S.B_out * S.T * (2 * cfg.encoder_ffn_dim + 24 * cfg.d_model + 64)
+        if not dev.type == "cuda":
+            return True
+        total = getattr(self, "_dev_total_mem", None)
+        if total is None:
+            total = self._dev_total_mem = torch.cuda.get_device_properties(dev).total_memory
+        free = total - torch.cuda.memory_allocated(dev)          # (the allocator's own books: no driver call, nothing that could wait for the device)
+        return need < SPLIT_BWD_MEM_FRACTION * free
+
     def _shadow(self, G, dev):
         """Zeroed fp32 stand-ins for the VECTOR gradients of the layers (LayerNorm affine, biases, diagonal FDDT): the second half's
         row reductions land here and are added to the real gradients layer by layer, behind the first half's -- a fixed order."""
